@@ -1,0 +1,258 @@
+"""Generate the golden output vectors by running the REFERENCE's own source files.
+
+Runs only in the build container (``/root/reference`` present); never on the GPU box.
+    python tests/golden/generate_golden.py [--only G1,G4]
+The reference files are imported from where they lie (by path, with a synthetic ``models``
+package so ``models/__init__.py`` — which eagerly imports ablation models that need
+``torch_geometric.nn`` — is not executed) on top of the third-party stand-ins of
+``pyg_standins.py``.  Weights and inputs come from the procedural filler; only outputs are stored.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("DIFFSPECTRA_REFERENCE", "/root/reference")
+
+from tests.golden import pyg_standins  # noqa: E402
+from tests.golden import cases  # noqa: E402
+from diffspectra_amd import filler  # noqa: E402
+
+
+def import_reference():
+    pyg_standins.install()
+    if REF not in sys.path:
+        sys.path.insert(1, REF)                     # for `from utils import *`, `import diffusion`
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [os.path.join(REF, "models")]    # package shell: submodules import, __init__ does not run
+    sys.modules["models"] = pkg
+    mods = types.SimpleNamespace()
+    mods.model_utils = importlib.import_module("models.utils")
+    mods.layers = importlib.import_module("models.layers")
+    mods.specformer = importlib.import_module("models.specformer")
+    mods.dmt = importlib.import_module("models.dmt")
+    mods.noise_schedule = importlib.import_module("diffusion.noise_schedule")
+    mods.top_utils = importlib.import_module("utils")
+    assert mods.top_utils.__file__.startswith(REF), mods.top_utils.__file__
+    mods.sampling = importlib.import_module("sampling")
+    return mods
+
+
+def ref_model(mods, version):
+    cfg = cases.config_for(version)
+    cfg.device = torch.device("cpu")
+    model = mods.model_utils._MODELS["DMT"](cfg)
+    model = torch.nn.DataParallel(model)            # as create_model does (models/utils.py:24-28)
+    model.load_state_dict(filler.fill_state_dict(model.state_dict()), strict=True)
+    model.eval()
+    return cfg, model
+
+
+def g0_manifest(mods):
+    for version in ("ir", "allspectra"):
+        _, model = ref_model(mods, version)
+        sd = model.state_dict()
+        entries = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]
+        n_param = sum(p.numel() for p in model.parameters())
+        trainable = [n for n, p in model.named_parameters() if p.requires_grad]
+        with open(cases.fixture_path(f"state_dict_manifest_{version}.json"), "w") as f:
+            json.dump({"entries": entries, "n_params": n_param, "n_trainable_tensors": len(trainable),
+                       "param_order": [n for n, _ in model.named_parameters()]}, f)
+        print("G0", version, len(entries), "entries", n_param, "params")
+
+
+def g1_schedule(mods):
+    ns = mods.noise_schedule.NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0)
+    out = {}
+    for S in (50, 1000):
+        t_arr = torch.linspace(ns.T, 1e-3, S)
+        s_arr = torch.cat([t_arr[1:], torch.zeros(1)])
+        a_t, s_t = zip(*[ns.marginal_prob(t) for t in t_arr])
+        a_s, s_s = zip(*[ns.marginal_prob(s) for s in s_arr])
+        # exact c_x / c_pred / noise_level out of the reference sampler: one single-step sampler per i with
+        # x = (+1,-1) [zero CoM] and a constant fake model (x_mean = c_x*x + c_pred*pred, sampling.py:604-606).
+        node_mask = torch.ones(1, 2, 1)
+        edge_mask = torch.tensor([0.0, 1.0, 1.0, 0.0]).reshape(4, 1)
+        seen = {}
+
+        def fake_zero(vec_t, x, nm, em, **kw):
+            seen["nl"] = kw["noise_level"][0].clone()
+            return torch.zeros_like(x), torch.zeros_like(kw["edge_x"])
+
+        def fake_unit(vec_t, x, nm, em, **kw):
+            p = torch.zeros_like(x)
+            p[0, 0, :], p[0, 1, :] = 1.0, -1.0
+            return p, torch.ones_like(kw["edge_x"])
+
+        c_x, c_p, nl = [], [], []
+        for i in range(S):
+            smp = mods.sampling.AncestralSampler(ns, t_arr[i:i + 1], True, True, True, lambda a, b: (a, b))
+            smp.s_array = s_arr[i:i + 1]
+            x = torch.zeros(1, 2, 9)
+            x[0, 0, :], x[0, 1, :] = 1.0, -1.0
+            xm, em = smp.sampling(fake_zero, x, node_mask, edge_mask, torch.ones(1, 2, 2, 2), None)
+            c_x.append(xm[0, 0, 0].clone())
+            assert torch.equal(em[0, 0, 1, 0], xm[0, 0, 0])
+            xm, _ = smp.sampling(fake_unit, torch.zeros(1, 2, 9), node_mask, edge_mask, torch.zeros(1, 2, 2, 2), None)
+            c_p.append(xm[0, 0, 0].clone())
+            nl.append(seen["nl"])
+        out.update({f"S{S}_t": t_arr, f"S{S}_s": s_arr, f"S{S}_alpha_t": torch.stack(a_t), f"S{S}_sigma_t": torch.stack(s_t),
+                    f"S{S}_alpha_s": torch.stack(a_s), f"S{S}_sigma_s": torch.stack(s_s),
+                    f"S{S}_c_x": torch.stack(c_x), f"S{S}_c_pred": torch.stack(c_p), f"S{S}_noise_level": torch.stack(nl)})
+    cases.save_npz("g1_schedule.npz", **{k: v.numpy() for k, v in out.items()})
+    print("G1 done")
+
+
+def g2_specformer(mods):
+    out = {}
+    for version in ("ir", "allspectra"):
+        cfg, model = ref_model(mods, version)
+        ctx = cases.spectra_for(version, 4)
+        with torch.no_grad():
+            z = model.module.cond_encoder(ctx)
+            out[f"{version}_z"] = z.numpy()
+            out[f"{version}_ctx"] = model.module.cond_lin(z).numpy()
+    cases.save_npz("g2_specformer.npz", **out)
+    print("G2 done")
+
+
+def g3_components(mods):
+    cfg, model = ref_model(mods, "ir")
+    blk = model.module.e_block_0
+    inp = cases.block_inputs()
+    out = {}
+    with torch.no_grad():
+        d2 = mods.model_utils.coord2dist(inp["pos"], inp["edge_index"])
+        out["d2"] = d2.numpy()
+        dist = blk.dist_layer(d2, inp["edge_time_emb"])
+        out["cond_gaussian"] = dist.numpy()
+        cd = inp["pos"][inp["edge_index"][0]] - inp["pos"][inp["edge_index"][1]]
+        out["coors_norm"] = blk.equi_update.coord_norm(cd).numpy()
+        out["trans_mix"] = blk.attn_mpnn(inp["h"], inp["edge_index"], inp["edge_attr"], inp["extra_heads"]).numpy()
+        out["equi_update"] = blk.equi_update(inp["h"], inp["pos"], inp["edge_index"], inp["edge_attr"], dist,
+                                             inp["edge_time_emb"], inp["extra_heads"]).numpy()
+        h, e, pos = blk(inp["pos"], inp["h"], inp["edge_attr"], inp["edge_index"], inp["node_mask"],
+                        inp["extra_heads"], inp["node_time_emb"], inp["edge_time_emb"])
+        out["block_h"], out["block_e"], out["block_pos"] = h.numpy(), e.numpy(), pos.numpy()
+        nl = torch.tensor([-7.5, -1.0, 0.0, 0.3, 9.0])
+        out["time_mlp"] = model.module.time_mlp(nl).numpy()
+    cases.save_npz("g3_components.npz", **out)
+    print("G3 done")
+
+
+def g4_forward(mods):
+    out = {}
+    for version in ("ir", "allspectra"):
+        cfg, model = ref_model(mods, version)
+        for first in (True, False):
+            a = cases.forward_inputs(version, first)
+            with torch.no_grad():
+                xh, ef = model(torch.zeros(len(cases.RAGGED)), a["xh"], a["node_mask"], a["edge_mask"],
+                               context=a["context"], edge_x=a["edge_x"], noise_level=a["noise_level"],
+                               cond_x=a["cond_x"], cond_edge_x=a["cond_edge_x"])
+            tag = f"{version}_{'first' if first else 'general'}"
+            out[tag + "_xh"], out[tag + "_edge"] = xh.numpy(), ef.numpy()
+            print("G4", tag, float(xh.abs().max()), float(ef.abs().max()))
+    cases.save_npz("g4_forward.npz", **out)
+
+
+class _ReplayRandn:
+    """Replays queued tensors for ``torch.randn`` calls of matching shape (reference noise samplers draw
+    pos [B,N,3], feat [B,N,6], edge [B,2,N,N] per step: models/utils.py:69,78,102)."""
+
+    def __init__(self, queue):
+        self.queue = list(queue)
+
+    def __call__(self, *size, **kw):
+        if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+            size = tuple(size[0])
+        t = self.queue.pop(0)
+        assert tuple(t.shape) == tuple(size), (t.shape, size)
+        return t.clone()
+
+
+def g5_trajectory(mods):
+    out = {}
+    for version, steps in (("allspectra", 5), ("ir", 50)):
+        cfg, model = ref_model(mods, version)
+        cfg.sampling.steps = steps
+        tr = cases.trajectory_inputs(version, steps)
+        ns = mods.noise_schedule.NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0)
+        time_steps = torch.linspace(ns.T, 1e-3, steps)
+        sampler = mods.sampling.AncestralSampler(ns, time_steps, True, True, True,
+                                                 mods.top_utils.get_self_cond_fn(cfg), sampling_temperature=1.0)
+        queue = list(tr["raw0"])
+        for r in tr["raws"]:
+            queue += list(r)
+        replay = _ReplayRandn(queue)
+        real_randn = torch.randn
+        mods.model_utils.torch.randn = replay        # same module object as torch; restored below
+        try:
+            B, N = len(tr["n_atoms"]), max(tr["n_atoms"])
+            z = mods.model_utils.sample_combined_position_feature_noise(B, N, 6, tr["node_mask"])
+            ez = mods.model_utils.sample_symmetric_edge_feature_noise(B, N, 2, tr["edge_mask"])
+            with torch.no_grad():
+                x_mean, e_mean = sampler.sampling(model, z, tr["node_mask"], tr["edge_mask"], ez, tr["context"])
+        finally:
+            torch.randn = real_randn
+        assert not replay.queue
+        inv = mods.top_utils.get_data_inverse_scaler(cfg)
+        pos, one_hot, fc, et = mods.sampling.post_process(x_mean.clone(), 5, True, tr["node_mask"], inv, e_mean.clone(),
+                                                          tr["edge_mask"], True)
+        mols = mods.sampling.mol_process(one_hot, pos, fc, tr["n_atoms"], et)
+        tag = f"{version}_S{steps}"
+        out[tag + "_x_mean"], out[tag + "_edge_mean"] = x_mean.numpy(), e_mean.numpy()
+        out[tag + "_pos"], out[tag + "_atom_type"] = pos.numpy(), one_hot.argmax(-1).numpy()
+        out[tag + "_fc"], out[tag + "_edge_type"] = fc.numpy(), et.numpy()
+        for m, (p, at, e, c) in enumerate(mols):
+            out[f"{tag}_mol{m}_pos"], out[f"{tag}_mol{m}_atom"] = p.numpy(), at.numpy()
+            out[f"{tag}_mol{m}_edge"], out[f"{tag}_mol{m}_fc"] = e.numpy(), c.numpy()
+        print("G5", tag, float(x_mean.abs().max()))
+    cases.save_npz("g5_trajectory.npz", **out)
+
+
+def g6_post_process(mods):
+    cfg = cases.config_for("ir")
+    inv = mods.top_utils.get_data_inverse_scaler(cfg)
+    n_atoms = [2, 5, 7]
+    node_mask, edge_mask = filler.masks_from_n_atoms(n_atoms)
+    B, N = 3, 7
+    xh = filler.normal("g6.xh", (B, N, 9)) * node_mask
+    # edge channels swept across the 0.5 / 1.5 / 2.5 bucket thresholds of sampling.py:73-82 after (x+1)/2 (*3)
+    grid = torch.linspace(-1.2, 1.2, B * N * N * 2).reshape(B, N, N, 2)
+    exact = torch.tensor([0.0, -2.0 / 3.0, 0.0, 2.0 / 3.0, 1.0, -1.0])   # (x+1)/2*3 = 1.5, 0.5, 1.5, 2.5, 3, 0
+    grid[0, 0, 1:7, 1] = exact
+    grid[0, 1:7, 0, 0] = torch.tensor([0.0, 1e-7, -1e-7, 0.5, -0.5, 1.0])  # exist threshold (x+1)/2 >= 0.5
+    edge_x = grid * edge_mask.reshape(B, N, N, 1)
+    pos, one_hot, fc, et = mods.sampling.post_process(xh.clone(), 5, True, node_mask, inv, edge_x.clone(), edge_mask, True)
+    cases.save_npz("g6_post_process.npz", pos=pos.numpy(), atom_type=one_hot.argmax(-1).numpy(),
+                   one_hot=one_hot.numpy(), fc=fc.numpy(), edge_type=et.numpy(), xh=xh.numpy(), edge_x=edge_x.numpy())
+    print("G6 done")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    mods = import_reference()
+    todo = {"G0": g0_manifest, "G1": g1_schedule, "G2": g2_specformer, "G3": g3_components, "G4": g4_forward,
+            "G5": g5_trajectory, "G6": g6_post_process}
+    only = [s for s in args.only.split(",") if s]
+    for k, fn in todo.items():
+        if not only or k in only:
+            fn(mods)
+
+
+if __name__ == "__main__":
+    main()

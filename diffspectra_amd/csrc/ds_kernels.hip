@@ -1,0 +1,1043 @@
+// gfx950 kernels + C-ABI for the DMT denoiser evaluation, the ancestral update and post-processing.
+// Reference arithmetic being reproduced: models/dmt.py:306-412 and the files cited in include/diffspectra_hip.h.
+// Layout and fusion plan: DESIGN.md §3-§4.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/diffspectra_hip.h"
+#include "ds_device.h"
+
+#define ADAC DS_ADA_COLS
+
+namespace {
+
+struct Ctx {  // by-value kernel argument: everything a stage needs
+  ds_layout L;
+  ds_workspace ws;
+  const float* wbase;
+  const int64_t* woff;  // device copy of ds_weights::off
+  float edge_th, cutoff;
+};
+
+__device__ __forceinline__ const float* BW(const Ctx& c, int blk, int slot) {
+  return c.wbase + c.woff[blk * DS_W_BLOCK_SLOTS + slot];
+}
+__device__ __forceinline__ const float* GW(const Ctx& c, int slot) {
+  return c.wbase + c.woff[DS_NBLOCKS * DS_W_BLOCK_SLOTS + slot];
+}
+
+// CondGaussianLayer feature k of the modulated squared distance x (layers.py:291-295,331-334).
+__device__ __forceinline__ float rbf_feature(float x, int k, const float* __restrict__ mean, const float* __restrict__ stdv,
+                                             const float* __restrict__ astd) {
+  if (k == 0) return x;
+  const float z = (x - mean[k - 1]) / stdv[k - 1];
+  return expf(-0.5f * (z * z)) / astd[k - 1];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prologue: sinusoid features of the noise level (layers.py:283-288), [B,24] (17 used, rest 0).
+__global__ void k_time_feat(Ctx c, const float* __restrict__ noise_level) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= c.L.B) return;
+  const float* w = GW(c, DS_GW_SIN_W);
+  const float x = noise_level[b];
+  float* f = c.ws.tfeat + (size_t)b * 24;
+  f[0] = x;
+  for (int i = 0; i < 8; ++i) {
+    const float fr = ((x * w[i]) * 2.0f) * 3.14159265358979323846f;
+    f[1 + i] = sinf(fr);
+    f[9 + i] = cosf(fr);
+  }
+  for (int i = 17; i < 24; ++i) f[i] = 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Init (dmt.py:323-345,363-377): per-pair adjacency bits + "any non-zero conditioning distance" flag.
+__global__ void k_pair_flags(Ctx c, const float* __restrict__ cond_x, const float* __restrict__ cond_edge_x) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= c.L.Pp) return;
+  int bits = 3;
+  if (cond_x != nullptr) {
+    const int da = c.L.node_dense[c.L.pair_a[p]], db = c.L.node_dense[c.L.pair_b[p]];
+    const float* pa = cond_x + (size_t)da * 9;
+    const float* pb = cond_x + (size_t)db * 9;
+    const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+    const float d2 = dx * dx + dy * dy + dz * dz;
+    const int m = c.L.pair_mol[p];
+    const int lb = db - m * c.L.N;
+    const float ce = cond_edge_x[((size_t)da * c.L.N + lb) * 2 + 0];
+    bits = (ce >= c.edge_th ? 1 : 0) | (d2 <= c.cutoff ? 2 : 0);
+    if (d2 != 0.0f) atomicOr(&c.ws.flags[0], 1);
+  }
+  c.ws.adj[p] = bits;
+}
+
+// Node init: packed positions, h0 = node_emb([h, cond_h]) (12 -> 256), atom_hids[:, 0:256] = h0.
+__global__ __launch_bounds__(256) void k_node_init(Ctx c, const float* __restrict__ xh, const float* __restrict__ cond_x) {
+  const int row = blockIdx.x;
+  const int col = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float in[16];
+  const int d = c.L.node_dense[row];
+  if (col < 6) in[col] = xh[(size_t)d * 9 + 3 + col];
+  else if (col < 12) in[col] = cond_x ? cond_x[(size_t)d * 9 + 3 + (col - 6)] : 0.0f;
+  if (col < 3) c.ws.pos[(size_t)row * 4 + col] = xh[(size_t)d * 9 + col];
+  if (col == 3) c.ws.pos[(size_t)row * 4 + 3] = 0.0f;
+  __syncthreads();
+  const float* W = GW(c, DS_GW_NODE_EMB_W);
+  float acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc += in[k] * wp_at(W, 256, k, col);
+  acc += GW(c, DS_GW_NODE_EMB_B)[col];
+  c.ws.h[(size_t)row * 256 + col] = acc;
+  c.ws.atom_hids[(size_t)row * 768 + col] = acc;
+}
+
+// Pair init: edge_attr0 = edge_emb([edge_x(2), cond_edge_x(2), dist(64)]) (68 -> 64); edge_hids[:, 0:64].
+__global__ __launch_bounds__(256) void k_pair_init(Ctx c, const float* __restrict__ edge_x, const float* __restrict__ cond_x,
+                                                   const float* __restrict__ cond_edge_x) {
+  constexpr int T = 64;
+  __shared__ __attribute__((aligned(16))) float X[T][72 + DS_LDP];
+  __shared__ __attribute__((aligned(16))) float xs[T];
+  const int tid = threadIdx.x, row0 = blockIdx.x * T;
+  const bool use_rbf = (cond_x != nullptr) && (c.ws.flags[0] != 0);   // dmt.py:364-368
+  if (tid < T) {
+    const int p = row0 + tid;
+    float x = 0.0f;
+    float e0 = 0, e1 = 0, c0 = 0, c1 = 0;
+    if (p < c.L.Pp) {
+      const int da = c.L.node_dense[c.L.pair_a[p]], db = c.L.node_dense[c.L.pair_b[p]];
+      const int m = c.L.pair_mol[p];
+      const size_t eidx = ((size_t)da * c.L.N + (db - m * c.L.N)) * 2;
+      e0 = edge_x[eidx]; e1 = edge_x[eidx + 1];
+      if (cond_x != nullptr) {
+        c0 = cond_edge_x[eidx]; c1 = cond_edge_x[eidx + 1];
+        const float* pa = cond_x + (size_t)da * 9;
+        const float* pb = cond_x + (size_t)db * 9;
+        const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        const float* ad = c.ws.ada + (size_t)m * ADAC + DS_ADA_TOP;
+        x = use_rbf ? d2 * (ad[0] + 1.0f) + ad[1] : d2;
+      }
+    }
+    X[tid][0] = e0; X[tid][1] = e1; X[tid][2] = c0; X[tid][3] = c1;
+    xs[tid] = x;
+  }
+  __syncthreads();
+  const float* mean = GW(c, DS_GW_RBF_MEAN);
+  const float* stdv = GW(c, DS_GW_RBF_STD);
+  const float* astd = GW(c, DS_GW_RBF_ASTD);
+  for (int idx = tid; idx < T * 64; idx += 256) {
+    const int row = idx >> 6, k = idx & 63;
+    float v = 0.0f;
+    if (row0 + row < c.L.Pp) v = use_rbf ? rbf_feature(xs[row], k, mean, stdv, astd) : xs[row];  // zeros repeat (dmt.py:365)
+    X[row][4 + k] = v;
+  }
+  __syncthreads();
+  const float* W = GW(c, DS_GW_EDGE_EMB_W);
+  const float* bias = GW(c, DS_GW_EDGE_EMB_B);
+  for (int idx = tid; idx < T * 64; idx += 256) {
+    const int row = idx >> 6, col = idx & 63;
+    const int p = row0 + row;
+    if (p >= c.L.Pp) continue;
+    float acc = 0.0f;
+    for (int k = 0; k < 68; ++k) acc += X[row][k] * wp_at(W, 64, k, col);
+    acc += bias[col];
+    c.ws.e[(size_t)p * 64 + col] = acc;
+    c.ws.edge_hids[(size_t)p * 192 + col] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block stage A (pairs): d^2 -> CondGaussian RBF -> edge_emb(128->64) -> LN -> modulate -> tanh(lin_edge0/1).
+// dmt.py:136-139,145-149; layers.py:165-166,183.
+__global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
+  constexpr int T = 64;
+  __shared__ __attribute__((aligned(16))) float X[T][128 + DS_LDP];
+  __shared__ __attribute__((aligned(16))) float Y[T][64 + DS_LDP];
+  __shared__ __attribute__((aligned(16))) float xs[T];
+  __shared__ int rmol[T];
+  const int tid = threadIdx.x, row0 = blockIdx.x * T;
+  if (tid < T) {
+    const int p = row0 + tid;
+    float x = 0.0f;
+    int m = 0;
+    if (p < c.L.Pp) {
+      m = c.L.pair_mol[p];
+      const float* pa = c.ws.pos + (size_t)c.L.pair_a[p] * 4;
+      const float* pb = c.ws.pos + (size_t)c.L.pair_b[p] * 4;
+      const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      const float* ad = c.ws.ada + (size_t)m * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_DIST;
+      x = d2 * (ad[0] + 1.0f) + ad[1];   // scale, shift (layers.py:330-331)
+    }
+    xs[tid] = x;
+    rmol[tid] = m;
+  }
+  __syncthreads();
+  {
+    const float* mean = BW(c, blk, DS_BW_RBF_MEAN);
+    const float* stdv = BW(c, blk, DS_BW_RBF_STD);
+    const float* astd = BW(c, blk, DS_BW_RBF_ASTD);
+    for (int idx = tid; idx < T * 64; idx += 256) {
+      const int row = idx >> 6, k = idx & 63;
+      const int p = row0 + row;
+      float v = 0.0f, ev = 0.0f;
+      if (p < c.L.Pp) {
+        v = rbf_feature(xs[row], k, mean, stdv, astd);
+        ev = c.ws.e[(size_t)p * 64 + k];
+        c.ws.dist[(size_t)p * 64 + k] = v;
+      }
+      X[row][k] = v;
+      X[row][64 + k] = ev;
+    }
+  }
+  __syncthreads();
+  {
+    const float* bias = BW(c, blk, DS_BW_EDGE_EMB_B);
+    tile_gemm<2, 1>(&X[0][0], 128 + DS_LDP, 128, BW(c, blk, DS_BW_EDGE_EMB_W), 64, 2,
+                    [&](int row, int col, float v) { Y[row][col] = v + bias[col]; });
+  }
+  __syncthreads();
+  for (int row = tid >> 6; row < T; row += 4) {
+    const float* ad = c.ws.ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
+    ln_mod_row<64>(&Y[row][0], ad, ad + 64);   // edge_shift_msa, edge_scale_msa
+  }
+  __syncthreads();
+  {
+    float* te0 = c.ws.te0;
+    float* te1 = c.ws.te1;
+    const int Pp = c.L.Pp;
+    tile_gemm<2, 2>(&Y[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_E0_W), 256, 8, [&](int row, int col, float v) {
+      if (row0 + row < Pp) te0[(size_t)(row0 + row) * 256 + col] = tanhf(v);
+    });
+    tile_gemm<2, 2>(&Y[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_E1_W), 256, 8, [&](int row, int col, float v) {
+      if (row0 + row < Pp) te1[(size_t)(row0 + row) * 256 + col] = tanhf(v);
+    });
+  }
+}
+
+// Block stage B (nodes): LN -> modulate -> q|k|v projection (256 -> 768).  dmt.py:148; layers.py:147-149.
+__global__ __launch_bounds__(256) void k_node_qkv(Ctx c, int blk) {
+  constexpr int T = 32;
+  __shared__ __attribute__((aligned(16))) float X[T][256 + DS_LDP];
+  __shared__ int rmol[T];
+  const int tid = threadIdx.x, row0 = blockIdx.x * T;
+  if (tid < T) rmol[tid] = (row0 + tid < c.L.Nn) ? c.L.node_mol[row0 + tid] : 0;
+  for (int idx = tid; idx < T * 64; idx += 256) {
+    const int row = idx >> 6, k4 = idx & 63;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (row0 + row < c.L.Nn) v = reinterpret_cast<const float4*>(c.ws.h + (size_t)(row0 + row) * 256)[k4];
+    reinterpret_cast<float4*>(&X[row][0])[k4] = v;
+  }
+  __syncthreads();
+  for (int row = tid >> 6; row < T; row += 4) {
+    const float* ad = c.ws.ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
+    ln_mod_row<256>(&X[row][0], ad, ad + 256);   // node_shift_msa, node_scale_msa
+  }
+  __syncthreads();
+  const float* bias = BW(c, blk, DS_BW_QKV_B);
+  float* qkv = c.ws.qkv;
+  const int Nn = c.L.Nn;
+  tile_gemm<1, 1>(&X[0][0], 256 + DS_LDP, 256, BW(c, blk, DS_BW_QKV_W), 768, 24, [&](int row, int col, float v) {
+    if (row0 + row < Nn) qkv[(size_t)(row0 + row) * 768 + col] = v + bias[col];
+  });
+}
+
+// Block stage C (one workgroup per molecule): 16-head edge-modulated attention, softmax over sources per
+// (target, head), heads 0-1 are the adjacency heads (0 -> -1e10).  layers.py:159-186 + PyG softmax/propagate.
+__global__ __launch_bounds__(256) void k_attention(Ctx c) {
+  constexpr int MAXN = 32;
+  __shared__ __attribute__((aligned(16))) float Q[MAXN * 256];
+  __shared__ __attribute__((aligned(16))) float K[MAXN * 256];
+  __shared__ __attribute__((aligned(16))) float V[MAXN * 256];
+  __shared__ __attribute__((aligned(16))) float Lg[DS_MAX_ATOMS * DS_MAX_ATOMS * 16];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
+  const int p0 = c.L.pair_off[m], P = c.L.pair_off[m + 1] - p0;
+  if (n <= 0) return;
+  for (int idx = tid; idx < n * 64; idx += 256) {
+    const int a = idx >> 6, k4 = idx & 63;
+    const float4* src = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + a) * 768);
+    reinterpret_cast<float4*>(Q)[a * 64 + k4] = src[k4];
+    reinterpret_cast<float4*>(K)[a * 64 + k4] = src[64 + k4];
+    reinterpret_cast<float4*>(V)[a * 64 + k4] = src[128 + k4];
+  }
+  __syncthreads();
+  // phase 1: logits of both directions of every pair; source a -> target b uses q_b * k_a * tanh(e0_ab)
+  for (int it = tid; it < P * 14; it += 256) {
+    const int pl = it / 14, hd = it - pl * 14;
+    const int p = p0 + pl;
+    const int a = c.L.pair_a[p] - n0, b = c.L.pair_b[p] - n0;
+    const float* t0 = c.ws.te0 + (size_t)p * 256 + hd * 18;
+    const float* qa = Q + a * 256 + hd * 18; const float* qb = Q + b * 256 + hd * 18;
+    const float* ka = K + a * 256 + hd * 18; const float* kb = K + b * 256 + hd * 18;
+    float s_ab = 0.0f, s_ba = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < 18; ++ch) {
+      const float e = t0[ch];
+      s_ab += (qb[ch] * ka[ch]) * e;
+      s_ba += (qa[ch] * kb[ch]) * e;
+    }
+    Lg[(b * n + a) * 16 + 2 + hd] = s_ab / 4.0f;   // / sqrt(out_channels = 16) (layers.py:167)
+    Lg[(a * n + b) * 16 + 2 + hd] = s_ba / 4.0f;
+    if (hd == 0) {
+      const int bits = c.ws.adj[p];
+      const float h0 = (bits & 1) ? 1.0f : -1e10f, h1 = (bits & 2) ? 1.0f : -1e10f;   // layers.py:171-174
+      Lg[(b * n + a) * 16 + 0] = h0; Lg[(b * n + a) * 16 + 1] = h1;
+      Lg[(a * n + b) * 16 + 0] = h0; Lg[(a * n + b) * 16 + 1] = h1;
+    }
+  }
+  __syncthreads();
+  // phase 2: softmax over sources s != t for each (target t, head)
+  for (int it = tid; it < n * 16; it += 256) {
+    const int t = it >> 4, hd = it & 15;
+    float mx = -INFINITY;
+    for (int s = 0; s < n; ++s) if (s != t) mx = fmaxf(mx, Lg[(t * n + s) * 16 + hd]);
+    float sum = 0.0f;
+    for (int s = 0; s < n; ++s) if (s != t) {
+      const float e = expf(Lg[(t * n + s) * 16 + hd] - mx);
+      Lg[(t * n + s) * 16 + hd] = e;
+      sum += e;
+    }
+    const float den = sum + 1e-16f;
+    for (int s = 0; s < n; ++s) if (s != t) Lg[(t * n + s) * 16 + hd] /= den;
+  }
+  __syncthreads();
+  // phase 3: out[t, c] = sum_s (v[s,c] * tanh(e1)[pair(s,t), c]) * alpha[t, s, head(c)]
+  {
+    const int col = tid, hd = tid >> 4;
+    for (int t = 0; t < n; ++t) {
+      float acc = 0.0f;
+      for (int s = 0; s < n; ++s) {
+        if (s == t) continue;
+        const int a = s < t ? s : t, b = s < t ? t : s;
+        const int pl = a * (2 * n - a - 1) / 2 + (b - a - 1);
+        const float g = c.ws.te1[(size_t)(p0 + pl) * 256 + col];
+        acc += (V[s * 256 + col] * g) * Lg[(t * n + s) * 16 + hd];
+      }
+      c.ws.attn[(size_t)(n0 + t) * 256 + col] = acc;
+    }
+  }
+}
+
+// Block stage D (nodes): node2edge partial, gated residual, LN, modulate, FF(256->512->256), gated residual,
+// per-block readout slice (256->64) and the node parts of equi_update.input_lin (256->512).  dmt.py:156-163,387,39-45.
+__global__ __launch_bounds__(256) void k_node_update(Ctx c, int blk) {
+  constexpr int T = 32;
+  __shared__ __attribute__((aligned(16))) float A0[T][256 + DS_LDP];
+  __shared__ __attribute__((aligned(16))) float H2[T][256 + DS_LDP];
+  __shared__ __attribute__((aligned(16))) float F1[T][512 + DS_LDP];
+  __shared__ int rmol[T];
+  const int tid = threadIdx.x, row0 = blockIdx.x * T;
+  const int Nn = c.L.Nn;
+  if (tid < T) rmol[tid] = (row0 + tid < Nn) ? c.L.node_mol[row0 + tid] : 0;
+  for (int idx = tid; idx < T * 64; idx += 256) {
+    const int row = idx >> 6, k4 = idx & 63;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (row0 + row < Nn) v = reinterpret_cast<const float4*>(c.ws.attn + (size_t)(row0 + row) * 256)[k4];
+    reinterpret_cast<float4*>(&A0[row][0])[k4] = v;
+  }
+  __syncthreads();
+  {
+    float* u = c.ws.u;
+    tile_gemm<1, 1>(&A0[0][0], 256 + DS_LDP, 256, BW(c, blk, DS_BW_N2E_W), 64, 2, [&](int row, int col, float v) {
+      if (row0 + row < Nn) u[(size_t)(row0 + row) * 64 + col] = v;
+    });
+  }
+  for (int idx = tid; idx < T * 256; idx += 256) {   // h_in + gate_msa * attn (dmt.py:159)
+    const int row = idx >> 8, col = idx & 255;
+    float v = 0.0f;
+    if (row0 + row < Nn) {
+      const float* ad = c.ws.ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
+      v = c.ws.h[(size_t)(row0 + row) * 256 + col] + ad[512 + col] * A0[row][col];
+    }
+    H2[row][col] = v;
+  }
+  __syncthreads();
+  for (int row = tid >> 6; row < T; row += 4) {
+    const float* ad = c.ws.ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
+    ln_mod_row<256>(&H2[row][0], ad + 768, ad + 1024);   // node_shift_mlp, node_scale_mlp (dmt.py:160)
+  }
+  __syncthreads();
+  {
+    const float* b1 = BW(c, blk, DS_BW_FF1_B);
+    tile_gemm<1, 1>(&H2[0][0], 256 + DS_LDP, 256, BW(c, blk, DS_BW_FF1_W), 512, 16,
+                    [&](int row, int col, float v) { F1[row][col] = ds_silu(v + b1[col]); });
+  }
+  __syncthreads();
+  {
+    const float* b2 = BW(c, blk, DS_BW_FF2_B);
+    float* h = c.ws.h;
+    const float* ada = c.ws.ada;
+    tile_gemm<1, 1>(&F1[0][0], 512 + DS_LDP, 512, BW(c, blk, DS_BW_FF2_W), 256, 8, [&](int row, int col, float v) {
+      const float* ad = ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
+      const float out = H2[row][col] + ad[1280 + col] * (v + b2[col]);   // node_gate_mlp (dmt.py:162)
+      A0[row][col] = out;
+      if (row0 + row < Nn) h[(size_t)(row0 + row) * 256 + col] = out;
+    });
+  }
+  __syncthreads();
+  {
+    const float* br = BW(c, blk, DS_BW_NODE_RO_B);
+    float* ah = c.ws.atom_hids;
+    float* ac = c.ws.ac;
+    tile_gemm<1, 1>(&A0[0][0], 256 + DS_LDP, 256, BW(c, blk, DS_BW_NODE_RO_W), 64, 2, [&](int row, int col, float v) {
+      if (row0 + row < Nn) ah[(size_t)(row0 + row) * 768 + 256 + 64 * blk + col] = v + br[col];
+    });
+    tile_gemm<1, 1>(&A0[0][0], 256 + DS_LDP, 256, BW(c, blk, DS_BW_AC_W), 512, 16, [&](int row, int col, float v) {
+      if (row0 + row < Nn) ac[(size_t)(row0 + row) * 512 + col] = v;
+    });
+  }
+}
+
+// Block stage E (pairs): h_edge = node2edge(h_a + h_b), gated residual, LN, modulate, FF(64->128->64), gated
+// residual, readout slice (64->16), edge+dist part of equi_update.input_lin (128->256).  dmt.py:156-157,165-169,388.
+__global__ __launch_bounds__(256) void k_edge_update(Ctx c, int blk) {
+  constexpr int T = 64;
+  __shared__ __attribute__((aligned(16))) float E2[T][64 + DS_LDP];
+  __shared__ __attribute__((aligned(16))) float F[T][128 + DS_LDP];
+  __shared__ __attribute__((aligned(16))) float EO[T][128 + DS_LDP];
+  __shared__ int rmol[T];
+  const int tid = threadIdx.x, row0 = blockIdx.x * T;
+  const int Pp = c.L.Pp;
+  if (tid < T) rmol[tid] = (row0 + tid < Pp) ? c.L.pair_mol[row0 + tid] : 0;
+  __syncthreads();
+  {
+    const float* bn = BW(c, blk, DS_BW_N2E_B);
+    for (int idx = tid; idx < T * 64; idx += 256) {
+      const int row = idx >> 6, col = idx & 63;
+      const int p = row0 + row;
+      float v = 0.0f, dv = 0.0f;
+      if (p < Pp) {
+        const float* ad = c.ws.ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
+        const float he = (c.ws.u[(size_t)c.L.pair_a[p] * 64 + col] + c.ws.u[(size_t)c.L.pair_b[p] * 64 + col]) + bn[col];
+        v = c.ws.e[(size_t)p * 64 + col] + ad[128 + col] * he;   // edge_gate_msa (dmt.py:165)
+        dv = c.ws.dist[(size_t)p * 64 + col];
+      }
+      E2[row][col] = v;
+      EO[row][64 + col] = dv;
+    }
+  }
+  __syncthreads();
+  for (int row = tid >> 6; row < T; row += 4) {
+    const float* ad = c.ws.ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
+    ln_mod_row<64>(&E2[row][0], ad + 192, ad + 256);   // edge_shift_mlp, edge_scale_mlp (dmt.py:166)
+  }
+  __syncthreads();
+  {
+    const float* b3 = BW(c, blk, DS_BW_FF3_B);
+    tile_gemm<2, 2>(&E2[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_FF3_W), 128, 4,
+                    [&](int row, int col, float v) { F[row][col] = ds_silu(v + b3[col]); });
+  }
+  __syncthreads();
+  {
+    const float* b4 = BW(c, blk, DS_BW_FF4_B);
+    float* e = c.ws.e;
+    const float* ada = c.ws.ada;
+    tile_gemm<2, 1>(&F[0][0], 128 + DS_LDP, 128, BW(c, blk, DS_BW_FF4_W), 64, 2, [&](int row, int col, float v) {
+      const float* ad = ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
+      const float out = E2[row][col] + ad[320 + col] * (v + b4[col]);   // edge_gate_mlp (dmt.py:168)
+      EO[row][col] = out;
+      if (row0 + row < Pp) e[(size_t)(row0 + row) * 64 + col] = out;
+    });
+  }
+  __syncthreads();
+  {
+    const float* br = BW(c, blk, DS_BW_EDGE_RO_B);
+    const float* bd = BW(c, blk, DS_BW_ED_B);
+    float* eh = c.ws.edge_hids;
+    float* ed = c.ws.ed;
+    tile_gemm<2, 1>(&EO[0][0], 128 + DS_LDP, 64, BW(c, blk, DS_BW_EDGE_RO_W), 32, 1, [&](int row, int col, float v) {
+      if (row0 + row < Pp && col < 16) eh[(size_t)(row0 + row) * 192 + 64 + 16 * blk + col] = v + br[col];
+    });
+    tile_gemm<2, 2>(&EO[0][0], 128 + DS_LDP, 128, BW(c, blk, DS_BW_ED_W), 256, 8, [&](int row, int col, float v) {
+      if (row0 + row < Pp) ed[(size_t)(row0 + row) * 256 + col] = v + bd[col];
+    });
+  }
+}
+
+// Block stage F (one workgroup per molecule): MultiCondEquiUpdate over directed edges (row r -> col cc) in tiles
+// of 64, position aggregation on the row atom, per-layer CoM removal.  dmt.py:37-60,385-386; layers.py:344-347.
+__global__ __launch_bounds__(256) void k_equi_update(Ctx c, int blk, int last) {
+  constexpr int T = 64;
+  __shared__ __attribute__((aligned(16))) float X[T][256 + DS_LDP];
+  __shared__ __attribute__((aligned(16))) float Y[T][256 + DS_LDP];
+  __shared__ __attribute__((aligned(16))) float part[4][T][4];
+  __shared__ __attribute__((aligned(16))) float trans[T][4];
+  __shared__ __attribute__((aligned(16))) float P0[32][4];
+  __shared__ __attribute__((aligned(16))) float P1[32][4];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
+  const int p0 = c.L.pair_off[m];
+  if (n <= 0) return;
+  if (tid < n) {
+    const float* pp = c.ws.pos + (size_t)(n0 + tid) * 4;
+    P0[tid][0] = pp[0]; P0[tid][1] = pp[1]; P0[tid][2] = pp[2]; P0[tid][3] = 0.0f;
+  }
+  const int E = n * (n - 1);
+  const float* ad = c.ws.ada + (size_t)m * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EQUI;
+  const float cscale = BW(c, blk, DS_BW_COORD_SCALE)[0];
+  float dpx = 0.0f, dpy = 0.0f, dpz = 0.0f;   // thread r < n owns atom r
+  __syncthreads();
+  for (int e0 = 0; e0 < E; e0 += T) {
+    const int rows = min(T, E - e0);
+    for (int idx = tid; idx < T * 64; idx += 256) {
+      const int row = idx >> 6, k4 = idx & 63;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (row < rows) {
+        const int eidx = e0 + row;
+        const int r = eidx / (n - 1);
+        int cc = eidx - r * (n - 1);
+        cc += (cc >= r);
+        const int a = r < cc ? r : cc, b = r < cc ? cc : r;
+        const int pl = a * (2 * n - a - 1) / 2 + (b - a - 1);
+        const float4 va = reinterpret_cast<const float4*>(c.ws.ac + (size_t)(n0 + r) * 512)[k4];
+        const float4 vc = reinterpret_cast<const float4*>(c.ws.ac + (size_t)(n0 + cc) * 512 + 256)[k4];
+        const float4 ve = reinterpret_cast<const float4*>(c.ws.ed + (size_t)(p0 + pl) * 256)[k4];
+        v.x = (va.x + vc.x) + ve.x; v.y = (va.y + vc.y) + ve.y; v.z = (va.z + vc.z) + ve.z; v.w = (va.w + vc.w) + ve.w;
+      }
+      reinterpret_cast<float4*>(&X[row][0])[k4] = v;
+    }
+    __syncthreads();
+    for (int row = tid >> 6; row < T; row += 4) ln_mod_row<256>(&X[row][0], ad, ad + 256);   // shift, scale (dmt.py:44-45)
+    __syncthreads();
+    {
+      const float* b0 = BW(c, blk, DS_BW_CM0_B);
+      tile_gemm<2, 2>(&X[0][0], 256 + DS_LDP, 256, BW(c, blk, DS_BW_CM0_W), 256, 8,
+                      [&](int row, int col, float v) { Y[row][col] = ds_silu(v + b0[col]); });
+    }
+    __syncthreads();
+    {  // coord_mlp.2 (256 -> 3): K split over the 4 waves, partial sums through LDS
+      const int wave = tid >> 6;
+      f32x16 acc[2];
+      acc_zero<2>(acc);
+      wave_mma<2>(&Y[0][0], 256 + DS_LDP, BW(c, blk, DS_BW_CM2_W), 32, 0, wave * 8, wave * 8 + 8, acc);
+      acc_foreach<2>(acc, 0, 0, [&](int row, int col, float v) { if (col < 3) part[wave][row][col] = v; });
+    }
+    __syncthreads();
+    if (tid < T) {
+      float tx = 0.0f, ty = 0.0f, tz = 0.0f;
+      if (tid < rows) {
+        const int eidx = e0 + tid;
+        const int r = eidx / (n - 1);
+        int cc = eidx - r * (n - 1);
+        cc += (cc >= r);
+        const int a = r < cc ? r : cc, b = r < cc ? cc : r;
+        const int pl = a * (2 * n - a - 1) / 2 + (b - a - 1);
+        const int bits = c.ws.adj[p0 + pl];
+        float inv[3];
+#pragma unroll
+        for (int hI = 0; hI < 3; ++hI)
+          inv[hI] = tanhf(((part[0][tid][hI] + part[1][tid][hI]) + part[2][tid][hI]) + part[3][tid][hI]);
+        const float w = ((inv[0] + ((bits & 1) ? inv[1] : 0.0f)) + ((bits & 2) ? inv[2] : 0.0f)) / 3.0f;   // dmt.py:51-53
+        const float dx = P0[r][0] - P0[cc][0], dy = P0[r][1] - P0[cc][1], dz = P0[r][2] - P0[cc][2];
+        const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);   // layers.py:345-346
+        tx = (dx / nrm * cscale) * w; ty = (dy / nrm * cscale) * w; tz = (dz / nrm * cscale) * w;
+      }
+      trans[tid][0] = tx; trans[tid][1] = ty; trans[tid][2] = tz;
+    }
+    __syncthreads();
+    if (tid < n) {   // scatter-add on the row atom in edge order (dmt.py:57)
+      const int lo = max(e0, tid * (n - 1)), hi = min(e0 + rows, (tid + 1) * (n - 1));
+      for (int eidx = lo; eidx < hi; ++eidx) { dpx += trans[eidx - e0][0]; dpy += trans[eidx - e0][1]; dpz += trans[eidx - e0][2]; }
+    }
+    __syncthreads();
+  }
+  if (tid < n) { P1[tid][0] = P0[tid][0] + dpx; P1[tid][1] = P0[tid][1] + dpy; P1[tid][2] = P0[tid][2] + dpz; }
+  __syncthreads();
+  if (tid < n) {   // remove_mean_with_mask (models/utils.py:38-45)
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    for (int a = 0; a < n; ++a) { sx += P1[a][0]; sy += P1[a][1]; sz += P1[a][2]; }
+    const float fn = (float)n;
+    const float ox = P1[tid][0] - sx / fn, oy = P1[tid][1] - sy / fn, oz = P1[tid][2] - sz / fn;
+    float* pp = c.ws.pos + (size_t)(n0 + tid) * 4;
+    pp[0] = ox; pp[1] = oy; pp[2] = oz;
+    if (last && (isnan(ox) || isnan(oy) || isnan(oz))) atomicOr(&c.ws.flags[1], 1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Readout: node_pred_mlp (768->256->128->6) -> out_xh[..., 3:9] (dmt.py:391-393).
+__global__ __launch_bounds__(256) void k_node_readout(Ctx c, float* __restrict__ out_xh) {
+  constexpr int T = 32;
+  __shared__ __attribute__((aligned(16))) float X[T][768 + DS_LDP];
+  __shared__ __attribute__((aligned(16))) float Y1[T][256 + DS_LDP];
+  __shared__ __attribute__((aligned(16))) float Y2[T][128 + DS_LDP];
+  const int tid = threadIdx.x, row0 = blockIdx.x * T;
+  const int Nn = c.L.Nn;
+  for (int idx = tid; idx < T * 192; idx += 256) {
+    const int row = idx / 192, k4 = idx - row * 192;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (row0 + row < Nn) v = reinterpret_cast<const float4*>(c.ws.atom_hids + (size_t)(row0 + row) * 768)[k4];
+    reinterpret_cast<float4*>(&X[row][0])[k4] = v;
+  }
+  __syncthreads();
+  {
+    const float* b = GW(c, DS_GW_NP0_B);
+    tile_gemm<1, 1>(&X[0][0], 768 + DS_LDP, 768, GW(c, DS_GW_NP0_W), 256, 8,
+                    [&](int row, int col, float v) { Y1[row][col] = ds_silu(v + b[col]); });
+  }
+  __syncthreads();
+  {
+    const float* b = GW(c, DS_GW_NP2_B);
+    tile_gemm<1, 1>(&Y1[0][0], 256 + DS_LDP, 256, GW(c, DS_GW_NP2_W), 128, 4,
+                    [&](int row, int col, float v) { Y2[row][col] = ds_silu(v + b[col]); });
+  }
+  __syncthreads();
+  {
+    const float* b = GW(c, DS_GW_NP4_B);
+    const int* nd = c.L.node_dense;
+    tile_gemm<1, 1>(&Y2[0][0], 128 + DS_LDP, 128, GW(c, DS_GW_NP4_W), 32, 1, [&](int row, int col, float v) {
+      if (row0 + row < Nn && col < 6) out_xh[(size_t)nd[row0 + row] * 9 + 3 + col] = v + b[col];
+    });
+  }
+}
+
+// Readout: edge_exist_mlp / edge_type_mlp (192->64->32->1 each) -> dense symmetric out_edge (dmt.py:394-399).
+__global__ __launch_bounds__(256) void k_edge_readout(Ctx c, float* __restrict__ out_edge) {
+  constexpr int T = 64;
+  __shared__ __attribute__((aligned(16))) float X[T][192 + DS_LDP];
+  __shared__ __attribute__((aligned(16))) float Y1[T][64 + DS_LDP];
+  __shared__ __attribute__((aligned(16))) float Y2[T][32 + DS_LDP];
+  const int tid = threadIdx.x, row0 = blockIdx.x * T;
+  const int Pp = c.L.Pp;
+  for (int idx = tid; idx < T * 48; idx += 256) {
+    const int row = idx / 48, k4 = idx - row * 48;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (row0 + row < Pp) v = reinterpret_cast<const float4*>(c.ws.edge_hids + (size_t)(row0 + row) * 192)[k4];
+    reinterpret_cast<float4*>(&X[row][0])[k4] = v;
+  }
+  __syncthreads();
+  for (int ch = 0; ch < 2; ++ch) {   // channel 0: edge_exist_mlp, channel 1: edge_type_mlp (dmt.py:394)
+    const int g0 = ch == 0 ? DS_GW_EX0_W : DS_GW_ET0_W;
+    {
+      const float* b = GW(c, g0 + 1);
+      tile_gemm<2, 1>(&X[0][0], 192 + DS_LDP, 192, GW(c, g0), 64, 2,
+                      [&](int row, int col, float v) { Y1[row][col] = ds_silu(v + b[col]); });
+    }
+    __syncthreads();
+    {
+      const float* b = GW(c, g0 + 3);
+      tile_gemm<2, 1>(&Y1[0][0], 64 + DS_LDP, 64, GW(c, g0 + 2), 32, 1,
+                      [&](int row, int col, float v) { Y2[row][col] = ds_silu(v + b[col]); });
+    }
+    __syncthreads();
+    {
+      const float* b = GW(c, g0 + 5);
+      const ds_layout L = c.L;
+      tile_gemm<2, 1>(&Y2[0][0], 32 + DS_LDP, 32, GW(c, g0 + 4), 32, 1, [&](int row, int col, float v) {
+        const int p = row0 + row;
+        if (p < Pp && col == 0) {
+          const int da = L.node_dense[L.pair_a[p]], db = L.node_dense[L.pair_b[p]];
+          const int mN = L.pair_mol[p] * L.N;
+          const float val = v + b[0];   // 0.5*(x + x) == x: the symmetrisation of dmt.py:399 is exact here
+          out_edge[((size_t)da * L.N + (db - mN)) * 2 + ch] = val;
+          out_edge[((size_t)db * L.N + (da - mN)) * 2 + ch] = val;
+        }
+      });
+    }
+    __syncthreads();
+  }
+}
+
+// Final positions: mask, NaN guard (whole batch -> zeros), CoM removal (dmt.py:402-412).
+__global__ void k_final_pos(Ctx c, float* __restrict__ out_xh) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= c.L.B) return;
+  const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
+  const bool nan = c.ws.flags[1] != 0;
+  float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+  for (int a = 0; a < n; ++a) {
+    const float* pp = c.ws.pos + (size_t)(n0 + a) * 4;
+    if (!nan) { sx += pp[0]; sy += pp[1]; sz += pp[2]; }
+  }
+  const float fn = (float)n;
+  for (int a = 0; a < n; ++a) {
+    const float* pp = c.ws.pos + (size_t)(n0 + a) * 4;
+    float* o = out_xh + (size_t)c.L.node_dense[n0 + a] * 9;
+    const float px = nan ? 0.0f : pp[0], py = nan ? 0.0f : pp[1], pz = nan ? 0.0f : pp[2];
+    o[0] = px - sx / fn; o[1] = py - sy / fn; o[2] = pz - sz / fn;
+  }
+}
+
+// temb = tm3_out (+ ctx); store SiLU(temb) — the input of every *time_mlp Linear (dmt.py:354; nn.SiLU first in each).
+__global__ void k_temb_finish(Ctx c, const float* __restrict__ tm3, int tm3_rows, const float* __restrict__ ctx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)c.L.B * 1024) return;
+  const size_t b = i >> 10, col = i & 1023;
+  float v = tm3[(tm3_rows == 1 ? 0 : b) * 1024 + col];
+  if (ctx) v += ctx[i];
+  c.ws.temb_silu[i] = ds_silu(v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic GEMM (see header).  64x128 output tile per workgroup, A staged through LDS in K-chunks of 64.
+// Row-group addressing lets A be an unfold view (SpecFormer patches), C a slice of a [B, L, D] token buffer and
+// R a per-position table broadcast over molecules, without any host-side copy.
+struct GemmArgs {
+  const float* A; int64_t lda; int a_grp_rows; int64_t a_grp_stride;
+  const float* Wp; const float* bias;
+  float* C; int64_t ldc; int c_grp_rows; int64_t c_grp_stride;
+  int M, K, N, Npad;
+  const float* R; int64_t ldr; int r_grp_rows;
+  const float* cs; const float* csh;
+  int a_silu;
+};
+
+__device__ __forceinline__ size_t grp_off(int row, int64_t ld, int grp_rows, int64_t grp_stride) {
+  if (grp_rows <= 0) return (size_t)row * ld;
+  const int g = row / grp_rows;
+  return (size_t)g * grp_stride + (size_t)(row - g * grp_rows) * ld;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+  constexpr int T = 64, KC = 64;
+  __shared__ __attribute__((aligned(16))) float X[T][KC + DS_LDP];
+  __shared__ size_t arow[T];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int row0 = blockIdx.x * T;
+  const int col0 = (blockIdx.y * 4 + wave) * 32;
+  const bool active = col0 < g.Npad;
+  if (tid < T) arow[tid] = (row0 + tid < g.M) ? grp_off(row0 + tid, g.lda, g.a_grp_rows, g.a_grp_stride) : 0;
+  f32x16 acc[2];
+  acc_zero<2>(acc);
+  const int Kpad = (g.K + 7) & ~7;
+  for (int k0 = 0; k0 < Kpad; k0 += KC) {
+    __syncthreads();
+    for (int idx = tid; idx < T * KC; idx += 256) {
+      const int row = idx >> 6, k = idx & 63;
+      float v = 0.0f;
+      if (row0 + row < g.M && k0 + k < g.K) {
+        v = g.A[arow[row] + k0 + k];
+        if (g.a_silu) v = ds_silu(v);
+      }
+      X[row][k] = v;
+    }
+    __syncthreads();
+    if (active) {
+      const int kgs = min(KC, Kpad - k0) >> 3;
+      wave_mma<2>(&X[0][0], KC + DS_LDP, g.Wp + (size_t)(k0 >> 3) * 2 * g.Npad * 4, g.Npad, col0, 0, kgs, acc);
+    }
+  }
+  if (!active) return;
+  acc_foreach<2>(acc, 0, col0, [&](int row, int col, float v) {
+    const int gr = row0 + row;
+    if (gr < g.M && col < g.N) {
+      if (g.bias) v += g.bias[col];
+      v = ds_act<ACT>(v);
+      if (g.R) v += g.R[(size_t)(g.r_grp_rows > 0 ? gr % g.r_grp_rows : gr) * g.ldr + col];
+      if (g.cs) v = v * g.cs[col] + g.csh[col];
+      g.C[grp_off(gr, g.ldc, g.c_grp_rows, g.c_grp_stride) + col] = v;
+    }
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ancestral update, one workgroup per molecule (sampling.py:604-624; models/utils.py:38-45,67-106).
+__global__ __launch_bounds__(256) void k_sampler_step(ds_layout L, float c_x, float c_pred, float sigma, float temp,
+                                                      float* __restrict__ x, float* __restrict__ edge_x,
+                                                      const float* __restrict__ pred, const float* __restrict__ edge_pred,
+                                                      const float* __restrict__ raw_pos, const float* __restrict__ raw_feat,
+                                                      const float* __restrict__ raw_edge, float* __restrict__ x_mean,
+                                                      float* __restrict__ edge_mean) {
+  __shared__ __attribute__((aligned(16))) float mean[3];
+  __shared__ int dn[32];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0;
+  if (n <= 0) return;
+  if (tid < n) dn[tid] = L.node_dense[n0 + tid];
+  __syncthreads();
+  if (tid < 3) {
+    float s = 0.0f;
+    for (int a = 0; a < n; ++a) s += raw_pos[(size_t)dn[a] * 3 + tid];
+    mean[tid] = s / (float)n;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n * 9; idx += 256) {
+    const int a = idx / 9, ch = idx - a * 9;
+    const size_t d = (size_t)dn[a];
+    const float nz = ch < 3 ? raw_pos[d * 3 + ch] - mean[ch] : raw_feat[d * 6 + (ch - 3)];
+    const float xm = c_x * x[d * 9 + ch] + c_pred * pred[d * 9 + ch];
+    x_mean[d * 9 + ch] = xm;
+    x[d * 9 + ch] = xm + (sigma * nz) * temp;
+  }
+  const int N = L.N;
+  for (int idx = tid; idx < n * n * 2; idx += 256) {
+    const int ch = idx & 1, ij = idx >> 1;
+    const int a = ij / n, b = ij - a * n;
+    if (a == b) continue;
+    const int la = dn[a] - m * N, lb = dn[b] - m * N;
+    const int hi = la > lb ? la : lb, lo = la > lb ? lb : la;
+    const float nz = raw_edge[(((size_t)m * 2 + ch) * N + hi) * N + lo];   // tril(-1) + transpose
+    const size_t o = ((size_t)dn[a] * N + lb) * 2 + ch;
+    const float em = c_x * edge_x[o] + c_pred * edge_pred[o];
+    edge_mean[o] = em;
+    edge_x[o] = em + (sigma * nz) * temp;
+  }
+}
+
+// post_process (sampling.py:53-97) with the inverse scaler of utils.py:88-103 (norms 1,4,4,1; centered).
+__global__ void k_post_process(ds_layout L, const float* __restrict__ xh, const float* __restrict__ edge_x,
+                               float* __restrict__ pos_out, int32_t* __restrict__ atom_type, int32_t* __restrict__ fc,
+                               float* __restrict__ edge_type) {
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0;
+  const int N = L.N;
+  for (int a = tid; a < n; a += blockDim.x) {
+    const size_t d = (size_t)L.node_dense[n0 + a];
+    const float* r = xh + d * 9;
+    pos_out[d * 3 + 0] = r[0] * 1.0f; pos_out[d * 3 + 1] = r[1] * 1.0f; pos_out[d * 3 + 2] = r[2] * 1.0f;
+    int best = 0;
+    float bv = (r[3] * 4.0f + 1.0f) / 2.0f;
+    for (int t = 1; t < 5; ++t) {
+      const float v = (r[3 + t] * 4.0f + 1.0f) / 2.0f;
+      if (v > bv) { bv = v; best = t; }
+    }
+    atom_type[d] = best;
+    fc[d] = (int32_t)rintf(r[8] * 4.0f);
+  }
+  for (int idx = tid; idx < n * n; idx += blockDim.x) {
+    const int a = idx / n, b = idx - a * n;
+    if (a == b) continue;
+    const int da = L.node_dense[n0 + a], lb = L.node_dense[n0 + b] - m * N;
+    const size_t o = (size_t)da * N + lb;
+    const float ex = (edge_x[o * 2 + 0] * 1.0f + 1.0f) / 2.0f;
+    const float t = ((edge_x[o * 2 + 1] * 1.0f + 1.0f) / 2.0f) * 3.0f;
+    float et = 0.0f;
+    if (t >= 2.5f) et = 3.0f; else if (t >= 1.5f) et = 2.0f; else if (t >= 0.5f) et = 1.0f;
+    edge_type[o] = (ex >= 0.5f ? 1.0f : 0.0f) * et;
+  }
+}
+
+// SpecFormer residual-score attention (specformer.py:401-424): one workgroup per (molecule, head, 64-query tile).
+// qkv [B, L, 3*heads*dk] (q | k | v); scores [B, heads, L, L] holds prev on entry (if has_prev) and the new
+// pre-softmax scores on exit; out [B, L, heads*dk].
+__global__ __launch_bounds__(64) void k_spec_attention(const float* __restrict__ qkv, float* __restrict__ scores,
+                                                       float* __restrict__ out, int B, int L, int heads, float scale,
+                                                       int has_prev) {
+  constexpr int DK = 8;
+  extern __shared__ __attribute__((aligned(16))) float kv[];   // K [L][8] then V [L][8]
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int D = heads * DK;
+  float* Ks = kv;
+  float* Vs = kv + (size_t)L * DK;
+  for (int idx = tid; idx < L * DK; idx += 64) {
+    const int j = idx / DK, d = idx - j * DK;
+    const float* base = qkv + ((size_t)b * L + j) * 3 * D + h * DK + d;
+    Ks[idx] = base[D];
+    Vs[idx] = base[2 * D];
+  }
+  __syncthreads();
+  const int i = q0 + tid;
+  if (i >= L) return;
+  float q[DK];
+  for (int d = 0; d < DK; ++d) q[d] = qkv[((size_t)b * L + i) * 3 * D + h * DK + d];
+  float* srow = scores + (((size_t)b * heads + h) * L + i) * L;
+  float mx = -INFINITY;
+  for (int j = 0; j < L; ++j) {
+    float s = 0.0f;
+#pragma unroll
+    for (int d = 0; d < DK; ++d) s += q[d] * Ks[j * DK + d];
+    s *= scale;
+    if (has_prev) s += srow[j];
+    srow[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  float den = 0.0f, o[DK];
+  for (int d = 0; d < DK; ++d) o[d] = 0.0f;
+  for (int j = 0; j < L; ++j) {
+    const float p = expf(srow[j] - mx);
+    den += p;
+#pragma unroll
+    for (int d = 0; d < DK; ++d) o[d] += p * Vs[j * DK + d];
+  }
+  for (int d = 0; d < DK; ++d) out[((size_t)b * L + i) * D + h * DK + d] = o[d] / den;
+}
+
+__global__ void k_layernorm_affine(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ bt,
+                                   float* __restrict__ y, int rows, int cols, float eps) {
+  const int row = blockIdx.x, lane = threadIdx.x;   // one wave per row
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * cols;
+  float s = 0.0f;
+  for (int k = lane; k < cols; k += 64) s += xr[k];
+  const float mean = wave_sum(s) / (float)cols;
+  float v = 0.0f;
+  for (int k = lane; k < cols; k += 64) { const float d = xr[k] - mean; v += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)cols + eps);
+  for (int k = lane; k < cols; k += 64) y[(size_t)row * cols + k] = (xr[k] - mean) * rstd * g[k] + bt[k];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+bool make_ctx(Ctx& c, const ds_weights* w, const ds_layout* L, const ds_workspace* ws, hipStream_t s) {
+  if (!w || !L || !ws || !w->base) return false;
+  if (L->max_n > DS_MAX_ATOMS || L->B <= 0 || !w->off_dev) return false;
+  (void)s;
+  c.L = *L; c.ws = *ws; c.wbase = w->base;
+  c.woff = w->off_dev;
+  c.edge_th = w->edge_th; c.cutoff = w->spatial_cut_off;
+  return c.woff != nullptr;
+}
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? DS_OK : DS_ERR_LAUNCH; }
+
+int gemm_dispatch(const GemmArgs& g, int act, hipStream_t s) {
+  if (!g.A || !g.Wp || !g.C || g.M <= 0 || g.K <= 0 || g.N <= 0 || (g.cs && !g.csh)) return DS_ERR_ARG;
+  dim3 grid((g.M + 63) / 64, (g.Npad + 127) / 128);
+  switch (act) {
+    case 0: hipLaunchKernelGGL(k_gemm<0>, grid, dim3(256), 0, s, g); break;
+    case 1: hipLaunchKernelGGL(k_gemm<1>, grid, dim3(256), 0, s, g); break;
+    case 2: hipLaunchKernelGGL(k_gemm<2>, grid, dim3(256), 0, s, g); break;
+    case 3: hipLaunchKernelGGL(k_gemm<3>, grid, dim3(256), 0, s, g); break;
+    default: return DS_ERR_ARG;
+  }
+  return launch_status();
+}
+
+int gemm_simple(const float* A, int64_t lda, const float* Wp, const float* bias, float* C, int64_t ldc, int M, int K, int N,
+                int act, int a_silu, hipStream_t s) {
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.Wp = Wp; g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.K = K; g.N = N;
+  g.Npad = (N + 31) & ~31; g.a_silu = a_silu;
+  return gemm_dispatch(g, act, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+void ds_struct_sizes(int64_t* out) {
+  out[0] = sizeof(ds_weights);
+  out[1] = sizeof(ds_layout);
+  out[2] = sizeof(ds_workspace);
+  out[3] = sizeof(ds_gemm_args);
+}
+
+int ds_gemm(const ds_gemm_args* a, void* stream) {
+  if (!a) return DS_ERR_ARG;
+  GemmArgs g{};
+  g.A = a->A; g.lda = a->lda; g.a_grp_rows = a->a_grp_rows; g.a_grp_stride = a->a_grp_stride;
+  g.Wp = a->Wp; g.bias = a->bias;
+  g.C = a->C; g.ldc = a->ldc; g.c_grp_rows = a->c_grp_rows; g.c_grp_stride = a->c_grp_stride;
+  g.M = a->M; g.K = a->K; g.N = a->N; g.Npad = (a->N + 31) & ~31;
+  g.R = a->R; g.ldr = a->ldr; g.r_grp_rows = a->r_grp_rows;
+  g.cs = a->col_scale; g.csh = a->col_shift; g.a_silu = a->a_silu;
+  return gemm_dispatch(g, a->act, (hipStream_t)stream);
+}
+
+int ds_stage_time(const ds_weights* w, const ds_layout* L, ds_workspace* ws, const float* noise_level, const float* ctx_emb,
+                  void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c;
+  if (!make_ctx(c, w, L, ws, s) || !noise_level) return DS_ERR_ARG;
+  const int B = L->B;
+  const int64_t* off = w->off + DS_NBLOCKS * DS_W_BLOCK_SLOTS;
+  hipLaunchKernelGGL(k_time_feat, dim3((B + 63) / 64), dim3(64), 0, s, c, noise_level);
+  // time_mlp: Linear(17,1024) -> GELU -> Linear(1024,1024)  (dmt.py:252-257); tmid reuses ws->tmid, output in ws->ada scratch
+  int st = gemm_simple(ws->tfeat, 24, w->base + off[DS_GW_TM1_W], w->base + off[DS_GW_TM1_B], ws->tmid, 1024, B, 24, 1024, 2, 0, s);
+  if (st) return st;
+  float* tm3 = ws->ada;   // [B,1024] scratch inside the (larger) ada buffer, consumed before ada is produced
+  st = gemm_simple(ws->tmid, 1024, w->base + off[DS_GW_TM3_W], w->base + off[DS_GW_TM3_B], tm3, 1024, B, 1024, 1024, 0, 0, s);
+  if (st) return st;
+  const size_t tot = (size_t)B * 1024;
+  hipLaunchKernelGGL(k_temb_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, c, (const float*)tm3, B, ctx_emb);
+  // every *time_mlp Linear of the model in one GEMM: [B,1024] x [1024, DS_ADA_COLS]
+  st = gemm_simple(ws->temb_silu, 1024, w->base + off[DS_GW_ADA_W], w->base + off[DS_GW_ADA_B], ws->ada, ADAC, B, 1024, ADAC, 0, 0, s);
+  return st ? st : launch_status();
+}
+
+int ds_stage_init(const ds_weights* w, const ds_layout* L, ds_workspace* ws, const float* xh, const float* edge_x,
+                  const float* cond_x, const float* cond_edge_x, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c;
+  if (!make_ctx(c, w, L, ws, s) || !xh || !edge_x || ((cond_x == nullptr) != (cond_edge_x == nullptr))) return DS_ERR_ARG;
+  if (hipMemsetAsync(ws->flags, 0, 8 * sizeof(int32_t), s) != hipSuccess) return DS_ERR_LAUNCH;
+  if (L->Pp > 0) hipLaunchKernelGGL(k_pair_flags, dim3((L->Pp + 255) / 256), dim3(256), 0, s, c, cond_x, cond_edge_x);
+  hipLaunchKernelGGL(k_node_init, dim3(L->Nn), dim3(256), 0, s, c, xh, cond_x);
+  if (L->Pp > 0) hipLaunchKernelGGL(k_pair_init, dim3((L->Pp + 63) / 64), dim3(256), 0, s, c, edge_x, cond_x, cond_edge_x);
+  return launch_status();
+}
+
+int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, int blk, int last, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c;
+  if (!make_ctx(c, w, L, ws, s) || blk < 0 || blk >= DS_NBLOCKS) return DS_ERR_ARG;
+  const int pt = (L->Pp + 63) / 64, nt = (L->Nn + 31) / 32;
+  if (pt > 0) hipLaunchKernelGGL(k_edge_geom, dim3(pt), dim3(256), 0, s, c, blk);
+  hipLaunchKernelGGL(k_node_qkv, dim3(nt), dim3(256), 0, s, c, blk);
+  hipLaunchKernelGGL(k_attention, dim3(L->B), dim3(256), 0, s, c);
+  hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk);
+  if (pt > 0) hipLaunchKernelGGL(k_edge_update, dim3(pt), dim3(256), 0, s, c, blk);
+  hipLaunchKernelGGL(k_equi_update, dim3(L->B), dim3(256), 0, s, c, blk, last);
+  return launch_status();
+}
+
+int ds_stage_readout(const ds_weights* w, const ds_layout* L, ds_workspace* ws, float* out_xh, float* out_edge, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c;
+  if (!make_ctx(c, w, L, ws, s) || !out_xh || !out_edge) return DS_ERR_ARG;
+  const size_t nx = (size_t)L->B * L->N * 9, ne = (size_t)L->B * L->N * L->N * 2;
+  if (hipMemsetAsync(out_xh, 0, nx * sizeof(float), s) != hipSuccess) return DS_ERR_LAUNCH;
+  if (hipMemsetAsync(out_edge, 0, ne * sizeof(float), s) != hipSuccess) return DS_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_node_readout, dim3((L->Nn + 31) / 32), dim3(256), 0, s, c, out_xh);
+  if (L->Pp > 0) hipLaunchKernelGGL(k_edge_readout, dim3((L->Pp + 63) / 64), dim3(256), 0, s, c, out_edge);
+  hipLaunchKernelGGL(k_final_pos, dim3((L->B + 63) / 64), dim3(64), 0, s, c, out_xh);
+  return launch_status();
+}
+
+int ds_forward(const ds_weights* w, const ds_layout* L, ds_workspace* ws, const float* xh, const float* edge_x,
+               const float* cond_x, const float* cond_edge_x, const float* noise_level, const float* ctx_emb, float* out_xh,
+               float* out_edge, void* stream) {
+  int st = ds_stage_time(w, L, ws, noise_level, ctx_emb, stream);
+  if (st) return st;
+  st = ds_stage_init(w, L, ws, xh, edge_x, cond_x, cond_edge_x, stream);
+  if (st) return st;
+  for (int b = 0; b < DS_NBLOCKS; ++b) {
+    st = ds_stage_block(w, L, ws, b, b == DS_NBLOCKS - 1, stream);
+    if (st) return st;
+  }
+  return ds_stage_readout(w, L, ws, out_xh, out_edge, stream);
+}
+
+int ds_sampler_step(const ds_layout* L, float c_x, float c_pred, float sigma, float temperature, float* x, float* edge_x,
+                     const float* pred, const float* edge_pred, const float* raw_pos, const float* raw_feat,
+                     const float* raw_edge, float* x_mean, float* edge_mean, void* stream) {
+  if (!L || !x || !edge_x || !pred || !edge_pred || !raw_pos || !raw_feat || !raw_edge || !x_mean || !edge_mean) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_sampler_step, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, c_x, c_pred, sigma, temperature, x,
+                     edge_x, pred, edge_pred, raw_pos, raw_feat, raw_edge, x_mean, edge_mean);
+  return launch_status();
+}
+
+int ds_post_process(const ds_layout* L, const float* xh, const float* edge_x, float* pos_out, int32_t* atom_type, int32_t* fc,
+                    float* edge_type, void* stream) {
+  if (!L || !xh || !edge_x || !pos_out || !atom_type || !fc || !edge_type) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t nb = (size_t)L->B * L->N;
+  if (hipMemsetAsync(pos_out, 0, nb * 3 * sizeof(float), s) != hipSuccess) return DS_ERR_LAUNCH;
+  if (hipMemsetAsync(atom_type, 0, nb * sizeof(int32_t), s) != hipSuccess) return DS_ERR_LAUNCH;
+  if (hipMemsetAsync(fc, 0, nb * sizeof(int32_t), s) != hipSuccess) return DS_ERR_LAUNCH;
+  if (hipMemsetAsync(edge_type, 0, nb * L->N * sizeof(float), s) != hipSuccess) return DS_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_post_process, dim3(L->B), dim3(128), 0, s, *L, xh, edge_x, pos_out, atom_type, fc, edge_type);
+  return launch_status();
+}
+
+int ds_spec_attention(const float* qkv, float* scores, float* out, int B, int L, int heads, int dk, float scale, int has_prev,
+                      void* stream) {
+  if (!qkv || !scores || !out || dk != 8 || B <= 0 || L <= 0) return DS_ERR_ARG;
+  dim3 grid((L + 63) / 64, heads, B);
+  hipLaunchKernelGGL(k_spec_attention, grid, dim3(64), (size_t)L * 8 * 2 * sizeof(float), (hipStream_t)stream, qkv, scores, out, B,
+                     L, heads, scale, has_prev);
+  return launch_status();
+}
+
+int ds_layernorm_affine(const float* x, const float* gamma, const float* beta, float* y, int rows, int cols, float eps,
+                        void* stream) {
+  if (!x || !gamma || !beta || !y || rows <= 0 || cols <= 0) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_layernorm_affine, dim3(rows), dim3(64), 0, (hipStream_t)stream, x, gamma, beta, y, rows, cols, eps);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,426 @@
+"""ctypes binding to ``libdiffspectra_hip.so`` + the host plumbing around it.
+
+Everything arithmetic happens in the HIP library (``csrc/ds_kernels.hip``); this module packs the
+reference-named parameters into the library's MFMA-operand layout once, builds the packed-ragged index
+tables from ``node_mask``, owns the (torch-allocated) device workspace and issues the C-ABI calls on
+torch's current HIP stream.  There is NO fallback: if the library is missing or no GPU is visible the
+calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libdiffspectra_hip.so")
+HEADER_PATH = os.path.join(_ROOT, "include", "diffspectra_hip.h")
+
+_c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+
+
+def _parse_header():
+    txt = open(HEADER_PATH).read()
+    txt_nc = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+
+    def enum_names(name):
+        body = re.search(r"enum\s+%s\s*\{(.*?)\}" % name, txt_nc, flags=re.S).group(1)
+        return [t.split("=")[0].strip() for t in body.split(",") if t.strip()]
+
+    defs = {}
+    for m in re.finditer(r"#define\s+(DS_\w+)\s+(\(?[-\w\s\*\+\(\)]+?\)?)\s*$", txt_nc, flags=re.M):
+        defs[m.group(1)] = m.group(2)
+    consts: Dict[str, int] = {}
+    for _ in range(4):  # resolve nested defines
+        for k, v in defs.items():
+            if k in consts:
+                continue
+            try:
+                consts[k] = int(eval(v, {"__builtins__": {}}, consts))
+            except Exception:
+                pass
+    blk = enum_names("ds_block_slot")
+    glb = enum_names("ds_global_slot")
+    exports = re.findall(r"^\s*(?:int|void)\s+(ds_\w+)\s*\(", txt_nc, flags=re.M)
+    return consts, blk, glb, exports
+
+
+CONSTS, BLOCK_SLOTS, GLOBAL_SLOTS, EXPORTS = _parse_header()
+NB = CONSTS["DS_NBLOCKS"]
+W_BLOCK_SLOTS = len(BLOCK_SLOTS) - 1      # last enumerator is the count
+W_GLOBAL_SLOTS = len(GLOBAL_SLOTS) - 1
+W_NUM_SLOTS = NB * W_BLOCK_SLOTS + W_GLOBAL_SLOTS
+ADA_COLS = CONSTS["DS_ADA_COLS"]
+ADA_STRIDE = CONSTS["DS_ADA_BLOCK_STRIDE"]
+MAX_ATOMS = CONSTS["DS_MAX_ATOMS"]
+
+
+class DsWeights(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("off_dev", C.c_void_p), ("off", C.c_int64 * W_NUM_SLOTS),
+                ("edge_th", C.c_float), ("spatial_cut_off", C.c_float)]
+
+
+class DsLayout(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("Nn", C.c_int32), ("Pp", C.c_int32),
+                ("max_n", C.c_int32), ("_pad", C.c_int32),
+                ("node_off", C.c_void_p), ("pair_off", C.c_void_p), ("node_dense", C.c_void_p),
+                ("node_mol", C.c_void_p), ("pair_a", C.c_void_p), ("pair_b", C.c_void_p), ("pair_mol", C.c_void_p)]
+
+
+_WS_FIELDS = ["pos", "h", "e", "atom_hids", "edge_hids", "tfeat", "tmid", "temb_silu", "ada", "qkv", "te0", "te1",
+              "dist", "attn", "u", "ac", "ed", "adj", "flags"]
+
+
+class DsWorkspace(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _WS_FIELDS]
+
+
+class DsGemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("a_grp_rows", C.c_int32), ("_p0", C.c_int32),
+                ("a_grp_stride", C.c_int64), ("Wp", C.c_void_p), ("bias", C.c_void_p),
+                ("C", C.c_void_p), ("ldc", C.c_int64), ("c_grp_rows", C.c_int32), ("_p1", C.c_int32),
+                ("c_grp_stride", C.c_int64), ("M", C.c_int32), ("K", C.c_int32), ("N", C.c_int32), ("act", C.c_int32),
+                ("R", C.c_void_p), ("ldr", C.c_int64), ("r_grp_rows", C.c_int32), ("a_silu", C.c_int32),
+                ("col_scale", C.c_void_p), ("col_shift", C.c_void_p)]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load the HIP library; fail loudly if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+                           "diffspectra_amd has no CPU/PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    sizes = (C.c_int64 * 4)()
+    lib.ds_struct_sizes(sizes)
+    mine = [C.sizeof(DsWeights), C.sizeof(DsLayout), C.sizeof(DsWorkspace), C.sizeof(DsGemmArgs)]
+    if list(sizes) != mine:
+        raise RuntimeError(f"C-ABI struct layout mismatch: library {list(sizes)} vs binding {mine}")
+    for name in EXPORTS:
+        fn = getattr(lib, name)          # AttributeError if the header declares something the .so lacks
+        fn.restype = None if name == "ds_struct_sizes" else C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(status: int, what: str):
+    if status != 0:
+        raise RuntimeError(f"{what} failed with status {status} "
+                           f"({ {-1: 'bad argument', -2: 'HIP launch error'}.get(status, 'unknown')})")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+# ----------------------------------------------------------------------------------------- weight packing
+
+def pack_linear(weight: torch.Tensor, n_pad_to: int = 32) -> torch.Tensor:
+    """torch Linear weight [N_out, K_in] → MFMA-B packed [Kp/8][2][Np][4] with k = 8*kg + 4*half + s."""
+    w = weight.detach().to(torch.float32).cpu()
+    N, K = w.shape
+    Kp, Np = (K + 7) // 8 * 8, (N + n_pad_to - 1) // n_pad_to * n_pad_to
+    b = torch.zeros(Kp, Np)
+    b[:K, :N] = w.t()
+    return b.view(Kp // 8, 2, 4, Np).permute(0, 1, 3, 2).contiguous().reshape(-1)
+
+
+def pad_vec(v: torch.Tensor, to: int = 32) -> torch.Tensor:
+    v = v.detach().to(torch.float32).cpu().reshape(-1)
+    out = torch.zeros((v.numel() + to - 1) // to * to)
+    out[:v.numel()] = v
+    return out
+
+
+def _rbf_tables(sd, name):
+    """CondGaussianLayer tables padded 63 → 64 (entry 63 is never read; kept at 1 so it is harmless)."""
+    mean = sd[name + ".means.weight"].float().view(-1)
+    std = sd[name + ".stds.weight"].float().view(-1).abs() + 1e-5          # layers.py:333
+    a = (2 * 3.14159) ** 0.5                                               # layers.py:293-294 (truncated pi)
+    astd = a * std                                                         # fp32 product, as torch evaluates it
+    one = torch.ones(1)
+    return torch.cat([mean, one]), torch.cat([std, one]), torch.cat([astd, one])
+
+
+def pack_dmt_weights(sd: Dict[str, torch.Tensor]):
+    """Reference-named DMT state dict (no ``module.`` prefix) → (flat fp32 tensor, slot offsets)."""
+    sd = {k: v.detach().float().cpu() for k, v in sd.items() if not k.startswith("cond_encoder.")}
+    chunks: List[torch.Tensor] = []
+    offsets = [0] * W_NUM_SLOTS
+    cursor = 0
+
+    def put(slot_index, t):
+        nonlocal cursor
+        pad = (-cursor) % 64                     # 256-byte alignment of every slot
+        if pad:
+            chunks.append(torch.zeros(pad))
+            cursor += pad
+        offsets[slot_index] = cursor
+        chunks.append(t.reshape(-1).float())
+        cursor += t.numel()
+
+    def bslot(b, name):
+        return b * W_BLOCK_SLOTS + BLOCK_SLOTS.index(name)
+
+    def gslot(name):
+        return NB * W_BLOCK_SLOTS + GLOBAL_SLOTS.index(name)
+
+    def cat_pad_rows(ws, pads):
+        rows = []
+        for w, p in zip(ws, pads):
+            rows.append(w)
+            if p > w.shape[0]:
+                rows.append(torch.zeros(p - w.shape[0], w.shape[1]))
+        return torch.cat(rows, 0)
+
+    ada_rows, ada_bias = [], []
+    for b in range(NB):
+        p = f"e_block_{b}."
+        put(bslot(b, "DS_BW_EDGE_EMB_W"), pack_linear(sd[p + "edge_emb.weight"]))
+        put(bslot(b, "DS_BW_EDGE_EMB_B"), pad_vec(sd[p + "edge_emb.bias"]))
+        put(bslot(b, "DS_BW_E0_W"), pack_linear(sd[p + "attn_mpnn.lin_edge0.weight"]))
+        put(bslot(b, "DS_BW_E1_W"), pack_linear(sd[p + "attn_mpnn.lin_edge1.weight"]))
+        wq, wk, wv = (sd[p + f"attn_mpnn.lin_{n}.weight"] for n in ("query", "key", "value"))
+        bq, bk, bv = (sd[p + f"attn_mpnn.lin_{n}.bias"] for n in ("query", "key", "value"))
+        put(bslot(b, "DS_BW_QKV_W"), pack_linear(cat_pad_rows([wq, wk, wv], [256, 256, 256])))
+        put(bslot(b, "DS_BW_QKV_B"), torch.cat([pad_vec(bq, 256), pad_vec(bk, 256), pad_vec(bv, 256)]))
+        put(bslot(b, "DS_BW_N2E_W"), pack_linear(sd[p + "node2edge_lin.weight"]))
+        put(bslot(b, "DS_BW_N2E_B"), pad_vec(sd[p + "node2edge_lin.bias"]))
+        for i, nm in ((1, "FF1"), (2, "FF2"), (3, "FF3"), (4, "FF4")):
+            put(bslot(b, f"DS_BW_{nm}_W"), pack_linear(sd[p + f"ff_linear{i}.weight"]))
+            put(bslot(b, f"DS_BW_{nm}_B"), pad_vec(sd[p + f"ff_linear{i}.bias"]))
+        put(bslot(b, "DS_BW_NODE_RO_W"), pack_linear(sd[f"node_{b}.weight"]))
+        put(bslot(b, "DS_BW_NODE_RO_B"), pad_vec(sd[f"node_{b}.bias"]))
+        put(bslot(b, "DS_BW_EDGE_RO_W"), pack_linear(sd[f"edge_{b}.weight"]))
+        put(bslot(b, "DS_BW_EDGE_RO_B"), pad_vec(sd[f"edge_{b}.bias"]))
+        win = sd[p + "equi_update.input_lin.weight"]                       # [256, 640] = [h_row | h_col | e | dist]
+        put(bslot(b, "DS_BW_AC_W"), pack_linear(torch.cat([win[:, 0:256], win[:, 256:512]], 0)))
+        put(bslot(b, "DS_BW_ED_W"), pack_linear(win[:, 512:640]))
+        put(bslot(b, "DS_BW_ED_B"), pad_vec(sd[p + "equi_update.input_lin.bias"]))
+        put(bslot(b, "DS_BW_CM0_W"), pack_linear(sd[p + "equi_update.coord_mlp.0.weight"]))
+        put(bslot(b, "DS_BW_CM0_B"), pad_vec(sd[p + "equi_update.coord_mlp.0.bias"]))
+        put(bslot(b, "DS_BW_CM2_W"), pack_linear(sd[p + "equi_update.coord_mlp.2.weight"]))
+        mean, std, astd = _rbf_tables(sd, p + "dist_layer")
+        put(bslot(b, "DS_BW_RBF_MEAN"), mean)
+        put(bslot(b, "DS_BW_RBF_STD"), std)
+        put(bslot(b, "DS_BW_RBF_ASTD"), astd)
+        put(bslot(b, "DS_BW_COORD_SCALE"), pad_vec(sd[p + "equi_update.coord_norm.scale"]))
+        ws = [sd[p + "node_time_mlp.1.weight"], sd[p + "edge_time_mlp.1.weight"],
+              sd[p + "equi_update.time_mlp.1.weight"], sd[p + "dist_layer.time_mlp.1.weight"]]
+        bs = [sd[p + "node_time_mlp.1.bias"], sd[p + "edge_time_mlp.1.bias"],
+              sd[p + "equi_update.time_mlp.1.bias"], sd[p + "dist_layer.time_mlp.1.bias"]]
+        ada_rows.append(cat_pad_rows(ws, [1536, 384, 512, 32]))
+        ada_bias.append(torch.cat([pad_vec(x, p_) for x, p_ in zip(bs, [1536, 384, 512, 32])]))
+    ada_rows.append(cat_pad_rows([sd["dist_layer.time_mlp.1.weight"]], [32]))
+    ada_bias.append(pad_vec(sd["dist_layer.time_mlp.1.bias"], 32))
+    ada_w, ada_b = torch.cat(ada_rows, 0), torch.cat(ada_bias)
+    assert ada_w.shape == (ADA_COLS, 1024) and ada_b.numel() == ADA_COLS and ada_rows[0].shape[0] == ADA_STRIDE
+    put(gslot("DS_GW_SIN_W"), pad_vec(sd["time_mlp.0.weights"]))
+    put(gslot("DS_GW_TM1_W"), pack_linear(sd["time_mlp.1.weight"]))
+    put(gslot("DS_GW_TM1_B"), pad_vec(sd["time_mlp.1.bias"]))
+    put(gslot("DS_GW_TM3_W"), pack_linear(sd["time_mlp.3.weight"]))
+    put(gslot("DS_GW_TM3_B"), pad_vec(sd["time_mlp.3.bias"]))
+    put(gslot("DS_GW_ADA_W"), pack_linear(ada_w))
+    put(gslot("DS_GW_ADA_B"), ada_b)
+    put(gslot("DS_GW_NODE_EMB_W"), pack_linear(sd["node_emb.weight"]))
+    put(gslot("DS_GW_NODE_EMB_B"), pad_vec(sd["node_emb.bias"]))
+    put(gslot("DS_GW_EDGE_EMB_W"), pack_linear(sd["edge_emb.weight"]))
+    put(gslot("DS_GW_EDGE_EMB_B"), pad_vec(sd["edge_emb.bias"]))
+    mean, std, astd = _rbf_tables(sd, "dist_layer")
+    put(gslot("DS_GW_RBF_MEAN"), mean)
+    put(gslot("DS_GW_RBF_STD"), std)
+    put(gslot("DS_GW_RBF_ASTD"), astd)
+    for mlp, tag in (("node_pred_mlp", "NP"), ("edge_exist_mlp", "EX"), ("edge_type_mlp", "ET")):
+        for i in (0, 2, 4):
+            put(gslot(f"DS_GW_{tag}{i}_W"), pack_linear(sd[f"{mlp}.{i}.weight"]))
+            put(gslot(f"DS_GW_{tag}{i}_B"), pad_vec(sd[f"{mlp}.{i}.bias"]))
+    return torch.cat(chunks), offsets
+
+
+# ----------------------------------------------------------------------------------------- layout
+
+class Layout:
+    """Packed-ragged index tables for one (node_mask) batch structure."""
+
+    def __init__(self, node_mask: torch.Tensor, device):
+        nm = node_mask.detach().reshape(node_mask.shape[0], node_mask.shape[1]).to("cpu")
+        valid = (nm != 0).numpy()
+        B, N = valid.shape
+        n_atoms = valid.sum(1).astype(np.int64)
+        if n_atoms.max(initial=0) > MAX_ATOMS:
+            raise ValueError(f"molecule with {int(n_atoms.max())} atoms exceeds DS_MAX_ATOMS={MAX_ATOMS}")
+        node_off = np.zeros(B + 1, np.int64)
+        node_off[1:] = np.cumsum(n_atoms)
+        pair_cnt = n_atoms * (n_atoms - 1) // 2
+        pair_off = np.zeros(B + 1, np.int64)
+        pair_off[1:] = np.cumsum(pair_cnt)
+        bb, ii = np.nonzero(valid)                                   # row-major → molecule-major, index-ascending
+        node_dense = (bb * N + ii).astype(np.int32)
+        node_mol = bb.astype(np.int32)
+        pa, pb, pm = [], [], []
+        tri_cache = {}
+        for m in range(B):
+            n = int(n_atoms[m])
+            if n < 2:
+                continue
+            if n not in tri_cache:
+                tri_cache[n] = np.triu_indices(n, 1)                # (a asc, b asc): p = a(2n-a-1)/2 + (b-a-1)
+            a, b = tri_cache[n]
+            pa.append(a + node_off[m]); pb.append(b + node_off[m]); pm.append(np.full(a.shape, m))
+        cat = lambda xs: np.concatenate(xs).astype(np.int32) if xs else np.zeros(0, np.int32)
+        self.B, self.N, self.Nn, self.Pp = B, N, int(node_off[-1]), int(pair_off[-1])
+        self.max_n = int(n_atoms.max(initial=0))
+        self.n_atoms = n_atoms
+        self.valid = valid
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.t = dict(node_off=dev(node_off.astype(np.int32)), pair_off=dev(pair_off.astype(np.int32)),
+                      node_dense=dev(node_dense), node_mol=dev(node_mol), pair_a=dev(cat(pa)), pair_b=dev(cat(pb)),
+                      pair_mol=dev(cat(pm)))
+        self.c = DsLayout(B=B, N=N, Nn=self.Nn, Pp=self.Pp, max_n=self.max_n, _pad=0,
+                          **{k: v.data_ptr() for k, v in self.t.items()})
+
+    def check_edge_mask(self, edge_mask: torch.Tensor):
+        """The path assumes edge_mask = outer(node_mask) minus the diagonal, as every reference caller builds it."""
+        v = torch.from_numpy(self.valid)
+        want = (v.unsqueeze(1) & v.unsqueeze(2)) & ~torch.eye(self.N, dtype=torch.bool).unsqueeze(0)
+        got = edge_mask.detach().reshape(self.B, self.N, self.N).cpu() != 0
+        if not torch.equal(want, got):
+            raise ValueError("edge_mask is not node_mask ⊗ node_mask minus the diagonal; unsupported graph structure")
+
+
+class Workspace:
+    def __init__(self, L: Layout, device):
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+        Nn, Pp, B = max(L.Nn, 1), max(L.Pp, 1), L.B
+        self.t = dict(pos=f(Nn, 4), h=f(Nn, 256), e=f(Pp, 64), atom_hids=f(Nn, 768), edge_hids=f(Pp, 192),
+                      tfeat=f(B, 24), tmid=f(B, 1024), temb_silu=f(B, 1024), ada=f(B, ADA_COLS), qkv=f(Nn, 768),
+                      te0=f(Pp, 256), te1=f(Pp, 256), dist=f(Pp, 64), attn=f(Nn, 256), u=f(Nn, 64), ac=f(Nn, 512),
+                      ed=f(Pp, 256), adj=torch.zeros(Pp, dtype=torch.int32, device=device),
+                      flags=torch.zeros(8, dtype=torch.int32, device=device))
+        self.c = DsWorkspace(**{k: self.t[k].data_ptr() for k in _WS_FIELDS})
+
+
+# ----------------------------------------------------------------------------------------- engine
+
+class DmtEngine:
+    """Owns packed weights on one GPU and runs the C-ABI stages."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], config, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DmtEngine needs a HIP device (torch device type 'cuda'); there is no CPU path")
+        self.lib = load_library()
+        self.cfg = config
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        flat, offsets = pack_dmt_weights(sd)
+        self.wflat = flat.to(self.device)
+        self.woff = torch.tensor(offsets, dtype=torch.int64, device=self.device)
+        self.w = DsWeights(base=self.wflat.data_ptr(), off_dev=self.woff.data_ptr(),
+                           off=(C.c_int64 * W_NUM_SLOTS)(*offsets), edge_th=float(config.model.edge_quan_th),
+                           spatial_cut_off=float(config.model.spatial_cut_off))
+        from .spec_engine import SpecEngine
+        self.spec = SpecEngine(sd, config, self.device, self.lib)
+        self._layouts: Dict[tuple, tuple] = {}
+
+    # layout/workspace cache: keyed on the mask's bytes (cheap: B*N bytes) so equal structures share tables
+    def layout_for(self, node_mask: torch.Tensor, edge_mask: Optional[torch.Tensor] = None, validate: bool = False):
+        key_t = (node_mask.detach().reshape(node_mask.shape[0], -1) != 0).to("cpu")
+        key = (tuple(key_t.shape), key_t.numpy().tobytes())
+        hit = self._layouts.get(key)
+        if hit is None:
+            L = Layout(node_mask, self.device)
+            if len(self._layouts) >= 4:
+                self._layouts.pop(next(iter(self._layouts)))
+            hit = (L, Workspace(L, self.device))
+            self._layouts[key] = hit
+        if validate and edge_mask is not None:
+            hit[0].check_edge_mask(edge_mask)
+        return hit
+
+    def context_embedding(self, context) -> Optional[torch.Tensor]:
+        """cond_lin(SpecFormer(context)) [B,1024] (dmt.py:348-350)."""
+        if context is None:
+            return None
+        return self.spec.encode(context)
+
+    def forward(self, L: Layout, ws: Workspace, xh, edge_x, noise_level, cond_x, cond_edge_x, ctx_emb,
+                out_xh=None, out_edge=None):
+        dev = self.device
+        xh, edge_x, noise_level = _f32c(xh, dev), _f32c(edge_x, dev), _f32c(noise_level, dev)
+        cond_x = None if cond_x is None else _f32c(cond_x, dev)
+        cond_edge_x = None if cond_edge_x is None else _f32c(cond_edge_x, dev)
+        ctx_emb = None if ctx_emb is None else _f32c(ctx_emb, dev)
+        if out_xh is None:
+            out_xh = torch.empty(L.B, L.N, 9, dtype=torch.float32, device=dev)
+        if out_edge is None:
+            out_edge = torch.empty(L.B, L.N, L.N, 2, dtype=torch.float32, device=dev)
+        st = self.lib.ds_forward(C.byref(self.w), C.byref(L.c), C.byref(ws.c), _ptr(xh), _ptr(edge_x), _ptr(cond_x),
+                                 _ptr(cond_edge_x), _ptr(noise_level), _ptr(ctx_emb), _ptr(out_xh), _ptr(out_edge),
+                                 _stream())
+        _check(st, "ds_forward")
+        return out_xh, out_edge
+
+    # stage-level calls for the parity tests
+    def stage_time(self, L, ws, noise_level, ctx_emb):
+        _check(self.lib.ds_stage_time(C.byref(self.w), C.byref(L.c), C.byref(ws.c), _ptr(noise_level), _ptr(ctx_emb),
+                                      _stream()), "ds_stage_time")
+
+    def stage_init(self, L, ws, xh, edge_x, cond_x, cond_edge_x):
+        _check(self.lib.ds_stage_init(C.byref(self.w), C.byref(L.c), C.byref(ws.c), _ptr(xh), _ptr(edge_x),
+                                      _ptr(cond_x), _ptr(cond_edge_x), _stream()), "ds_stage_init")
+
+    def stage_block(self, L, ws, blk, last=False):
+        _check(self.lib.ds_stage_block(C.byref(self.w), C.byref(L.c), C.byref(ws.c), C.c_int(blk), C.c_int(int(last)),
+                                       _stream()), "ds_stage_block")
+
+    def stage_readout(self, L, ws, out_xh, out_edge):
+        _check(self.lib.ds_stage_readout(C.byref(self.w), C.byref(L.c), C.byref(ws.c), _ptr(out_xh), _ptr(out_edge),
+                                         _stream()), "ds_stage_readout")
+
+    def sampler_step(self, L, c_x, c_pred, sigma, temperature, x, edge_x, pred, edge_pred, raw_pos, raw_feat, raw_edge,
+                     x_mean, edge_mean):
+        st = self.lib.ds_sampler_step(C.byref(L.c), C.c_float(c_x), C.c_float(c_pred), C.c_float(sigma),
+                                      C.c_float(temperature), _ptr(x), _ptr(edge_x), _ptr(pred), _ptr(edge_pred),
+                                      _ptr(raw_pos), _ptr(raw_feat), _ptr(raw_edge), _ptr(x_mean), _ptr(edge_mean),
+                                      _stream())
+        _check(st, "ds_sampler_step")
+
+    def post_process(self, L, xh, edge_x):
+        dev = self.device
+        pos = torch.empty(L.B, L.N, 3, dtype=torch.float32, device=dev)
+        atom = torch.empty(L.B, L.N, dtype=torch.int32, device=dev)
+        fc = torch.empty(L.B, L.N, dtype=torch.int32, device=dev)
+        et = torch.empty(L.B, L.N, L.N, dtype=torch.float32, device=dev)
+        st = self.lib.ds_post_process(C.byref(L.c), _ptr(_f32c(xh, dev)), _ptr(_f32c(edge_x, dev)), _ptr(pos), _ptr(atom),
+                                      _ptr(fc), _ptr(et), _stream())
+        _check(st, "ds_post_process")
+        return pos, atom, fc, et
+
+
+def gemm(lib, A, lda, Wp, bias, Cout, ldc, M, K, N, act=0, R=None, ldr=0, r_grp_rows=0, col_scale=None, col_shift=None,
+         a_silu=0, a_grp=(0, 0), c_grp=(0, 0)):
+    """Raw ds_gemm call; A / Wp / C etc. are tensors or integer device addresses."""
+    addr = lambda t: None if t is None else (t if isinstance(t, int) else t.data_ptr())
+    args = DsGemmArgs(A=addr(A), lda=lda, a_grp_rows=a_grp[0], _p0=0, a_grp_stride=a_grp[1], Wp=addr(Wp), bias=addr(bias),
+                      C=addr(Cout), ldc=ldc, c_grp_rows=c_grp[0], _p1=0, c_grp_stride=c_grp[1], M=M, K=K, N=N, act=act,
+                      R=addr(R), ldr=ldr, r_grp_rows=r_grp_rows, a_silu=a_silu, col_scale=addr(col_scale),
+                      col_shift=addr(col_shift))
+    _check(lib.ds_gemm(C.byref(args), _stream()), "ds_gemm")

@@ -1,0 +1,409 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle and the committed golden vectors.
+
+Tolerances (fp32): per-kernel 1e-5 abs (+1e-5 rel), single forward 2e-5, 50-step trajectory 5e-4;
+integer outputs (atom type argmax, charges, bond orders) must be bit-exact.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import dmt as odmt
+from tests.golden import cases
+from tests.helpers import procedural_state_dict, max_abs_diff
+
+pytestmark = pytest.mark.gpu
+
+TOL_KERNEL = 1e-5
+TOL_FORWARD = 2e-5
+TOL_TRAJ = 5e-4
+
+
+def close(a, b, atol, rtol=1e-5):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    err = (a - b).abs()
+    lim = atol + rtol * b.abs()
+    bad = err > lim
+    if bad.any():
+        idx = torch.nonzero(bad)[0].tolist()
+        return False, f"max err {float(err.max()):.3e} (limit {atol:g}); first bad index {idx}: {float(a[tuple(idx)])} vs {float(b[tuple(idx)])}; n_bad {int(bad.sum())}/{bad.numel()}"
+    return True, f"max err {float(err.max()):.3e}"
+
+
+def assert_close(a, b, atol, what="", rtol=1e-5):
+    ok, msg = close(a, b, atol, rtol)
+    assert ok, f"{what}: {msg}"
+
+
+_MODELS = {}
+
+
+def gpu_model(version, device):
+    if version not in _MODELS:
+        from diffspectra_amd import filler
+        from diffspectra_amd.config import qm9s_config
+        from diffspectra_amd.registry import create_model
+        import diffspectra_amd.dmt  # noqa: F401
+        cfg = qm9s_config(version, device=device)
+        model = create_model(cfg)
+        filler.fill_module_(model)
+        model.eval()
+        _MODELS[version] = (cfg, model)
+    return _MODELS[version]
+
+
+def to_dev(a, d):
+    if a is None:
+        return None
+    if isinstance(a, (list, tuple)):
+        return [x.to(d) for x in a]
+    return a.to(d)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+
+@pytest.mark.parametrize("M,K,N,act", [(64, 64, 32, 0), (70, 24, 1024, 2), (5, 1024, 1024, 0), (130, 256, 96, 1),
+                                       (33, 56, 128, 3), (257, 128, 384, 0), (4, 1000, 40, 0)])
+def test_gemm_vs_torch(gpu_device, M, K, N, act):
+    """MFMA fragment layout, packing, K/N padding and guards of ds_gemm (asymmetric random operands)."""
+    from diffspectra_amd import engine as E
+    lib = E.load_library()
+    g = torch.Generator().manual_seed(M * 1000 + K + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    cs, csh = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    ref = torch.nn.functional.linear(A.double(), W.double(), b.double())
+    ref = [lambda x: x, torch.nn.functional.silu, torch.nn.functional.gelu, torch.tanh][act](ref)
+    ref2 = (ref + R.double()) * cs.double() + csh.double()
+    d = gpu_device
+    Wp = E.pack_linear(W).to(d)
+    out = torch.full((M, N), float("nan"), device=d)
+    E.gemm(lib, A.to(d), K, Wp, E.pad_vec(b).to(d), out, N, M, K, N, act=act)
+    assert_close(out, ref, 2e-5, f"gemm {M}x{K}x{N} act{act}", rtol=2e-5)
+    out2 = torch.full((M, N), float("nan"), device=d)
+    E.gemm(lib, A.to(d), K, Wp, E.pad_vec(b).to(d), out2, N, M, K, N, act=act, R=R.to(d), ldr=N,
+           col_scale=cs.to(d), col_shift=csh.to(d))
+    assert_close(out2, ref2, 4e-5, f"gemm+residual+affine {M}x{K}x{N}", rtol=4e-5)
+
+
+def test_gemm_identity_asymmetric(gpu_device):
+    """A = I with an asymmetric B: catches a transposed C/D fragment map (cdna guide §3)."""
+    from diffspectra_amd import engine as E
+    lib = E.load_library()
+    d = gpu_device
+    K = N = 64
+    W = torch.arange(N * K, dtype=torch.float32).reshape(N, K) * 0.01 + torch.arange(N).reshape(N, 1) * 3.0
+    A = torch.eye(64)
+    out = torch.zeros(64, N, device=d)
+    E.gemm(lib, A.to(d), K, E.pack_linear(W).to(d), None, out, N, 64, K, N)
+    assert torch.equal(out.cpu(), W.t().contiguous()), "C/D fragment layout or packing is transposed/permuted"
+
+
+def test_gemm_row_groups(gpu_device):
+    """Unfold-view A, grouped C and broadcast residual (the SpecFormer patch projection)."""
+    from diffspectra_amd import engine as E
+    lib = E.load_library()
+    d = gpu_device
+    B, Lspec, pl, st = 3, 701, 20, 10
+    npatch = (Lspec - pl) // st + 1
+    g = torch.Generator().manual_seed(7)
+    spec = torch.randn(B, Lspec, generator=g)
+    W, b = torch.randn(128, pl, generator=g) / pl ** 0.5, torch.randn(128, generator=g)
+    pos = torch.randn(npatch, 128, generator=g)
+    Ltot = npatch + 5
+    z = torch.zeros(B, Ltot, 128, device=d)
+    E.gemm(lib, spec.to(d), st, E.pack_linear(W).to(d), E.pad_vec(b).to(d), z.data_ptr() + 4 * 5 * 128, 128, B * npatch, pl, 128,
+           R=pos.to(d), ldr=128, r_grp_rows=npatch, a_grp=(npatch, Lspec), c_grp=(npatch, Ltot * 128))
+    ref = torch.nn.functional.linear(spec.unfold(-1, pl, st), W, b) + pos
+    assert_close(z[:, 5:], ref, 1e-5, "grouped gemm")
+    assert float(z[:, :5].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ stages
+
+def _oracle_edge_maps(L, N):
+    """Index of every packed pair (a<b) in the oracle's directed edge list (row-major nonzero order)."""
+    nd = L.t["node_dense"].cpu().long()
+    pa, pb = nd[L.t["pair_a"].cpu().long()], nd[L.t["pair_b"].cpu().long()]
+    valid = torch.from_numpy(L.valid)
+    adj = (valid.unsqueeze(1) & valid.unsqueeze(2)) & ~torch.eye(N, dtype=torch.bool).unsqueeze(0)
+    eid = torch.full(adj.shape, -1, dtype=torch.long)
+    eid[adj] = torch.arange(int(adj.sum()))
+    b = pa // N
+    return eid[b, pa % N, pb % N], eid[b, pb % N, pa % N], nd
+
+
+@pytest.mark.parametrize("first", [True, False])
+def test_stages_vs_oracle(gpu_device, first):
+    """time/adaLN table, init, each of the 8 blocks (h, e, pos) and the readout, localising any mismatch."""
+    cfg, model = gpu_model("ir", gpu_device)
+    cpu_cfg, sd = procedural_state_dict("ir")
+    a = cases.forward_inputs("ir", first, n_atoms=[3, 9, 18, 29, 2, 1, 12])
+    eng = model.module.engine()
+    d = gpu_device
+    L, ws = eng.layout_for(a["node_mask"], a["edge_mask"], validate=True)
+    ctx_cpu = oracle.context_embedding(sd, a["context"], cpu_cfg)
+    ref_out = oracle.dmt_forward(sd, cpu_cfg, a["xh"], a["node_mask"], a["edge_mask"], a["edge_x"], a["noise_level"],
+                                 a["cond_x"], a["cond_edge_x"], context_emb=ctx_cpu, return_debug=True)
+    ref_xh, ref_edge, dbg = ref_out
+    N = L.N
+    fwd, bwd, nd = _oracle_edge_maps(L, N)
+    # --- time embedding + adaLN table
+    xh, edge_x, nl = a["xh"].to(d), a["edge_x"].to(d), a["noise_level"].to(d)
+    cx, ce = to_dev(a["cond_x"], d), to_dev(a["cond_edge_x"], d)
+    ctx = ctx_cpu.to(d)
+    eng.stage_time(L, ws, nl, ctx)
+    temb = odmt.time_embedding(sd, a["noise_level"]) + ctx_cpu
+    silu = torch.nn.functional.silu(temb)
+    assert_close(ws.t["temb_silu"], silu, TOL_KERNEL, "SiLU(time_emb)")
+    from diffspectra_amd import engine as E
+    ada = ws.t["ada"].cpu()
+    for blk in (0, 7):
+        base = blk * E.ADA_STRIDE
+        for name, off, width in (("node_time_mlp", 0, 1536), ("edge_time_mlp", 1536, 384), ("equi_update.time_mlp", 1920, 512),
+                                 ("dist_layer.time_mlp", 2432, 2)):
+            want = odmt._lin(sd, f"e_block_{blk}.{name}.1", silu)
+            assert_close(ada[:, base + off: base + off + width], want, TOL_KERNEL, f"adaLN table block {blk} {name}")
+    assert_close(ada[:, 8 * E.ADA_STRIDE: 8 * E.ADA_STRIDE + 2], odmt._lin(sd, "dist_layer.time_mlp.1", silu), TOL_KERNEL, "adaLN top dist")
+    # --- init
+    eng.stage_init(L, ws, xh, edge_x, cx, ce)
+    torch.cuda.synchronize()
+    for blk in range(8):
+        eng.stage_block(L, ws, blk, last=(blk == 7))
+        torch.cuda.synchronize()
+        h_ref = dbg[f"h_{blk}"][nd]
+        pos_ref = dbg[f"pos_{blk}"][nd]
+        e_ref = dbg[f"e_{blk}"]
+        assert_close(ws.t["h"], h_ref, TOL_KERNEL * 2, f"block {blk} node features")
+        assert_close(ws.t["e"], e_ref[fwd], TOL_KERNEL * 2, f"block {blk} edge features (a->b)")
+        assert_close(ws.t["e"], e_ref[bwd], TOL_KERNEL * 2, f"block {blk} edge features (b->a)")
+        assert_close(ws.t["pos"][:, :3], pos_ref, TOL_KERNEL * 2, f"block {blk} positions")
+    out_xh = torch.empty(L.B, N, 9, device=d)
+    out_edge = torch.empty(L.B, N, N, 2, device=d)
+    eng.stage_readout(L, ws, out_xh, out_edge)
+    assert_close(out_xh, ref_xh, TOL_FORWARD, "forward xh")
+    assert_close(out_edge, ref_edge, TOL_FORWARD, "forward edges")
+    assert float((out_xh.cpu() * (1 - a["node_mask"])).abs().max()) == 0.0
+    assert torch.equal(out_edge, out_edge.transpose(1, 2))
+
+
+# ------------------------------------------------------------------------------------------------ goldens
+
+@pytest.mark.parametrize("version", ["ir", "allspectra"])
+def test_g2_specformer_golden(gpu_device, version):
+    cfg, model = gpu_model(version, gpu_device)
+    g = cases.load_npz("g2_specformer.npz")
+    ctx = model.module.engine().context_embedding(to_dev(cases.spectra_for(version, 4), gpu_device))
+    assert_close(ctx, g[f"{version}_ctx"], TOL_KERNEL * 2, f"SpecFormer+cond_lin {version}")
+
+
+@pytest.mark.parametrize("version", ["ir", "allspectra"])
+@pytest.mark.parametrize("first", [True, False])
+def test_g4_forward_golden(gpu_device, version, first):
+    """model(...) through the reference call convention against the reference's own output."""
+    cfg, model = gpu_model(version, gpu_device)
+    g = cases.load_npz("g4_forward.npz")
+    a = cases.forward_inputs(version, first)
+    d = gpu_device
+    xh, ef = model(torch.zeros(4, device=d), a["xh"].to(d), a["node_mask"].to(d), a["edge_mask"].to(d),
+                   context=to_dev(a["context"], d), edge_x=a["edge_x"].to(d), noise_level=a["noise_level"].to(d),
+                   cond_x=to_dev(a["cond_x"], d), cond_edge_x=to_dev(a["cond_edge_x"], d))
+    tag = f"{version}_{'first' if first else 'general'}"
+    assert_close(xh, g[tag + "_xh"], TOL_FORWARD, tag + " xh")
+    assert_close(ef, g[tag + "_edge"], TOL_FORWARD, tag + " edge")
+
+
+def test_forward_requires_kwargs(gpu_device):
+    cfg, model = gpu_model("ir", gpu_device)
+    a = cases.forward_inputs("ir", True)
+    d = gpu_device
+    with pytest.raises(KeyError):      # reference raises KeyError for a missing edge_x/cond_x (dmt.py:321)
+        model(torch.zeros(4, device=d), a["xh"].to(d), a["node_mask"].to(d), a["edge_mask"].to(d), context=a["context"].to(d),
+              noise_level=a["noise_level"].to(d))
+
+
+@pytest.mark.parametrize("version,steps", [("allspectra", 5), ("ir", 50)])
+def test_g5_trajectory_golden(gpu_device, version, steps):
+    """Injected-noise ancestral trajectories + post-processing; integer outputs bit-exact."""
+    from diffspectra_amd import sampling as S
+    from diffspectra_amd.noise_schedule import NoiseScheduleVP
+    from diffspectra_amd.scalers import get_data_inverse_scaler
+    cfg, model = gpu_model(version, gpu_device)
+    cfg = cfg.clone()
+    cfg.sampling.steps = steps
+    g = cases.load_npz("g5_trajectory.npz")
+    tr = cases.trajectory_inputs(version, steps)
+    d = gpu_device
+    sampler = S._make_sampler(cfg, NoiseScheduleVP("cosine"), 1e-3, 1.0)
+    sampler.noise_fn = lambda i: tr["raws"][i]
+    z = oracle.combined_noise(*tr["raw0"][:2], tr["node_mask"])
+    ez = oracle.symmetric_edge_noise(tr["raw0"][2], tr["edge_mask"])
+    x_mean, e_mean = sampler.sampling(model, z.to(d), tr["node_mask"].to(d), tr["edge_mask"].to(d), ez.to(d),
+                                      to_dev(tr["context"], d))
+    tag = f"{version}_S{steps}"
+    assert_close(x_mean, g[tag + "_x_mean"], TOL_TRAJ, tag + " x_mean")
+    assert_close(e_mean, g[tag + "_edge_mean"], TOL_TRAJ, tag + " edge_mean")
+    eng = model.module.engine()
+    pos, one_hot, fc, et = S.post_process(x_mean, 5, True, tr["node_mask"].to(d), get_data_inverse_scaler(cfg), e_mean,
+                                          tr["edge_mask"].to(d), True, engine=eng)
+    mism = int((one_hot.argmax(-1).cpu() != g[tag + "_atom_type"]).sum())
+    assert mism == 0, f"{mism} atom-type argmax mismatches"
+    assert torch.equal(fc.squeeze(-1).cpu(), g[tag + "_fc"].squeeze(-1).long()), "formal charges differ"
+    assert torch.equal(et.cpu(), g[tag + "_edge_type"]), "bond orders differ"
+    mols = S.mol_process(one_hot, pos, fc, tr["n_atoms"], et)
+    for m, (p, at, e, c) in enumerate(mols):
+        assert_close(p, g[f"{tag}_mol{m}_pos"], TOL_TRAJ, f"mol {m} pos")
+        assert torch.equal(at, g[f"{tag}_mol{m}_atom"]) and torch.equal(e, g[f"{tag}_mol{m}_edge"])
+        assert torch.equal(c, g[f"{tag}_mol{m}_fc"])
+
+
+def test_g6_post_process_golden(gpu_device):
+    from diffspectra_amd import filler
+    cfg, model = gpu_model("ir", gpu_device)
+    g = cases.load_npz("g6_post_process.npz")
+    node_mask, edge_mask = filler.masks_from_n_atoms([2, 5, 7])
+    eng = model.module.engine()
+    L, _ = eng.layout_for(node_mask, edge_mask, validate=True)
+    pos, atom, fc, et = eng.post_process(L, g["xh"].to(gpu_device), g["edge_x"].to(gpu_device))
+    assert torch.equal(pos.cpu(), g["pos"])
+    valid = node_mask.squeeze(-1).bool()
+    assert torch.equal(atom.cpu().long()[valid], g["atom_type"][valid])
+    assert torch.equal(fc.cpu().long(), g["fc"].squeeze(-1).long())
+    assert torch.equal(et.cpu(), g["edge_type"])
+
+
+def test_sampler_step_vs_oracle(gpu_device):
+    from diffspectra_amd import filler
+    cfg, model = gpu_model("ir", gpu_device)
+    eng = model.module.engine()
+    n_atoms = [4, 29, 11, 2]
+    x, ex, node_mask, edge_mask = filler.synthetic_state(n_atoms, "ss.x")
+    p, pe, _, _ = filler.synthetic_state(n_atoms, "ss.p")
+    B, N = 4, 29
+    raw = (filler.normal("ss.rp", (B, N, 3)), filler.normal("ss.rf", (B, N, 6)), filler.normal("ss.re", (B, 2, N, N)))
+    c_x, c_p, sig, temp = 0.8125, 0.31, 0.27, 0.9
+    xm_ref = c_x * x + c_p * p
+    x_ref = xm_ref + sig * oracle.combined_noise(raw[0], raw[1], node_mask) * temp
+    em_ref = c_x * ex + c_p * pe
+    e_ref = em_ref + sig * oracle.symmetric_edge_noise(raw[2], edge_mask) * temp
+    d = gpu_device
+    L, _ = eng.layout_for(node_mask, edge_mask)
+    xd, exd = x.to(d).clone(), ex.to(d).clone()
+    xm, em = torch.zeros(B, N, 9, device=d), torch.zeros(B, N, N, 2, device=d)
+    eng.sampler_step(L, c_x, c_p, sig, temp, xd, exd, p.to(d), pe.to(d), raw[0].to(d), raw[1].to(d), raw[2].to(d), xm, em)
+    for got, want, nm in ((xm, xm_ref, "x_mean"), (xd, x_ref, "x"), (em, em_ref, "edge_mean"), (exd, e_ref, "edge_x")):
+        assert_close(got, want, 2e-6, nm)
+
+
+# ------------------------------------------------------------------------------------------------ properties at full size
+
+def _random_rotation(seed):
+    g = torch.Generator().manual_seed(seed)
+    q, r = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+    q = q * torch.sign(torch.diagonal(r))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q.float()
+
+
+def test_full_size_properties(gpu_device):
+    """BASELINE-size batch (all-spectra, QM9 size histogram): invariants, SE(3) equivariance, batch independence."""
+    from diffspectra_amd import filler
+    cfg, model = gpu_model("allspectra", gpu_device)
+    eng = model.module.engine()
+    d = gpu_device
+    n_atoms = filler.sample_n_atoms(256, seed=0).tolist()
+    n_atoms[0], n_atoms[1] = 29, 3
+    x, ex, node_mask, edge_mask = filler.synthetic_state(n_atoms, "fs.x")
+    cx, cex, _, _ = filler.synthetic_state(n_atoms, "fs.c")
+    B, N = len(n_atoms), 29
+    nl = filler.uniform("fs.nl", (B,), -6, 6)
+    ctx_emb = filler.normal("fs.ctx", (B, 1024)) * 0.5
+    L, ws = eng.layout_for(node_mask, edge_mask, validate=True)
+    out, oute = eng.forward(L, ws, x.to(d), ex.to(d), nl.to(d), cx.to(d), cex.to(d), ctx_emb.to(d))
+    out, oute = out.cpu(), oute.cpu()
+    assert torch.isfinite(out).all() and torch.isfinite(oute).all()
+    assert float((out * (1 - node_mask)).abs().max()) == 0.0
+    assert float((oute * (1 - edge_mask.reshape(B, N, N, 1))).abs().max()) == 0.0
+    assert float(out[:, :, :3].sum(1).abs().max()) < 1e-5, "CoM"
+    assert torch.equal(oute, oute.transpose(1, 2)), "edge symmetry"
+    # SE(3): rotate + translate-free (CoM) inputs -> positions rotate, types/edges invariant
+    Rm = _random_rotation(3)
+    xr, cxr = x.clone(), cx.clone()
+    xr[:, :, :3] = x[:, :, :3] @ Rm.T
+    cxr[:, :, :3] = cx[:, :, :3] @ Rm.T
+    outr, outer = eng.forward(L, ws, xr.to(d), ex.to(d), nl.to(d), cxr.to(d), cex.to(d), ctx_emb.to(d))
+    assert_close(outr.cpu()[:, :, :3], out[:, :, :3] @ Rm.T, 5e-5, "rotation equivariance of positions")
+    assert_close(outr.cpu()[:, :, 3:], out[:, :, 3:], 5e-5, "rotation invariance of type logits")
+    assert_close(outer.cpu(), oute, 5e-5, "rotation invariance of edge logits")
+    # batch independence + agreement with the oracle on a slice
+    sel = [0, 1, 17, 101]
+    cpu_cfg, sd = procedural_state_dict("allspectra")
+    for b in sel:
+        n = n_atoms[b]
+        nm1, em1 = filler.masks_from_n_atoms([n])
+        ref, refe = oracle.dmt_forward(sd, cpu_cfg, x[b:b + 1, :n], nm1, em1, ex[b:b + 1, :n, :n], nl[b:b + 1], cx[b:b + 1, :n],
+                                       cex[b:b + 1, :n, :n], context_emb=ctx_emb[b:b + 1])
+        assert_close(out[b:b + 1, :n], ref, TOL_FORWARD, f"molecule {b} (n={n}) vs single-molecule oracle")
+        assert_close(oute[b:b + 1, :n, :n], refe, TOL_FORWARD, f"molecule {b} edges vs oracle")
+
+
+def test_permutation_equivariance(gpu_device):
+    from diffspectra_amd import filler
+    cfg, model = gpu_model("ir", gpu_device)
+    eng = model.module.engine()
+    d = gpu_device
+    n_atoms = [13, 7]
+    x, ex, node_mask, edge_mask = filler.synthetic_state(n_atoms, "pe.x")
+    cx, cex, _, _ = filler.synthetic_state(n_atoms, "pe.c")
+    nl = filler.uniform("pe.nl", (2,), -3, 3)
+    ctx = filler.normal("pe.ctx", (2, 1024)) * 0.5
+    L, ws = eng.layout_for(node_mask, edge_mask)
+    out, oute = eng.forward(L, ws, x.to(d), ex.to(d), nl.to(d), cx.to(d), cex.to(d), ctx.to(d))
+    perm = torch.randperm(13, generator=torch.Generator().manual_seed(5))
+    def permute(t, e):
+        t2, e2 = t.clone(), e.clone()
+        t2[0, :13] = t[0, perm]
+        e2[0, :13, :13] = e[0, perm][:, perm]
+        return t2, e2
+    xp, exp_ = permute(x, ex)
+    cxp, cexp = permute(cx, cex)
+    outp, outep = eng.forward(L, ws, xp.to(d), exp_.to(d), nl.to(d), cxp.to(d), cexp.to(d), ctx.to(d))
+    want, wante = permute(out.cpu(), oute.cpu())
+    assert_close(outp.cpu(), want, 5e-5, "atom permutation equivariance")
+    assert_close(outep.cpu(), wante, 5e-5, "atom permutation equivariance (edges)")
+
+
+def test_non_prefix_mask_and_errors(gpu_device):
+    """Valid atoms need not be a prefix; bad structures raise instead of computing garbage."""
+    from diffspectra_amd import filler
+    cfg, model = gpu_model("ir", gpu_device)
+    eng = model.module.engine()
+    d = gpu_device
+    cpu_cfg, sd = procedural_state_dict("ir")
+    node_mask = torch.zeros(2, 8, 1)
+    node_mask[0, [0, 2, 3, 6]] = 1
+    node_mask[1, 1:6] = 1
+    em = (node_mask.squeeze(-1).unsqueeze(1) * node_mask.squeeze(-1).unsqueeze(2)) * (~torch.eye(8, dtype=torch.bool)).unsqueeze(0)
+    edge_mask = em.reshape(-1, 1)
+    x = filler.normal("np.x", (2, 8, 9)) * node_mask
+    x[:, :, :3] = x[:, :, :3] - (x[:, :, :3].sum(1, keepdim=True) / node_mask.sum(1, keepdim=True)) * node_mask
+    e = filler.normal("np.e", (2, 8, 8, 2))
+    e = (e + e.transpose(1, 2)) * em.unsqueeze(-1)
+    nl = torch.tensor([0.3, -2.0])
+    ctx = filler.normal("np.ctx", (2, 1024)) * 0.5
+    L, ws = eng.layout_for(node_mask, edge_mask, validate=True)
+    out, oute = eng.forward(L, ws, x.to(d), e.to(d), nl.to(d), None, None, ctx.to(d))
+    ref, refe = oracle.dmt_forward(sd, cpu_cfg, x, node_mask, edge_mask, e, nl, None, None, context_emb=ctx)
+    assert_close(out, ref, TOL_FORWARD, "non-prefix mask xh")
+    assert_close(oute, refe, TOL_FORWARD, "non-prefix mask edges")
+    bad = edge_mask.clone()
+    bad[1] = 1 - bad[1]
+    with pytest.raises(ValueError):
+        eng.layout_for(node_mask, bad, validate=True)
+    with pytest.raises(ValueError):
+        eng.layout_for(torch.ones(1, 40, 1))          # more atoms than DS_MAX_ATOMS

@@ -1,0 +1,206 @@
+"""Headline benchmark: molecules/sec for 1000-step QM9S all-spectra conditional sampling (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+N>1 is launched by the driver through torch.distributed.run, one rank per GPU.  A *step* is one complete
+sampling pass over one micro-batch of ``--mols`` molecules per GPU: SpecFormer conditioning (once per molecule) +
+initial noise + ``--denoise-steps`` (1000) DMT evaluations with the fused ancestral update + post-processing.
+Molecules are independent, so ranks own disjoint molecules (weak scaling) and the only collective is the final
+all_gather of the fixed-size result records over RCCL.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  "roofline":     live HIP-event timing of the dominant kernel (k_equi_update) vs the fp32-MFMA peak,
+  "cpu_baseline": the CPU oracle (faithful restatement of the reference path) timed on this host on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (155 measured)
+EQUI_MACS_PER_DIRECTED_EDGE = 256 * 256 + 256 * 3   # coord_mlp.0 + coord_mlp.2 (SURVEY §8d constants)
+
+
+def algorithmic_macs(n_atoms) -> int:
+    """de-duplicated GEMM MACs of one DMT evaluation over a batch."""
+    n = np.asarray(n_atoms, dtype=np.int64)
+    N, E, B = int(n.sum()), int((n * (n - 1)).sum()), len(n)
+    return 8 * (620544 * N + 157184 * E + 2492416 * B) + (233216 * N + 33088 * E + 1330176 * B)
+
+
+def cpu_baseline(version: str, denoise_steps: int, sample_mols: int = 8, sample_steps: int = 2):
+    """Time the CPU oracle (reference algorithm, SpecFormer re-encoded every step as the reference does) on the host."""
+    import oracle
+    from diffspectra_amd import filler
+    from diffspectra_amd.config import qm9s_config
+    from diffspectra_amd.params import build_dmt_tree, Holder
+    cfg = qm9s_config(version)
+    tree = Holder()
+    build_dmt_tree(tree, cfg)
+    sd = filler.fill_state_dict(tree.state_dict())
+    n_atoms = filler.sample_n_atoms(sample_mols, seed=0).tolist()
+    x, ex, node_mask, edge_mask = filler.synthetic_state(n_atoms, "cpu.x")
+    ctx = filler.synthetic_spectra(sample_mols, version, seed=1)
+    nl = torch.zeros(sample_mols)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)                   # every core this process may run on
+    cond = (None, None)
+    times = []
+    for i in range(sample_steps + 1):              # first iteration = warm-up (and first-step branch)
+        t0 = time.perf_counter()
+        out = oracle.dmt_forward(sd, cfg, x, node_mask, edge_mask, ex, nl, cond[0], cond[1], context=ctx)
+        times.append(time.perf_counter() - t0)
+        cond = out
+    per_step = float(np.mean(times[1:]))
+    return {"value": sample_mols / (per_step * denoise_steps), "unit": "molecules/sec", "cores": int(cores), "kind": "port",
+            "sample": f"{sample_mols} molecules (QM9 size histogram, seed 0), {sample_steps} timed denoise steps of the "
+                      f"faithful CPU oracle ({per_step:.3f} s/step), extrapolated to {denoise_steps} steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mols", type=int, default=2048, help="molecules per GPU per step (one sampling micro-batch)")
+    ap.add_argument("--denoise-steps", type=int, default=1000)
+    ap.add_argument("--spectra", default="allspectra")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-kernel", type=int, default=5, help="block-stage kernel timed with HIP events (5 = equi_update)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    from diffspectra_amd import filler, sampling as S, engine as E
+    from diffspectra_amd.config import qm9s_config
+    from diffspectra_amd.noise_schedule import NoiseScheduleVP
+    from diffspectra_amd.registry import create_model
+    from diffspectra_amd.scalers import get_data_inverse_scaler
+    import diffspectra_amd.dmt  # noqa: F401
+
+    cfg = qm9s_config(args.spectra, device=device, steps=args.denoise_steps)
+    model = create_model(cfg)
+    filler.fill_module_(model)
+    model.eval()
+    eng = model.module.engine()
+    lib = eng.lib
+
+    # workload: this rank's shard of the synthetic evaluation set (QM9S second-half size histogram)
+    M = args.mols
+    all_atoms = filler.sample_n_atoms(world * M, seed=0)
+    n_atoms = all_atoms[rank * M:(rank + 1) * M].tolist()
+    context = filler.synthetic_spectra(world * M, args.spectra, seed=1)
+    context = [c[rank * M:(rank + 1) * M].to(device) for c in context] if isinstance(context, list) else context[rank * M:(rank + 1) * M].to(device)
+    node_mask, edge_mask = S.build_masks(n_atoms, M, device)
+    max_n = node_mask.shape[1]
+    sampler = S._make_sampler(cfg, NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0,
+                                                   continuous_beta_1=cfg.sde.continuous_beta_1), 1e-3,
+                              cfg.eval.sampling_temperature)
+    inv = get_data_inverse_scaler(cfg)
+    torch.manual_seed(42 + rank)
+
+    def one_step():
+        z, edge_z = S.initial_noise(M, max_n, 6, 2, node_mask, edge_mask)
+        x_node, x_edge = sampler.sampling(model, z, node_mask, edge_mask, edge_z, context)
+        pos, one_hot, fc, edge_types = S.post_process(x_node, 5, True, node_mask, inv, x_edge, edge_mask, True, engine=eng)
+        rec = torch.cat([pos.reshape(M, -1), one_hot.argmax(-1).float(), fc.reshape(M, -1).float(),
+                         edge_types.reshape(M, -1)], dim=1)            # fixed-size record per molecule
+        if world > 1:
+            out = torch.empty(world * M, rec.shape[1], device=device)
+            dist.all_gather_into_tensor(out, rec.contiguous())         # the only collective: final gather over xGMI
+            rec = out
+        return rec
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    every = max(1, (args.steps * args.denoise_steps * 8) // 2000)
+    E._check(lib.ds_profile_config(C.c_int(args.profile_kernel), C.c_int(every), C.c_int(4096)), "ds_profile_config")
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec = one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    tot_ms, samples = C.c_double(0.0), C.c_int64(0)
+    E._check(lib.ds_profile_read(C.byref(tot_ms), C.byref(samples)), "ds_profile_read")
+    lib.ds_profile_config(C.c_int(-1), C.c_int(1), C.c_int(0))
+    assert torch.isfinite(rec).all()
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = world * M * args.steps / elapsed
+        n = np.asarray(n_atoms, dtype=np.int64)
+        E_dir = int((n * (n - 1)).sum())
+        kern_ms = tot_ms.value / max(1, samples.value)
+        kernel_names = ["k_edge_geom", "k_node_qkv", "k_attention", "k_node_update", "k_edge_update", "k_equi_update"]
+        roofline = None
+        if samples.value > 0 and args.profile_kernel == 5:
+            flop = 2.0 * EQUI_MACS_PER_DIRECTED_EDGE * E_dir
+            ach = flop / (kern_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "k_equi_update", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                        "avg_launch_ms": kern_ms, "launches_timed": int(samples.value),
+                        "algorithmic_flop_per_launch": flop}
+        elif samples.value > 0:
+            roofline = {"bound": "mfma", "kernel": kernel_names[args.profile_kernel], "avg_launch_ms": kern_ms,
+                        "launches_timed": int(samples.value), "achieved": None, "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": None, "traffic": None}
+        fwd_flop = 2.0 * algorithmic_macs(n_atoms)
+        whole = fwd_flop * args.denoise_steps * args.steps / elapsed / 1e12
+        line = {
+            "metric": "molecules/sec, 1000-step QM9S all-spectra sampling", "value": value, "unit": "molecules/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"QM9S {args.spectra}, DMT + SpecFormer (no pretrain, random-init procedural weights), "
+                                   f"{args.denoise_steps} denoise steps, {M} molecules per GPU per step "
+                                   f"(n_atoms ~ qm9_second_half histogram, mean {float(n.mean()):.2f})",
+                       "molecules_per_gpu_per_step": M, "denoise_steps": args.denoise_steps, "parallelism": f"dp{world} (molecule shards)"},
+            "roofline": roofline,
+            "whole_path": {"algorithmic_tflops_per_gpu": whole, "frac_of_fp32_mfma_peak": whole / PEAK_FP32_MFMA_TFLOPS,
+                           "algorithmic_gflop_per_molecule_step": fwd_flop / M / 1e9},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.spectra, args.denoise_steps)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

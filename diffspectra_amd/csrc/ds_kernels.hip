@@ -6,6 +6,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <utility>
+#include <vector>
+
 #include "../../include/diffspectra_hip.h"
 #include "ds_device.h"
 
@@ -905,6 +908,30 @@ int gemm_simple(const float* A, int64_t lda, const float* Wp, const float* bias,
   return gemm_dispatch(g, act, s);
 }
 
+// ---- optional HIP-event timing of one block-stage kernel (bench.py's live roofline measurement) ----
+struct ProfState {
+  int kernel = -1;          // 0 edge_geom, 1 node_qkv, 2 attention, 3 node_update, 4 edge_update, 5 equi_update
+  int every = 1;
+  long long seen = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  size_t used = 0;
+};
+ProfState g_prof;
+
+struct ProfScope {   // records start/stop events around one launch when sampling says so
+  hipStream_t s;
+  bool on = false;
+  ProfScope(int kernel, hipStream_t st) : s(st) {
+    if (g_prof.kernel != kernel) return;
+    if ((g_prof.seen++ % g_prof.every) != 0 || g_prof.used >= g_prof.pool.size()) return;
+    on = true;
+    (void)hipEventRecord(g_prof.pool[g_prof.used].first, s);
+  }
+  ~ProfScope() {
+    if (on) (void)hipEventRecord(g_prof.pool[g_prof.used++].second, s);
+  }
+};
+
 }  // namespace
 
 extern "C" {
@@ -966,12 +993,12 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   Ctx c;
   if (!make_ctx(c, w, L, ws, s) || blk < 0 || blk >= DS_NBLOCKS) return DS_ERR_ARG;
   const int pt = (L->Pp + 63) / 64, nt = (L->Nn + 31) / 32;
-  if (pt > 0) hipLaunchKernelGGL(k_edge_geom, dim3(pt), dim3(256), 0, s, c, blk);
-  hipLaunchKernelGGL(k_node_qkv, dim3(nt), dim3(256), 0, s, c, blk);
-  hipLaunchKernelGGL(k_attention, dim3(L->B), dim3(256), 0, s, c);
-  hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk);
-  if (pt > 0) hipLaunchKernelGGL(k_edge_update, dim3(pt), dim3(256), 0, s, c, blk);
-  hipLaunchKernelGGL(k_equi_update, dim3(L->B), dim3(256), 0, s, c, blk, last);
+  if (pt > 0) { ProfScope ps(0, s); hipLaunchKernelGGL(k_edge_geom, dim3(pt), dim3(256), 0, s, c, blk); }
+  { ProfScope ps(1, s); hipLaunchKernelGGL(k_node_qkv, dim3(nt), dim3(256), 0, s, c, blk); }
+  { ProfScope ps(2, s); hipLaunchKernelGGL(k_attention, dim3(L->B), dim3(256), 0, s, c); }
+  { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }
+  if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3(pt), dim3(256), 0, s, c, blk); }
+  { ProfScope ps(5, s); hipLaunchKernelGGL(k_equi_update, dim3(L->B), dim3(256), 0, s, c, blk, last); }
   return launch_status();
 }
 
@@ -1031,6 +1058,33 @@ int ds_spec_attention(const float* qkv, float* scores, float* out, int B, int L,
   hipLaunchKernelGGL(k_spec_attention, grid, dim3(64), (size_t)L * 8 * 2 * sizeof(float), (hipStream_t)stream, qkv, scores, out, B,
                      L, heads, scale, has_prev);
   return launch_status();
+}
+
+int ds_profile_config(int kernel, int every, int max_samples) {
+  for (auto& e : g_prof.pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  g_prof.pool.clear();
+  g_prof.used = 0; g_prof.seen = 0;
+  g_prof.kernel = kernel; g_prof.every = every > 0 ? every : 1;
+  if (kernel < 0) return DS_OK;
+  if (kernel > 5 || max_samples <= 0) return DS_ERR_ARG;
+  g_prof.pool.resize((size_t)max_samples);
+  for (auto& e : g_prof.pool)
+    if (hipEventCreate(&e.first) != hipSuccess || hipEventCreate(&e.second) != hipSuccess) return DS_ERR_LAUNCH;
+  return DS_OK;
+}
+
+int ds_profile_read(double* total_ms, int64_t* samples) {
+  if (!total_ms || !samples) return DS_ERR_ARG;
+  double tot = 0.0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(g_prof.pool[i].second) != hipSuccess) return DS_ERR_LAUNCH;
+    if (hipEventElapsedTime(&ms, g_prof.pool[i].first, g_prof.pool[i].second) != hipSuccess) return DS_ERR_LAUNCH;
+    tot += ms;
+  }
+  *total_ms = tot; *samples = (int64_t)g_prof.used;
+  g_prof.used = 0; g_prof.seen = 0;
+  return DS_OK;
 }
 
 int ds_layernorm_affine(const float* x, const float* gamma, const float* beta, float* y, int rows, int cols, float eps,

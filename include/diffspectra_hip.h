@@ -186,6 +186,13 @@ int ds_spec_attention(const float* qkv, float* scores, float* out, int B, int L,
 int ds_layernorm_affine(const float* x, const float* gamma, const float* beta, float* y, int rows, int cols,
                         float eps, void* stream);
 
+/* Measurement hook (bench.py roofline leg): time every `every`-th launch of one block-stage kernel with HIP events
+ * recorded on the launch stream.  kernel: 0 edge_geom, 1 node_qkv, 2 attention, 3 node_update, 4 edge_update,
+ * 5 equi_update; kernel < 0 disables.  ds_profile_read synchronises the recorded events, returns the summed
+ * duration and the sample count, and resets the counters.  Process-global instrumentation state; off by default. */
+int ds_profile_config(int kernel, int every, int max_samples);
+int ds_profile_read(double* total_ms, int64_t* samples);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,52 @@
+"""Time ds_forward + ds_sampler_step on synthetic QM9-sized batches (development tool; bench.py is the contract)."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffspectra_amd import filler  # noqa: E402
+from diffspectra_amd.config import qm9s_config  # noqa: E402
+from diffspectra_amd.registry import create_model  # noqa: E402
+import diffspectra_amd.dmt  # noqa: F401,E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mols", type=int, default=1024)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--version", default="allspectra")
+    args = ap.parse_args()
+    d = torch.device("cuda:0")
+    cfg = qm9s_config(args.version, device=d)
+    model = create_model(cfg)
+    filler.fill_module_(model)
+    eng = model.module.engine()
+    n_atoms = filler.sample_n_atoms(args.mols, seed=0).tolist()
+    x, ex, node_mask, edge_mask = filler.synthetic_state(n_atoms, "tf.x")
+    cx, cex, _, _ = filler.synthetic_state(n_atoms, "tf.c")
+    B = len(n_atoms)
+    nl = torch.full((B,), 0.5)
+    ctx = filler.normal("tf.ctx", (B, 1024)) * 0.5
+    L, ws = eng.layout_for(node_mask, edge_mask)
+    x, ex, cx, cex, nl, ctx = (t.to(d) for t in (x, ex, cx, cex, nl, ctx))
+    out = torch.empty(B, L.N, 9, device=d)
+    oute = torch.empty(B, L.N, L.N, 2, device=d)
+    for _ in range(2):
+        eng.forward(L, ws, x, ex, nl, cx, cex, ctx, out, oute)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        eng.forward(L, ws, x, ex, nl, cx, cex, ctx, out, oute)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.iters
+    E = sum(n * (n - 1) for n in n_atoms)
+    macs = 8 * (620544 * sum(n_atoms) + 157184 * E + 2492416 * B) + (233216 * sum(n_atoms) + 33088 * E + 1330176 * B)
+    print(f"mols {B} Nn {L.Nn} Pp {L.Pp}: {dt * 1e3:.3f} ms/forward, {dt / B * 1e6:.2f} us/mol-step, "
+          f"{2 * macs / dt / 1e12:.2f} TFLOP/s algorithmic, {B / dt / 1000:.1f} mol/s @1000 steps")
+
+
+if __name__ == "__main__":
+    main()

@@ -32,6 +32,32 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 EQUI_MACS_PER_DIRECTED_EDGE = 256 * 256 + 256 * 3   # coord_mlp.0 + coord_mlp.2 (SURVEY §8d constants)
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg: str) -> None:
+    """Progress on stderr (stdout carries only the JSON line)."""
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores() -> int:
+    """CPU cores this process can actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def algorithmic_macs(n_atoms) -> int:
     """de-duplicated GEMM MACs of one DMT evaluation over a batch."""
     n = np.asarray(n_atoms, dtype=np.int64)
@@ -39,7 +65,7 @@ def algorithmic_macs(n_atoms) -> int:
     return 8 * (620544 * N + 157184 * E + 2492416 * B) + (233216 * N + 33088 * E + 1330176 * B)
 
 
-def cpu_baseline(version: str, denoise_steps: int, sample_mols: int = 8, sample_steps: int = 2):
+def cpu_baseline(version: str, denoise_steps: int, sample_mols: int = 64, sample_steps: int = 8):
     """Time the CPU oracle (reference algorithm, SpecFormer re-encoded every step as the reference does) on the host."""
     import oracle
     from diffspectra_amd import filler
@@ -53,8 +79,8 @@ def cpu_baseline(version: str, denoise_steps: int, sample_mols: int = 8, sample_
     x, ex, node_mask, edge_mask = filler.synthetic_state(n_atoms, "cpu.x")
     ctx = filler.synthetic_spectra(sample_mols, version, seed=1)
     nl = torch.zeros(sample_mols)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    torch.set_num_threads(cores)                   # every core this process may run on
+    cores = usable_cores()
+    torch.set_num_threads(cores)                   # every core this process may run on (cgroup quota respected)
     cond = (None, None)
     times = []
     for i in range(sample_steps + 1):              # first iteration = warm-up (and first-step branch)
@@ -105,12 +131,16 @@ def main():
     from diffspectra_amd.scalers import get_data_inverse_scaler
     import diffspectra_amd.dmt  # noqa: F401
 
+    if rank == 0:
+        log("library built; creating model")
     cfg = qm9s_config(args.spectra, device=device, steps=args.denoise_steps)
     model = create_model(cfg)
     filler.fill_module_(model)
     model.eval()
     eng = model.module.engine()
     lib = eng.lib
+    if rank == 0:
+        log("weights packed on device")
 
     # workload: this rank's shard of the synthetic evaluation set (QM9S second-half size histogram)
     M = args.mols
@@ -125,6 +155,11 @@ def main():
                               cfg.eval.sampling_temperature)
     inv = get_data_inverse_scaler(cfg)
     torch.manual_seed(42 + rank)
+    if rank == 0:
+        def progress(i, n):
+            torch.cuda.synchronize()
+            log(f"  denoise step {i}/{n}")
+        sampler.progress_fn = progress if os.environ.get("BENCH_QUIET", "0") != "1" else None
 
     def one_step():
         z, edge_z = S.initial_noise(M, max_n, 6, 2, node_mask, edge_mask)
@@ -143,14 +178,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for w in range(args.warmup):
         one_step()
+        if rank == 0:
+            log(f"warmup step {w + 1}/{args.warmup} done")
+    sampler.progress_fn = None                       # no host syncs inside the timed region
     every = max(1, (args.steps * args.denoise_steps * 8) // 2000)
     E._check(lib.ds_profile_config(C.c_int(args.profile_kernel), C.c_int(every), C.c_int(4096)), "ds_profile_config")
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
         rec = one_step()
+        if rank == 0:
+            log(f"timed step {k + 1}/{args.steps} enqueued")
     sync()
     elapsed = time.perf_counter() - t0
     tot_ms, samples = C.c_double(0.0), C.c_int64(0)
@@ -194,6 +234,7 @@ def main():
             "whole_path": {"algorithmic_tflops_per_gpu": whole, "frac_of_fp32_mfma_peak": whole / PEAK_FP32_MFMA_TFLOPS,
                            "algorithmic_gflop_per_molecule_step": fwd_flop / M / 1e9},
         }
+        log(f"GPU timing done: {value:.2f} molecules/sec; timing CPU baseline")
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.spectra, args.denoise_steps)
         print(json.dumps(line), flush=True)

@@ -45,6 +45,7 @@ class AncestralSampler:
         self.cond_process_fn = cond_process_fn
         self.sampling_temperature = sampling_temperature
         self.noise_fn: Optional[Callable] = None     # noise_fn(i) -> (raw_pos, raw_feat, raw_edge): injected randn draws
+        self.progress_fn: Optional[Callable] = None  # progress_fn(i, n_steps), called every 100 steps (long runs)
         self._table = None
 
     def coefficient_table(self):
@@ -97,6 +98,8 @@ class AncestralSampler:
                        torch.randn((B, 2, N, N), device=dev)]
             eng.sampler_step(L, c_x, c_pred, sigma, temp, x, edge_x, pred[cur], edge_pred[cur], raw[0], raw[1], raw[2],
                              x_mean, edge_mean)
+            if self.progress_fn is not None and (i + 1) % 100 == 0:
+                self.progress_fn(i + 1, len(coef))
         return x_mean, edge_mean
 
 

@@ -124,7 +124,7 @@ def main():
         entry.build()
     if world > 1:
         dist.barrier()
-    from diffspectra_amd import filler, sampling as S, engine as E
+    from diffspectra_amd import filler, sampling as S, engine as E, shard
     from diffspectra_amd.config import qm9s_config
     from diffspectra_amd.noise_schedule import NoiseScheduleVP
     from diffspectra_amd.registry import create_model
@@ -165,13 +165,8 @@ def main():
         z, edge_z = S.initial_noise(M, max_n, 6, 2, node_mask, edge_mask)
         x_node, x_edge = sampler.sampling(model, z, node_mask, edge_mask, edge_z, context)
         pos, one_hot, fc, edge_types = S.post_process(x_node, 5, True, node_mask, inv, x_edge, edge_mask, True, engine=eng)
-        rec = torch.cat([pos.reshape(M, -1), one_hot.argmax(-1).float(), fc.reshape(M, -1).float(),
-                         edge_types.reshape(M, -1)], dim=1)            # fixed-size record per molecule
-        if world > 1:
-            out = torch.empty(world * M, rec.shape[1], device=device)
-            dist.all_gather_into_tensor(out, rec.contiguous())         # the only collective: final gather over xGMI
-            rec = out
-        return rec
+        rec = shard.pack_records(pos, one_hot.argmax(-1), fc, edge_types)     # fixed-size record per molecule
+        return shard.gather_records(rec)                                # the only collective: final gather over xGMI
 
     def sync():
         if world > 1:

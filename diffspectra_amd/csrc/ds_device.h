@@ -35,23 +35,49 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
 // acc[m] += X[m*32 .. m*32+31][8*kg0 .. 8*kg1) * Wp[.., col0 .. col0+31]
-template <int MT>
+// Software-pipelined: the B fragments (L2/MALL latency, 300-900 cycles) of the NEXT group of 4 k-groups are
+// requested before the current group's MFMAs issue, so one wave per SIMD already covers the load latency.
+// TRANS = true swaps the MFMA operands: the accumulator then holds the TRANSPOSED block — lane l owns row
+// (l & 31) of the X tile and register reg is output column col0 + acc_row(reg, l >> 5) — which is exactly the B-operand
+// layout a following MFMA needs to contract over those columns without touching LDS (k_equi_flat).
+template <int MT, bool TRANS = false>
 __device__ __forceinline__ void wave_mma(const float* X, int ldx, const float* __restrict__ Wp, int Npad, int col0,
                                          int kg0, int kg1, f32x16 (&acc)[MT]) {
+  constexpr int G = 4;
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const float4* wp = reinterpret_cast<const float4*>(Wp) + (size_t)hh * Npad + col0 + r;
+  const size_t wstride = (size_t)2 * Npad;
   const float* xr = X + r * ldx + 4 * hh;
-#pragma unroll 2
-  for (int kg = kg0; kg < kg1; ++kg) {
-    const float4 b = wp[(size_t)kg * 2 * Npad];
+  float4 bc[G], bn[G];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const float4 a = *reinterpret_cast<const float4*>(xr + m * 32 * ldx + kg * 8);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[m], 0, 0, 0);
+  for (int j = 0; j < G; ++j) bc[j] = wp[(size_t)min(kg0 + j, kg1 - 1) * wstride];
+  for (int g = kg0; g < kg1; g += G) {
+    if (g + G < kg1) {
+#pragma unroll
+      for (int j = 0; j < G; ++j) bn[j] = wp[(size_t)min(g + G + j, kg1 - 1) * wstride];
     }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      if (g + j < kg1) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float4 a = *reinterpret_cast<const float4*>(xr + m * 32 * ldx + (g + j) * 8);
+          if (TRANS) {
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[j].x, a.x, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[j].y, a.y, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[j].z, a.z, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[j].w, a.w, acc[m], 0, 0, 0);
+          } else {
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bc[j].x, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bc[j].y, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bc[j].z, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bc[j].w, acc[m], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) bc[j] = bn[j];
   }
 }
 
@@ -83,6 +109,9 @@ __device__ __forceinline__ void tile_gemm(const float* X, int ldx, int K, const 
   constexpr int RG = MTOT / MT;
   for (int it = wave; it < nch * RG; it += nw) {
     const int ch = it / RG, rg = it % RG;
+    // compiler barrier: without it LICM hoists the loop-invariant A-fragment LDS reads of ALL k-groups out of this
+    // loop (256 VGPRs, spills, occupancy 1); re-reading LDS per chunk is nearly free next to the MFMAs.
+    asm volatile("" ::: "memory");
     f32x16 acc[MT];
     acc_zero<MT>(acc);
     wave_mma<MT>(X + rg * MT * 32 * ldx, ldx, Wp, Npad, ch * 32, 0, K >> 3, acc);

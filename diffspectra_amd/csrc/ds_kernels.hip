@@ -461,104 +461,151 @@ __global__ __launch_bounds__(256) void k_edge_update(Ctx c, int blk) {
   }
 }
 
-// Block stage F (one workgroup per molecule): MultiCondEquiUpdate over directed edges (row r -> col cc) in tiles
-// of 64, position aggregation on the row atom, per-layer CoM removal.  dmt.py:37-60,385-386; layers.py:344-347.
-__global__ __launch_bounds__(256) void k_equi_update(Ctx c, int blk, int last) {
+// Block stage F (flat tiles of 64 directed edges r -> c): MultiCondEquiUpdate.  dmt.py:37-60; layers.py:344-347.
+// x = A_r + C_c + ed_{rc} -> LN -> modulate -> [256->256, SiLU] -> [256->3] -> tanh -> head mix -> CoorsNorm -> sum over c.
+// The 256->256 GEMM is computed TRANSPOSED (lane = edge row, registers = output features) so that its SiLU'd
+// accumulators are directly the B operand of the 256->3 MFMA: the hidden activations never touch LDS, X is the only
+// large LDS tile (66.5 kB -> two workgroups per CU overlap each other's gather/LN phases with MFMA work).
+__global__ __launch_bounds__(256, 2) void k_equi_flat(Ctx c, int blk) {
   constexpr int T = 64;
   __shared__ __attribute__((aligned(16))) float X[T][256 + DS_LDP];
-  __shared__ __attribute__((aligned(16))) float Y[T][256 + DS_LDP];
   __shared__ __attribute__((aligned(16))) float part[4][T][4];
   __shared__ __attribute__((aligned(16))) float trans[T][4];
-  __shared__ __attribute__((aligned(16))) float P0[32][4];
-  __shared__ __attribute__((aligned(16))) float P1[32][4];
-  const int m = blockIdx.x, tid = threadIdx.x;
-  const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
-  const int p0 = c.L.pair_off[m];
-  if (n <= 0) return;
-  if (tid < n) {
-    const float* pp = c.ws.pos + (size_t)(n0 + tid) * 4;
-    P0[tid][0] = pp[0]; P0[tid][1] = pp[1]; P0[tid][2] = pp[2]; P0[tid][3] = 0.0f;
+  __shared__ int rsrc[T], rdst[T], rpair[T], rmol[T];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5;
+  const int E = 2 * c.L.Pp;
+  const int e0 = blockIdx.x * T;
+  const int rows = min(T, E - e0);
+  if (tid < T) {
+    int sN = -1, dN = 0, pr = 0, m = 0;
+    if (tid < rows) {
+      sN = c.L.dir_src[e0 + tid]; dN = c.L.dir_dst[e0 + tid]; pr = c.L.dir_pair[e0 + tid];
+      m = c.L.node_mol[sN];
+    }
+    rsrc[tid] = sN; rdst[tid] = dN; rpair[tid] = pr; rmol[tid] = m;
   }
-  const int E = n * (n - 1);
-  const float* ad = c.ws.ada + (size_t)m * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EQUI;
-  const float cscale = BW(c, blk, DS_BW_COORD_SCALE)[0];
-  float dpx = 0.0f, dpy = 0.0f, dpz = 0.0f;   // thread r < n owns atom r
-  __syncthreads();
-  for (int e0 = 0; e0 < E; e0 += T) {
-    const int rows = min(T, E - e0);
-    for (int idx = tid; idx < T * 64; idx += 256) {
-      const int row = idx >> 6, k4 = idx & 63;
-      float4 v = make_float4(0, 0, 0, 0);
-      if (row < rows) {
-        const int eidx = e0 + row;
-        const int r = eidx / (n - 1);
-        int cc = eidx - r * (n - 1);
-        cc += (cc >= r);
-        const int a = r < cc ? r : cc, b = r < cc ? cc : r;
-        const int pl = a * (2 * n - a - 1) / 2 + (b - a - 1);
-        const float4 va = reinterpret_cast<const float4*>(c.ws.ac + (size_t)(n0 + r) * 512)[k4];
-        const float4 vc = reinterpret_cast<const float4*>(c.ws.ac + (size_t)(n0 + cc) * 512 + 256)[k4];
-        const float4 ve = reinterpret_cast<const float4*>(c.ws.ed + (size_t)(p0 + pl) * 256)[k4];
-        v.x = (va.x + vc.x) + ve.x; v.y = (va.y + vc.y) + ve.y; v.z = (va.z + vc.z) + ve.z; v.w = (va.w + vc.w) + ve.w;
-      }
-      reinterpret_cast<float4*>(&X[row][0])[k4] = v;
-    }
-    __syncthreads();
-    for (int row = tid >> 6; row < T; row += 4) ln_mod_row<256>(&X[row][0], ad, ad + 256);   // shift, scale (dmt.py:44-45)
-    __syncthreads();
-    {
-      const float* b0 = BW(c, blk, DS_BW_CM0_B);
-      tile_gemm<2, 2>(&X[0][0], 256 + DS_LDP, 256, BW(c, blk, DS_BW_CM0_W), 256, 8,
-                      [&](int row, int col, float v) { Y[row][col] = ds_silu(v + b0[col]); });
-    }
-    __syncthreads();
-    {  // coord_mlp.2 (256 -> 3): K split over the 4 waves, partial sums through LDS
-      const int wave = tid >> 6;
-      f32x16 acc[2];
-      acc_zero<2>(acc);
-      wave_mma<2>(&Y[0][0], 256 + DS_LDP, BW(c, blk, DS_BW_CM2_W), 32, 0, wave * 8, wave * 8 + 8, acc);
-      acc_foreach<2>(acc, 0, 0, [&](int row, int col, float v) { if (col < 3) part[wave][row][col] = v; });
-    }
-    __syncthreads();
-    if (tid < T) {
-      float tx = 0.0f, ty = 0.0f, tz = 0.0f;
-      if (tid < rows) {
-        const int eidx = e0 + tid;
-        const int r = eidx / (n - 1);
-        int cc = eidx - r * (n - 1);
-        cc += (cc >= r);
-        const int a = r < cc ? r : cc, b = r < cc ? cc : r;
-        const int pl = a * (2 * n - a - 1) / 2 + (b - a - 1);
-        const int bits = c.ws.adj[p0 + pl];
-        float inv[3];
+  // per-lane constants of this wave's two 32-feature chunks: coord_mlp.0 bias and the coord_mlp.2 A-fragments
+  const float* b0 = BW(c, blk, DS_BW_CM0_B);
+  const float* w2 = BW(c, blk, DS_BW_CM2_W);
+  float b0f[2][16], w2f[2][16];
 #pragma unroll
-        for (int hI = 0; hI < 3; ++hI)
-          inv[hI] = tanhf(((part[0][tid][hI] + part[1][tid][hI]) + part[2][tid][hI]) + part[3][tid][hI]);
-        const float w = ((inv[0] + ((bits & 1) ? inv[1] : 0.0f)) + ((bits & 2) ? inv[2] : 0.0f)) / 3.0f;   // dmt.py:51-53
-        const float dx = P0[r][0] - P0[cc][0], dy = P0[r][1] - P0[cc][1], dz = P0[r][2] - P0[cc][2];
-        const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);   // layers.py:345-346
-        tx = (dx / nrm * cscale) * w; ty = (dy / nrm * cscale) * w; tz = (dz / nrm * cscale) * w;
-      }
-      trans[tid][0] = tx; trans[tid][1] = ty; trans[tid][2] = tz;
+  for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int f = (wave + 4 * cc) * 32 + acc_row(i, hh);
+      b0f[cc][i] = b0[f];
+      w2f[cc][i] = (lane & 31) < 3 ? wp_at(w2, 32, f, lane & 31) : 0.0f;
     }
-    __syncthreads();
-    if (tid < n) {   // scatter-add on the row atom in edge order (dmt.py:57)
-      const int lo = max(e0, tid * (n - 1)), hi = min(e0 + rows, (tid + 1) * (n - 1));
-      for (int eidx = lo; eidx < hi; ++eidx) { dpx += trans[eidx - e0][0]; dpy += trans[eidx - e0][1]; dpz += trans[eidx - e0][2]; }
-    }
-    __syncthreads();
-  }
-  if (tid < n) { P1[tid][0] = P0[tid][0] + dpx; P1[tid][1] = P0[tid][1] + dpy; P1[tid][2] = P0[tid][2] + dpz; }
   __syncthreads();
-  if (tid < n) {   // remove_mean_with_mask (models/utils.py:38-45)
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    for (int a = 0; a < n; ++a) { sx += P1[a][0]; sy += P1[a][1]; sz += P1[a][2]; }
-    const float fn = (float)n;
-    const float ox = P1[tid][0] - sx / fn, oy = P1[tid][1] - sy / fn, oz = P1[tid][2] - sz / fn;
-    float* pp = c.ws.pos + (size_t)(n0 + tid) * 4;
-    pp[0] = ox; pp[1] = oy; pp[2] = oz;
-    if (last && (isnan(ox) || isnan(oy) || isnan(oz))) atomicOr(&c.ws.flags[1], 1);
+  for (int it = 0; it < 4; ++it) {   // gather 64 rows x 64 float4, 4 independent items in flight per thread
+    float4 va[4], vc[4], ve[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + (it * 4 + u) * 256;
+      const int row = idx >> 6, k4 = idx & 63;
+      if (row < rows) {
+        va[u] = reinterpret_cast<const float4*>(c.ws.ac + (size_t)rsrc[row] * 512)[k4];
+        vc[u] = reinterpret_cast<const float4*>(c.ws.ac + (size_t)rdst[row] * 512 + 256)[k4];
+        ve[u] = reinterpret_cast<const float4*>(c.ws.ed + (size_t)rpair[row] * 256)[k4];
+      } else {
+        va[u] = vc[u] = ve[u] = make_float4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + (it * 4 + u) * 256;
+      float4 v;
+      v.x = (va[u].x + vc[u].x) + ve[u].x; v.y = (va[u].y + vc[u].y) + ve[u].y;
+      v.z = (va[u].z + vc[u].z) + ve[u].z; v.w = (va[u].w + vc[u].w) + ve[u].w;
+      reinterpret_cast<float4*>(&X[idx >> 6][0])[idx & 63] = v;
+    }
   }
+  __syncthreads();
+  for (int row = wave; row < T; row += 4) {
+    const float* ad = c.ws.ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EQUI;
+    ln_mod_row<256>(&X[row][0], ad, ad + 256);   // shift, scale (dmt.py:44-45)
+  }
+  __syncthreads();
+  {
+    f32x16 acc2[2];
+    acc_zero<2>(acc2);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      asm volatile("" ::: "memory");   // keep the A-fragment LDS reads inside each chunk (see tile_gemm)
+      f32x16 acc1[2];
+      acc_zero<2>(acc1);
+      wave_mma<2, true>(&X[0][0], 256 + DS_LDP, BW(c, blk, DS_BW_CM0_W), 256, (wave + 4 * cc) * 32, 0, 32, acc1);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float y = ds_silu(acc1[m][i] + b0f[cc][i]);                       // coord_mlp.0 + SiLU (dmt.py:32-33)
+          acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[cc][i], y, acc2[m], 0, 0, 0);   // coord_mlp.2 partial (dmt.py:34)
+        }
+    }
+    if (hh == 0) {   // out[j][row]: j = register 0..2 of the lower half, row = m*32 + lane
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        part[wave][m * 32 + lane][0] = acc2[m][0];
+        part[wave][m * 32 + lane][1] = acc2[m][1];
+        part[wave][m * 32 + lane][2] = acc2[m][2];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < T) {
+    float tx = 0.0f, ty = 0.0f, tz = 0.0f;
+    if (tid < rows) {
+      const int bits = c.ws.adj[rpair[tid]];
+      float inv[3];
+#pragma unroll
+      for (int hI = 0; hI < 3; ++hI)
+        inv[hI] = tanhf(((part[0][tid][hI] + part[1][tid][hI]) + part[2][tid][hI]) + part[3][tid][hI]);
+      const float w = ((inv[0] + ((bits & 1) ? inv[1] : 0.0f)) + ((bits & 2) ? inv[2] : 0.0f)) / 3.0f;   // dmt.py:51-53
+      const float* pr = c.ws.pos + (size_t)rsrc[tid] * 4;
+      const float* pc = c.ws.pos + (size_t)rdst[tid] * 4;
+      const float dx = pr[0] - pc[0], dy = pr[1] - pc[1], dz = pr[2] - pc[2];
+      const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);   // layers.py:345-346
+      const float cscale = BW(c, blk, DS_BW_COORD_SCALE)[0];
+      tx = (dx / nrm * cscale) * w; ty = (dy / nrm * cscale) * w; tz = (dz / nrm * cscale) * w;
+    }
+    trans[tid][0] = tx; trans[tid][1] = ty; trans[tid][2] = tz;
+  }
+  __syncthreads();
+  // segmented sum over the consecutive rows of one row-atom, then one atomic per (tile, atom): a row-atom's <= 28
+  // edges span at most two tiles, so every dpos entry receives at most two adds onto zero — order-independent.
+  if (tid < rows && (tid == 0 || rsrc[tid] != rsrc[tid - 1])) {
+    const int sN = rsrc[tid];
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    for (int r2 = tid; r2 < rows && rsrc[r2] == sN; ++r2) { sx += trans[r2][0]; sy += trans[r2][1]; sz += trans[r2][2]; }
+    float* dp = c.ws.dpos + (size_t)sN * 4;
+    atomicAdd(dp + 0, sx); atomicAdd(dp + 1, sy); atomicAdd(dp + 2, sz);
+  }
+}
+
+// pos += dpos, per-layer CoM removal (dmt.py:58,385-386; models/utils.py:38-45); re-zeroes dpos for the next block.
+__global__ void k_pos_update(Ctx c, int last) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= c.L.B) return;
+  const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
+  float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+  for (int a = 0; a < n; ++a) {
+    float* pp = c.ws.pos + (size_t)(n0 + a) * 4;
+    float* dp = c.ws.dpos + (size_t)(n0 + a) * 4;
+    const float x = pp[0] + dp[0], y = pp[1] + dp[1], z = pp[2] + dp[2];
+    pp[0] = x; pp[1] = y; pp[2] = z;
+    dp[0] = 0.0f; dp[1] = 0.0f; dp[2] = 0.0f;
+    sx += x; sy += y; sz += z;
+  }
+  const float fn = (float)n;
+  bool bad = false;
+  for (int a = 0; a < n; ++a) {
+    float* pp = c.ws.pos + (size_t)(n0 + a) * 4;
+    const float x = pp[0] - sx / fn, y = pp[1] - sy / fn, z = pp[2] - sz / fn;
+    pp[0] = x; pp[1] = y; pp[2] = z;
+    bad = bad || isnan(x) || isnan(y) || isnan(z);
+  }
+  if (last && bad) atomicOr(&c.ws.flags[1], 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -982,6 +1029,7 @@ int ds_stage_init(const ds_weights* w, const ds_layout* L, ds_workspace* ws, con
   Ctx c;
   if (!make_ctx(c, w, L, ws, s) || !xh || !edge_x || ((cond_x == nullptr) != (cond_edge_x == nullptr))) return DS_ERR_ARG;
   if (hipMemsetAsync(ws->flags, 0, 8 * sizeof(int32_t), s) != hipSuccess) return DS_ERR_LAUNCH;
+  if (hipMemsetAsync(ws->dpos, 0, (size_t)(L->Nn > 0 ? L->Nn : 1) * 4 * sizeof(float), s) != hipSuccess) return DS_ERR_LAUNCH;
   if (L->Pp > 0) hipLaunchKernelGGL(k_pair_flags, dim3((L->Pp + 255) / 256), dim3(256), 0, s, c, cond_x, cond_edge_x);
   hipLaunchKernelGGL(k_node_init, dim3(L->Nn), dim3(256), 0, s, c, xh, cond_x);
   if (L->Pp > 0) hipLaunchKernelGGL(k_pair_init, dim3((L->Pp + 63) / 64), dim3(256), 0, s, c, edge_x, cond_x, cond_edge_x);
@@ -998,7 +1046,8 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   { ProfScope ps(2, s); hipLaunchKernelGGL(k_attention, dim3(L->B), dim3(256), 0, s, c); }
   { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3(pt), dim3(256), 0, s, c, blk); }
-  { ProfScope ps(5, s); hipLaunchKernelGGL(k_equi_update, dim3(L->B), dim3(256), 0, s, c, blk, last); }
+  if (pt > 0) { ProfScope ps(5, s); hipLaunchKernelGGL(k_equi_flat, dim3((2 * L->Pp + 63) / 64), dim3(256), 0, s, c, blk); }
+  hipLaunchKernelGGL(k_pos_update, dim3((L->B + 63) / 64), dim3(64), 0, s, c, last);
   return launch_status();
 }
 

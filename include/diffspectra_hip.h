@@ -106,6 +106,9 @@ typedef struct ds_layout {
   const int32_t* pair_a;             /* [Pp]  packed node row of the smaller local index */
   const int32_t* pair_b;             /* [Pp]  packed node row of the larger local index */
   const int32_t* pair_mol;           /* [Pp] */
+  const int32_t* dir_src;            /* [2*Pp] directed edges (r -> c), molecule-major, r-major, c ascending: row atom */
+  const int32_t* dir_dst;            /* [2*Pp] col atom (packed node rows) */
+  const int32_t* dir_pair;           /* [2*Pp] pair row of {r, c} */
 } ds_layout;
 
 typedef struct ds_workspace {        /* all device fp32 unless noted; sizes in floats */
@@ -126,6 +129,7 @@ typedef struct ds_workspace {        /* all device fp32 unless noted; sizes in f
   float* u;          /* [Nn,64]  node2edge_lin weight applied per node (no bias) */
   float* ac;         /* [Nn,512] input_lin row part | col part */
   float* ed;         /* [Pp,256] input_lin edge+dist part + bias */
+  float* dpos;       /* [Nn,4]   position increments of the current block (zero between blocks) */
   int32_t* adj;      /* [Pp]     bit0: cond_adj_2d, bit1: cond_adj_spatial */
   int32_t* flags;    /* [8]      0: any nonzero cond distance, 1: NaN in positions */
 } ds_workspace;

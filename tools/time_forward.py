@@ -44,6 +44,18 @@ def main():
     dt = (time.perf_counter() - t0) / args.iters
     E = sum(n * (n - 1) for n in n_atoms)
     macs = 8 * (620544 * sum(n_atoms) + 157184 * E + 2492416 * B) + (233216 * sum(n_atoms) + 33088 * E + 1330176 * B)
+    import ctypes as C
+    names = ["edge_geom", "node_qkv", "attention", "node_update", "edge_update", "equi_update"]
+    per = []
+    for kid in range(6):
+        eng.lib.ds_profile_config(C.c_int(kid), C.c_int(1), C.c_int(256))
+        for _ in range(3):
+            eng.forward(L, ws, x, ex, nl, cx, cex, ctx, out, oute)
+        tot, cnt = C.c_double(0), C.c_int64(0)
+        eng.lib.ds_profile_read(C.byref(tot), C.byref(cnt))
+        per.append(tot.value / max(1, cnt.value))
+    eng.lib.ds_profile_config(C.c_int(-1), C.c_int(1), C.c_int(0))
+    print("  per-launch ms: " + ", ".join(f"{n} {t:.3f}" for n, t in zip(names, per)) + f" | block sum {sum(per):.3f}")
     print(f"mols {B} Nn {L.Nn} Pp {L.Pp}: {dt * 1e3:.3f} ms/forward, {dt / B * 1e6:.2f} us/mol-step, "
           f"{2 * macs / dt / 1e12:.2f} TFLOP/s algorithmic, {B / dt / 1000:.1f} mol/s @1000 steps")
 

@@ -248,81 +248,94 @@ __global__ __launch_bounds__(256) void k_node_qkv(Ctx c, int blk) {
   });
 }
 
-// Block stage C (one workgroup per molecule): 16-head edge-modulated attention, softmax over sources per
-// (target, head), heads 0-1 are the adjacency heads (0 -> -1e10).  layers.py:159-186 + PyG softmax/propagate.
-__global__ __launch_bounds__(256) void k_attention(Ctx c) {
-  constexpr int MAXN = 32;
-  __shared__ __attribute__((aligned(16))) float Q[MAXN * 256];
-  __shared__ __attribute__((aligned(16))) float K[MAXN * 256];
-  __shared__ __attribute__((aligned(16))) float V[MAXN * 256];
-  __shared__ __attribute__((aligned(16))) float Lg[DS_MAX_ATOMS * DS_MAX_ATOMS * 16];
-  const int m = blockIdx.x, tid = threadIdx.x;
-  const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
-  const int p0 = c.L.pair_off[m], P = c.L.pair_off[m + 1] - p0;
-  if (n <= 0) return;
-  for (int idx = tid; idx < n * 64; idx += 256) {
-    const int a = idx >> 6, k4 = idx & 63;
-    const float4* src = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + a) * 768);
-    reinterpret_cast<float4*>(Q)[a * 64 + k4] = src[k4];
-    reinterpret_cast<float4*>(K)[a * 64 + k4] = src[64 + k4];
-    reinterpret_cast<float4*>(V)[a * 64 + k4] = src[128 + k4];
-  }
-  __syncthreads();
-  // phase 1: logits of both directions of every pair; source a -> target b uses q_b * k_a * tanh(e0_ab)
-  for (int it = tid; it < P * 14; it += 256) {
-    const int pl = it / 14, hd = it - pl * 14;
-    const int p = p0 + pl;
-    const int a = c.L.pair_a[p] - n0, b = c.L.pair_b[p] - n0;
-    const float* t0 = c.ws.te0 + (size_t)p * 256 + hd * 18;
-    const float* qa = Q + a * 256 + hd * 18; const float* qb = Q + b * 256 + hd * 18;
-    const float* ka = K + a * 256 + hd * 18; const float* kb = K + b * 256 + hd * 18;
-    float s_ab = 0.0f, s_ba = 0.0f;
-#pragma unroll
-    for (int ch = 0; ch < 18; ++ch) {
-      const float e = t0[ch];
-      s_ab += (qb[ch] * ka[ch]) * e;
-      s_ba += (qa[ch] * kb[ch]) * e;
-    }
-    Lg[(b * n + a) * 16 + 2 + hd] = s_ab / 4.0f;   // / sqrt(out_channels = 16) (layers.py:167)
-    Lg[(a * n + b) * 16 + 2 + hd] = s_ba / 4.0f;
-    if (hd == 0) {
+// Block stage C1 (flat over pairs): attention logits of both directions of every pair, 14 learned heads
+// (q_t . k_s . tanh(e0) over 18 channels, / sqrt(16)) + the 2 adjacency heads (0 -> -1e10).  layers.py:165-174.
+// lg[p][0][h]: source a -> target b;  lg[p][1][h]: source b -> target a.  16 pairs x 16 head slots per workgroup.
+__global__ __launch_bounds__(256) void k_attn_logits(Ctx c) {
+  const int tid = threadIdx.x;
+  const int p = blockIdx.x * 16 + (tid >> 4), hs = tid & 15;
+  if (p >= c.L.Pp) return;
+  float* out = c.ws.lg + (size_t)p * 32;
+  if (hs >= 14) {
+    if (hs == 14) {
       const int bits = c.ws.adj[p];
       const float h0 = (bits & 1) ? 1.0f : -1e10f, h1 = (bits & 2) ? 1.0f : -1e10f;   // layers.py:171-174
-      Lg[(b * n + a) * 16 + 0] = h0; Lg[(b * n + a) * 16 + 1] = h1;
-      Lg[(a * n + b) * 16 + 0] = h0; Lg[(a * n + b) * 16 + 1] = h1;
+      out[0] = h0; out[1] = h1; out[16] = h0; out[17] = h1;
     }
+    return;
   }
-  __syncthreads();
-  // phase 2: softmax over sources s != t for each (target t, head)
+  const int a = c.L.pair_a[p], b = c.L.pair_b[p];
+  const float2* t0 = reinterpret_cast<const float2*>(c.ws.te0 + (size_t)p * 256 + hs * 18);
+  const float2* qa = reinterpret_cast<const float2*>(c.ws.qkv + (size_t)a * 768 + hs * 18);
+  const float2* qb = reinterpret_cast<const float2*>(c.ws.qkv + (size_t)b * 768 + hs * 18);
+  const float2* ka = reinterpret_cast<const float2*>(c.ws.qkv + (size_t)a * 768 + 256 + hs * 18);
+  const float2* kb = reinterpret_cast<const float2*>(c.ws.qkv + (size_t)b * 768 + 256 + hs * 18);
+  float s_ab = 0.0f, s_ba = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const float2 e = t0[j], xa = qa[j], xb = qb[j], ya = ka[j], yb = kb[j];
+    s_ab += (xb.x * ya.x) * e.x; s_ab += (xb.y * ya.y) * e.y;
+    s_ba += (xa.x * yb.x) * e.x; s_ba += (xa.y * yb.y) * e.y;
+  }
+  out[2 + hs] = s_ab / 4.0f;        // / sqrt(out_channels = 16) (layers.py:167)
+  out[16 + 2 + hs] = s_ba / 4.0f;
+}
+
+// Block stage C2 (one workgroup per TARGET atom, 2 kB LDS -> 8 workgroups/CU hide the gather latency): segment softmax
+// over the sources (PyG softmax: max-shift, exp, / (sum + 1e-16)) and out[t] = sum_s (v_s * tanh(e1)_{st}) * alpha,
+// sources in ascending order as the reference's scatter-add visits them.  layers.py:178-186.
+__global__ __launch_bounds__(256) void k_attn_agg(Ctx c) {
+  __shared__ float al[32][16];
+  const int trow = blockIdx.x, tid = threadIdx.x;
+  const int m = c.L.node_mol[trow];
+  const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
+  const int p0 = c.L.pair_off[m];
+  const int t = trow - n0;
   for (int it = tid; it < n * 16; it += 256) {
-    const int t = it >> 4, hd = it & 15;
-    float mx = -INFINITY;
-    for (int s = 0; s < n; ++s) if (s != t) mx = fmaxf(mx, Lg[(t * n + s) * 16 + hd]);
-    float sum = 0.0f;
-    for (int s = 0; s < n; ++s) if (s != t) {
-      const float e = expf(Lg[(t * n + s) * 16 + hd] - mx);
-      Lg[(t * n + s) * 16 + hd] = e;
-      sum += e;
+    const int s = it >> 4, h = it & 15;
+    if (s != t) {
+      const int lo = s < t ? s : t, hi = s < t ? t : s;
+      const int pl = lo * (2 * n - lo - 1) / 2 + (hi - lo - 1);
+      al[s][h] = c.ws.lg[(size_t)(p0 + pl) * 32 + (s < t ? 0 : 16) + h];
     }
-    const float den = sum + 1e-16f;
-    for (int s = 0; s < n; ++s) if (s != t) Lg[(t * n + s) * 16 + hd] /= den;
   }
   __syncthreads();
-  // phase 3: out[t, c] = sum_s (v[s,c] * tanh(e1)[pair(s,t), c]) * alpha[t, s, head(c)]
-  {
-    const int col = tid, hd = tid >> 4;
-    for (int t = 0; t < n; ++t) {
-      float acc = 0.0f;
-      for (int s = 0; s < n; ++s) {
-        if (s == t) continue;
-        const int a = s < t ? s : t, b = s < t ? t : s;
-        const int pl = a * (2 * n - a - 1) / 2 + (b - a - 1);
-        const float g = c.ws.te1[(size_t)(p0 + pl) * 256 + col];
-        acc += (V[s * 256 + col] * g) * Lg[(t * n + s) * 16 + hd];
-      }
-      c.ws.attn[(size_t)(n0 + t) * 256 + col] = acc;
-    }
+  if (tid < 16) {
+    float mx = -INFINITY;
+    for (int s = 0; s < n; ++s) if (s != t) mx = fmaxf(mx, al[s][tid]);
+    float sum = 0.0f;
+    for (int s = 0; s < n; ++s) if (s != t) { const float e = expf(al[s][tid] - mx); al[s][tid] = e; sum += e; }
+    const float den = sum + 1e-16f;
+    for (int s = 0; s < n; ++s) if (s != t) al[s][tid] /= den;
   }
+  __syncthreads();
+  const int col = tid, hd = tid >> 4;
+  const float* vbase = c.ws.qkv + (size_t)n0 * 768 + 512 + col;
+  const float* gbase = c.ws.te1 + (size_t)p0 * 256 + col;
+  float acc = 0.0f;
+  int s = 0;
+  for (; s + 4 <= n; s += 4) {   // 4 sources per trip: 8 independent loads in flight
+    float v[4], g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ss = s + u;
+      const int sq = ss == t ? (t == 0 ? 1 : 0) : ss;            // any valid source; its term is masked below
+      const int lo = sq < t ? sq : t, hi = sq < t ? t : sq;
+      const int pl = lo * (2 * n - lo - 1) / 2 + (hi - lo - 1);
+      v[u] = vbase[(size_t)sq * 768];
+      g[u] = n > 1 ? gbase[(size_t)pl * 256] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (s + u != t) acc += (v[u] * g[u]) * al[s + u][hd];
+  }
+  for (; s < n; ++s) {
+    if (s == t) continue;
+    const int lo = s < t ? s : t, hi = s < t ? t : s;
+    const int pl = lo * (2 * n - lo - 1) / 2 + (hi - lo - 1);
+    acc += (vbase[(size_t)s * 768] * gbase[(size_t)pl * 256]) * al[s][hd];
+  }
+  c.ws.attn[(size_t)trow * 256 + col] = acc;
 }
 
 // Block stage D (nodes): node2edge partial, gated residual, LN, modulate, FF(256->512->256), gated residual,
@@ -957,7 +970,7 @@ int gemm_simple(const float* A, int64_t lda, const float* Wp, const float* bias,
 
 // ---- optional HIP-event timing of one block-stage kernel (bench.py's live roofline measurement) ----
 struct ProfState {
-  int kernel = -1;          // 0 edge_geom, 1 node_qkv, 2 attention, 3 node_update, 4 edge_update, 5 equi_update
+  int kernel = -1;          // 0 edge_geom, 1 node_qkv, 2 attn_logits, 3 node_update, 4 edge_update, 5 equi_flat, 6 attn_agg
   int every = 1;
   long long seen = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
@@ -1043,7 +1056,8 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   const int pt = (L->Pp + 63) / 64, nt = (L->Nn + 31) / 32;
   if (pt > 0) { ProfScope ps(0, s); hipLaunchKernelGGL(k_edge_geom, dim3(pt), dim3(256), 0, s, c, blk); }
   { ProfScope ps(1, s); hipLaunchKernelGGL(k_node_qkv, dim3(nt), dim3(256), 0, s, c, blk); }
-  { ProfScope ps(2, s); hipLaunchKernelGGL(k_attention, dim3(L->B), dim3(256), 0, s, c); }
+  if (pt > 0) { ProfScope ps(2, s); hipLaunchKernelGGL(k_attn_logits, dim3((L->Pp + 15) / 16), dim3(256), 0, s, c); }
+  { ProfScope ps(6, s); hipLaunchKernelGGL(k_attn_agg, dim3(L->Nn), dim3(256), 0, s, c); }
   { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3(pt), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(5, s); hipLaunchKernelGGL(k_equi_flat, dim3((2 * L->Pp + 63) / 64), dim3(256), 0, s, c, blk); }
@@ -1115,7 +1129,7 @@ int ds_profile_config(int kernel, int every, int max_samples) {
   g_prof.used = 0; g_prof.seen = 0;
   g_prof.kernel = kernel; g_prof.every = every > 0 ? every : 1;
   if (kernel < 0) return DS_OK;
-  if (kernel > 5 || max_samples <= 0) return DS_ERR_ARG;
+  if (kernel > 6 || max_samples <= 0) return DS_ERR_ARG;
   g_prof.pool.resize((size_t)max_samples);
   for (auto& e : g_prof.pool)
     if (hipEventCreate(&e.first) != hipSuccess || hipEventCreate(&e.second) != hipSuccess) return DS_ERR_LAUNCH;

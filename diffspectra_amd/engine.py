@@ -74,7 +74,7 @@ class DsLayout(C.Structure):
 
 
 _WS_FIELDS = ["pos", "h", "e", "atom_hids", "edge_hids", "tfeat", "tmid", "temb_silu", "ada", "qkv", "te0", "te1",
-              "dist", "attn", "u", "ac", "ed", "dpos", "adj", "flags"]
+              "dist", "attn", "u", "ac", "ed", "lg", "dpos", "adj", "flags"]
 
 
 class DsWorkspace(C.Structure):
@@ -320,7 +320,7 @@ class Workspace:
         self.t = dict(pos=f(Nn, 4), h=f(Nn, 256), e=f(Pp, 64), atom_hids=f(Nn, 768), edge_hids=f(Pp, 192),
                       tfeat=f(B, 24), tmid=f(B, 1024), temb_silu=f(B, 1024), ada=f(B, ADA_COLS), qkv=f(Nn, 768),
                       te0=f(Pp, 256), te1=f(Pp, 256), dist=f(Pp, 64), attn=f(Nn, 256), u=f(Nn, 64), ac=f(Nn, 512),
-                      ed=f(Pp, 256), dpos=torch.zeros(Nn, 4, dtype=torch.float32, device=device),
+                      ed=f(Pp, 256), lg=f(Pp, 32), dpos=torch.zeros(Nn, 4, dtype=torch.float32, device=device),
                       adj=torch.zeros(Pp, dtype=torch.int32, device=device),
                       flags=torch.zeros(8, dtype=torch.int32, device=device))
         self.c = DsWorkspace(**{k: self.t[k].data_ptr() for k in _WS_FIELDS})

@@ -129,6 +129,7 @@ typedef struct ds_workspace {        /* all device fp32 unless noted; sizes in f
   float* u;          /* [Nn,64]  node2edge_lin weight applied per node (no bias) */
   float* ac;         /* [Nn,512] input_lin row part | col part */
   float* ed;         /* [Pp,256] input_lin edge+dist part + bias */
+  float* lg;         /* [Pp,2,16] attention logits: [p][0] source a -> target b, [p][1] source b -> target a */
   float* dpos;       /* [Nn,4]   position increments of the current block (zero between blocks) */
   int32_t* adj;      /* [Pp]     bit0: cond_adj_2d, bit1: cond_adj_spatial */
   int32_t* flags;    /* [8]      0: any nonzero cond distance, 1: NaN in positions */
@@ -191,8 +192,8 @@ int ds_layernorm_affine(const float* x, const float* gamma, const float* beta, f
                         float eps, void* stream);
 
 /* Measurement hook (bench.py roofline leg): time every `every`-th launch of one block-stage kernel with HIP events
- * recorded on the launch stream.  kernel: 0 edge_geom, 1 node_qkv, 2 attention, 3 node_update, 4 edge_update,
- * 5 equi_update; kernel < 0 disables.  ds_profile_read synchronises the recorded events, returns the summed
+ * recorded on the launch stream.  kernel: 0 edge_geom, 1 node_qkv, 2 attn_logits, 3 node_update, 4 edge_update,
+ * 5 equi_flat, 6 attn_agg; kernel < 0 disables.  ds_profile_read synchronises the recorded events, returns the summed
  * duration and the sample count, and resets the counters.  Process-global instrumentation state; off by default. */
 int ds_profile_config(int kernel, int every, int max_samples);
 int ds_profile_read(double* total_ms, int64_t* samples);

@@ -45,9 +45,9 @@ def main():
     E = sum(n * (n - 1) for n in n_atoms)
     macs = 8 * (620544 * sum(n_atoms) + 157184 * E + 2492416 * B) + (233216 * sum(n_atoms) + 33088 * E + 1330176 * B)
     import ctypes as C
-    names = ["edge_geom", "node_qkv", "attention", "node_update", "edge_update", "equi_update"]
+    names = ["edge_geom", "node_qkv", "attn_logits", "node_update", "edge_update", "equi_flat", "attn_agg"]
     per = []
-    for kid in range(6):
+    for kid in range(7):
         eng.lib.ds_profile_config(C.c_int(kid), C.c_int(1), C.c_int(256))
         for _ in range(3):
             eng.forward(L, ws, x, ex, nl, cx, cex, ctx, out, oute)

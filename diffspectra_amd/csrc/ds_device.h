@@ -14,14 +14,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define DS_LDP 4  // LDS row padding (floats)
 
-__device__ __forceinline__ float ds_silu(float x) { return x / (1.0f + expf(-x)); }
+// Transcendentals: hardware exp2/rcp based forms (abs. error ~1e-7, far inside the 1e-5 per-kernel gate); the
+// libm versions cost 3-5x the VALU issue slots and these sit in MFMA epilogues.
+__device__ __forceinline__ float ds_silu(float x) { return __fdividef(x, 1.0f + __expf(-x)); }
+__device__ __forceinline__ float ds_tanh(float x) {
+  const float e = __expf(-2.0f * fabsf(x));
+  return copysignf(__fdividef(1.0f - e, 1.0f + e), x);
+}
 __device__ __forceinline__ float ds_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 template <int ACT>
 __device__ __forceinline__ float ds_act(float x) {
   if (ACT == 1) return ds_silu(x);
   if (ACT == 2) return ds_gelu(x);
-  if (ACT == 3) return tanhf(x);
+  if (ACT == 3) return ds_tanh(x);
   return x;
 }
 
@@ -42,12 +48,13 @@ __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 *
 // layout a following MFMA needs to contract over those columns without touching LDS (k_equi_flat).
 template <int MT, bool TRANS = false>
 __device__ __forceinline__ void wave_mma(const float* X, int ldx, const float* __restrict__ Wp, int Npad, int col0,
-                                         int kg0, int kg1, f32x16 (&acc)[MT]) {
+                                         int kg0, int kg1, f32x16 (&acc)[MT], int xkg0 = 0) {
+  // xkg0: k-group of the weight matrix that column 0 of X corresponds to (X holds a K-slice of the operand)
   constexpr int G = 4;
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const float4* wp = reinterpret_cast<const float4*>(Wp) + (size_t)hh * Npad + col0 + r;
   const size_t wstride = (size_t)2 * Npad;
-  const float* xr = X + r * ldx + 4 * hh;
+  const float* xr = X + r * ldx + 4 * hh - xkg0 * 8;
   float4 bc[G], bn[G];
 #pragma unroll
   for (int j = 0; j < G; ++j) bc[j] = wp[(size_t)min(kg0 + j, kg1 - 1) * wstride];

@@ -213,10 +213,10 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
     float* te1 = c.ws.te1;
     const int Pp = c.L.Pp;
     tile_gemm<2, 2>(&Y[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_E0_W), 256, 8, [&](int row, int col, float v) {
-      if (row0 + row < Pp) te0[(size_t)(row0 + row) * 256 + col] = tanhf(v);
+      if (row0 + row < Pp) te0[(size_t)(row0 + row) * 256 + col] = ds_tanh(v);
     });
     tile_gemm<2, 2>(&Y[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_E1_W), 256, 8, [&](int row, int col, float v) {
-      if (row0 + row < Pp) te1[(size_t)(row0 + row) * 256 + col] = tanhf(v);
+      if (row0 + row < Pp) te1[(size_t)(row0 + row) * 256 + col] = ds_tanh(v);
     });
   }
 }
@@ -338,107 +338,155 @@ __global__ __launch_bounds__(256) void k_attn_agg(Ctx c) {
   c.ws.attn[(size_t)trow * 256 + col] = acc;
 }
 
-// Block stage D (nodes): node2edge partial, gated residual, LN, modulate, FF(256->512->256), gated residual,
-// per-block readout slice (256->64) and the node parts of equi_update.input_lin (256->512).  dmt.py:156-163,387,39-45.
-__global__ __launch_bounds__(256) void k_node_update(Ctx c, int blk) {
-  constexpr int T = 32;
-  __shared__ __attribute__((aligned(16))) float A0[T][256 + DS_LDP];
-  __shared__ __attribute__((aligned(16))) float H2[T][256 + DS_LDP];
-  __shared__ __attribute__((aligned(16))) float F1[T][512 + DS_LDP];
+// Block stage D (nodes, 32 rows): node2edge partial, gated residual, LN, modulate, FF(256->512->256) in two
+// hidden halves (the 256-wide half aliases the attention tile, FF2 accumulators persist in registers), gated residual
+// in place, per-block readout slice (256->64) and the node parts of equi_update.input_lin (256->512).
+// dmt.py:156-163,387,39-45.  66.5 kB LDS -> two workgroups per CU.
+__global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
+  constexpr int T = 32, LD = 256 + DS_LDP;
+  __shared__ __attribute__((aligned(16))) float B1[T][LD];   // attention tile, then FF hidden halves
+  __shared__ __attribute__((aligned(16))) float H2[T][LD];   // normalised residual stream, then h_out in place
   __shared__ int rmol[T];
-  const int tid = threadIdx.x, row0 = blockIdx.x * T;
+  const int tid = threadIdx.x, wave = tid >> 6, row0 = blockIdx.x * T;
   const int Nn = c.L.Nn;
+  const float* ada = c.ws.ada;
   if (tid < T) rmol[tid] = (row0 + tid < Nn) ? c.L.node_mol[row0 + tid] : 0;
-  for (int idx = tid; idx < T * 64; idx += 256) {
-    const int row = idx >> 6, k4 = idx & 63;
-    float4 v = make_float4(0, 0, 0, 0);
-    if (row0 + row < Nn) v = reinterpret_cast<const float4*>(c.ws.attn + (size_t)(row0 + row) * 256)[k4];
-    reinterpret_cast<float4*>(&A0[row][0])[k4] = v;
+  __syncthreads();
+  for (int it = 0; it < 2; ++it) {   // 32 rows x 64 float4: attention output and the gated residual, 4 items in flight
+    float4 va[4], vh[4], vg[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + (it * 4 + u) * 256, row = idx >> 6, k4 = idx & 63;
+      if (row0 + row < Nn) {
+        va[u] = reinterpret_cast<const float4*>(c.ws.attn + (size_t)(row0 + row) * 256)[k4];
+        vh[u] = reinterpret_cast<const float4*>(c.ws.h + (size_t)(row0 + row) * 256)[k4];
+        vg[u] = reinterpret_cast<const float4*>(ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE + 512)[k4];
+      } else {
+        va[u] = vh[u] = vg[u] = make_float4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + (it * 4 + u) * 256, row = idx >> 6, k4 = idx & 63;
+      reinterpret_cast<float4*>(&B1[row][0])[k4] = va[u];
+      float4 r;   // h_in + gate_msa * attn (dmt.py:159)
+      r.x = vh[u].x + vg[u].x * va[u].x; r.y = vh[u].y + vg[u].y * va[u].y;
+      r.z = vh[u].z + vg[u].z * va[u].z; r.w = vh[u].w + vg[u].w * va[u].w;
+      reinterpret_cast<float4*>(&H2[row][0])[k4] = r;
+    }
   }
   __syncthreads();
   {
     float* u = c.ws.u;
-    tile_gemm<1, 1>(&A0[0][0], 256 + DS_LDP, 256, BW(c, blk, DS_BW_N2E_W), 64, 2, [&](int row, int col, float v) {
+    tile_gemm<1, 1>(&B1[0][0], LD, 256, BW(c, blk, DS_BW_N2E_W), 64, 2, [&](int row, int col, float v) {
       if (row0 + row < Nn) u[(size_t)(row0 + row) * 64 + col] = v;
     });
   }
-  for (int idx = tid; idx < T * 256; idx += 256) {   // h_in + gate_msa * attn (dmt.py:159)
-    const int row = idx >> 8, col = idx & 255;
-    float v = 0.0f;
-    if (row0 + row < Nn) {
-      const float* ad = c.ws.ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
-      v = c.ws.h[(size_t)(row0 + row) * 256 + col] + ad[512 + col] * A0[row][col];
-    }
-    H2[row][col] = v;
-  }
-  __syncthreads();
-  for (int row = tid >> 6; row < T; row += 4) {
-    const float* ad = c.ws.ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
+  for (int row = wave; row < T; row += 4) {
+    const float* ad = ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
     ln_mod_row<256>(&H2[row][0], ad + 768, ad + 1024);   // node_shift_mlp, node_scale_mlp (dmt.py:160)
   }
-  __syncthreads();
+  __syncthreads();   // H2 normalised; every wave is done reading B1 (node2edge)
   {
     const float* b1 = BW(c, blk, DS_BW_FF1_B);
-    tile_gemm<1, 1>(&H2[0][0], 256 + DS_LDP, 256, BW(c, blk, DS_BW_FF1_W), 512, 16,
-                    [&](int row, int col, float v) { F1[row][col] = ds_silu(v + b1[col]); });
-  }
-  __syncthreads();
-  {
+    const float* W1 = BW(c, blk, DS_BW_FF1_W);
+    const float* W2 = BW(c, blk, DS_BW_FF2_W);
+    f32x16 acc2[2][1];
+    acc_zero<1>(acc2[0]);
+    acc_zero<1>(acc2[1]);
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {   // this wave's two 32-column chunks of the 256-wide hidden half
+        asm volatile("" ::: "memory");
+        const int ch = wave + 4 * cc;
+        f32x16 acc[1];
+        acc_zero<1>(acc);
+        wave_mma<1>(&H2[0][0], LD, W1, 512, (half * 8 + ch) * 32, 0, 32, acc);
+        acc_foreach<1>(acc, 0, ch * 32, [&](int row, int col, float v) { B1[row][col] = ds_silu(v + b1[half * 256 + col]); });
+      }
+      __syncthreads();
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        asm volatile("" ::: "memory");
+        wave_mma<1>(&B1[0][0], LD, W2, 256, (wave + 4 * cc) * 32, half * 32, half * 32 + 32, acc2[cc], half * 32);
+      }
+      __syncthreads();
+    }
     const float* b2 = BW(c, blk, DS_BW_FF2_B);
     float* h = c.ws.h;
-    const float* ada = c.ws.ada;
-    tile_gemm<1, 1>(&F1[0][0], 512 + DS_LDP, 512, BW(c, blk, DS_BW_FF2_W), 256, 8, [&](int row, int col, float v) {
-      const float* ad = ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
-      const float out = H2[row][col] + ad[1280 + col] * (v + b2[col]);   // node_gate_mlp (dmt.py:162)
-      A0[row][col] = out;
-      if (row0 + row < Nn) h[(size_t)(row0 + row) * 256 + col] = out;
-    });
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+      acc_foreach<1>(acc2[cc], 0, (wave + 4 * cc) * 32, [&](int row, int col, float v) {
+        const float* ad = ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
+        const float out = H2[row][col] + ad[1280 + col] * (v + b2[col]);   // node_gate_mlp (dmt.py:162); in place
+        H2[row][col] = out;
+        if (row0 + row < Nn) h[(size_t)(row0 + row) * 256 + col] = out;
+      });
   }
   __syncthreads();
   {
     const float* br = BW(c, blk, DS_BW_NODE_RO_B);
     float* ah = c.ws.atom_hids;
     float* ac = c.ws.ac;
-    tile_gemm<1, 1>(&A0[0][0], 256 + DS_LDP, 256, BW(c, blk, DS_BW_NODE_RO_W), 64, 2, [&](int row, int col, float v) {
+    tile_gemm<1, 1>(&H2[0][0], LD, 256, BW(c, blk, DS_BW_NODE_RO_W), 64, 2, [&](int row, int col, float v) {
       if (row0 + row < Nn) ah[(size_t)(row0 + row) * 768 + 256 + 64 * blk + col] = v + br[col];
     });
-    tile_gemm<1, 1>(&A0[0][0], 256 + DS_LDP, 256, BW(c, blk, DS_BW_AC_W), 512, 16, [&](int row, int col, float v) {
+    tile_gemm<1, 1>(&H2[0][0], LD, 256, BW(c, blk, DS_BW_AC_W), 512, 16, [&](int row, int col, float v) {
       if (row0 + row < Nn) ac[(size_t)(row0 + row) * 512 + col] = v;
     });
   }
 }
 
-// Block stage E (pairs): h_edge = node2edge(h_a + h_b), gated residual, LN, modulate, FF(64->128->64), gated
-// residual, readout slice (64->16), edge+dist part of equi_update.input_lin (128->256).  dmt.py:156-157,165-169,388.
-__global__ __launch_bounds__(256) void k_edge_update(Ctx c, int blk) {
+// Block stage E (pairs, 64 rows): h_edge = node2edge(h_a + h_b), gated residual, LN, modulate, FF(64->128->64), gated
+// residual in place, readout slice (64->16), edge+dist part of equi_update.input_lin (128->256, contracted from two
+// LDS tiles).  dmt.py:156-157,165-169,388.  68.6 kB LDS -> two workgroups per CU.
+__global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
   constexpr int T = 64;
-  __shared__ __attribute__((aligned(16))) float E2[T][64 + DS_LDP];
+  __shared__ __attribute__((aligned(16))) float E2[T][64 + DS_LDP];   // residual stream, then e_out in place
   __shared__ __attribute__((aligned(16))) float F[T][128 + DS_LDP];
-  __shared__ __attribute__((aligned(16))) float EO[T][128 + DS_LDP];
-  __shared__ int rmol[T];
-  const int tid = threadIdx.x, row0 = blockIdx.x * T;
+  __shared__ __attribute__((aligned(16))) float D[T][64 + DS_LDP];    // CondGaussian features of this block
+  __shared__ int rmol[T], rpa[T], rpb[T];
+  const int tid = threadIdx.x, wave = tid >> 6, row0 = blockIdx.x * T;
   const int Pp = c.L.Pp;
-  if (tid < T) rmol[tid] = (row0 + tid < Pp) ? c.L.pair_mol[row0 + tid] : 0;
+  const float* ada = c.ws.ada;
+  if (tid < T) {
+    const bool ok = row0 + tid < Pp;
+    rmol[tid] = ok ? c.L.pair_mol[row0 + tid] : 0;
+    rpa[tid] = ok ? c.L.pair_a[row0 + tid] : 0;
+    rpb[tid] = ok ? c.L.pair_b[row0 + tid] : 0;
+  }
   __syncthreads();
   {
-    const float* bn = BW(c, blk, DS_BW_N2E_B);
-    for (int idx = tid; idx < T * 64; idx += 256) {
-      const int row = idx >> 6, col = idx & 63;
+    const float4* bn = reinterpret_cast<const float4*>(BW(c, blk, DS_BW_N2E_B));
+    float4 ua[4], ub[4], ve[4], vd[4], vg[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {   // 64 rows x 16 float4, all gathers of this thread in flight together
+      const int idx = tid + u * 256, row = idx >> 4, k4 = idx & 15;
       const int p = row0 + row;
-      float v = 0.0f, dv = 0.0f;
       if (p < Pp) {
-        const float* ad = c.ws.ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
-        const float he = (c.ws.u[(size_t)c.L.pair_a[p] * 64 + col] + c.ws.u[(size_t)c.L.pair_b[p] * 64 + col]) + bn[col];
-        v = c.ws.e[(size_t)p * 64 + col] + ad[128 + col] * he;   // edge_gate_msa (dmt.py:165)
-        dv = c.ws.dist[(size_t)p * 64 + col];
+        ua[u] = reinterpret_cast<const float4*>(c.ws.u + (size_t)rpa[row] * 64)[k4];
+        ub[u] = reinterpret_cast<const float4*>(c.ws.u + (size_t)rpb[row] * 64)[k4];
+        ve[u] = reinterpret_cast<const float4*>(c.ws.e + (size_t)p * 64)[k4];
+        vd[u] = reinterpret_cast<const float4*>(c.ws.dist + (size_t)p * 64)[k4];
+        vg[u] = reinterpret_cast<const float4*>(ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE + 128)[k4];
+      } else {
+        ua[u] = ub[u] = ve[u] = vd[u] = vg[u] = make_float4(0, 0, 0, 0);
       }
-      E2[row][col] = v;
-      EO[row][64 + col] = dv;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + u * 256, row = idx >> 4, k4 = idx & 15;
+      const float4 b = bn[k4];
+      float4 r;   // e_in + edge_gate_msa * node2edge_lin(h_a + h_b) (dmt.py:156-157,165)
+      r.x = ve[u].x + vg[u].x * ((ua[u].x + ub[u].x) + b.x); r.y = ve[u].y + vg[u].y * ((ua[u].y + ub[u].y) + b.y);
+      r.z = ve[u].z + vg[u].z * ((ua[u].z + ub[u].z) + b.z); r.w = ve[u].w + vg[u].w * ((ua[u].w + ub[u].w) + b.w);
+      reinterpret_cast<float4*>(&E2[row][0])[k4] = r;
+      reinterpret_cast<float4*>(&D[row][0])[k4] = vd[u];
     }
   }
   __syncthreads();
-  for (int row = tid >> 6; row < T; row += 4) {
-    const float* ad = c.ws.ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
+  for (int row = wave; row < T; row += 4) {
+    const float* ad = ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
     ln_mod_row<64>(&E2[row][0], ad + 192, ad + 256);   // edge_shift_mlp, edge_scale_mlp (dmt.py:166)
   }
   __syncthreads();
@@ -451,11 +499,10 @@ __global__ __launch_bounds__(256) void k_edge_update(Ctx c, int blk) {
   {
     const float* b4 = BW(c, blk, DS_BW_FF4_B);
     float* e = c.ws.e;
-    const float* ada = c.ws.ada;
     tile_gemm<2, 1>(&F[0][0], 128 + DS_LDP, 128, BW(c, blk, DS_BW_FF4_W), 64, 2, [&](int row, int col, float v) {
       const float* ad = ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
-      const float out = E2[row][col] + ad[320 + col] * (v + b4[col]);   // edge_gate_mlp (dmt.py:168)
-      EO[row][col] = out;
+      const float out = E2[row][col] + ad[320 + col] * (v + b4[col]);   // edge_gate_mlp (dmt.py:168); in place
+      E2[row][col] = out;
       if (row0 + row < Pp) e[(size_t)(row0 + row) * 64 + col] = out;
     });
   }
@@ -463,14 +510,24 @@ __global__ __launch_bounds__(256) void k_edge_update(Ctx c, int blk) {
   {
     const float* br = BW(c, blk, DS_BW_EDGE_RO_B);
     const float* bd = BW(c, blk, DS_BW_ED_B);
+    const float* Wd = BW(c, blk, DS_BW_ED_W);
     float* eh = c.ws.edge_hids;
     float* ed = c.ws.ed;
-    tile_gemm<2, 1>(&EO[0][0], 128 + DS_LDP, 64, BW(c, blk, DS_BW_EDGE_RO_W), 32, 1, [&](int row, int col, float v) {
+    tile_gemm<2, 1>(&E2[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_EDGE_RO_W), 32, 1, [&](int row, int col, float v) {
       if (row0 + row < Pp && col < 16) eh[(size_t)(row0 + row) * 192 + 64 + 16 * blk + col] = v + br[col];
     });
-    tile_gemm<2, 2>(&EO[0][0], 128 + DS_LDP, 128, BW(c, blk, DS_BW_ED_W), 256, 8, [&](int row, int col, float v) {
-      if (row0 + row < Pp) ed[(size_t)(row0 + row) * 256 + col] = v + bd[col];
-    });
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {   // [e_out | dist] (128) -> 256: rows 0-63 of W from E2, rows 64-127 from D
+      asm volatile("" ::: "memory");
+      const int ch = wave + 4 * cc;
+      f32x16 acc[2];
+      acc_zero<2>(acc);
+      wave_mma<2>(&E2[0][0], 64 + DS_LDP, Wd, 256, ch * 32, 0, 8, acc);
+      wave_mma<2>(&D[0][0], 64 + DS_LDP, Wd, 256, ch * 32, 8, 16, acc, 8);
+      acc_foreach<2>(acc, 0, ch * 32, [&](int row, int col, float v) {
+        if (row0 + row < Pp) ed[(size_t)(row0 + row) * 256 + col] = v + bd[col];
+      });
+    }
   }
 }
 

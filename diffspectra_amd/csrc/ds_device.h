@@ -31,9 +31,44 @@ __device__ __forceinline__ float ds_act(float x) {
   return x;
 }
 
+// Cross-lane sums on the DPP path (no LDS crossbar round trips): quad xor-1, quad xor-2, row_half_mirror, row_mirror
+// leave every lane of a 16-lane row holding the row's sum; the wave sum adds the four rows via two more steps.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = row16_sum(v);
+  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));   // xor 16 inside each 32-lane half
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) +
+         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+}
+
+// LayerNorm(no affine, eps 1e-6, biased variance) + modulate on register-resident rows.
+// 256-wide row: one float4 per lane of a wave.  64-wide row: one float4 per lane of a 16-lane DPP row.
+__device__ __forceinline__ float4 ln_mod_reg256(float4 v, float4 sh, float4 sc) {
+  const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
+  v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+  const float var = wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 256.0f);
+  const float rstd = 1.0f / sqrtf(var + 1e-6f);
+  v.x = v.x * rstd * (1.0f + sc.x) + sh.x; v.y = v.y * rstd * (1.0f + sc.y) + sh.y;
+  v.z = v.z * rstd * (1.0f + sc.z) + sh.z; v.w = v.w * rstd * (1.0f + sc.w) + sh.w;
+  return v;
+}
+__device__ __forceinline__ float4 ln_mod_reg64(float4 v, float4 sh, float4 sc) {
+  const float mean = row16_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 64.0f);
+  v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+  const float var = row16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 64.0f);
+  const float rstd = 1.0f / sqrtf(var + 1e-6f);
+  v.x = v.x * rstd * (1.0f + sc.x) + sh.x; v.y = v.y * rstd * (1.0f + sc.y) + sh.y;
+  v.z = v.z * rstd * (1.0f + sc.z) + sh.z; v.w = v.w * rstd * (1.0f + sc.w) + sh.w;
   return v;
 }
 
@@ -156,5 +191,56 @@ __device__ __forceinline__ void ln_mod_row(float* row, const float* __restrict__
     const float var = wave_sum(v * v) * (1.0f / 64.0f);
     const float rstd = 1.0f / sqrtf(var + 1e-6f);
     row[lane] = v * rstd * (1.0f + scale[lane]) + shift[lane];
+  }
+}
+
+// LayerNorm + modulate of a whole LDS tile: wave w owns rows w, w+NWV, ...  The per-row adaLN shift/scale vectors live
+// in global memory (one row of the ada table per molecule); ALL of a wave's rows are requested before the first
+// reduction so the L2/HBM latency is paid once per tile instead of once per row (it was 28 % of k_equi_flat).
+template <int W, int RPW, int NWV>
+__device__ __forceinline__ void ln_mod_tile(float* X, int ldx, const int* rmol, const float* __restrict__ ada, size_t ada_ld,
+                                            int shift_off, int scale_off) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (W == 256) {
+    float4 sh[RPW], sc[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const float* a = ada + (size_t)rmol[wave + NWV * j] * ada_ld;
+      sh[j] = reinterpret_cast<const float4*>(a + shift_off)[lane];
+      sc[j] = reinterpret_cast<const float4*>(a + scale_off)[lane];
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      float* row = X + (size_t)(wave + NWV * j) * ldx;
+      float4 v = reinterpret_cast<float4*>(row)[lane];
+      const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
+      v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+      const float var = wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 256.0f);
+      const float rstd = 1.0f / sqrtf(var + 1e-6f);
+      v.x = v.x * rstd * (1.0f + sc[j].x) + sh[j].x;
+      v.y = v.y * rstd * (1.0f + sc[j].y) + sh[j].y;
+      v.z = v.z * rstd * (1.0f + sc[j].z) + sh[j].z;
+      v.w = v.w * rstd * (1.0f + sc[j].w) + sh[j].w;
+      reinterpret_cast<float4*>(row)[lane] = v;
+    }
+  } else {
+    float sh[RPW], sc[RPW], v[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const float* a = ada + (size_t)rmol[wave + NWV * j] * ada_ld;
+      sh[j] = a[shift_off + lane];
+      sc[j] = a[scale_off + lane];
+      v[j] = X[(size_t)(wave + NWV * j) * ldx + lane];
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {   // independent rows: the reductions of different rows interleave
+      const float mean = wave_sum(v[j]) * (1.0f / 64.0f);
+      v[j] -= mean;
+      const float var = wave_sum(v[j] * v[j]) * (1.0f / 64.0f);
+      const float rstd = 1.0f / sqrtf(var + 1e-6f);
+      v[j] = v[j] * rstd * (1.0f + sc[j]) + sh[j];
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) X[(size_t)(wave + NWV * j) * ldx + lane] = v[j];
   }
 }

@@ -14,6 +14,21 @@
 
 #define ADAC DS_ADA_COLS
 
+// Diagnostic build only (-DDS_STAMPS): per-phase shader-clock sums of wave 0 of every workgroup, accumulated into
+// the tail of ws.flags (64-bit counters at int32 index 16 + 2*phase).  Never compiled into the shipped library.
+#ifdef DS_STAMPS
+#define DS_STAMP_INIT() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
+#define DS_STAMP(i)                                                                                     \
+  do {                                                                                                  \
+    const unsigned long long _t1 = __builtin_amdgcn_s_memtime();                                        \
+    if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(c.ws.flags + 16) + (i), _t1 - _t0); \
+    _t0 = _t1;                                                                                          \
+  } while (0)
+#else
+#define DS_STAMP_INIT()
+#define DS_STAMP(i)
+#endif
+
 namespace {
 
 struct Ctx {  // by-value kernel argument: everything a stage needs
@@ -203,10 +218,7 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
                     [&](int row, int col, float v) { Y[row][col] = v + bias[col]; });
   }
   __syncthreads();
-  for (int row = tid >> 6; row < T; row += 4) {
-    const float* ad = c.ws.ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
-    ln_mod_row<64>(&Y[row][0], ad, ad + 64);   // edge_shift_msa, edge_scale_msa
-  }
+  ln_mod_tile<64, 16, 4>(&Y[0][0], 64 + DS_LDP, rmol, c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE, ADAC, 0, 64);   // edge_shift_msa, edge_scale_msa
   __syncthreads();
   {
     float* te0 = c.ws.te0;
@@ -228,16 +240,27 @@ __global__ __launch_bounds__(256) void k_node_qkv(Ctx c, int blk) {
   __shared__ int rmol[T];
   const int tid = threadIdx.x, row0 = blockIdx.x * T;
   if (tid < T) rmol[tid] = (row0 + tid < c.L.Nn) ? c.L.node_mol[row0 + tid] : 0;
-  for (int idx = tid; idx < T * 64; idx += 256) {
-    const int row = idx >> 6, k4 = idx & 63;
-    float4 v = make_float4(0, 0, 0, 0);
-    if (row0 + row < c.L.Nn) v = reinterpret_cast<const float4*>(c.ws.h + (size_t)(row0 + row) * 256)[k4];
-    reinterpret_cast<float4*>(&X[row][0])[k4] = v;
-  }
   __syncthreads();
-  for (int row = tid >> 6; row < T; row += 4) {
-    const float* ad = c.ws.ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
-    ln_mod_row<256>(&X[row][0], ad, ad + 256);   // node_shift_msa, node_scale_msa
+  {
+    const float* adn = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
+    for (int it = 0; it < 2; ++it) {   // 32 rows x 64 float4; each wave holds whole rows -> LN + modulate in registers
+      float4 v[4], sh[4], sc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = tid + (it * 4 + u) * 256, row = idx >> 6, k4 = idx & 63;
+        v[u] = reinterpret_cast<const float4*>(c.ws.h + (size_t)min(row0 + row, c.L.Nn - 1) * 256)[k4];
+        sh[u] = reinterpret_cast<const float4*>(adn + (size_t)rmol[row] * ADAC)[k4];          // node_shift_msa
+        sc[u] = reinterpret_cast<const float4*>(adn + (size_t)rmol[row] * ADAC + 256)[k4];    // node_scale_msa
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = ln_mod_reg256(v[u], sh[u], sc[u]);   // dmt.py:148
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = tid + (it * 4 + u) * 256, row = idx >> 6, k4 = idx & 63;
+        if (row0 + row >= c.L.Nn) v[u] = make_float4(0, 0, 0, 0);
+        reinterpret_cast<float4*>(&X[row][0])[k4] = v[u];
+      }
+    }
   }
   __syncthreads();
   const float* bias = BW(c, blk, DS_BW_QKV_B);
@@ -352,26 +375,28 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
   const float* ada = c.ws.ada;
   if (tid < T) rmol[tid] = (row0 + tid < Nn) ? c.L.node_mol[row0 + tid] : 0;
   __syncthreads();
-  for (int it = 0; it < 2; ++it) {   // 32 rows x 64 float4: attention output and the gated residual, 4 items in flight
-    float4 va[4], vh[4], vg[4];
+  for (int it = 0; it < 2; ++it) {   // 32 rows x 64 float4; whole rows per wave -> residual, LN, modulate in registers
+    float4 va[4], vh[4], vg[4], sh[4], sc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = tid + (it * 4 + u) * 256, row = idx >> 6, k4 = idx & 63;
-      if (row0 + row < Nn) {
-        va[u] = reinterpret_cast<const float4*>(c.ws.attn + (size_t)(row0 + row) * 256)[k4];
-        vh[u] = reinterpret_cast<const float4*>(c.ws.h + (size_t)(row0 + row) * 256)[k4];
-        vg[u] = reinterpret_cast<const float4*>(ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE + 512)[k4];
-      } else {
-        va[u] = vh[u] = vg[u] = make_float4(0, 0, 0, 0);
-      }
+      const size_t gr = (size_t)min(row0 + row, Nn - 1);   // clamp instead of branching: loads stay batched
+      const float* ad = ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
+      va[u] = reinterpret_cast<const float4*>(c.ws.attn + gr * 256)[k4];
+      vh[u] = reinterpret_cast<const float4*>(c.ws.h + gr * 256)[k4];
+      vg[u] = reinterpret_cast<const float4*>(ad + 512)[k4];    // node_gate_msa
+      sh[u] = reinterpret_cast<const float4*>(ad + 768)[k4];    // node_shift_mlp
+      sc[u] = reinterpret_cast<const float4*>(ad + 1024)[k4];   // node_scale_mlp
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = tid + (it * 4 + u) * 256, row = idx >> 6, k4 = idx & 63;
+      if (row0 + row >= Nn) va[u] = vh[u] = make_float4(0, 0, 0, 0);
       reinterpret_cast<float4*>(&B1[row][0])[k4] = va[u];
       float4 r;   // h_in + gate_msa * attn (dmt.py:159)
       r.x = vh[u].x + vg[u].x * va[u].x; r.y = vh[u].y + vg[u].y * va[u].y;
       r.z = vh[u].z + vg[u].z * va[u].z; r.w = vh[u].w + vg[u].w * va[u].w;
+      r = ln_mod_reg256(r, sh[u], sc[u]);   // norm2_node + modulate (dmt.py:160)
       reinterpret_cast<float4*>(&H2[row][0])[k4] = r;
     }
   }
@@ -381,10 +406,6 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
     tile_gemm<1, 1>(&B1[0][0], LD, 256, BW(c, blk, DS_BW_N2E_W), 64, 2, [&](int row, int col, float v) {
       if (row0 + row < Nn) u[(size_t)(row0 + row) * 64 + col] = v;
     });
-  }
-  for (int row = wave; row < T; row += 4) {
-    const float* ad = ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
-    ln_mod_row<256>(&H2[row][0], ad + 768, ad + 1024);   // node_shift_mlp, node_scale_mlp (dmt.py:160)
   }
   __syncthreads();   // H2 normalised; every wave is done reading B1 (node2edge)
   {
@@ -458,36 +479,33 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
   __syncthreads();
   {
     const float4* bn = reinterpret_cast<const float4*>(BW(c, blk, DS_BW_N2E_B));
-    float4 ua[4], ub[4], ve[4], vd[4], vg[4];
+    float4 ua[4], ub[4], ve[4], vd[4], vg[4], sh[4], sc[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {   // 64 rows x 16 float4, all gathers of this thread in flight together
+    for (int u = 0; u < 4; ++u) {   // 64 rows x 16 float4 (one 16-lane DPP row per tile row), all gathers in flight together
       const int idx = tid + u * 256, row = idx >> 4, k4 = idx & 15;
       const int p = row0 + row;
-      if (p < Pp) {
-        ua[u] = reinterpret_cast<const float4*>(c.ws.u + (size_t)rpa[row] * 64)[k4];
-        ub[u] = reinterpret_cast<const float4*>(c.ws.u + (size_t)rpb[row] * 64)[k4];
-        ve[u] = reinterpret_cast<const float4*>(c.ws.e + (size_t)p * 64)[k4];
-        vd[u] = reinterpret_cast<const float4*>(c.ws.dist + (size_t)p * 64)[k4];
-        vg[u] = reinterpret_cast<const float4*>(ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE + 128)[k4];
-      } else {
-        ua[u] = ub[u] = ve[u] = vd[u] = vg[u] = make_float4(0, 0, 0, 0);
-      }
+      const size_t pc = (size_t)min(p, Pp - 1);   // clamp instead of branching: loads stay batched
+      const float* ad = ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
+      ua[u] = reinterpret_cast<const float4*>(c.ws.u + (size_t)rpa[row] * 64)[k4];
+      ub[u] = reinterpret_cast<const float4*>(c.ws.u + (size_t)rpb[row] * 64)[k4];
+      ve[u] = reinterpret_cast<const float4*>(c.ws.e + pc * 64)[k4];
+      vd[u] = reinterpret_cast<const float4*>(c.ws.dist + pc * 64)[k4];
+      vg[u] = reinterpret_cast<const float4*>(ad + 128)[k4];   // edge_gate_msa
+      sh[u] = reinterpret_cast<const float4*>(ad + 192)[k4];   // edge_shift_mlp
+      sc[u] = reinterpret_cast<const float4*>(ad + 256)[k4];   // edge_scale_mlp
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = tid + u * 256, row = idx >> 4, k4 = idx & 15;
+      if (row0 + row >= Pp) ua[u] = ub[u] = ve[u] = vd[u] = make_float4(0, 0, 0, 0);
       const float4 b = bn[k4];
       float4 r;   // e_in + edge_gate_msa * node2edge_lin(h_a + h_b) (dmt.py:156-157,165)
       r.x = ve[u].x + vg[u].x * ((ua[u].x + ub[u].x) + b.x); r.y = ve[u].y + vg[u].y * ((ua[u].y + ub[u].y) + b.y);
       r.z = ve[u].z + vg[u].z * ((ua[u].z + ub[u].z) + b.z); r.w = ve[u].w + vg[u].w * ((ua[u].w + ub[u].w) + b.w);
+      r = ln_mod_reg64(r, sh[u], sc[u]);   // norm2_edge + modulate (dmt.py:166)
       reinterpret_cast<float4*>(&E2[row][0])[k4] = r;
       reinterpret_cast<float4*>(&D[row][0])[k4] = vd[u];
     }
-  }
-  __syncthreads();
-  for (int row = wave; row < T; row += 4) {
-    const float* ad = ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
-    ln_mod_row<64>(&E2[row][0], ad + 192, ad + 256);   // edge_shift_mlp, edge_scale_mlp (dmt.py:166)
   }
   __syncthreads();
   {
@@ -536,77 +554,91 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
 // The 256->256 GEMM is computed TRANSPOSED (lane = edge row, registers = output features) so that its SiLU'd
 // accumulators are directly the B operand of the 256->3 MFMA: the hidden activations never touch LDS, X is the only
 // large LDS tile (66.5 kB -> two workgroups per CU overlap each other's gather/LN phases with MFMA work).
-__global__ __launch_bounds__(256, 2) void k_equi_flat(Ctx c, int blk) {
-  constexpr int T = 64;
+template <int NW, int T>
+__global__ __launch_bounds__(NW * 64, NW / 2) void k_equi_flat(Ctx c, int blk) {   // two workgroups per CU
+  constexpr int NT = NW * 64, CPW = 8 / NW;   // threads, 32-feature chunks per wave
+  constexpr int MT = T / 32;
   __shared__ __attribute__((aligned(16))) float X[T][256 + DS_LDP];
-  __shared__ __attribute__((aligned(16))) float part[4][T][4];
+  __shared__ __attribute__((aligned(16))) float part[NW][T][4];
   __shared__ __attribute__((aligned(16))) float trans[T][4];
   __shared__ int rsrc[T], rdst[T], rpair[T], rmol[T];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5;
   const int E = 2 * c.L.Pp;
   const int e0 = blockIdx.x * T;
   const int rows = min(T, E - e0);
+  DS_STAMP_INIT();
   if (tid < T) {
-    int sN = -1, dN = 0, pr = 0, m = 0;
+    int sN = 0, dN = 0, pr = 0, m = 0;
     if (tid < rows) {
       sN = c.L.dir_src[e0 + tid]; dN = c.L.dir_dst[e0 + tid]; pr = c.L.dir_pair[e0 + tid];
-      m = c.L.node_mol[sN];
+      m = c.L.dir_mol[e0 + tid];
     }
     rsrc[tid] = sN; rdst[tid] = dN; rpair[tid] = pr; rmol[tid] = m;
   }
-  // per-lane constants of this wave's two 32-feature chunks: coord_mlp.0 bias and the coord_mlp.2 A-fragments
+  __syncthreads();
+  DS_STAMP(0);
+  {
+    const float* adq = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EQUI;
+    // A wave owns RPW whole rows, so their index-table entries are wave-uniform (scalar loads, SALU address math) and
+    // LayerNorm + modulate run in registers (DPP reductions) before the one LDS store: no second pass, no extra barrier.
+    // The gathers of all rows are issued ahead of their first use; the phase is bound by the ~2.7 us memory round trip.
+    constexpr int RPW = T / NW;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    float4 v[RPW];
+    int mm[RPW];
+    {
+      float4 va[RPW], vc[RPW], ve[RPW];
+#pragma unroll
+      for (int u = 0; u < RPW; ++u) {
+        const int row = wv + u * NW;                                 // rows past the end gather edge 0 and are zeroed below
+        const int eg = row < rows ? e0 + row : 0;
+        const int sN = c.L.dir_src[eg], dN = c.L.dir_dst[eg], pr = c.L.dir_pair[eg];
+        mm[u] = c.L.dir_mol[eg];
+        va[u] = reinterpret_cast<const float4*>(c.ws.ac + (size_t)sN * 512)[lane];
+        vc[u] = reinterpret_cast<const float4*>(c.ws.ac + (size_t)dN * 512 + 256)[lane];
+        ve[u] = reinterpret_cast<const float4*>(c.ws.ed + (size_t)pr * 256)[lane];
+      }
+#pragma unroll
+      for (int u = 0; u < RPW; ++u) {
+        v[u].x = (va[u].x + vc[u].x) + ve[u].x; v[u].y = (va[u].y + vc[u].y) + ve[u].y;
+        v[u].z = (va[u].z + vc[u].z) + ve[u].z; v[u].w = (va[u].w + vc[u].w) + ve[u].w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      const float4 sh = reinterpret_cast<const float4*>(adq + (size_t)mm[u] * ADAC)[lane];         // shift (dmt.py:44)
+      const float4 sc = reinterpret_cast<const float4*>(adq + (size_t)mm[u] * ADAC + 256)[lane];   // scale
+      const int row = wv + u * NW;
+      float4 o = ln_mod_reg256(v[u], sh, sc);   // input_lin -> ln -> modulate (dmt.py:45)
+      if (row >= rows) o = make_float4(0, 0, 0, 0);
+      reinterpret_cast<float4*>(&X[row][0])[lane] = o;
+    }
+  }
+  // per-lane constants, requested while the other waves finish their rows
   const float* b0 = BW(c, blk, DS_BW_CM0_B);
   const float* w2 = BW(c, blk, DS_BW_CM2_W);
-  float b0f[2][16], w2f[2][16];
+  float b0f[CPW][16], w2f[CPW][16];
 #pragma unroll
-  for (int cc = 0; cc < 2; ++cc)
+  for (int cc = 0; cc < CPW; ++cc)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int f = (wave + 4 * cc) * 32 + acc_row(i, hh);
+      const int f = (wave + NW * cc) * 32 + acc_row(i, hh);
       b0f[cc][i] = b0[f];
       w2f[cc][i] = (lane & 31) < 3 ? wp_at(w2, 32, f, lane & 31) : 0.0f;
     }
   __syncthreads();
-  for (int it = 0; it < 4; ++it) {   // gather 64 rows x 64 float4, 4 independent items in flight per thread
-    float4 va[4], vc[4], ve[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + (it * 4 + u) * 256;
-      const int row = idx >> 6, k4 = idx & 63;
-      if (row < rows) {
-        va[u] = reinterpret_cast<const float4*>(c.ws.ac + (size_t)rsrc[row] * 512)[k4];
-        vc[u] = reinterpret_cast<const float4*>(c.ws.ac + (size_t)rdst[row] * 512 + 256)[k4];
-        ve[u] = reinterpret_cast<const float4*>(c.ws.ed + (size_t)rpair[row] * 256)[k4];
-      } else {
-        va[u] = vc[u] = ve[u] = make_float4(0, 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + (it * 4 + u) * 256;
-      float4 v;
-      v.x = (va[u].x + vc[u].x) + ve[u].x; v.y = (va[u].y + vc[u].y) + ve[u].y;
-      v.z = (va[u].z + vc[u].z) + ve[u].z; v.w = (va[u].w + vc[u].w) + ve[u].w;
-      reinterpret_cast<float4*>(&X[idx >> 6][0])[idx & 63] = v;
-    }
-  }
-  __syncthreads();
-  for (int row = wave; row < T; row += 4) {
-    const float* ad = c.ws.ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EQUI;
-    ln_mod_row<256>(&X[row][0], ad, ad + 256);   // shift, scale (dmt.py:44-45)
-  }
-  __syncthreads();
+  DS_STAMP(1);
   {
-    f32x16 acc2[2];
-    acc_zero<2>(acc2);
+    f32x16 acc2[MT];
+    acc_zero<MT>(acc2);
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
+    for (int cc = 0; cc < CPW; ++cc) {
       asm volatile("" ::: "memory");   // keep the A-fragment LDS reads inside each chunk (see tile_gemm)
-      f32x16 acc1[2];
-      acc_zero<2>(acc1);
-      wave_mma<2, true>(&X[0][0], 256 + DS_LDP, BW(c, blk, DS_BW_CM0_W), 256, (wave + 4 * cc) * 32, 0, 32, acc1);
+      f32x16 acc1[MT];
+      acc_zero<MT>(acc1);
+      wave_mma<MT, true>(&X[0][0], 256 + DS_LDP, BW(c, blk, DS_BW_CM0_W), 256, (wave + NW * cc) * 32, 0, 32, acc1);
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float y = ds_silu(acc1[m][i] + b0f[cc][i]);                       // coord_mlp.0 + SiLU (dmt.py:32-33)
@@ -615,7 +647,7 @@ __global__ __launch_bounds__(256, 2) void k_equi_flat(Ctx c, int blk) {
     }
     if (hh == 0) {   // out[j][row]: j = register 0..2 of the lower half, row = m*32 + lane
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int m = 0; m < MT; ++m) {
         part[wave][m * 32 + lane][0] = acc2[m][0];
         part[wave][m * 32 + lane][1] = acc2[m][1];
         part[wave][m * 32 + lane][2] = acc2[m][2];
@@ -623,14 +655,19 @@ __global__ __launch_bounds__(256, 2) void k_equi_flat(Ctx c, int blk) {
     }
   }
   __syncthreads();
+  DS_STAMP(2);
   if (tid < T) {
     float tx = 0.0f, ty = 0.0f, tz = 0.0f;
     if (tid < rows) {
       const int bits = c.ws.adj[rpair[tid]];
       float inv[3];
 #pragma unroll
-      for (int hI = 0; hI < 3; ++hI)
-        inv[hI] = tanhf(((part[0][tid][hI] + part[1][tid][hI]) + part[2][tid][hI]) + part[3][tid][hI]);
+      for (int hI = 0; hI < 3; ++hI) {
+        float sacc = part[0][tid][hI];
+#pragma unroll
+        for (int w2i = 1; w2i < NW; ++w2i) sacc += part[w2i][tid][hI];
+        inv[hI] = tanhf(sacc);
+      }
       const float w = ((inv[0] + ((bits & 1) ? inv[1] : 0.0f)) + ((bits & 2) ? inv[2] : 0.0f)) / 3.0f;   // dmt.py:51-53
       const float* pr = c.ws.pos + (size_t)rsrc[tid] * 4;
       const float* pc = c.ws.pos + (size_t)rdst[tid] * 4;
@@ -642,6 +679,7 @@ __global__ __launch_bounds__(256, 2) void k_equi_flat(Ctx c, int blk) {
     trans[tid][0] = tx; trans[tid][1] = ty; trans[tid][2] = tz;
   }
   __syncthreads();
+  DS_STAMP(3);
   // segmented sum over the consecutive rows of one row-atom, then one atomic per (tile, atom): a row-atom's <= 28
   // edges span at most two tiles, so every dpos entry receives at most two adds onto zero — order-independent.
   if (tid < rows && (tid == 0 || rsrc[tid] != rsrc[tid - 1])) {
@@ -651,6 +689,7 @@ __global__ __launch_bounds__(256, 2) void k_equi_flat(Ctx c, int blk) {
     float* dp = c.ws.dpos + (size_t)sN * 4;
     atomicAdd(dp + 0, sx); atomicAdd(dp + 1, sy); atomicAdd(dp + 2, sz);
   }
+  DS_STAMP(4);
 }
 
 // pos += dpos, per-layer CoM removal (dmt.py:58,385-386; models/utils.py:38-45); re-zeroes dpos for the next block.
@@ -1117,7 +1156,7 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   { ProfScope ps(6, s); hipLaunchKernelGGL(k_attn_agg, dim3(L->Nn), dim3(256), 0, s, c); }
   { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3(pt), dim3(256), 0, s, c, blk); }
-  if (pt > 0) { ProfScope ps(5, s); hipLaunchKernelGGL(k_equi_flat, dim3((2 * L->Pp + 63) / 64), dim3(256), 0, s, c, blk); }
+  if (pt > 0) { ProfScope ps(5, s); hipLaunchKernelGGL((k_equi_flat<8, 64>), dim3((2 * L->Pp + 63) / 64), dim3(512), 0, s, c, blk); }
   hipLaunchKernelGGL(k_pos_update, dim3((L->B + 63) / 64), dim3(64), 0, s, c, last);
   return launch_status();
 }

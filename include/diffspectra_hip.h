@@ -109,6 +109,7 @@ typedef struct ds_layout {
   const int32_t* dir_src;            /* [2*Pp] directed edges (r -> c), molecule-major, r-major, c ascending: row atom */
   const int32_t* dir_dst;            /* [2*Pp] col atom (packed node rows) */
   const int32_t* dir_pair;           /* [2*Pp] pair row of {r, c} */
+  const int32_t* dir_mol;            /* [2*Pp] molecule */
 } ds_layout;
 
 typedef struct ds_workspace {        /* all device fp32 unless noted; sizes in floats */
@@ -132,7 +133,7 @@ typedef struct ds_workspace {        /* all device fp32 unless noted; sizes in f
   float* lg;         /* [Pp,2,16] attention logits: [p][0] source a -> target b, [p][1] source b -> target a */
   float* dpos;       /* [Nn,4]   position increments of the current block (zero between blocks) */
   int32_t* adj;      /* [Pp]     bit0: cond_adj_2d, bit1: cond_adj_spatial */
-  int32_t* flags;    /* [8]      0: any nonzero cond distance, 1: NaN in positions */
+  int32_t* flags;    /* [64]     0: any nonzero cond distance, 1: NaN in positions; [16..] diagnostic-build counters */
 } ds_workspace;
 
 /* sizeof() of ds_weights, ds_layout, ds_workspace, ds_gemm_args for the binding's layout self-check: out[0..3]. */

@@ -56,6 +56,13 @@ def main():
         per.append(tot.value / max(1, cnt.value))
     eng.lib.ds_profile_config(C.c_int(-1), C.c_int(1), C.c_int(0))
     print("  per-launch ms: " + ", ".join(f"{n} {t:.3f}" for n, t in zip(names, per)) + f" | block sum {sum(per):.3f}")
+    if os.environ.get("DIFFSPECTRA_HIP_LIB"):
+        ws.t["flags"].zero_()
+        eng.forward(L, ws, x, ex, nl, cx, cex, ctx, out, oute)
+        torch.cuda.synchronize()
+        st = ws.t["flags"][16:64].cpu().view(torch.int64)
+        tot = float(st.sum())
+        print("  stamp shares (wave 0 cycles per phase): " + ", ".join(f"P{i} {float(v) / max(tot, 1):.3f}" for i, v in enumerate(st.tolist()) if v) + f" | total cycles/WG-launch {tot:.3e}")
     print(f"mols {B} Nn {L.Nn} Pp {L.Pp}: {dt * 1e3:.3f} ms/forward, {dt / B * 1e6:.2f} us/mol-step, "
           f"{2 * macs / dt / 1e12:.2f} TFLOP/s algorithmic, {B / dt / 1000:.1f} mol/s @1000 steps")
 

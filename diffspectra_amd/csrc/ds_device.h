@@ -141,6 +141,29 @@ __device__ __forceinline__ void acc_foreach(const f32x16 (&acc)[MT], int row_bas
     for (int i = 0; i < 16; ++i) f(row_base + m * 32 + acc_row(i, hh), col0 + r, acc[m][i]);
 }
 
+// Store a lane's accumulator block to a row-major global matrix: dst points at element (tile row 0, col0) of the
+// destination, LD is its compile-time row stride.  One 64-bit base per lane; the 16*MT row offsets are immediates; full
+// tiles (rows_valid >= 32*MT) take a guard-free path.  f(col_in_chunk_lane, value) -> value applies bias / activation.
+template <int MT, int LD, class F>
+__device__ __forceinline__ void acc_store(const f32x16 (&acc)[MT], float* __restrict__ dst, int rows_valid, F f) {
+  const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+  float* p = dst + (size_t)(4 * hh) * LD + r;
+  if (rows_valid >= 32 * MT) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) p[(m * 32 + (i & 3) + 8 * (i >> 2)) * LD] = f(r, acc[m][i]);
+  } else {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = m * 32 + (i & 3) + 8 * (i >> 2);
+        if (row + 4 * hh < rows_valid) p[row * LD] = f(r, acc[m][i]);
+      }
+  }
+}
+
 // Whole-workgroup tile GEMM: Y = epi(X[ROWS][K] * Wp[:, 0..NCH*32)), ROWS = 32*MTOT.
 // Waves split (column chunk, row tile) work items round-robin; each item is a 32*MT x 32 output block.
 template <int MTOT, int MT, class F>
@@ -158,6 +181,23 @@ __device__ __forceinline__ void tile_gemm(const float* X, int ldx, int K, const 
     acc_zero<MT>(acc);
     wave_mma<MT>(X + rg * MT * 32 * ldx, ldx, Wp, Npad, ch * 32, 0, K >> 3, acc);
     acc_foreach<MT>(acc, rg * MT * 32, ch * 32, epi);
+  }
+}
+
+// Same work split, but the epilogue receives the whole accumulator block: g(chunk, row_group, acc).
+template <int MTOT, int MT, class G>
+__device__ __forceinline__ void tile_gemm_blk(const float* X, int ldx, int K, const float* __restrict__ Wp, int Npad, int nch,
+                                              G g) {
+  static_assert(MTOT % MT == 0, "row tiling");
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  constexpr int RG = MTOT / MT;
+  for (int it = wave; it < nch * RG; it += nw) {
+    const int ch = it / RG, rg = it % RG;
+    asm volatile("" ::: "memory");
+    f32x16 acc[MT];
+    acc_zero<MT>(acc);
+    wave_mma<MT>(X + rg * MT * 32 * ldx, ldx, Wp, Npad, ch * 32, 0, K >> 3, acc);
+    g(ch, rg, acc);
   }
 }
 

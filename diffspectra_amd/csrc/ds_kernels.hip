@@ -194,21 +194,25 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
     rmol[tid] = m;
   }
   __syncthreads();
-  {
-    const float* mean = BW(c, blk, DS_BW_RBF_MEAN);
-    const float* stdv = BW(c, blk, DS_BW_RBF_STD);
-    const float* astd = BW(c, blk, DS_BW_RBF_ASTD);
-    for (int idx = tid; idx < T * 64; idx += 256) {
-      const int row = idx >> 6, k = idx & 63;
-      const int p = row0 + row;
-      float v = 0.0f, ev = 0.0f;
-      if (p < c.L.Pp) {
-        v = rbf_feature(xs[row], k, mean, stdv, astd);
-        ev = c.ws.e[(size_t)p * 64 + k];
-        c.ws.dist[(size_t)p * 64 + k] = v;
-      }
+  {   // thread owns feature k of rows rb, rb+4, ...: its RBF centre/width are constants, the 16 e loads issue together
+    const int k = tid & 63, rb = tid >> 6;
+    const float mk = k ? BW(c, blk, DS_BW_RBF_MEAN)[k - 1] : 0.0f;
+    const float sk = k ? BW(c, blk, DS_BW_RBF_STD)[k - 1] : 1.0f;
+    const float ak = k ? BW(c, blk, DS_BW_RBF_ASTD)[k - 1] : 1.0f;
+    const int Pp = c.L.Pp;
+    float ev[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ev[j] = c.ws.e[(size_t)min(row0 + rb + 4 * j, Pp - 1) * 64 + k];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = rb + 4 * j, p = row0 + row;
+      const float x = xs[row];
+      const float z = __fdividef(x - mk, sk);
+      float v = k ? __fdividef(__expf(-0.5f * (z * z)), ak) : x;   // layers.py:291-295,334 (k = 0 is the raw x')
+      if (p >= Pp) { v = 0.0f; ev[j] = 0.0f; }
       X[row][k] = v;
-      X[row][64 + k] = ev;
+      X[row][64 + k] = ev[j];
+      if (p < Pp) c.ws.dist[(size_t)p * 64 + k] = v;
     }
   }
   __syncthreads();
@@ -221,14 +225,14 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
   ln_mod_tile<64, 16, 4>(&Y[0][0], 64 + DS_LDP, rmol, c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE, ADAC, 0, 64);   // edge_shift_msa, edge_scale_msa
   __syncthreads();
   {
-    float* te0 = c.ws.te0;
-    float* te1 = c.ws.te1;
-    const int Pp = c.L.Pp;
-    tile_gemm<2, 2>(&Y[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_E0_W), 256, 8, [&](int row, int col, float v) {
-      if (row0 + row < Pp) te0[(size_t)(row0 + row) * 256 + col] = ds_tanh(v);
+    float* te0 = c.ws.te0 + (size_t)row0 * 256;
+    float* te1 = c.ws.te1 + (size_t)row0 * 256;
+    const int valid = c.L.Pp - row0;
+    tile_gemm_blk<2, 2>(&Y[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_E0_W), 256, 8, [&](int ch, int, const f32x16 (&acc)[2]) {
+      acc_store<2, 256>(acc, te0 + ch * 32, valid, [](int, float v) { return ds_tanh(v); });   // layers.py:165-166
     });
-    tile_gemm<2, 2>(&Y[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_E1_W), 256, 8, [&](int row, int col, float v) {
-      if (row0 + row < Pp) te1[(size_t)(row0 + row) * 256 + col] = ds_tanh(v);
+    tile_gemm_blk<2, 2>(&Y[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_E1_W), 256, 8, [&](int ch, int, const f32x16 (&acc)[2]) {
+      acc_store<2, 256>(acc, te1 + ch * 32, valid, [](int, float v) { return ds_tanh(v); });   // layers.py:183
     });
   }
 }
@@ -264,10 +268,11 @@ __global__ __launch_bounds__(256) void k_node_qkv(Ctx c, int blk) {
   }
   __syncthreads();
   const float* bias = BW(c, blk, DS_BW_QKV_B);
-  float* qkv = c.ws.qkv;
-  const int Nn = c.L.Nn;
-  tile_gemm<1, 1>(&X[0][0], 256 + DS_LDP, 256, BW(c, blk, DS_BW_QKV_W), 768, 24, [&](int row, int col, float v) {
-    if (row0 + row < Nn) qkv[(size_t)(row0 + row) * 768 + col] = v + bias[col];
+  float* qkv = c.ws.qkv + (size_t)row0 * 768;
+  const int valid = c.L.Nn - row0;
+  tile_gemm_blk<1, 1>(&X[0][0], 256 + DS_LDP, 256, BW(c, blk, DS_BW_QKV_W), 768, 24, [&](int ch, int, const f32x16 (&acc)[1]) {
+    const float b = bias[ch * 32 + (threadIdx.x & 31)];
+    acc_store<1, 768>(acc, qkv + ch * 32, valid, [b](int, float v) { return v + b; });
   });
 }
 
@@ -402,9 +407,9 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
   }
   __syncthreads();
   {
-    float* u = c.ws.u;
-    tile_gemm<1, 1>(&B1[0][0], LD, 256, BW(c, blk, DS_BW_N2E_W), 64, 2, [&](int row, int col, float v) {
-      if (row0 + row < Nn) u[(size_t)(row0 + row) * 64 + col] = v;
+    float* u = c.ws.u + (size_t)row0 * 64;
+    tile_gemm_blk<1, 1>(&B1[0][0], LD, 256, BW(c, blk, DS_BW_N2E_W), 64, 2, [&](int ch, int, const f32x16 (&acc)[1]) {
+      acc_store<1, 64>(acc, u + ch * 32, Nn - row0, [](int, float v) { return v; });
     });
   }
   __syncthreads();   // H2 normalised; every wave is done reading B1 (node2edge)
@@ -435,25 +440,35 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
     }
     const float* b2 = BW(c, blk, DS_BW_FF2_B);
     float* h = c.ws.h;
+    // node_gate_mlp (dmt.py:162) is per molecule: fetch the gate column of the tile's first / last molecule once per lane
+    const int mA = rmol[0], mB = rmol[T - 1];
+    const float* gsec = ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE + 1280;
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-      acc_foreach<1>(acc2[cc], 0, (wave + 4 * cc) * 32, [&](int row, int col, float v) {
-        const float* ad = ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
-        const float out = H2[row][col] + ad[1280 + col] * (v + b2[col]);   // node_gate_mlp (dmt.py:162); in place
+    for (int cc = 0; cc < 2; ++cc) {
+      const int col = (wave + 4 * cc) * 32 + (tid & 31);
+      const float gA = gsec[(size_t)mA * ADAC + col], gB = gsec[(size_t)mB * ADAC + col], bb = b2[col];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = acc_row(i, (tid & 63) >> 5);
+        const int m = rmol[row];
+        const float g = m == mA ? gA : (m == mB ? gB : gsec[(size_t)m * ADAC + col]);
+        const float out = H2[row][col] + g * (acc2[cc][0][i] + bb);   // in place
         H2[row][col] = out;
         if (row0 + row < Nn) h[(size_t)(row0 + row) * 256 + col] = out;
-      });
+      }
+    }
   }
   __syncthreads();
   {
     const float* br = BW(c, blk, DS_BW_NODE_RO_B);
     float* ah = c.ws.atom_hids;
     float* ac = c.ws.ac;
-    tile_gemm<1, 1>(&H2[0][0], LD, 256, BW(c, blk, DS_BW_NODE_RO_W), 64, 2, [&](int row, int col, float v) {
-      if (row0 + row < Nn) ah[(size_t)(row0 + row) * 768 + 256 + 64 * blk + col] = v + br[col];
+    tile_gemm_blk<1, 1>(&H2[0][0], LD, 256, BW(c, blk, DS_BW_NODE_RO_W), 64, 2, [&](int ch, int, const f32x16 (&acc)[1]) {
+      const float b = br[ch * 32 + (threadIdx.x & 31)];
+      acc_store<1, 768>(acc, ah + (size_t)row0 * 768 + 256 + 64 * blk + ch * 32, Nn - row0, [b](int, float v) { return v + b; });
     });
-    tile_gemm<1, 1>(&H2[0][0], LD, 256, BW(c, blk, DS_BW_AC_W), 512, 16, [&](int row, int col, float v) {
-      if (row0 + row < Nn) ac[(size_t)(row0 + row) * 512 + col] = v;
+    tile_gemm_blk<1, 1>(&H2[0][0], LD, 256, BW(c, blk, DS_BW_AC_W), 512, 16, [&](int ch, int, const f32x16 (&acc)[1]) {
+      acc_store<1, 512>(acc, ac + (size_t)row0 * 512 + ch * 32, Nn - row0, [](int, float v) { return v; });
     });
   }
 }
@@ -463,6 +478,7 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
 // LDS tiles).  dmt.py:156-157,165-169,388.  68.6 kB LDS -> two workgroups per CU.
 __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
   constexpr int T = 64;
+  const int lane_ = threadIdx.x & 63;
   __shared__ __attribute__((aligned(16))) float E2[T][64 + DS_LDP];   // residual stream, then e_out in place
   __shared__ __attribute__((aligned(16))) float F[T][128 + DS_LDP];
   __shared__ __attribute__((aligned(16))) float D[T][64 + DS_LDP];    // CondGaussian features of this block
@@ -517,11 +533,22 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
   {
     const float* b4 = BW(c, blk, DS_BW_FF4_B);
     float* e = c.ws.e;
-    tile_gemm<2, 1>(&F[0][0], 128 + DS_LDP, 128, BW(c, blk, DS_BW_FF4_W), 64, 2, [&](int row, int col, float v) {
-      const float* ad = ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
-      const float out = E2[row][col] + ad[320 + col] * (v + b4[col]);   // edge_gate_mlp (dmt.py:168); in place
-      E2[row][col] = out;
-      if (row0 + row < Pp) e[(size_t)(row0 + row) * 64 + col] = out;
+    // edge_gate_mlp (dmt.py:168) is per molecule; a tile of consecutive pair rows touches the first and the last
+    // molecule almost always, so their gate columns are fetched once per lane instead of once per element.
+    const int mA = rmol[0], mB = rmol[T - 1];
+    const float* gsec = ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE + 320;
+    tile_gemm_blk<2, 1>(&F[0][0], 128 + DS_LDP, 128, BW(c, blk, DS_BW_FF4_W), 64, 2, [&](int ch, int rg, const f32x16 (&acc)[1]) {
+      const int col = ch * 32 + (lane_ & 31);
+      const float gA = gsec[(size_t)mA * ADAC + col], gB = gsec[(size_t)mB * ADAC + col], bb = b4[col];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = rg * 32 + acc_row(i, lane_ >> 5);
+        const int m = rmol[row];
+        const float g = m == mA ? gA : (m == mB ? gB : gsec[(size_t)m * ADAC + col]);
+        const float out = E2[row][col] + g * (acc[0][i] + bb);   // in place
+        E2[row][col] = out;
+        if (row0 + row < Pp) e[(size_t)(row0 + row) * 64 + col] = out;
+      }
     });
   }
   __syncthreads();
@@ -542,9 +569,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
       acc_zero<2>(acc);
       wave_mma<2>(&E2[0][0], 64 + DS_LDP, Wd, 256, ch * 32, 0, 8, acc);
       wave_mma<2>(&D[0][0], 64 + DS_LDP, Wd, 256, ch * 32, 8, 16, acc, 8);
-      acc_foreach<2>(acc, 0, ch * 32, [&](int row, int col, float v) {
-        if (row0 + row < Pp) ed[(size_t)(row0 + row) * 256 + col] = v + bd[col];
-      });
+      const float b = bd[ch * 32 + (lane_ & 31)];
+      acc_store<2, 256>(acc, ed + (size_t)row0 * 256 + ch * 32, Pp - row0, [b](int, float v) { return v + b; });
     }
   }
 }

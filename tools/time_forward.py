@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--mols", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--version", default="allspectra")
+    ap.add_argument("--spec", action="store_true", help="also time the SpecFormer conditioning encoder")
     args = ap.parse_args()
     d = torch.device("cuda:0")
     cfg = qm9s_config(args.version, device=d)
@@ -44,6 +45,15 @@ def main():
     dt = (time.perf_counter() - t0) / args.iters
     E = sum(n * (n - 1) for n in n_atoms)
     macs = 8 * (620544 * sum(n_atoms) + 157184 * E + 2492416 * B) + (233216 * sum(n_atoms) + 33088 * E + 1330176 * B)
+    if args.spec:
+        spectra = filler.synthetic_spectra(B, args.version, seed=1)
+        spectra = [t.to(d) for t in spectra] if isinstance(spectra, list) else spectra.to(d)
+        eng.context_embedding(spectra)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng.context_embedding(spectra)
+        torch.cuda.synchronize()
+        print(f"  SpecFormer + cond_lin for {B} molecules: {(time.perf_counter() - t1) * 1e3:.1f} ms (once per 1000 steps)")
     import ctypes as C
     names = ["edge_geom", "node_qkv", "attn_logits", "node_update", "edge_update", "equi_flat", "attn_agg"]
     per = []

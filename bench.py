@@ -8,7 +8,7 @@ Molecules are independent, so ranks own disjoint molecules (weak scaling) and th
 all_gather of the fixed-size result records over RCCL.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     live HIP-event timing of the dominant kernel (k_equi_update) vs the fp32-MFMA peak,
+  "roofline":     live HIP-event timing of the dominant kernel (k_equi_flat) vs the fp32-MFMA peak,
   "cpu_baseline": the CPU oracle (faithful restatement of the reference path) timed on this host on a bounded sample.
 """
 from __future__ import annotations
@@ -65,6 +65,19 @@ def algorithmic_macs(n_atoms) -> int:
     return 8 * (620544 * N + 157184 * E + 2492416 * B) + (233216 * N + 33088 * E + 1330176 * B)
 
 
+def pmc_traffic(kernel: str, mols: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json).
+
+    bench.py cannot run the profiler on itself; the counters are collected with `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` in separate passes of this same workload (tools/pmc_report.py) and scaled per molecule."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        rec = json.load(open(path))[kernel]
+        return rec["bytes_per_launch_per_molecule"] * mols, os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def cpu_baseline(version: str, denoise_steps: int, sample_mols: int = 64, sample_steps: int = 8):
     """Time the CPU oracle (reference algorithm, SpecFormer re-encoded every step as the reference does) on the host."""
     import oracle
@@ -99,11 +112,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mols", type=int, default=2048, help="molecules per GPU per step (one sampling micro-batch)")
+    ap.add_argument("--mols", type=int, default=4096, help="molecules per GPU per step (one sampling micro-batch)")
     ap.add_argument("--denoise-steps", type=int, default=1000)
     ap.add_argument("--spectra", default="allspectra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-kernel", type=int, default=5, help="block-stage kernel timed with HIP events (5 = equi_update)")
+    ap.add_argument("--profile-kernel", type=int, default=5, help="block-stage kernel timed with HIP events (5 = k_equi_flat)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,14 +215,16 @@ def main():
         n = np.asarray(n_atoms, dtype=np.int64)
         E_dir = int((n * (n - 1)).sum())
         kern_ms = tot_ms.value / max(1, samples.value)
-        kernel_names = ["k_edge_geom", "k_node_qkv", "k_attention", "k_node_update", "k_edge_update", "k_equi_update"]
+        kernel_names = ["k_edge_geom", "k_node_qkv", "k_attn_logits", "k_node_update", "k_edge_update", "k_equi_flat", "k_attn_agg"]
         roofline = None
         if samples.value > 0 and args.profile_kernel == 5:
             flop = 2.0 * EQUI_MACS_PER_DIRECTED_EDGE * E_dir
             ach = flop / (kern_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "k_equi_update", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                        "avg_launch_ms": kern_ms, "launches_timed": int(samples.value),
+            traffic, traffic_src = pmc_traffic("k_equi_flat", M)
+            roofline = {"bound": "mfma", "kernel": "k_equi_flat", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                        "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 PMC, separate passes)",
+                        "traffic_source": traffic_src, "avg_launch_ms": kern_ms, "launches_timed": int(samples.value),
                         "algorithmic_flop_per_launch": flop}
         elif samples.value > 0:
             roofline = {"bound": "mfma", "kernel": kernel_names[args.profile_kernel], "avg_launch_ms": kern_ms,

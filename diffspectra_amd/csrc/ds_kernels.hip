@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
 // accumulators are directly the B operand of the 256->3 MFMA: the hidden activations never touch LDS, X is the only
 // large LDS tile (66.5 kB -> two workgroups per CU overlap each other's gather/LN phases with MFMA work).
 template <int NW, int T>
-__global__ __launch_bounds__(NW * 64, NW / 2) void k_equi_flat(Ctx c, int blk) {   // two workgroups per CU
+__global__ __launch_bounds__(NW * 64, T == 64 ? NW / 2 : NW / 4) void k_equi_flat(Ctx c, int blk) {   // 2 (T=64) or 1 workgroups per CU
   constexpr int NT = NW * 64, CPW = 8 / NW;   // threads, 32-feature chunks per wave
   constexpr int MT = T / 32;
   __shared__ __attribute__((aligned(16))) float X[T][256 + DS_LDP];
@@ -608,36 +608,37 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_equi_flat(Ctx c, int blk) {
     // A wave owns RPW whole rows, so their index-table entries are wave-uniform (scalar loads, SALU address math) and
     // LayerNorm + modulate run in registers (DPP reductions) before the one LDS store: no second pass, no extra barrier.
     // The gathers of all rows are issued ahead of their first use; the phase is bound by the ~2.7 us memory round trip.
-    constexpr int RPW = T / NW;
+    constexpr int RPW = T / NW, BATCH = RPW < 8 ? RPW : 8;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    float4 v[RPW];
-    int mm[RPW];
-    {
-      float4 va[RPW], vc[RPW], ve[RPW];
+    for (int b0 = 0; b0 < RPW; b0 += BATCH) {
+      float4 va[BATCH], vc[BATCH], ve[BATCH], sh[BATCH], sc[BATCH];
+      int sN[BATCH], dN[BATCH], pr[BATCH], mm[BATCH];
 #pragma unroll
-      for (int u = 0; u < RPW; ++u) {
-        const int row = wv + u * NW;                                 // rows past the end gather edge 0 and are zeroed below
+      for (int u = 0; u < BATCH; ++u) {   // wave-uniform index-table entries: scalar loads, issued together
+        const int row = wv + (b0 + u) * NW;                          // rows past the end gather edge 0 and are zeroed below
         const int eg = row < rows ? e0 + row : 0;
-        const int sN = c.L.dir_src[eg], dN = c.L.dir_dst[eg], pr = c.L.dir_pair[eg];
-        mm[u] = c.L.dir_mol[eg];
-        va[u] = reinterpret_cast<const float4*>(c.ws.ac + (size_t)sN * 512)[lane];
-        vc[u] = reinterpret_cast<const float4*>(c.ws.ac + (size_t)dN * 512 + 256)[lane];
-        ve[u] = reinterpret_cast<const float4*>(c.ws.ed + (size_t)pr * 256)[lane];
+        sN[u] = c.L.dir_src[eg]; dN[u] = c.L.dir_dst[eg]; pr[u] = c.L.dir_pair[eg]; mm[u] = c.L.dir_mol[eg];
       }
+      __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks every load next to its use (load -> wait -> LN per row)
 #pragma unroll
-      for (int u = 0; u < RPW; ++u) {
-        v[u].x = (va[u].x + vc[u].x) + ve[u].x; v[u].y = (va[u].y + vc[u].y) + ve[u].y;
-        v[u].z = (va[u].z + vc[u].z) + ve[u].z; v[u].w = (va[u].w + vc[u].w) + ve[u].w;
+      for (int u = 0; u < BATCH; ++u) {   // 5*BATCH independent 1-kB row loads in flight: one memory round trip per batch
+        va[u] = reinterpret_cast<const float4*>(c.ws.ac + (size_t)sN[u] * 512)[lane];
+        vc[u] = reinterpret_cast<const float4*>(c.ws.ac + (size_t)dN[u] * 512 + 256)[lane];
+        ve[u] = reinterpret_cast<const float4*>(c.ws.ed + (size_t)pr[u] * 256)[lane];
+        sh[u] = reinterpret_cast<const float4*>(adq + (size_t)mm[u] * ADAC)[lane];          // shift (dmt.py:44)
+        sc[u] = reinterpret_cast<const float4*>(adq + (size_t)mm[u] * ADAC + 256)[lane];    // scale
       }
-    }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < RPW; ++u) {
-      const float4 sh = reinterpret_cast<const float4*>(adq + (size_t)mm[u] * ADAC)[lane];         // shift (dmt.py:44)
-      const float4 sc = reinterpret_cast<const float4*>(adq + (size_t)mm[u] * ADAC + 256)[lane];   // scale
-      const int row = wv + u * NW;
-      float4 o = ln_mod_reg256(v[u], sh, sc);   // input_lin -> ln -> modulate (dmt.py:45)
-      if (row >= rows) o = make_float4(0, 0, 0, 0);
-      reinterpret_cast<float4*>(&X[row][0])[lane] = o;
+      for (int u = 0; u < BATCH; ++u) {
+        const int row = wv + (b0 + u) * NW;
+        float4 v;
+        v.x = (va[u].x + vc[u].x) + ve[u].x; v.y = (va[u].y + vc[u].y) + ve[u].y;
+        v.z = (va[u].z + vc[u].z) + ve[u].z; v.w = (va[u].w + vc[u].w) + ve[u].w;
+        v = ln_mod_reg256(v, sh[u], sc[u]);   // input_lin -> ln -> modulate (dmt.py:45)
+        if (row >= rows) v = make_float4(0, 0, 0, 0);
+        reinterpret_cast<float4*>(&X[row][0])[lane] = v;
+      }
     }
   }
   // per-lane constants, requested while the other waves finish their rows

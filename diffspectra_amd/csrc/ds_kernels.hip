@@ -575,73 +575,68 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
   }
 }
 
-// Block stage F (flat tiles of 64 directed edges r -> c): MultiCondEquiUpdate.  dmt.py:37-60; layers.py:344-347.
-// x = A_r + C_c + ed_{rc} -> LN -> modulate -> [256->256, SiLU] -> [256->3] -> tanh -> head mix -> CoorsNorm -> sum over c.
+// Block stage F (flat tiles of 32 pairs = 64 directed edges): MultiCondEquiUpdate.  dmt.py:37-60; layers.py:344-347.
+// Tile row 2q is pair q's edge a -> b, row 2q+1 its edge b -> a, so one gather of ed_p, ac[a], ac[b] and one adaLN row
+// serve both directions (ed is read from HBM once per step instead of twice).
+// x = A_r + C_c + ed_{rc} -> LN -> modulate -> [256->256, SiLU] -> [256->3] -> tanh -> head mix -> CoorsNorm; the per-edge
+// translation vectors go to tr[2p + dir] and k_pos_update sums them per atom in the reference's edge order.
 // The 256->256 GEMM is computed TRANSPOSED (lane = edge row, registers = output features) so that its SiLU'd
 // accumulators are directly the B operand of the 256->3 MFMA: the hidden activations never touch LDS, X is the only
 // large LDS tile (66.5 kB -> two workgroups per CU overlap each other's gather/LN phases with MFMA work).
-template <int NW, int T>
-__global__ __launch_bounds__(NW * 64, T == 64 ? NW / 2 : NW / 4) void k_equi_flat(Ctx c, int blk) {   // 2 (T=64) or 1 workgroups per CU
-  constexpr int NT = NW * 64, CPW = 8 / NW;   // threads, 32-feature chunks per wave
-  constexpr int MT = T / 32;
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void k_equi_pairs(Ctx c, int blk) {
+  constexpr int T = 64, TP = 32, MT = 2, CPW = 8 / NW, PPW = TP / NW;   // rows, pairs, m-tiles, chunks / pairs per wave
   __shared__ __attribute__((aligned(16))) float X[T][256 + DS_LDP];
   __shared__ __attribute__((aligned(16))) float part[NW][T][4];
-  __shared__ __attribute__((aligned(16))) float trans[T][4];
-  __shared__ int rsrc[T], rdst[T], rpair[T], rmol[T];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5;
-  const int E = 2 * c.L.Pp;
-  const int e0 = blockIdx.x * T;
-  const int rows = min(T, E - e0);
+  const int Pp = c.L.Pp;
+  const int p0 = blockIdx.x * TP;
+  const int npairs = min(TP, Pp - p0);
   DS_STAMP_INIT();
-  if (tid < T) {
-    int sN = 0, dN = 0, pr = 0, m = 0;
-    if (tid < rows) {
-      sN = c.L.dir_src[e0 + tid]; dN = c.L.dir_dst[e0 + tid]; pr = c.L.dir_pair[e0 + tid];
-      m = c.L.dir_mol[e0 + tid];
-    }
-    rsrc[tid] = sN; rdst[tid] = dN; rpair[tid] = pr; rmol[tid] = m;
-  }
-  __syncthreads();
-  DS_STAMP(0);
   {
     const float* adq = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EQUI;
-    // A wave owns RPW whole rows, so their index-table entries are wave-uniform (scalar loads, SALU address math) and
+    // A wave owns whole rows, so the pair-table entries are wave-uniform (scalar loads, SALU address math) and
     // LayerNorm + modulate run in registers (DPP reductions) before the one LDS store: no second pass, no extra barrier.
-    // The gathers of all rows are issued ahead of their first use; the phase is bound by the ~2.7 us memory round trip.
-    constexpr int RPW = T / NW, BATCH = RPW < 8 ? RPW : 8;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    for (int b0 = 0; b0 < RPW; b0 += BATCH) {
-      float4 va[BATCH], vc[BATCH], ve[BATCH], sh[BATCH], sc[BATCH];
-      int sN[BATCH], dN[BATCH], pr[BATCH], mm[BATCH];
+    constexpr int BATCH = PPW < 2 ? PPW : 2;
+    for (int b0 = 0; b0 < PPW; b0 += BATCH) {
+      float4 Aa[BATCH], Ca[BATCH], Ab[BATCH], Cb[BATCH], ve[BATCH], sh[BATCH], sc[BATCH];
+      int na[BATCH], nb[BATCH], pm[BATCH], pp[BATCH];
 #pragma unroll
-      for (int u = 0; u < BATCH; ++u) {   // wave-uniform index-table entries: scalar loads, issued together
-        const int row = wv + (b0 + u) * NW;                          // rows past the end gather edge 0 and are zeroed below
-        const int eg = row < rows ? e0 + row : 0;
-        sN[u] = c.L.dir_src[eg]; dN[u] = c.L.dir_dst[eg]; pr[u] = c.L.dir_pair[eg]; mm[u] = c.L.dir_mol[eg];
+      for (int u = 0; u < BATCH; ++u) {
+        const int q = wv + (b0 + u) * NW;                              // pairs past the end gather pair 0, zeroed below
+        pp[u] = q < npairs ? p0 + q : 0;
+        na[u] = c.L.pair_a[pp[u]]; nb[u] = c.L.pair_b[pp[u]]; pm[u] = c.L.pair_mol[pp[u]];
       }
       __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks every load next to its use (load -> wait -> LN per row)
 #pragma unroll
-      for (int u = 0; u < BATCH; ++u) {   // 5*BATCH independent 1-kB row loads in flight: one memory round trip per batch
-        va[u] = reinterpret_cast<const float4*>(c.ws.ac + (size_t)sN[u] * 512)[lane];
-        vc[u] = reinterpret_cast<const float4*>(c.ws.ac + (size_t)dN[u] * 512 + 256)[lane];
-        ve[u] = reinterpret_cast<const float4*>(c.ws.ed + (size_t)pr[u] * 256)[lane];
-        sh[u] = reinterpret_cast<const float4*>(adq + (size_t)mm[u] * ADAC)[lane];          // shift (dmt.py:44)
-        sc[u] = reinterpret_cast<const float4*>(adq + (size_t)mm[u] * ADAC + 256)[lane];    // scale
+      for (int u = 0; u < BATCH; ++u) {   // 7 independent 1-kB row loads per pair in flight
+        const float4* ra = reinterpret_cast<const float4*>(c.ws.ac + (size_t)na[u] * 512);
+        const float4* rb = reinterpret_cast<const float4*>(c.ws.ac + (size_t)nb[u] * 512);
+        Aa[u] = ra[lane]; Ca[u] = ra[64 + lane]; Ab[u] = rb[lane]; Cb[u] = rb[64 + lane];
+        ve[u] = reinterpret_cast<const float4*>(c.ws.ed + (size_t)pp[u] * 256)[lane];
+        sh[u] = reinterpret_cast<const float4*>(adq + (size_t)pm[u] * ADAC)[lane];          // shift (dmt.py:44)
+        sc[u] = reinterpret_cast<const float4*>(adq + (size_t)pm[u] * ADAC + 256)[lane];    // scale
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
-        const int row = wv + (b0 + u) * NW;
-        float4 v;
-        v.x = (va[u].x + vc[u].x) + ve[u].x; v.y = (va[u].y + vc[u].y) + ve[u].y;
-        v.z = (va[u].z + vc[u].z) + ve[u].z; v.w = (va[u].w + vc[u].w) + ve[u].w;
-        v = ln_mod_reg256(v, sh[u], sc[u]);   // input_lin -> ln -> modulate (dmt.py:45)
-        if (row >= rows) v = make_float4(0, 0, 0, 0);
-        reinterpret_cast<float4*>(&X[row][0])[lane] = v;
+        const int q = wv + (b0 + u) * NW;
+        float4 x1, x2;   // row a -> b: input_lin([h_a, h_b, e, d]);  row b -> a: input_lin([h_b, h_a, e, d])  (dmt.py:39,45)
+        x1.x = (Aa[u].x + Cb[u].x) + ve[u].x; x1.y = (Aa[u].y + Cb[u].y) + ve[u].y;
+        x1.z = (Aa[u].z + Cb[u].z) + ve[u].z; x1.w = (Aa[u].w + Cb[u].w) + ve[u].w;
+        x2.x = (Ab[u].x + Ca[u].x) + ve[u].x; x2.y = (Ab[u].y + Ca[u].y) + ve[u].y;
+        x2.z = (Ab[u].z + Ca[u].z) + ve[u].z; x2.w = (Ab[u].w + Ca[u].w) + ve[u].w;
+        x1 = ln_mod_reg256(x1, sh[u], sc[u]);
+        x2 = ln_mod_reg256(x2, sh[u], sc[u]);
+        if (q >= npairs) x1 = x2 = make_float4(0, 0, 0, 0);
+        reinterpret_cast<float4*>(&X[2 * q][0])[lane] = x1;
+        reinterpret_cast<float4*>(&X[2 * q + 1][0])[lane] = x2;
       }
     }
   }
-  // per-lane constants, requested while the other waves finish their rows
+  // per-lane constants of this wave's 32-feature chunks (coord_mlp.0 bias, coord_mlp.2 A-fragments), requested while the
+  // other waves finish their rows
   const float* b0 = BW(c, blk, DS_BW_CM0_B);
   const float* w2 = BW(c, blk, DS_BW_CM2_W);
   float b0f[CPW][16], w2f[CPW][16];
@@ -654,7 +649,7 @@ __global__ __launch_bounds__(NW * 64, T == 64 ? NW / 2 : NW / 4) void k_equi_fla
       w2f[cc][i] = (lane & 31) < 3 ? wp_at(w2, 32, f, lane & 31) : 0.0f;
     }
   __syncthreads();
-  DS_STAMP(1);
+  DS_STAMP(0);
   {
     f32x16 acc2[MT];
     acc_zero<MT>(acc2);
@@ -682,66 +677,61 @@ __global__ __launch_bounds__(NW * 64, T == 64 ? NW / 2 : NW / 4) void k_equi_fla
     }
   }
   __syncthreads();
-  DS_STAMP(2);
-  if (tid < T) {
-    float tx = 0.0f, ty = 0.0f, tz = 0.0f;
-    if (tid < rows) {
-      const int bits = c.ws.adj[rpair[tid]];
-      float inv[3];
+  DS_STAMP(1);
+  if (tid < T && (tid >> 1) < npairs) {
+    const int p = p0 + (tid >> 1), dir = tid & 1;
+    const int na = c.L.pair_a[p], nb = c.L.pair_b[p];
+    const int bits = c.ws.adj[p];
+    float inv[3];
 #pragma unroll
-      for (int hI = 0; hI < 3; ++hI) {
-        float sacc = part[0][tid][hI];
+    for (int hI = 0; hI < 3; ++hI) {
+      float sacc = part[0][tid][hI];
 #pragma unroll
-        for (int w2i = 1; w2i < NW; ++w2i) sacc += part[w2i][tid][hI];
-        inv[hI] = tanhf(sacc);
-      }
-      const float w = ((inv[0] + ((bits & 1) ? inv[1] : 0.0f)) + ((bits & 2) ? inv[2] : 0.0f)) / 3.0f;   // dmt.py:51-53
-      const float* pr = c.ws.pos + (size_t)rsrc[tid] * 4;
-      const float* pc = c.ws.pos + (size_t)rdst[tid] * 4;
-      const float dx = pr[0] - pc[0], dy = pr[1] - pc[1], dz = pr[2] - pc[2];
-      const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);   // layers.py:345-346
-      const float cscale = BW(c, blk, DS_BW_COORD_SCALE)[0];
-      tx = (dx / nrm * cscale) * w; ty = (dy / nrm * cscale) * w; tz = (dz / nrm * cscale) * w;
+      for (int w2i = 1; w2i < NW; ++w2i) sacc += part[w2i][tid][hI];
+      inv[hI] = tanhf(sacc);
     }
-    trans[tid][0] = tx; trans[tid][1] = ty; trans[tid][2] = tz;
+    const float w = ((inv[0] + ((bits & 1) ? inv[1] : 0.0f)) + ((bits & 2) ? inv[2] : 0.0f)) / 3.0f;   // dmt.py:51-53
+    const float* pr = c.ws.pos + (size_t)(dir ? nb : na) * 4;   // row atom (edge_index[0])
+    const float* pc = c.ws.pos + (size_t)(dir ? na : nb) * 4;
+    const float dx = pr[0] - pc[0], dy = pr[1] - pc[1], dz = pr[2] - pc[2];
+    const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);   // layers.py:345-346
+    const float cscale = BW(c, blk, DS_BW_COORD_SCALE)[0];
+    float4 t;
+    t.x = (dx / nrm * cscale) * w; t.y = (dy / nrm * cscale) * w; t.z = (dz / nrm * cscale) * w; t.w = 0.0f;
+    reinterpret_cast<float4*>(c.ws.tr)[(size_t)p * 2 + dir] = t;   // coord_diff * inv (dmt.py:56)
   }
-  __syncthreads();
-  DS_STAMP(3);
-  // segmented sum over the consecutive rows of one row-atom, then one atomic per (tile, atom): a row-atom's <= 28
-  // edges span at most two tiles, so every dpos entry receives at most two adds onto zero — order-independent.
-  if (tid < rows && (tid == 0 || rsrc[tid] != rsrc[tid - 1])) {
-    const int sN = rsrc[tid];
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    for (int r2 = tid; r2 < rows && rsrc[r2] == sN; ++r2) { sx += trans[r2][0]; sy += trans[r2][1]; sz += trans[r2][2]; }
-    float* dp = c.ws.dpos + (size_t)sN * 4;
-    atomicAdd(dp + 0, sx); atomicAdd(dp + 1, sy); atomicAdd(dp + 2, sz);
-  }
-  DS_STAMP(4);
+  DS_STAMP(2);
 }
 
-// pos += dpos, per-layer CoM removal (dmt.py:58,385-386; models/utils.py:38-45); re-zeroes dpos for the next block.
-__global__ void k_pos_update(Ctx c, int last) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= c.L.B) return;
+// One wave per molecule: pos_r += sum_c trans(r -> c) in ascending c (the reference's scatter-add order, dmt.py:57-58),
+// then the per-layer CoM removal (dmt.py:385-386; models/utils.py:38-45).
+__global__ __launch_bounds__(64) void k_pos_update(Ctx c, int last) {
+  const int m = blockIdx.x, r = threadIdx.x;
   const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
-  float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-  for (int a = 0; a < n; ++a) {
-    float* pp = c.ws.pos + (size_t)(n0 + a) * 4;
-    float* dp = c.ws.dpos + (size_t)(n0 + a) * 4;
-    const float x = pp[0] + dp[0], y = pp[1] + dp[1], z = pp[2] + dp[2];
-    pp[0] = x; pp[1] = y; pp[2] = z;
-    dp[0] = 0.0f; dp[1] = 0.0f; dp[2] = 0.0f;
-    sx += x; sy += y; sz += z;
+  const int p0 = c.L.pair_off[m];
+  if (n <= 0) return;
+  float x = 0.0f, y = 0.0f, z = 0.0f;
+  if (r < n) {
+    const float4* tr = reinterpret_cast<const float4*>(c.ws.tr);
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    for (int cc = 0; cc < n; ++cc) {
+      if (cc == r) continue;
+      const int lo = r < cc ? r : cc, hi = r < cc ? cc : r;
+      const int pl = lo * (2 * n - lo - 1) / 2 + (hi - lo - 1);
+      const float4 t = tr[(size_t)(p0 + pl) * 2 + (r < cc ? 0 : 1)];
+      sx += t.x; sy += t.y; sz += t.z;
+    }
+    const float* pp = c.ws.pos + (size_t)(n0 + r) * 4;
+    x = pp[0] + sx; y = pp[1] + sy; z = pp[2] + sz;
   }
   const float fn = (float)n;
-  bool bad = false;
-  for (int a = 0; a < n; ++a) {
-    float* pp = c.ws.pos + (size_t)(n0 + a) * 4;
-    const float x = pp[0] - sx / fn, y = pp[1] - sy / fn, z = pp[2] - sz / fn;
-    pp[0] = x; pp[1] = y; pp[2] = z;
-    bad = bad || isnan(x) || isnan(y) || isnan(z);
+  const float mx = wave_sum(x) / fn, my = wave_sum(y) / fn, mz = wave_sum(z) / fn;
+  if (r < n) {
+    float* pp = c.ws.pos + (size_t)(n0 + r) * 4;
+    const float ox = x - mx, oy = y - my, oz = z - mz;
+    pp[0] = ox; pp[1] = oy; pp[2] = oz;
+    if (last && (isnan(ox) || isnan(oy) || isnan(oz))) atomicOr(&c.ws.flags[1], 1);
   }
-  if (last && bad) atomicOr(&c.ws.flags[1], 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1093,7 +1083,7 @@ int gemm_simple(const float* A, int64_t lda, const float* Wp, const float* bias,
 
 // ---- optional HIP-event timing of one block-stage kernel (bench.py's live roofline measurement) ----
 struct ProfState {
-  int kernel = -1;          // 0 edge_geom, 1 node_qkv, 2 attn_logits, 3 node_update, 4 edge_update, 5 equi_flat, 6 attn_agg
+  int kernel = -1;          // 0 edge_geom, 1 node_qkv, 2 attn_logits, 3 node_update, 4 edge_update, 5 equi_pairs, 6 attn_agg
   int every = 1;
   long long seen = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
@@ -1165,7 +1155,6 @@ int ds_stage_init(const ds_weights* w, const ds_layout* L, ds_workspace* ws, con
   Ctx c;
   if (!make_ctx(c, w, L, ws, s) || !xh || !edge_x || ((cond_x == nullptr) != (cond_edge_x == nullptr))) return DS_ERR_ARG;
   if (hipMemsetAsync(ws->flags, 0, 8 * sizeof(int32_t), s) != hipSuccess) return DS_ERR_LAUNCH;
-  if (hipMemsetAsync(ws->dpos, 0, (size_t)(L->Nn > 0 ? L->Nn : 1) * 4 * sizeof(float), s) != hipSuccess) return DS_ERR_LAUNCH;
   if (L->Pp > 0) hipLaunchKernelGGL(k_pair_flags, dim3((L->Pp + 255) / 256), dim3(256), 0, s, c, cond_x, cond_edge_x);
   hipLaunchKernelGGL(k_node_init, dim3(L->Nn), dim3(256), 0, s, c, xh, cond_x);
   if (L->Pp > 0) hipLaunchKernelGGL(k_pair_init, dim3((L->Pp + 63) / 64), dim3(256), 0, s, c, edge_x, cond_x, cond_edge_x);
@@ -1183,8 +1172,8 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   { ProfScope ps(6, s); hipLaunchKernelGGL(k_attn_agg, dim3(L->Nn), dim3(256), 0, s, c); }
   { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3(pt), dim3(256), 0, s, c, blk); }
-  if (pt > 0) { ProfScope ps(5, s); hipLaunchKernelGGL((k_equi_flat<8, 64>), dim3((2 * L->Pp + 63) / 64), dim3(512), 0, s, c, blk); }
-  hipLaunchKernelGGL(k_pos_update, dim3((L->B + 63) / 64), dim3(64), 0, s, c, last);
+  if (pt > 0) { ProfScope ps(5, s); hipLaunchKernelGGL(k_equi_pairs<8>, dim3((L->Pp + 31) / 32), dim3(512), 0, s, c, blk); }
+  hipLaunchKernelGGL(k_pos_update, dim3(L->B), dim3(64), 0, s, c, last);
   return launch_status();
 }
 

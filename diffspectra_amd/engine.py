@@ -69,12 +69,11 @@ class DsLayout(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("Nn", C.c_int32), ("Pp", C.c_int32),
                 ("max_n", C.c_int32), ("_pad", C.c_int32),
                 ("node_off", C.c_void_p), ("pair_off", C.c_void_p), ("node_dense", C.c_void_p),
-                ("node_mol", C.c_void_p), ("pair_a", C.c_void_p), ("pair_b", C.c_void_p), ("pair_mol", C.c_void_p),
-                ("dir_src", C.c_void_p), ("dir_dst", C.c_void_p), ("dir_pair", C.c_void_p), ("dir_mol", C.c_void_p)]
+                ("node_mol", C.c_void_p), ("pair_a", C.c_void_p), ("pair_b", C.c_void_p), ("pair_mol", C.c_void_p)]
 
 
 _WS_FIELDS = ["pos", "h", "e", "atom_hids", "edge_hids", "tfeat", "tmid", "temb_silu", "ada", "qkv", "te0", "te1",
-              "dist", "attn", "u", "ac", "ed", "lg", "dpos", "adj", "flags"]
+              "dist", "attn", "u", "ac", "ed", "lg", "tr", "adj", "flags"]
 
 
 class DsWorkspace(C.Structure):
@@ -276,22 +275,16 @@ class Layout:
         bb, ii = np.nonzero(valid)                                   # row-major → molecule-major, index-ascending
         node_dense = (bb * N + ii).astype(np.int32)
         node_mol = bb.astype(np.int32)
-        pa, pb, pm, ds_, dd_, dp_, dm_ = [], [], [], [], [], [], []
+        pa, pb, pm = [], [], []
         tri_cache = {}
         for m in range(B):
             n = int(n_atoms[m])
             if n < 2:
                 continue
             if n not in tri_cache:
-                a, b = np.triu_indices(n, 1)                         # (a asc, b asc): p = a(2n-a-1)/2 + (b-a-1)
-                r = np.repeat(np.arange(n), n - 1)                   # directed edges r -> c, r-major, c ascending
-                cc = np.tile(np.arange(n - 1), n)
-                cc = cc + (cc >= r)
-                lo, hi = np.minimum(r, cc), np.maximum(r, cc)
-                tri_cache[n] = (a, b, r, cc, lo * (2 * n - lo - 1) // 2 + (hi - lo - 1))
-            a, b, r, cc, pl = tri_cache[n]
+                tri_cache[n] = np.triu_indices(n, 1)                 # (a asc, b asc): p = a(2n-a-1)/2 + (b-a-1)
+            a, b = tri_cache[n]
             pa.append(a + node_off[m]); pb.append(b + node_off[m]); pm.append(np.full(a.shape, m))
-            ds_.append(r + node_off[m]); dd_.append(cc + node_off[m]); dp_.append(pl + pair_off[m]); dm_.append(np.full(r.shape, m))
         cat = lambda xs: np.concatenate(xs).astype(np.int32) if xs else np.zeros(0, np.int32)
         self.B, self.N, self.Nn, self.Pp = B, N, int(node_off[-1]), int(pair_off[-1])
         self.max_n = int(n_atoms.max(initial=0))
@@ -300,7 +293,7 @@ class Layout:
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         self.t = dict(node_off=dev(node_off.astype(np.int32)), pair_off=dev(pair_off.astype(np.int32)),
                       node_dense=dev(node_dense), node_mol=dev(node_mol), pair_a=dev(cat(pa)), pair_b=dev(cat(pb)),
-                      pair_mol=dev(cat(pm)), dir_src=dev(cat(ds_)), dir_dst=dev(cat(dd_)), dir_pair=dev(cat(dp_)), dir_mol=dev(cat(dm_)))
+                      pair_mol=dev(cat(pm)))
         self.c = DsLayout(B=B, N=N, Nn=self.Nn, Pp=self.Pp, max_n=self.max_n, _pad=0,
                           **{k: v.data_ptr() for k, v in self.t.items()})
 
@@ -320,7 +313,7 @@ class Workspace:
         self.t = dict(pos=f(Nn, 4), h=f(Nn, 256), e=f(Pp, 64), atom_hids=f(Nn, 768), edge_hids=f(Pp, 192),
                       tfeat=f(B, 24), tmid=f(B, 1024), temb_silu=f(B, 1024), ada=f(B, ADA_COLS), qkv=f(Nn, 768),
                       te0=f(Pp, 256), te1=f(Pp, 256), dist=f(Pp, 64), attn=f(Nn, 256), u=f(Nn, 64), ac=f(Nn, 512),
-                      ed=f(Pp, 256), lg=f(Pp, 32), dpos=torch.zeros(Nn, 4, dtype=torch.float32, device=device),
+                      ed=f(Pp, 256), lg=f(Pp, 32), tr=f(Pp, 8),
                       adj=torch.zeros(Pp, dtype=torch.int32, device=device),
                       flags=torch.zeros(64, dtype=torch.int32, device=device))
         self.c = DsWorkspace(**{k: self.t[k].data_ptr() for k in _WS_FIELDS})

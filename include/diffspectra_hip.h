@@ -106,10 +106,6 @@ typedef struct ds_layout {
   const int32_t* pair_a;             /* [Pp]  packed node row of the smaller local index */
   const int32_t* pair_b;             /* [Pp]  packed node row of the larger local index */
   const int32_t* pair_mol;           /* [Pp] */
-  const int32_t* dir_src;            /* [2*Pp] directed edges (r -> c), molecule-major, r-major, c ascending: row atom */
-  const int32_t* dir_dst;            /* [2*Pp] col atom (packed node rows) */
-  const int32_t* dir_pair;           /* [2*Pp] pair row of {r, c} */
-  const int32_t* dir_mol;            /* [2*Pp] molecule */
 } ds_layout;
 
 typedef struct ds_workspace {        /* all device fp32 unless noted; sizes in floats */
@@ -131,7 +127,7 @@ typedef struct ds_workspace {        /* all device fp32 unless noted; sizes in f
   float* ac;         /* [Nn,512] input_lin row part | col part */
   float* ed;         /* [Pp,256] input_lin edge+dist part + bias */
   float* lg;         /* [Pp,2,16] attention logits: [p][0] source a -> target b, [p][1] source b -> target a */
-  float* dpos;       /* [Nn,4]   position increments of the current block (zero between blocks) */
+  float* tr;         /* [Pp,2,4] per-edge translation vectors of the current block: [p][0] a -> b, [p][1] b -> a */
   int32_t* adj;      /* [Pp]     bit0: cond_adj_2d, bit1: cond_adj_spatial */
   int32_t* flags;    /* [64]     0: any nonzero cond distance, 1: NaN in positions; [16..] diagnostic-build counters */
 } ds_workspace;
@@ -194,7 +190,7 @@ int ds_layernorm_affine(const float* x, const float* gamma, const float* beta, f
 
 /* Measurement hook (bench.py roofline leg): time every `every`-th launch of one block-stage kernel with HIP events
  * recorded on the launch stream.  kernel: 0 edge_geom, 1 node_qkv, 2 attn_logits, 3 node_update, 4 edge_update,
- * 5 equi_flat, 6 attn_agg; kernel < 0 disables.  ds_profile_read synchronises the recorded events, returns the summed
+ * 5 equi_pairs, 6 attn_agg; kernel < 0 disables.  ds_profile_read synchronises the recorded events, returns the summed
  * duration and the sample count, and resets the counters.  Process-global instrumentation state; off by default. */
 int ds_profile_config(int kernel, int every, int max_samples);
 int ds_profile_read(double* total_ms, int64_t* samples);

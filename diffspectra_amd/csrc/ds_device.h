@@ -75,24 +75,45 @@ __device__ __forceinline__ float4 ln_mod_reg64(float4 v, float4 sh, float4 sc) {
 // Row of accumulator register `reg` (0..15) for a lane in half `hh` (lane>>5) of a 32x32 tile.
 __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
+// First group (4 k-groups) of B fragments of a wave_mma call.  Weights do not depend on anything a workgroup computes, so a
+// kernel requests the NEXT GEMM phase's first group BEFORE the barrier / epilogue in front of it and the L2 latency
+// (1-2 us under load: it was ~15k cycles of dead time per barrier-separated phase) overlaps with that work.
+struct BFrag {
+  float4 v[4];
+};
+__device__ __forceinline__ BFrag bfrag_load(const float* __restrict__ Wp, int Npad, int col0, int kg0, int kg1) {
+  const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+  const float4* wp = reinterpret_cast<const float4*>(Wp) + (size_t)hh * Npad + col0 + r;
+  BFrag f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) f.v[j] = wp[(size_t)min(kg0 + j, kg1 - 1) * 2 * Npad];
+  return f;
+}
+
 // acc[m] += X[m*32 .. m*32+31][8*kg0 .. 8*kg1) * Wp[.., col0 .. col0+31]
 // Software-pipelined: the B fragments (L2/MALL latency, 300-900 cycles) of the NEXT group of 4 k-groups are
 // requested before the current group's MFMAs issue, so one wave per SIMD already covers the load latency.
 // TRANS = true swaps the MFMA operands: the accumulator then holds the TRANSPOSED block — lane l owns row
 // (l & 31) of the X tile and register reg is output column col0 + acc_row(reg, l >> 5) — which is exactly the B-operand
-// layout a following MFMA needs to contract over those columns without touching LDS (k_equi_flat).
+// layout a following MFMA needs to contract over those columns without touching LDS (k_equi_pairs).
+// xkg0: k-group of the weight matrix that column 0 of X corresponds to (X holds a K-slice of the operand).
+// first: the call's first B group if the caller already requested it (bfrag_load with the same col0 / kg0 / kg1).
 template <int MT, bool TRANS = false>
 __device__ __forceinline__ void wave_mma(const float* X, int ldx, const float* __restrict__ Wp, int Npad, int col0,
-                                         int kg0, int kg1, f32x16 (&acc)[MT], int xkg0 = 0) {
-  // xkg0: k-group of the weight matrix that column 0 of X corresponds to (X holds a K-slice of the operand)
+                                         int kg0, int kg1, f32x16 (&acc)[MT], int xkg0 = 0, const BFrag* first = nullptr) {
   constexpr int G = 4;
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const float4* wp = reinterpret_cast<const float4*>(Wp) + (size_t)hh * Npad + col0 + r;
   const size_t wstride = (size_t)2 * Npad;
   const float* xr = X + r * ldx + 4 * hh - xkg0 * 8;
   float4 bc[G], bn[G];
+  if (first) {
 #pragma unroll
-  for (int j = 0; j < G; ++j) bc[j] = wp[(size_t)min(kg0 + j, kg1 - 1) * wstride];
+    for (int j = 0; j < G; ++j) bc[j] = first->v[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < G; ++j) bc[j] = wp[(size_t)min(kg0 + j, kg1 - 1) * wstride];
+  }
   for (int g = kg0; g < kg1; g += G) {
     if (g + G < kg1) {
 #pragma unroll
@@ -165,40 +186,49 @@ __device__ __forceinline__ void acc_store(const f32x16 (&acc)[MT], float* __rest
 }
 
 // Whole-workgroup tile GEMM: Y = epi(X[ROWS][K] * Wp[:, 0..NCH*32)), ROWS = 32*MTOT.
-// Waves split (column chunk, row tile) work items round-robin; each item is a 32*MT x 32 output block.
-template <int MTOT, int MT, class F>
-__device__ __forceinline__ void tile_gemm(const float* X, int ldx, int K, const float* __restrict__ Wp, int Npad, int nch,
-                                          F epi) {
+// Waves split (column chunk, row tile) work items round-robin; each item is a 32*MT x 32 output block.  The first B group
+// of the next item is requested before the current item's epilogue runs; tile_first() returns this wave's first item's
+// group so a kernel can request it ahead of the barrier in front of the GEMM.
+template <int MTOT, int MT>
+__device__ __forceinline__ BFrag tile_first(const float* __restrict__ Wp, int Npad, int K, int nch) {
+  constexpr int RG = MTOT / MT;
+  const int wave = threadIdx.x >> 6;
+  const int it = wave < nch * RG ? wave : 0;
+  return bfrag_load(Wp, Npad, (it / RG) * 32, 0, K >> 3);
+}
+
+// g(chunk, row_group, acc) receives the whole accumulator block of an item.
+template <int MTOT, int MT, class G>
+__device__ __forceinline__ void tile_gemm_blk(const float* X, int ldx, int K, const float* __restrict__ Wp, int Npad, int nch,
+                                              G g, const BFrag* first = nullptr) {
   static_assert(MTOT % MT == 0, "row tiling");
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   constexpr int RG = MTOT / MT;
-  for (int it = wave; it < nch * RG; it += nw) {
+  const int total = nch * RG;
+  if (wave >= total) return;
+  BFrag cur = first ? *first : bfrag_load(Wp, Npad, (wave / RG) * 32, 0, K >> 3);
+  for (int it = wave; it < total; it += nw) {
     const int ch = it / RG, rg = it % RG;
     // compiler barrier: without it LICM hoists the loop-invariant A-fragment LDS reads of ALL k-groups out of this
     // loop (256 VGPRs, spills, occupancy 1); re-reading LDS per chunk is nearly free next to the MFMAs.
     asm volatile("" ::: "memory");
     f32x16 acc[MT];
     acc_zero<MT>(acc);
-    wave_mma<MT>(X + rg * MT * 32 * ldx, ldx, Wp, Npad, ch * 32, 0, K >> 3, acc);
-    acc_foreach<MT>(acc, rg * MT * 32, ch * 32, epi);
+    wave_mma<MT>(X + rg * MT * 32 * ldx, ldx, Wp, Npad, ch * 32, 0, K >> 3, acc, 0, &cur);
+    const int nx = it + nw < total ? it + nw : it;
+    cur = bfrag_load(Wp, Npad, (nx / RG) * 32, 0, K >> 3);   // in flight during the epilogue below
+    g(ch, rg, acc);
   }
 }
 
-// Same work split, but the epilogue receives the whole accumulator block: g(chunk, row_group, acc).
-template <int MTOT, int MT, class G>
-__device__ __forceinline__ void tile_gemm_blk(const float* X, int ldx, int K, const float* __restrict__ Wp, int Npad, int nch,
-                                              G g) {
-  static_assert(MTOT % MT == 0, "row tiling");
-  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+// epi(row_in_tile, col, value) per accumulator element.
+template <int MTOT, int MT, class F>
+__device__ __forceinline__ void tile_gemm(const float* X, int ldx, int K, const float* __restrict__ Wp, int Npad, int nch,
+                                          F epi, const BFrag* first = nullptr) {
   constexpr int RG = MTOT / MT;
-  for (int it = wave; it < nch * RG; it += nw) {
-    const int ch = it / RG, rg = it % RG;
-    asm volatile("" ::: "memory");
-    f32x16 acc[MT];
-    acc_zero<MT>(acc);
-    wave_mma<MT>(X + rg * MT * 32 * ldx, ldx, Wp, Npad, ch * 32, 0, K >> 3, acc);
-    g(ch, rg, acc);
-  }
+  tile_gemm_blk<MTOT, MT>(X, ldx, K, Wp, Npad, nch, [&](int ch, int rg, const f32x16 (&acc)[MT]) {
+    acc_foreach<MT>(acc, rg * MT * 32, ch * 32, epi);
+  }, first);
 }
 
 // Read element (k, n) of an MFMA-packed weight (for the few VALU-sized projections).

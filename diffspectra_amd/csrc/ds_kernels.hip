@@ -215,12 +215,14 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
       if (p < Pp) c.ws.dist[(size_t)p * 64 + k] = v;
     }
   }
+  const BFrag pfe = tile_first<2, 1>(BW(c, blk, DS_BW_EDGE_EMB_W), 64, 128, 2);   // next GEMM's weights, ahead of the barrier
   __syncthreads();
   {
     const float* bias = BW(c, blk, DS_BW_EDGE_EMB_B);
     tile_gemm<2, 1>(&X[0][0], 128 + DS_LDP, 128, BW(c, blk, DS_BW_EDGE_EMB_W), 64, 2,
-                    [&](int row, int col, float v) { Y[row][col] = v + bias[col]; });
+                    [&](int row, int col, float v) { Y[row][col] = v + bias[col]; }, &pfe);
   }
+  const BFrag pf0 = tile_first<2, 2>(BW(c, blk, DS_BW_E0_W), 256, 64, 8);
   __syncthreads();
   ln_mod_tile<64, 16, 4>(&Y[0][0], 64 + DS_LDP, rmol, c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE, ADAC, 0, 64);   // edge_shift_msa, edge_scale_msa
   __syncthreads();
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
     const int valid = c.L.Pp - row0;
     tile_gemm_blk<2, 2>(&Y[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_E0_W), 256, 8, [&](int ch, int, const f32x16 (&acc)[2]) {
       acc_store<2, 256>(acc, te0 + ch * 32, valid, [](int, float v) { return ds_tanh(v); });   // layers.py:165-166
-    });
+    }, &pf0);
     tile_gemm_blk<2, 2>(&Y[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_E1_W), 256, 8, [&](int ch, int, const f32x16 (&acc)[2]) {
       acc_store<2, 256>(acc, te1 + ch * 32, valid, [](int, float v) { return ds_tanh(v); });   // layers.py:183
     });
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(256) void k_node_qkv(Ctx c, int blk) {
   __shared__ int rmol[T];
   const int tid = threadIdx.x, row0 = blockIdx.x * T;
   if (tid < T) rmol[tid] = (row0 + tid < c.L.Nn) ? c.L.node_mol[row0 + tid] : 0;
+  const BFrag pfq = tile_first<1, 1>(BW(c, blk, DS_BW_QKV_W), 768, 256, 24);   // GEMM weights requested before the staging
   __syncthreads();
   {
     const float* adn = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256) void k_node_qkv(Ctx c, int blk) {
   tile_gemm_blk<1, 1>(&X[0][0], 256 + DS_LDP, 256, BW(c, blk, DS_BW_QKV_W), 768, 24, [&](int ch, int, const f32x16 (&acc)[1]) {
     const float b = bias[ch * 32 + (threadIdx.x & 31)];
     acc_store<1, 768>(acc, qkv + ch * 32, valid, [b](int, float v) { return v + b; });
-  });
+  }, &pfq);
 }
 
 // Block stage C1 (flat over pairs): attention logits of both directions of every pair, 14 learned heads
@@ -412,6 +415,7 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
       acc_store<1, 64>(acc, u + ch * 32, Nn - row0, [](int, float v) { return v; });
     });
   }
+  const BFrag pf1 = bfrag_load(BW(c, blk, DS_BW_FF1_W), 512, wave * 32, 0, 32);   // FF1 weights, ahead of the barrier
   __syncthreads();   // H2 normalised; every wave is done reading B1 (node2edge)
   {
     const float* b1 = BW(c, blk, DS_BW_FF1_B);
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
         const int ch = wave + 4 * cc;
         f32x16 acc[1];
         acc_zero<1>(acc);
-        wave_mma<1>(&H2[0][0], LD, W1, 512, (half * 8 + ch) * 32, 0, 32, acc);
+        wave_mma<1>(&H2[0][0], LD, W1, 512, (half * 8 + ch) * 32, 0, 32, acc, 0, (half == 0 && cc == 0) ? &pf1 : nullptr);
         acc_foreach<1>(acc, 0, ch * 32, [&](int row, int col, float v) { B1[row][col] = ds_silu(v + b1[half * 256 + col]); });
       }
       __syncthreads();
@@ -492,6 +496,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
     rpa[tid] = ok ? c.L.pair_a[row0 + tid] : 0;
     rpb[tid] = ok ? c.L.pair_b[row0 + tid] : 0;
   }
+  const BFrag pf3 = tile_first<2, 2>(BW(c, blk, DS_BW_FF3_W), 128, 64, 4);   // weights of the next GEMM, ahead of the barrier
   __syncthreads();
   {
     const float4* bn = reinterpret_cast<const float4*>(BW(c, blk, DS_BW_N2E_B));
@@ -527,8 +532,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
   {
     const float* b3 = BW(c, blk, DS_BW_FF3_B);
     tile_gemm<2, 2>(&E2[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_FF3_W), 128, 4,
-                    [&](int row, int col, float v) { F[row][col] = ds_silu(v + b3[col]); });
+                    [&](int row, int col, float v) { F[row][col] = ds_silu(v + b3[col]); }, &pf3);
   }
+  const BFrag pf4 = tile_first<2, 1>(BW(c, blk, DS_BW_FF4_W), 64, 128, 2);
   __syncthreads();
   {
     const float* b4 = BW(c, blk, DS_BW_FF4_B);
@@ -549,8 +555,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
         E2[row][col] = out;
         if (row0 + row < Pp) e[(size_t)(row0 + row) * 64 + col] = out;
       }
-    });
+    }, &pf4);
   }
+  const BFrag pfd = bfrag_load(BW(c, blk, DS_BW_ED_W), 256, wave * 32, 0, 8);
   __syncthreads();
   {
     const float* br = BW(c, blk, DS_BW_EDGE_RO_B);
@@ -558,20 +565,20 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
     const float* Wd = BW(c, blk, DS_BW_ED_W);
     float* eh = c.ws.edge_hids;
     float* ed = c.ws.ed;
-    tile_gemm<2, 1>(&E2[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_EDGE_RO_W), 32, 1, [&](int row, int col, float v) {
-      if (row0 + row < Pp && col < 16) eh[(size_t)(row0 + row) * 192 + 64 + 16 * blk + col] = v + br[col];
-    });
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {   // [e_out | dist] (128) -> 256: rows 0-63 of W from E2, rows 64-127 from D
       asm volatile("" ::: "memory");
       const int ch = wave + 4 * cc;
       f32x16 acc[2];
       acc_zero<2>(acc);
-      wave_mma<2>(&E2[0][0], 64 + DS_LDP, Wd, 256, ch * 32, 0, 8, acc);
+      wave_mma<2>(&E2[0][0], 64 + DS_LDP, Wd, 256, ch * 32, 0, 8, acc, 0, cc == 0 ? &pfd : nullptr);
       wave_mma<2>(&D[0][0], 64 + DS_LDP, Wd, 256, ch * 32, 8, 16, acc, 8);
       const float b = bd[ch * 32 + (lane_ & 31)];
       acc_store<2, 256>(acc, ed + (size_t)row0 * 256 + ch * 32, Pp - row0, [b](int, float v) { return v + b; });
     }
+    tile_gemm<2, 1>(&E2[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_EDGE_RO_W), 32, 1, [&](int row, int col, float v) {
+      if (row0 + row < Pp && col < 16) eh[(size_t)(row0 + row) * 192 + 64 + 16 * blk + col] = v + br[col];
+    });
   }
 }
 
@@ -592,6 +599,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_equi_pairs(Ctx c, int blk) 
   const int Pp = c.L.Pp;
   const int p0 = blockIdx.x * TP;
   const int npairs = min(TP, Pp - p0);
+  const BFrag pfc = bfrag_load(BW(c, blk, DS_BW_CM0_W), 256, wave * 32, 0, 32);   // coord_mlp.0 weights, ahead of everything
   DS_STAMP_INIT();
   {
     const float* adq = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EQUI;
@@ -658,7 +666,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_equi_pairs(Ctx c, int blk) 
       asm volatile("" ::: "memory");   // keep the A-fragment LDS reads inside each chunk (see tile_gemm)
       f32x16 acc1[MT];
       acc_zero<MT>(acc1);
-      wave_mma<MT, true>(&X[0][0], 256 + DS_LDP, BW(c, blk, DS_BW_CM0_W), 256, (wave + NW * cc) * 32, 0, 32, acc1);
+      wave_mma<MT, true>(&X[0][0], 256 + DS_LDP, BW(c, blk, DS_BW_CM0_W), 256, (wave + NW * cc) * 32, 0, 32, acc1, 0,
+                         cc == 0 ? &pfc : nullptr);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll

@@ -8,7 +8,7 @@ Molecules are independent, so ranks own disjoint molecules (weak scaling) and th
 all_gather of the fixed-size result records over RCCL.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     live HIP-event timing of the dominant kernel (k_equi_flat) vs the fp32-MFMA peak,
+  "roofline":     live HIP-event timing of the dominant kernel (k_equi_pairs) vs the fp32-MFMA peak,
   "cpu_baseline": the CPU oracle (faithful restatement of the reference path) timed on this host on a bounded sample.
 """
 from __future__ import annotations
@@ -116,7 +116,9 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=1000)
     ap.add_argument("--spectra", default="allspectra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-kernel", type=int, default=5, help="block-stage kernel timed with HIP events (5 = k_equi_flat)")
+    ap.add_argument("--unconditional", action="store_true",
+                    help="BASELINE config 4: zero context embedding, SpecFormer skipped (build extension, DESIGN.md §7)")
+    ap.add_argument("--profile-kernel", type=int, default=5, help="block-stage kernel timed with HIP events (5 = k_equi_pairs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,7 +178,7 @@ def main():
 
     def one_step():
         z, edge_z = S.initial_noise(M, max_n, 6, 2, node_mask, edge_mask)
-        x_node, x_edge = sampler.sampling(model, z, node_mask, edge_mask, edge_z, context)
+        x_node, x_edge = sampler.sampling(model, z, node_mask, edge_mask, edge_z, None if args.unconditional else context)
         pos, one_hot, fc, edge_types = S.post_process(x_node, 5, True, node_mask, inv, x_edge, edge_mask, True, engine=eng)
         rec = shard.pack_records(pos, one_hot.argmax(-1), fc, edge_types)     # fixed-size record per molecule
         return shard.gather_records(rec)                                # the only collective: final gather over xGMI
@@ -215,13 +217,13 @@ def main():
         n = np.asarray(n_atoms, dtype=np.int64)
         E_dir = int((n * (n - 1)).sum())
         kern_ms = tot_ms.value / max(1, samples.value)
-        kernel_names = ["k_edge_geom", "k_node_qkv", "k_attn_logits", "k_node_update", "k_edge_update", "k_equi_flat", "k_attn_agg"]
+        kernel_names = ["k_edge_geom", "k_node_qkv", "k_attn_logits", "k_node_update", "k_edge_update", "k_equi_pairs", "k_attn_agg"]
         roofline = None
         if samples.value > 0 and args.profile_kernel == 5:
             flop = 2.0 * EQUI_MACS_PER_DIRECTED_EDGE * E_dir
             ach = flop / (kern_ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic("k_equi_flat", M)
-            roofline = {"bound": "mfma", "kernel": "k_equi_flat", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
+            traffic, traffic_src = pmc_traffic("k_equi_pairs", M)
+            roofline = {"bound": "mfma", "kernel": "k_equi_pairs", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                         "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 PMC, separate passes)",
                         "traffic_source": traffic_src, "avg_launch_ms": kern_ms, "launches_timed": int(samples.value),
@@ -236,7 +238,8 @@ def main():
             "metric": "molecules/sec, 1000-step QM9S all-spectra sampling", "value": value, "unit": "molecules/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"QM9S {args.spectra}, DMT + SpecFormer (no pretrain, random-init procedural weights), "
+            "config": {"workload": ("QM9S unconditional (zero context embedding), DMT only" if args.unconditional else
+                                    f"QM9S {args.spectra}, DMT + SpecFormer (no pretrain)") + ", random-init procedural weights, "
                                    f"{args.denoise_steps} denoise steps, {M} molecules per GPU per step "
                                    f"(n_atoms ~ qm9_second_half histogram, mean {float(n.mean()):.2f})",
                        "molecules_per_gpu_per_step": M, "denoise_steps": args.denoise_steps, "parallelism": f"dp{world} (molecule shards)"},

@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
 }
 
 // Block stage B (nodes): LN -> modulate -> q|k|v projection (256 -> 768).  dmt.py:148; layers.py:147-149.
-__global__ __launch_bounds__(256) void k_node_qkv(Ctx c, int blk) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_node_qkv(Ctx c, int blk) {
+  constexpr int NT = NW * 64;
   constexpr int T = 32;
   __shared__ __attribute__((aligned(16))) float X[T][256 + DS_LDP];
   __shared__ int rmol[T];
@@ -250,11 +252,11 @@ __global__ __launch_bounds__(256) void k_node_qkv(Ctx c, int blk) {
   __syncthreads();
   {
     const float* adn = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
-    for (int it = 0; it < 2; ++it) {   // 32 rows x 64 float4; each wave holds whole rows -> LN + modulate in registers
+    for (int it = 0; it < 512 / NT; ++it) {   // 32 rows x 64 float4; each wave holds whole rows -> LN + modulate in registers
       float4 v[4], sh[4], sc[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int idx = tid + (it * 4 + u) * 256, row = idx >> 6, k4 = idx & 63;
+        const int idx = tid + (it * 4 + u) * NT, row = idx >> 6, k4 = idx & 63;
         v[u] = reinterpret_cast<const float4*>(c.ws.h + (size_t)min(row0 + row, c.L.Nn - 1) * 256)[k4];
         sh[u] = reinterpret_cast<const float4*>(adn + (size_t)rmol[row] * ADAC)[k4];          // node_shift_msa
         sc[u] = reinterpret_cast<const float4*>(adn + (size_t)rmol[row] * ADAC + 256)[k4];    // node_scale_msa
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void k_node_qkv(Ctx c, int blk) {
       for (int u = 0; u < 4; ++u) v[u] = ln_mod_reg256(v[u], sh[u], sc[u]);   // dmt.py:148
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int idx = tid + (it * 4 + u) * 256, row = idx >> 6, k4 = idx & 63;
+        const int idx = tid + (it * 4 + u) * NT, row = idx >> 6, k4 = idx & 63;
         if (row0 + row >= c.L.Nn) v[u] = make_float4(0, 0, 0, 0);
         reinterpret_cast<float4*>(&X[row][0])[k4] = v[u];
       }
@@ -1176,7 +1178,7 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   if (!make_ctx(c, w, L, ws, s) || blk < 0 || blk >= DS_NBLOCKS) return DS_ERR_ARG;
   const int pt = (L->Pp + 63) / 64, nt = (L->Nn + 31) / 32;
   if (pt > 0) { ProfScope ps(0, s); hipLaunchKernelGGL(k_edge_geom, dim3(pt), dim3(256), 0, s, c, blk); }
-  { ProfScope ps(1, s); hipLaunchKernelGGL(k_node_qkv, dim3(nt), dim3(256), 0, s, c, blk); }
+  { ProfScope ps(1, s); hipLaunchKernelGGL(k_node_qkv<4>, dim3(nt), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(2, s); hipLaunchKernelGGL(k_attn_logits, dim3((L->Pp + 15) / 16), dim3(256), 0, s, c); }
   { ProfScope ps(6, s); hipLaunchKernelGGL(k_attn_agg, dim3(L->Nn), dim3(256), 0, s, c); }
   { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }

@@ -39,7 +39,8 @@ def qm9s_config(spectra_version: str = "allspectra", device="cpu", steps: int = 
     )
     sde = Config(schedule="cosine", continuous_beta_0=0.1, continuous_beta_1=20.0)
     sampling = Config(method="ancestral", steps=steps)
-    evaluate = Config(batch_size=batch_size, num_samples=num_samples, sampling_temperature=1.0)
+    evaluate = Config(batch_size=batch_size, num_samples=num_samples, sampling_temperature=1.0, enable_sampling=True,
+                      begin_ckpt=40, end_ckpt=40, ckpts="")
     return Config(
         exp_type="diffspectra", pred_edge=True, only_2D=False, data=data, model=model, sde=sde,
         sampling=sampling, eval=evaluate, seed=42, device=device,

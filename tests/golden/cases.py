@@ -13,6 +13,7 @@ from diffspectra_amd.config import qm9s_config, SPECTRUM_LENGTHS
 
 GOLDEN_DIR = os.path.dirname(os.path.abspath(__file__))
 RAGGED = [3, 9, 18, 29]          # n_atoms of the B=4 parity batch
+FULL_LENGTH_ATOMS = [4, 7, 11]   # molecules of the 1000-step golden trajectory (G7)
 
 
 def fixture_path(name: str) -> str:

@@ -181,12 +181,12 @@ class _ReplayRandn:
         return t.clone()
 
 
-def g5_trajectory(mods):
+def g5_trajectory(mods, plan=(("allspectra", 5, None), ("ir", 50, None)), fname="g5_trajectory.npz"):
     out = {}
-    for version, steps in (("allspectra", 5), ("ir", 50)):
+    for version, steps, n_atoms in plan:
         cfg, model = ref_model(mods, version)
         cfg.sampling.steps = steps
-        tr = cases.trajectory_inputs(version, steps)
+        tr = cases.trajectory_inputs(version, steps) if n_atoms is None else cases.trajectory_inputs(version, steps, n_atoms)
         ns = mods.noise_schedule.NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0)
         time_steps = torch.linspace(ns.T, 1e-3, steps)
         sampler = mods.sampling.AncestralSampler(ns, time_steps, True, True, True,
@@ -218,7 +218,12 @@ def g5_trajectory(mods):
             out[f"{tag}_mol{m}_pos"], out[f"{tag}_mol{m}_atom"] = p.numpy(), at.numpy()
             out[f"{tag}_mol{m}_edge"], out[f"{tag}_mol{m}_fc"] = e.numpy(), c.numpy()
         print("G5", tag, float(x_mean.abs().max()))
-    cases.save_npz("g5_trajectory.npz", **out)
+    cases.save_npz(fname, **out)
+
+
+def g7_full_length(mods):
+    """The metric's own step count: 1000 ancestral steps with injected noise on three small molecules."""
+    g5_trajectory(mods, plan=(("ir", 1000, cases.FULL_LENGTH_ATOMS),), fname="g7_trajectory_1000.npz")
 
 
 def g6_post_process(mods):
@@ -247,7 +252,7 @@ def main():
     torch.set_num_threads(8)
     mods = import_reference()
     todo = {"G0": g0_manifest, "G1": g1_schedule, "G2": g2_specformer, "G3": g3_components, "G4": g4_forward,
-            "G5": g5_trajectory, "G6": g6_post_process}
+            "G5": g5_trajectory, "G6": g6_post_process, "G7": g7_full_length}
     only = [s for s in args.only.split(",") if s]
     for k, fn in todo.items():
         if not only or k in only:

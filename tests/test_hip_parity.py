@@ -523,3 +523,33 @@ def test_evaluate_driver(gpu_device, tmp_path):
     with pytest.raises(FileNotFoundError):
         cfg.eval.begin_ckpt = cfg.eval.end_ckpt = 41
         EV.diffspectra_evaluate(cfg, str(tmp_path), ds)
+
+
+def test_g7_full_length_trajectory_golden(gpu_device):
+    """The metric's own length: 1000 injected-noise steps on the HIP path vs the reference's run; integers bit-exact."""
+    from diffspectra_amd import sampling as S
+    from diffspectra_amd.noise_schedule import NoiseScheduleVP
+    from diffspectra_amd.scalers import get_data_inverse_scaler
+    cfg, model = gpu_model("ir", gpu_device)
+    cfg = cfg.clone()
+    cfg.sampling.steps = 1000
+    g = cases.load_npz("g7_trajectory_1000.npz")
+    tr = cases.trajectory_inputs("ir", 1000, cases.FULL_LENGTH_ATOMS)
+    d = gpu_device
+    sampler = S._make_sampler(cfg, NoiseScheduleVP("cosine"), 1e-3, 1.0)
+    sampler.noise_fn = lambda i: tr["raws"][i]
+    z = oracle.combined_noise(*tr["raw0"][:2], tr["node_mask"])
+    ez = oracle.symmetric_edge_noise(tr["raw0"][2], tr["edge_mask"])
+    x_mean, e_mean = sampler.sampling(model, z.to(d), tr["node_mask"].to(d), tr["edge_mask"].to(d), ez.to(d), tr["context"].to(d))
+    tag = "ir_S1000"
+    ok_x, msg_x = close(x_mean, g[tag + "_x_mean"], TOL_TRAJ)
+    ok_e, msg_e = close(e_mean, g[tag + "_edge_mean"], TOL_TRAJ)
+    print("1000-step trajectory:", msg_x, "|", msg_e)
+    assert ok_x, msg_x
+    assert ok_e, msg_e
+    eng = model.module.engine()
+    pos, one_hot, fc, et = S.post_process(x_mean, 5, True, tr["node_mask"].to(d), get_data_inverse_scaler(cfg), e_mean,
+                                          tr["edge_mask"].to(d), True, engine=eng)
+    assert int((one_hot.argmax(-1).cpu() != g[tag + "_atom_type"]).sum()) == 0, "atom-type argmax mismatches after 1000 steps"
+    assert torch.equal(fc.squeeze(-1).cpu(), g[tag + "_fc"].squeeze(-1).long()), "formal charges differ after 1000 steps"
+    assert torch.equal(et.cpu(), g[tag + "_edge_type"]), "bond orders differ after 1000 steps"

@@ -124,3 +124,26 @@ def test_g6_post_process_thresholds():
     assert torch.equal(one_hot.to(g["one_hot"].dtype), g["one_hot"])
     assert torch.equal(fc.to(g["fc"].dtype), g["fc"])
     assert torch.equal(et, g["edge_type"])
+
+
+def test_g7_full_length_trajectory():
+    """1000 ancestral steps (the metric's own length) with injected noise: oracle vs the reference's own run."""
+    cfg, sd = procedural_state_dict("ir")
+    g = cases.load_npz("g7_trajectory_1000.npz")
+    tr = cases.trajectory_inputs("ir", 1000, cases.FULL_LENGTH_ATOMS)
+    ctx = oracle.context_embedding(sd, tr["context"], cfg)
+
+    def model_fn(x, edge_x, noise_level, cond_x, cond_edge_x):
+        return oracle.dmt_forward(sd, cfg, x, tr["node_mask"], tr["edge_mask"], edge_x, noise_level, cond_x, cond_edge_x,
+                                  context_emb=ctx)
+
+    z = oracle.combined_noise(tr["raw0"][0], tr["raw0"][1], tr["node_mask"])
+    ez = oracle.symmetric_edge_noise(tr["raw0"][2], tr["edge_mask"])
+    x_mean, e_mean = oracle.ancestral_sampling(model_fn, z, tr["node_mask"], tr["edge_mask"], ez, 1000, lambda i: tr["raws"][i])
+    tag = "ir_S1000"
+    assert max_abs_diff(x_mean, g[tag + "_x_mean"]) <= TOL_TRAJ
+    assert max_abs_diff(e_mean, g[tag + "_edge_mean"]) <= TOL_TRAJ
+    pos, one_hot, fc, et = oracle.post_process(x_mean, tr["node_mask"], e_mean, tr["edge_mask"])
+    assert torch.equal(one_hot.argmax(-1), g[tag + "_atom_type"])
+    assert torch.equal(fc.to(g[tag + "_fc"].dtype), g[tag + "_fc"])
+    assert torch.equal(et, g[tag + "_edge_type"])

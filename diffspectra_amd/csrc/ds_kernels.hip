@@ -479,108 +479,138 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
   }
 }
 
-// Block stage E (pairs, 64 rows): h_edge = node2edge(h_a + h_b), gated residual, LN, modulate, FF(64->128->64), gated
-// residual in place, readout slice (64->16), edge+dist part of equi_update.input_lin (128->256, contracted from two
-// LDS tiles).  dmt.py:156-157,165-169,388.  68.6 kB LDS -> two workgroups per CU.
+// Block stage E (pairs): h_edge = node2edge(h_a + h_b), gated residual, LN, modulate, FF(64->128->64), gated residual,
+// readout slice (64->16), edge+dist part of equi_update.input_lin (128->256).  dmt.py:156-157,165-169,388.
+// ROW-PARALLEL: every wave owns 32 pair rows from staging to the last store, with wave-private LDS tiles and NO workgroup
+// barrier (the five barrier-separated GEMM phases of the tile-parallel form cost ~15k cycles of dead time each).  The FF is
+// chained in registers: FF3 is computed transposed (lane = row, registers = hidden features) and its SiLU'd accumulators
+// are the B operand of the FF4 MFMAs; the gated residual is applied in that transposed layout with 16-byte LDS accesses.
 __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
-  constexpr int T = 64;
-  const int lane_ = threadIdx.x & 63;
-  __shared__ __attribute__((aligned(16))) float E2[T][64 + DS_LDP];   // residual stream, then e_out in place
-  __shared__ __attribute__((aligned(16))) float F[T][128 + DS_LDP];
-  __shared__ __attribute__((aligned(16))) float D[T][64 + DS_LDP];    // CondGaussian features of this block
-  __shared__ int rmol[T], rpa[T], rpb[T];
-  const int tid = threadIdx.x, wave = tid >> 6, row0 = blockIdx.x * T;
+  constexpr int R = 32, LDW = 64 + DS_LDP;
+  __shared__ __attribute__((aligned(16))) float E2s[4][R][LDW];   // residual stream, then e_out in place
+  __shared__ __attribute__((aligned(16))) float Ds[4][R][LDW];    // CondGaussian features of this block
+  __shared__ int idx_s[4][3][R];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5, r31 = lane & 31;
+  float(*E2)[LDW] = E2s[wave];
+  float(*D)[LDW] = Ds[wave];
+  int* rmol = idx_s[wave][0];
+  int* rpa = idx_s[wave][1];
+  int* rpb = idx_s[wave][2];
   const int Pp = c.L.Pp;
-  const float* ada = c.ws.ada;
-  if (tid < T) {
-    const bool ok = row0 + tid < Pp;
-    rmol[tid] = ok ? c.L.pair_mol[row0 + tid] : 0;
-    rpa[tid] = ok ? c.L.pair_a[row0 + tid] : 0;
-    rpb[tid] = ok ? c.L.pair_b[row0 + tid] : 0;
+  const int row0 = (blockIdx.x * 4 + wave) * R;
+  if (row0 >= Pp) return;                    // whole wave leaves; nothing below synchronises across waves
+  const int valid = min(R, Pp - row0);
+  const float* ada = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
+  if (lane < R) {
+    const int p = min(row0 + lane, Pp - 1);
+    rmol[lane] = c.L.pair_mol[p]; rpa[lane] = c.L.pair_a[p]; rpb[lane] = c.L.pair_b[p];
   }
-  const BFrag pf3 = tile_first<2, 2>(BW(c, blk, DS_BW_FF3_W), 128, 64, 4);   // weights of the next GEMM, ahead of the barrier
-  __syncthreads();
   {
     const float4* bn = reinterpret_cast<const float4*>(BW(c, blk, DS_BW_N2E_B));
-    float4 ua[4], ub[4], ve[4], vd[4], vg[4], sh[4], sc[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {   // 64 rows x 16 float4 (one 16-lane DPP row per tile row), all gathers in flight together
-      const int idx = tid + u * 256, row = idx >> 4, k4 = idx & 15;
-      const int p = row0 + row;
-      const size_t pc = (size_t)min(p, Pp - 1);   // clamp instead of branching: loads stay batched
-      const float* ad = ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
-      ua[u] = reinterpret_cast<const float4*>(c.ws.u + (size_t)rpa[row] * 64)[k4];
-      ub[u] = reinterpret_cast<const float4*>(c.ws.u + (size_t)rpb[row] * 64)[k4];
-      ve[u] = reinterpret_cast<const float4*>(c.ws.e + pc * 64)[k4];
-      vd[u] = reinterpret_cast<const float4*>(c.ws.dist + pc * 64)[k4];
-      vg[u] = reinterpret_cast<const float4*>(ad + 128)[k4];   // edge_gate_msa
-      sh[u] = reinterpret_cast<const float4*>(ad + 192)[k4];   // edge_shift_mlp
-      sc[u] = reinterpret_cast<const float4*>(ad + 256)[k4];   // edge_scale_mlp
-    }
+    for (int it = 0; it < 2; ++it) {   // 32 rows x 16 float4 (one 16-lane DPP row per tile row); 28 gathers in flight
+      float4 ua[4], ub[4], ve[4], vd[4], vg[4], sh[4], sc[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + u * 256, row = idx >> 4, k4 = idx & 15;
-      if (row0 + row >= Pp) ua[u] = ub[u] = ve[u] = vd[u] = make_float4(0, 0, 0, 0);
-      const float4 b = bn[k4];
-      float4 r;   // e_in + edge_gate_msa * node2edge_lin(h_a + h_b) (dmt.py:156-157,165)
-      r.x = ve[u].x + vg[u].x * ((ua[u].x + ub[u].x) + b.x); r.y = ve[u].y + vg[u].y * ((ua[u].y + ub[u].y) + b.y);
-      r.z = ve[u].z + vg[u].z * ((ua[u].z + ub[u].z) + b.z); r.w = ve[u].w + vg[u].w * ((ua[u].w + ub[u].w) + b.w);
-      r = ln_mod_reg64(r, sh[u], sc[u]);   // norm2_edge + modulate (dmt.py:166)
-      reinterpret_cast<float4*>(&E2[row][0])[k4] = r;
-      reinterpret_cast<float4*>(&D[row][0])[k4] = vd[u];
+      for (int u = 0; u < 4; ++u) {
+        const int idx = lane + (it * 4 + u) * 64, row = idx >> 4, k4 = idx & 15;
+        const size_t pc = (size_t)min(row0 + row, Pp - 1);   // clamp instead of branching: loads stay batched
+        const float* ad = ada + (size_t)rmol[row] * ADAC;
+        ua[u] = reinterpret_cast<const float4*>(c.ws.u + (size_t)rpa[row] * 64)[k4];
+        ub[u] = reinterpret_cast<const float4*>(c.ws.u + (size_t)rpb[row] * 64)[k4];
+        ve[u] = reinterpret_cast<const float4*>(c.ws.e + pc * 64)[k4];
+        vd[u] = reinterpret_cast<const float4*>(c.ws.dist + pc * 64)[k4];
+        vg[u] = reinterpret_cast<const float4*>(ad + 128)[k4];   // edge_gate_msa
+        sh[u] = reinterpret_cast<const float4*>(ad + 192)[k4];   // edge_shift_mlp
+        sc[u] = reinterpret_cast<const float4*>(ad + 256)[k4];   // edge_scale_mlp
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = lane + (it * 4 + u) * 64, row = idx >> 4, k4 = idx & 15;
+        const float4 b = bn[k4];
+        float4 r;   // e_in + edge_gate_msa * node2edge_lin(h_a + h_b) (dmt.py:156-157,165)
+        r.x = ve[u].x + vg[u].x * ((ua[u].x + ub[u].x) + b.x); r.y = ve[u].y + vg[u].y * ((ua[u].y + ub[u].y) + b.y);
+        r.z = ve[u].z + vg[u].z * ((ua[u].z + ub[u].z) + b.z); r.w = ve[u].w + vg[u].w * ((ua[u].w + ub[u].w) + b.w);
+        r = ln_mod_reg64(r, sh[u], sc[u]);   // norm2_edge + modulate (dmt.py:166)
+        if (row >= valid) { r = make_float4(0, 0, 0, 0); vd[u] = r; }
+        reinterpret_cast<float4*>(&E2[row][0])[k4] = r;
+        reinterpret_cast<float4*>(&D[row][0])[k4] = vd[u];
+      }
     }
   }
-  __syncthreads();
+  // ---- FF3 transposed: a3[hc][i] = hidden feature hc*32 + acc_row(i, hh) of row r31            (dmt.py:118-119)
+  f32x16 a3[4][1];
+#pragma unroll
+  for (int hc = 0; hc < 4; ++hc) {
+    acc_zero<1>(a3[hc]);
+    wave_mma<1, true>(&E2[0][0], LDW, BW(c, blk, DS_BW_FF3_W), 128, hc * 32, 0, 8, a3[hc]);
+  }
+  // ---- SiLU in registers, FF4 as MFMAs whose B operand is the hidden activation                (dmt.py:119-120)
+  f32x16 a4[2][1];
+  acc_zero<1>(a4[0]);
+  acc_zero<1>(a4[1]);
   {
     const float* b3 = BW(c, blk, DS_BW_FF3_B);
-    tile_gemm<2, 2>(&E2[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_FF3_W), 128, 4,
-                    [&](int row, int col, float v) { F[row][col] = ds_silu(v + b3[col]); }, &pf3);
+    const float* W4 = BW(c, blk, DS_BW_FF4_W);
+#pragma unroll
+    for (int hc = 0; hc < 4; ++hc)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f0 = hc * 32 + 8 * q + 4 * hh;                       // registers 4q..4q+3 hold features f0..f0+3
+        const float4 bb = *reinterpret_cast<const float4*>(b3 + f0);
+        const float bs[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float y = ds_silu(a3[hc][0][4 * q + j] + bs[j]);
+          a4[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp_at(W4, 64, f0 + j, r31), y, a4[0][0], 0, 0, 0);
+          a4[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp_at(W4, 64, f0 + j, 32 + r31), y, a4[1][0], 0, 0, 0);
+        }
+      }
   }
-  const BFrag pf4 = tile_first<2, 1>(BW(c, blk, DS_BW_FF4_W), 64, 128, 2);
-  __syncthreads();
+  // ---- gated residual in the transposed layout (lane = row, 4 consecutive features per register quad), in place
   {
     const float* b4 = BW(c, blk, DS_BW_FF4_B);
-    float* e = c.ws.e;
-    // edge_gate_mlp (dmt.py:168) is per molecule; a tile of consecutive pair rows touches the first and the last
-    // molecule almost always, so their gate columns are fetched once per lane instead of once per element.
-    const int mA = rmol[0], mB = rmol[T - 1];
-    const float* gsec = ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE + 320;
-    tile_gemm_blk<2, 1>(&F[0][0], 128 + DS_LDP, 128, BW(c, blk, DS_BW_FF4_W), 64, 2, [&](int ch, int rg, const f32x16 (&acc)[1]) {
-      const int col = ch * 32 + (lane_ & 31);
-      const float gA = gsec[(size_t)mA * ADAC + col], gB = gsec[(size_t)mB * ADAC + col], bb = b4[col];
+    const float* grow = ada + (size_t)rmol[r31] * ADAC + 320;          // edge_gate_mlp of this row's molecule (dmt.py:168)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = rg * 32 + acc_row(i, lane_ >> 5);
-        const int m = rmol[row];
-        const float g = m == mA ? gA : (m == mB ? gB : gsec[(size_t)m * ADAC + col]);
-        const float out = E2[row][col] + g * (acc[0][i] + bb);   // in place
-        E2[row][col] = out;
-        if (row0 + row < Pp) e[(size_t)(row0 + row) * 64 + col] = out;
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n0 = ft * 32 + 8 * q + 4 * hh;
+        const float4 g = *reinterpret_cast<const float4*>(grow + n0);
+        const float4 bb = *reinterpret_cast<const float4*>(b4 + n0);
+        float4 x = *reinterpret_cast<const float4*>(&E2[r31][n0]);
+        x.x += g.x * (a4[ft][0][4 * q + 0] + bb.x); x.y += g.y * (a4[ft][0][4 * q + 1] + bb.y);
+        x.z += g.z * (a4[ft][0][4 * q + 2] + bb.z); x.w += g.w * (a4[ft][0][4 * q + 3] + bb.w);
+        *reinterpret_cast<float4*>(&E2[r31][n0]) = x;
       }
-    }, &pf4);
   }
-  const BFrag pfd = bfrag_load(BW(c, blk, DS_BW_ED_W), 256, wave * 32, 0, 8);
-  __syncthreads();
+  // ---- e_out to global, coalesced (4 rows x 256 B per wave-instruction)
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int idx = lane + u * 64, row = idx >> 4, k4 = idx & 15;
+    const float4 v = reinterpret_cast<const float4*>(&E2[row][0])[k4];
+    if (row < valid) reinterpret_cast<float4*>(c.ws.e + (size_t)(row0 + row) * 64)[k4] = v;
+  }
+  // ---- [e_out | dist] (128) -> 256 (input_lin edge part + bias) and the 64 -> 16 readout slice
   {
-    const float* br = BW(c, blk, DS_BW_EDGE_RO_B);
     const float* bd = BW(c, blk, DS_BW_ED_B);
     const float* Wd = BW(c, blk, DS_BW_ED_W);
-    float* eh = c.ws.edge_hids;
-    float* ed = c.ws.ed;
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {   // [e_out | dist] (128) -> 256: rows 0-63 of W from E2, rows 64-127 from D
+    float* ed = c.ws.ed + (size_t)row0 * 256;
+    for (int ch = 0; ch < 8; ++ch) {
       asm volatile("" ::: "memory");
-      const int ch = wave + 4 * cc;
-      f32x16 acc[2];
-      acc_zero<2>(acc);
-      wave_mma<2>(&E2[0][0], 64 + DS_LDP, Wd, 256, ch * 32, 0, 8, acc, 0, cc == 0 ? &pfd : nullptr);
-      wave_mma<2>(&D[0][0], 64 + DS_LDP, Wd, 256, ch * 32, 8, 16, acc, 8);
-      const float b = bd[ch * 32 + (lane_ & 31)];
-      acc_store<2, 256>(acc, ed + (size_t)row0 * 256 + ch * 32, Pp - row0, [b](int, float v) { return v + b; });
+      f32x16 acc[1];
+      acc_zero<1>(acc);
+      wave_mma<1>(&E2[0][0], LDW, Wd, 256, ch * 32, 0, 8, acc);
+      wave_mma<1>(&D[0][0], LDW, Wd, 256, ch * 32, 8, 16, acc, 8);
+      const float b = bd[ch * 32 + r31];
+      acc_store<1, 256>(acc, ed + ch * 32, valid, [b](int, float v) { return v + b; });
     }
-    tile_gemm<2, 1>(&E2[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_EDGE_RO_W), 32, 1, [&](int row, int col, float v) {
-      if (row0 + row < Pp && col < 16) eh[(size_t)(row0 + row) * 192 + 64 + 16 * blk + col] = v + br[col];
-    });
+    f32x16 acc[1];
+    acc_zero<1>(acc);
+    wave_mma<1>(&E2[0][0], LDW, BW(c, blk, DS_BW_EDGE_RO_W), 32, 0, 0, 8, acc);
+    if (r31 < 16) {
+      const float b = BW(c, blk, DS_BW_EDGE_RO_B)[r31];
+      acc_store<1, 192>(acc, c.ws.edge_hids + (size_t)row0 * 192 + 64 + 16 * blk, valid, [b](int, float v) { return v + b; });
+    }
   }
 }
 
@@ -1182,7 +1212,7 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   if (pt > 0) { ProfScope ps(2, s); hipLaunchKernelGGL(k_attn_logits, dim3((L->Pp + 15) / 16), dim3(256), 0, s, c); }
   { ProfScope ps(6, s); hipLaunchKernelGGL(k_attn_agg, dim3(L->Nn), dim3(256), 0, s, c); }
   { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }
-  if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3(pt), dim3(256), 0, s, c, blk); }
+  if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3((L->Pp + 127) / 128), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(5, s); hipLaunchKernelGGL(k_equi_pairs<8>, dim3((L->Pp + 31) / 32), dim3(512), 0, s, c, blk); }
   hipLaunchKernelGGL(k_pos_update, dim3(L->B), dim3(64), 0, s, c, last);
   return launch_status();

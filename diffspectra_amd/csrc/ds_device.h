@@ -114,6 +114,11 @@ __device__ __forceinline__ void wave_mma(const float* X, int ldx, const float* _
 #pragma unroll
     for (int j = 0; j < G; ++j) bc[j] = wp[(size_t)min(kg0 + j, kg1 - 1) * wstride];
   }
+  // A fragments are double-buffered one k-group ahead: hipcc otherwise issues each ds_read_b128 right in front of the
+  // MFMA that consumes it and the LDS latency (~100 cycles per 512 cycles of MFMA) is exposed at 1-2 waves per SIMD.
+  float4 a_cur[MT], a_nxt[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) a_cur[m] = *reinterpret_cast<const float4*>(xr + m * 32 * ldx + kg0 * 8);
   for (int g = kg0; g < kg1; g += G) {
     if (g + G < kg1) {
 #pragma unroll
@@ -122,9 +127,13 @@ __device__ __forceinline__ void wave_mma(const float* X, int ldx, const float* _
 #pragma unroll
     for (int j = 0; j < G; ++j) {
       if (g + j < kg1) {
+        const int kn = min(g + j + 1, kg1 - 1);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_nxt[m] = *reinterpret_cast<const float4*>(xr + m * 32 * ldx + kn * 8);
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this k-group's MFMAs
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          const float4 a = *reinterpret_cast<const float4*>(xr + m * 32 * ldx + (g + j) * 8);
+          const float4 a = a_cur[m];
           if (TRANS) {
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[j].x, a.x, acc[m], 0, 0, 0);
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[j].y, a.y, acc[m], 0, 0, 0);
@@ -137,6 +146,8 @@ __device__ __forceinline__ void wave_mma(const float* X, int ldx, const float* _
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bc[j].w, acc[m], 0, 0, 0);
           }
         }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
       }
     }
 #pragma unroll

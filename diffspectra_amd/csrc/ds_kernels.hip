@@ -1101,8 +1101,83 @@ bool make_ctx(Ctx& c, const ds_weights* w, const ds_layout* L, const ds_workspac
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? DS_OK : DS_ERR_LAUNCH; }
 
+// Large plain GEMMs (the per-step adaLN table [B,1024] x [1024,19744] is 6 % of a denoising step): 128x128 output tile,
+// MT = 4 (each B fragment feeds 16 MFMAs), A double-buffered in LDS with the next K-chunk fetched into registers while
+// the current one is multiplied (one barrier per chunk), the next chunk's first B group requested ahead of that barrier.
+// Requires contiguous rows (no row groups), K % 64 == 0 and 16-byte aligned rows.
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void k_gemm_big(GemmArgs g) {
+  constexpr int T = 128, KC = 64, LD = KC + DS_LDP;
+  __shared__ __attribute__((aligned(16))) float X[2][T][LD];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int row0 = blockIdx.x * T;
+  const int col0 = (blockIdx.y * 4 + wave) * 32;
+  const bool active = col0 < g.Npad;
+  const int nchunks = g.K / KC;
+  float4 st[8];
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + u * 256, row = idx >> 4, k4 = idx & 15;
+      const size_t gr = (size_t)min(row0 + row, g.M - 1);
+      st[u] = reinterpret_cast<const float4*>(g.A + gr * g.lda + (size_t)kc * KC)[k4];
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + u * 256, row = idx >> 4, k4 = idx & 15;
+      float4 v = st[u];
+      if (g.a_silu) { v.x = ds_silu(v.x); v.y = ds_silu(v.y); v.z = ds_silu(v.z); v.w = ds_silu(v.w); }
+      if (row0 + row >= g.M) v = make_float4(0, 0, 0, 0);
+      reinterpret_cast<float4*>(&X[buf][row][0])[k4] = v;
+    }
+  };
+  f32x16 acc[4];
+  acc_zero<4>(acc);
+  fetch(0);
+  stash(0);
+  BFrag bf = bfrag_load(g.Wp, g.Npad, active ? col0 : 0, 0, 8);
+  __syncthreads();
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int cur = kc & 1;
+    if (kc + 1 < nchunks) fetch(kc + 1);
+    const float* wp = g.Wp + (size_t)(kc * (KC / 8)) * 2 * g.Npad * 4;
+    if (active) wave_mma<4>(&X[cur][0][0], LD, wp, g.Npad, col0, 0, KC / 8, acc, 0, &bf);
+    if (kc + 1 < nchunks) {
+      stash(cur ^ 1);
+      bf = bfrag_load(wp + (size_t)(KC / 8) * 2 * g.Npad * 4, g.Npad, active ? col0 : 0, 0, 8);
+    }
+    __syncthreads();
+  }
+  if (!active) return;
+  acc_foreach<4>(acc, 0, col0, [&](int row, int col, float v) {
+    const int gr = row0 + row;
+    if (gr < g.M && col < g.N) {
+      if (g.bias) v += g.bias[col];
+      v = ds_act<ACT>(v);
+      if (g.R) v += g.R[(size_t)(g.r_grp_rows > 0 ? gr % g.r_grp_rows : gr) * g.ldr + col];
+      if (g.cs) v = v * g.cs[col] + g.csh[col];
+      g.C[(size_t)gr * g.ldc + col] = v;
+    }
+  });
+}
+
 int gemm_dispatch(const GemmArgs& g, int act, hipStream_t s) {
   if (!g.A || !g.Wp || !g.C || g.M <= 0 || g.K <= 0 || g.N <= 0 || (g.cs && !g.csh)) return DS_ERR_ARG;
+  const bool big = g.M >= 512 && g.a_grp_rows <= 0 && g.c_grp_rows <= 0 && g.K % 64 == 0 && g.lda % 4 == 0 &&
+                   (reinterpret_cast<uintptr_t>(g.A) & 15) == 0;
+  if (big) {
+    dim3 gridb((g.M + 127) / 128, (g.Npad + 127) / 128);
+    switch (act) {
+      case 0: hipLaunchKernelGGL(k_gemm_big<0>, gridb, dim3(256), 0, s, g); break;
+      case 1: hipLaunchKernelGGL(k_gemm_big<1>, gridb, dim3(256), 0, s, g); break;
+      case 2: hipLaunchKernelGGL(k_gemm_big<2>, gridb, dim3(256), 0, s, g); break;
+      case 3: hipLaunchKernelGGL(k_gemm_big<3>, gridb, dim3(256), 0, s, g); break;
+      default: return DS_ERR_ARG;
+    }
+    return launch_status();
+  }
   dim3 grid((g.M + 63) / 64, (g.Npad + 127) / 128);
   switch (act) {
     case 0: hipLaunchKernelGGL(k_gemm<0>, grid, dim3(256), 0, s, g); break;

@@ -65,7 +65,8 @@ def to_dev(a, d):
 # ------------------------------------------------------------------------------------------------ GEMM
 
 @pytest.mark.parametrize("M,K,N,act", [(64, 64, 32, 0), (70, 24, 1024, 2), (5, 1024, 1024, 0), (130, 256, 96, 1),
-                                       (33, 56, 128, 3), (257, 128, 384, 0), (4, 1000, 40, 0)])
+                                       (33, 56, 128, 3), (257, 128, 384, 0), (4, 1000, 40, 0),
+                                       (700, 256, 200, 1), (1024, 1024, 160, 0)])   # the last two take the 128x128-tile kernel
 def test_gemm_vs_torch(gpu_device, M, K, N, act):
     """MFMA fragment layout, packing, K/N padding and guards of ds_gemm (asymmetric random operands)."""
     from diffspectra_amd import engine as E

@@ -281,37 +281,49 @@ __global__ __launch_bounds__(NW * 64) void k_node_qkv(Ctx c, int blk) {
   }, &pfq);
 }
 
-// Block stage C1 (flat over pairs): attention logits of both directions of every pair, 14 learned heads
+// Block stage C1 (one workgroup per molecule): attention logits of both directions of every pair, 14 learned heads
 // (q_t . k_s . tanh(e0) over 18 channels, / sqrt(16)) + the 2 adjacency heads (0 -> -1e10).  layers.py:165-174.
-// lg[p][0][h]: source a -> target b;  lg[p][1][h]: source b -> target a.  16 pairs x 16 head slots per workgroup.
-__global__ __launch_bounds__(256) void k_attn_logits(Ctx c) {
-  const int tid = threadIdx.x;
-  const int p = blockIdx.x * 16 + (tid >> 4), hs = tid & 15;
-  if (p >= c.L.Pp) return;
-  float* out = c.ws.lg + (size_t)p * 32;
-  if (hs >= 14) {
-    if (hs == 14) {
-      const int bits = c.ws.adj[p];
-      const float h0 = (bits & 1) ? 1.0f : -1e10f, h1 = (bits & 2) ? 1.0f : -1e10f;   // layers.py:171-174
-      out[0] = h0; out[1] = h1; out[16] = h0; out[17] = h1;
+// lg[p][0][h]: source a -> target b;  lg[p][1][h]: source b -> target a.  The molecule's q|k rows are staged in LDS once
+// (<= 58 kB) instead of being re-gathered from L2 for every 16 pairs; te0 streams through once.
+__global__ __launch_bounds__(256, 2) void k_attn_logits(Ctx c) {
+  __shared__ __attribute__((aligned(16))) float QK[DS_MAX_ATOMS * 512];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
+  const int p0 = c.L.pair_off[m], P = c.L.pair_off[m + 1] - p0;
+  if (P <= 0) return;
+  for (int idx = tid; idx < n * 128; idx += 256) {   // q (256) | k (256) of every atom
+    const int a = idx >> 7, k4 = idx & 127;
+    reinterpret_cast<float4*>(QK)[a * 128 + k4] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + a) * 768)[k4];
+  }
+  __syncthreads();
+  for (int it = tid; it < P * 16; it += 256) {
+    const int pl = it >> 4, hs = it & 15;
+    const int p = p0 + pl;
+    float* out = c.ws.lg + (size_t)p * 32;
+    if (hs >= 14) {
+      if (hs == 14) {
+        const int bits = c.ws.adj[p];
+        const float h0 = (bits & 1) ? 1.0f : -1e10f, h1 = (bits & 2) ? 1.0f : -1e10f;   // layers.py:171-174
+        out[0] = h0; out[1] = h1; out[16] = h0; out[17] = h1;
+      }
+      continue;
     }
-    return;
-  }
-  const int a = c.L.pair_a[p], b = c.L.pair_b[p];
-  const float2* t0 = reinterpret_cast<const float2*>(c.ws.te0 + (size_t)p * 256 + hs * 18);
-  const float2* qa = reinterpret_cast<const float2*>(c.ws.qkv + (size_t)a * 768 + hs * 18);
-  const float2* qb = reinterpret_cast<const float2*>(c.ws.qkv + (size_t)b * 768 + hs * 18);
-  const float2* ka = reinterpret_cast<const float2*>(c.ws.qkv + (size_t)a * 768 + 256 + hs * 18);
-  const float2* kb = reinterpret_cast<const float2*>(c.ws.qkv + (size_t)b * 768 + 256 + hs * 18);
-  float s_ab = 0.0f, s_ba = 0.0f;
+    const int a = c.L.pair_a[p] - n0, b = c.L.pair_b[p] - n0;
+    const float2* t0 = reinterpret_cast<const float2*>(c.ws.te0 + (size_t)p * 256 + hs * 18);
+    const float2* qa = reinterpret_cast<const float2*>(QK + a * 512 + hs * 18);
+    const float2* qb = reinterpret_cast<const float2*>(QK + b * 512 + hs * 18);
+    const float2* ka = reinterpret_cast<const float2*>(QK + a * 512 + 256 + hs * 18);
+    const float2* kb = reinterpret_cast<const float2*>(QK + b * 512 + 256 + hs * 18);
+    float s_ab = 0.0f, s_ba = 0.0f;
 #pragma unroll
-  for (int j = 0; j < 9; ++j) {
-    const float2 e = t0[j], xa = qa[j], xb = qb[j], ya = ka[j], yb = kb[j];
-    s_ab += (xb.x * ya.x) * e.x; s_ab += (xb.y * ya.y) * e.y;
-    s_ba += (xa.x * yb.x) * e.x; s_ba += (xa.y * yb.y) * e.y;
+    for (int j = 0; j < 9; ++j) {
+      const float2 e = t0[j], xa = qa[j], xb = qb[j], ya = ka[j], yb = kb[j];
+      s_ab += (xb.x * ya.x) * e.x; s_ab += (xb.y * ya.y) * e.y;
+      s_ba += (xa.x * yb.x) * e.x; s_ba += (xa.y * yb.y) * e.y;
+    }
+    out[2 + hs] = s_ab / 4.0f;        // / sqrt(out_channels = 16) (layers.py:167)
+    out[16 + 2 + hs] = s_ba / 4.0f;
   }
-  out[2 + hs] = s_ab / 4.0f;        // / sqrt(out_channels = 16) (layers.py:167)
-  out[16 + 2 + hs] = s_ba / 4.0f;
 }
 
 // Block stage C2 (one workgroup per TARGET atom, 2 kB LDS -> 8 workgroups/CU hide the gather latency): segment softmax
@@ -1284,7 +1296,7 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   const int pt = (L->Pp + 63) / 64, nt = (L->Nn + 31) / 32;
   if (pt > 0) { ProfScope ps(0, s); hipLaunchKernelGGL(k_edge_geom, dim3(pt), dim3(256), 0, s, c, blk); }
   { ProfScope ps(1, s); hipLaunchKernelGGL(k_node_qkv<4>, dim3(nt), dim3(256), 0, s, c, blk); }
-  if (pt > 0) { ProfScope ps(2, s); hipLaunchKernelGGL(k_attn_logits, dim3((L->Pp + 15) / 16), dim3(256), 0, s, c); }
+  if (pt > 0) { ProfScope ps(2, s); hipLaunchKernelGGL(k_attn_logits, dim3(L->B), dim3(256), 0, s, c); }
   { ProfScope ps(6, s); hipLaunchKernelGGL(k_attn_agg, dim3(L->Nn), dim3(256), 0, s, c); }
   { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3((L->Pp + 127) / 128), dim3(256), 0, s, c, blk); }

@@ -326,61 +326,68 @@ __global__ __launch_bounds__(256, 2) void k_attn_logits(Ctx c) {
   }
 }
 
-// Block stage C2 (one workgroup per TARGET atom, 2 kB LDS -> 8 workgroups/CU hide the gather latency): segment softmax
-// over the sources (PyG softmax: max-shift, exp, / (sum + 1e-16)) and out[t] = sum_s (v_s * tanh(e1)_{st}) * alpha,
-// sources in ascending order as the reference's scatter-add visits them.  layers.py:178-186.
-__global__ __launch_bounds__(256) void k_attn_agg(Ctx c) {
-  __shared__ float al[32][16];
-  const int trow = blockIdx.x, tid = threadIdx.x;
-  const int m = c.L.node_mol[trow];
+// Block stage C2 (one workgroup per molecule, one WAVE per target atom): segment softmax over the sources (PyG softmax:
+// max-shift, exp, / (sum + 1e-16)) and out[t] = sum_s (v_s * tanh(e1)_{st}) * alpha, sources in ascending order as the
+// reference's scatter-add visits them.  layers.py:178-186.  V is staged in LDS once per molecule; both readers of a te1
+// row (targets a and b) are waves of the same workgroup, so the second read is served on-chip.
+__global__ __launch_bounds__(512, 2) void k_attn_agg(Ctx c) {
+  constexpr int NW = 8;
+  __shared__ __attribute__((aligned(16))) float V[DS_MAX_ATOMS * 256];
+  __shared__ float al[NW][32][16];
+  const int m = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
   const int p0 = c.L.pair_off[m];
-  const int t = trow - n0;
-  for (int it = tid; it < n * 16; it += 256) {
-    const int s = it >> 4, h = it & 15;
-    if (s != t) {
+  if (n <= 0) return;
+  for (int idx = tid; idx < n * 64; idx += 512) {
+    const int a = idx >> 6, k4 = idx & 63;
+    reinterpret_cast<float4*>(V)[a * 64 + k4] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + a) * 768 + 512)[k4];
+  }
+  __syncthreads();
+  const int h = lane & 15, sq = lane >> 4;          // softmax phase: lane = (source mod 4, head)
+  const int hd = lane >> 2;                         // aggregation phase: lane owns channels 4*lane .. 4*lane+3 of head lane/4
+  const float4* te1 = reinterpret_cast<const float4*>(c.ws.te1) + (size_t)p0 * 64 + lane;
+  for (int t = wave; t < n; t += NW) {
+    float x[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int s = sq + 4 * j;
+      x[j] = -INFINITY;
+      if (s < n && s != t) {
+        const int lo = s < t ? s : t, hi = s < t ? t : s;
+        const int pl = lo * (2 * n - lo - 1) / 2 + (hi - lo - 1);
+        x[j] = c.ws.lg[(size_t)(p0 + pl) * 32 + (s < t ? 0 : 16) + h];
+      }
+      mx = fmaxf(mx, x[j]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      x[j] = (sq + 4 * j < n && sq + 4 * j != t) ? expf(x[j] - mx) : 0.0f;
+      sum += x[j];
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float den = sum + 1e-16f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) al[wave][sq + 4 * j][h] = x[j] / den;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int s = 0; s < n; ++s) {
+      if (s == t) continue;
       const int lo = s < t ? s : t, hi = s < t ? t : s;
       const int pl = lo * (2 * n - lo - 1) / 2 + (hi - lo - 1);
-      al[s][h] = c.ws.lg[(size_t)(p0 + pl) * 32 + (s < t ? 0 : 16) + h];
+      const float4 g = te1[(size_t)pl * 64];
+      const float4 v = reinterpret_cast<const float4*>(V)[s * 64 + lane];
+      const float a = al[wave][s][hd];
+      acc.x += (v.x * g.x) * a; acc.y += (v.y * g.y) * a; acc.z += (v.z * g.z) * a; acc.w += (v.w * g.w) * a;
     }
+    reinterpret_cast<float4*>(c.ws.attn + (size_t)(n0 + t) * 256)[lane] = acc;
+    __builtin_amdgcn_wave_barrier();   // al[wave] is rewritten for the next target
   }
-  __syncthreads();
-  if (tid < 16) {
-    float mx = -INFINITY;
-    for (int s = 0; s < n; ++s) if (s != t) mx = fmaxf(mx, al[s][tid]);
-    float sum = 0.0f;
-    for (int s = 0; s < n; ++s) if (s != t) { const float e = expf(al[s][tid] - mx); al[s][tid] = e; sum += e; }
-    const float den = sum + 1e-16f;
-    for (int s = 0; s < n; ++s) if (s != t) al[s][tid] /= den;
-  }
-  __syncthreads();
-  const int col = tid, hd = tid >> 4;
-  const float* vbase = c.ws.qkv + (size_t)n0 * 768 + 512 + col;
-  const float* gbase = c.ws.te1 + (size_t)p0 * 256 + col;
-  float acc = 0.0f;
-  int s = 0;
-  for (; s + 4 <= n; s += 4) {   // 4 sources per trip: 8 independent loads in flight
-    float v[4], g[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int ss = s + u;
-      const int sq = ss == t ? (t == 0 ? 1 : 0) : ss;            // any valid source; its term is masked below
-      const int lo = sq < t ? sq : t, hi = sq < t ? t : sq;
-      const int pl = lo * (2 * n - lo - 1) / 2 + (hi - lo - 1);
-      v[u] = vbase[(size_t)sq * 768];
-      g[u] = n > 1 ? gbase[(size_t)pl * 256] : 0.0f;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (s + u != t) acc += (v[u] * g[u]) * al[s + u][hd];
-  }
-  for (; s < n; ++s) {
-    if (s == t) continue;
-    const int lo = s < t ? s : t, hi = s < t ? t : s;
-    const int pl = lo * (2 * n - lo - 1) / 2 + (hi - lo - 1);
-    acc += (vbase[(size_t)s * 768] * gbase[(size_t)pl * 256]) * al[s][hd];
-  }
-  c.ws.attn[(size_t)trow * 256 + col] = acc;
 }
 
 // Block stage D (nodes, 32 rows): node2edge partial, gated residual, LN, modulate, FF(256->512->256) in two
@@ -1297,7 +1304,7 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   if (pt > 0) { ProfScope ps(0, s); hipLaunchKernelGGL(k_edge_geom, dim3(pt), dim3(256), 0, s, c, blk); }
   { ProfScope ps(1, s); hipLaunchKernelGGL(k_node_qkv<4>, dim3(nt), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(2, s); hipLaunchKernelGGL(k_attn_logits, dim3(L->B), dim3(256), 0, s, c); }
-  { ProfScope ps(6, s); hipLaunchKernelGGL(k_attn_agg, dim3(L->Nn), dim3(256), 0, s, c); }
+  { ProfScope ps(6, s); hipLaunchKernelGGL(k_attn_agg, dim3(L->B), dim3(512), 0, s, c); }
   { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3((L->Pp + 127) / 128), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(5, s); hipLaunchKernelGGL(k_equi_pairs<8>, dim3((L->Pp + 31) / 32), dim3(512), 0, s, c, blk); }

@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=1000)
     ap.add_argument("--spectra", default="allspectra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (1-GPU box, gloo backend)")
     ap.add_argument("--unconditional", action="store_true",
                     help="BASELINE config 4: zero context embedding, SpecFormer skipped (build extension, DESIGN.md §7)")
     ap.add_argument("--profile-kernel", type=int, default=5, help="block-stage kernel timed with HIP events (5 = k_equi_pairs)")
@@ -128,11 +130,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -163,7 +170,8 @@ def main():
     n_atoms = all_atoms[rank * M:(rank + 1) * M].tolist()
     context = filler.synthetic_spectra(world * M, args.spectra, seed=1)
     context = [c[rank * M:(rank + 1) * M].to(device) for c in context] if isinstance(context, list) else context[rank * M:(rank + 1) * M].to(device)
-    node_mask, edge_mask = S.build_masks(n_atoms, M, device)
+    # one padded width for every rank: the gathered records must have identical shapes on all ranks
+    node_mask, edge_mask = S.build_masks(n_atoms, M, device, max_n=int(all_atoms.max()))
     max_n = node_mask.shape[1]
     sampler = S._make_sampler(cfg, NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0,
                                                    continuous_beta_1=cfg.sde.continuous_beta_1), 1e-3,
@@ -208,7 +216,7 @@ def main():
     lib.ds_profile_config(C.c_int(-1), C.c_int(1), C.c_int(0))
     assert torch.isfinite(rec).all()
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

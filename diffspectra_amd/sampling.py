@@ -132,9 +132,10 @@ def mol_process(one_hot, x, formal_charges, n_nodes, edge_types=None):
     return mols
 
 
-def build_masks(n_nodes, batch_size, device):
-    """node_mask [B,N,1] / edge_mask [B*N*N,1] as sampling.py:432-439."""
-    max_n = max(n_nodes)
+def build_masks(n_nodes, batch_size, device, max_n=None):
+    """node_mask [B,N,1] / edge_mask [B*N*N,1] as sampling.py:432-439 (``max_n`` pads to a fixed width, e.g. so that
+    every rank of a sharded run produces records of the same size)."""
+    max_n = max(n_nodes) if max_n is None else max(int(max_n), max(n_nodes))
     node_mask = torch.zeros(batch_size, max_n)
     for i in range(batch_size):
         node_mask[i, 0:n_nodes[i]] = 1

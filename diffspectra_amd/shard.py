@@ -50,6 +50,10 @@ def gather_records(rec: torch.Tensor, counts=None) -> torch.Tensor:
     buf = rec
     if rec.shape[0] < m:
         buf = torch.cat([rec, rec.new_zeros(m - rec.shape[0], rec.shape[1])], 0)
-    out = torch.empty(world * m, rec.shape[1], dtype=rec.dtype, device=rec.device)
+    dev = rec.device
+    if dist.get_backend() == "gloo" and dev.type != "cpu":
+        buf = buf.cpu()                          # rehearsal path: gloo gathers host tensors; RCCL gathers in HBM
+    out = torch.empty(world * m, rec.shape[1], dtype=rec.dtype, device=buf.device)
     dist.all_gather_into_tensor(out, buf.contiguous())
+    out = out.to(dev)
     return torch.cat([out[r * m:r * m + counts[r]] for r in range(world)], 0)

@@ -277,7 +277,7 @@ __device__ __forceinline__ void ln_mod_row(float* row, const float* __restrict__
 
 // LayerNorm + modulate of a whole LDS tile: wave w owns rows w, w+NWV, ...  The per-row adaLN shift/scale vectors live
 // in global memory (one row of the ada table per molecule); ALL of a wave's rows are requested before the first
-// reduction so the L2/HBM latency is paid once per tile instead of once per row (it was 28 % of k_equi_flat).
+// reduction so the L2/HBM latency is paid once per tile instead of once per row (it was 28 % of the equivariant-update kernel).
 template <int W, int RPW, int NWV>
 __device__ __forceinline__ void ln_mod_tile(float* X, int ldx, const int* rmol, const float* __restrict__ ada, size_t ada_ld,
                                             int shift_off, int scale_off) {

@@ -57,7 +57,7 @@ __device__ __forceinline__ float4 ln_mod_reg256(float4 v, float4 sh, float4 sc) 
   const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
   v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
   const float var = wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 256.0f);
-  const float rstd = 1.0f / sqrtf(var + 1e-6f);
+  const float rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
   v.x = v.x * rstd * (1.0f + sc.x) + sh.x; v.y = v.y * rstd * (1.0f + sc.y) + sh.y;
   v.z = v.z * rstd * (1.0f + sc.z) + sh.z; v.w = v.w * rstd * (1.0f + sc.w) + sh.w;
   return v;
@@ -66,7 +66,7 @@ __device__ __forceinline__ float4 ln_mod_reg64(float4 v, float4 sh, float4 sc) {
   const float mean = row16_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 64.0f);
   v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
   const float var = row16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 64.0f);
-  const float rstd = 1.0f / sqrtf(var + 1e-6f);
+  const float rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
   v.x = v.x * rstd * (1.0f + sc.x) + sh.x; v.y = v.y * rstd * (1.0f + sc.y) + sh.y;
   v.z = v.z * rstd * (1.0f + sc.z) + sh.z; v.w = v.w * rstd * (1.0f + sc.w) + sh.w;
   return v;
@@ -257,7 +257,7 @@ __device__ __forceinline__ void ln_mod_row(float* row, const float* __restrict__
     const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
     v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
     const float var = wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 256.0f);
-    const float rstd = 1.0f / sqrtf(var + 1e-6f);
+    const float rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
     const float4 sh = reinterpret_cast<const float4*>(shift)[lane];
     const float4 sc = reinterpret_cast<const float4*>(scale)[lane];
     v.x = v.x * rstd * (1.0f + sc.x) + sh.x;
@@ -270,7 +270,7 @@ __device__ __forceinline__ void ln_mod_row(float* row, const float* __restrict__
     const float mean = wave_sum(v) * (1.0f / 64.0f);
     v -= mean;
     const float var = wave_sum(v * v) * (1.0f / 64.0f);
-    const float rstd = 1.0f / sqrtf(var + 1e-6f);
+    const float rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
     row[lane] = v * rstd * (1.0f + scale[lane]) + shift[lane];
   }
 }
@@ -297,7 +297,7 @@ __device__ __forceinline__ void ln_mod_tile(float* X, int ldx, const int* rmol, 
       const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
       v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
       const float var = wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 256.0f);
-      const float rstd = 1.0f / sqrtf(var + 1e-6f);
+      const float rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
       v.x = v.x * rstd * (1.0f + sc[j].x) + sh[j].x;
       v.y = v.y * rstd * (1.0f + sc[j].y) + sh[j].y;
       v.z = v.z * rstd * (1.0f + sc[j].z) + sh[j].z;
@@ -318,7 +318,7 @@ __device__ __forceinline__ void ln_mod_tile(float* X, int ldx, const int* rmol, 
       const float mean = wave_sum(v[j]) * (1.0f / 64.0f);
       v[j] -= mean;
       const float var = wave_sum(v[j] * v[j]) * (1.0f / 64.0f);
-      const float rstd = 1.0f / sqrtf(var + 1e-6f);
+      const float rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
       v[j] = v[j] * rstd * (1.0f + sc[j]) + sh[j];
     }
 #pragma unroll

@@ -650,6 +650,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_equi_pairs(Ctx c, int blk) 
   const int Pp = c.L.Pp;
   const int p0 = blockIdx.x * TP;
   const int npairs = min(TP, Pp - p0);
+  // The co-resident workgroup is usually inside its MFMA phase; without a priority bump its always-ready MFMA stream wins
+  // the SIMD's issue arbitration and this workgroup's gather / LayerNorm phase crawls (57k cycles instead of 13k alone).
+  __builtin_amdgcn_s_setprio(3);
   const BFrag pfc = bfrag_load(BW(c, blk, DS_BW_CM0_W), 256, wave * 32, 0, 32);   // coord_mlp.0 weights, ahead of everything
   DS_STAMP_INIT();
   {
@@ -661,11 +664,18 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_equi_pairs(Ctx c, int blk) 
     for (int b0 = 0; b0 < PPW; b0 += BATCH) {
       float4 Aa[BATCH], Ca[BATCH], Ab[BATCH], Cb[BATCH], ve[BATCH], sh[BATCH], sc[BATCH];
       int na[BATCH], nb[BATCH], pm[BATCH], pp[BATCH];
+      {   // pair-table entries: lane u fetches pair u's entries with VECTOR loads (3 loads in flight, one round trip) and
+          // readlane broadcasts them; wave-uniform scalar loads compile to s_load -> s_waitcnt -> s_load chains.
+        const int qv = wv + (b0 + (lane & (BATCH - 1))) * NW;
+        const int pv = qv < npairs ? p0 + qv : 0;                      // pairs past the end gather pair 0, zeroed below
+        const int av = c.L.pair_a[pv], bv = c.L.pair_b[pv], mv = c.L.pair_mol[pv];
 #pragma unroll
-      for (int u = 0; u < BATCH; ++u) {
-        const int q = wv + (b0 + u) * NW;                              // pairs past the end gather pair 0, zeroed below
-        pp[u] = q < npairs ? p0 + q : 0;
-        na[u] = c.L.pair_a[pp[u]]; nb[u] = c.L.pair_b[pp[u]]; pm[u] = c.L.pair_mol[pp[u]];
+        for (int u = 0; u < BATCH; ++u) {
+          pp[u] = __builtin_amdgcn_readlane(pv, u);
+          na[u] = __builtin_amdgcn_readlane(av, u);
+          nb[u] = __builtin_amdgcn_readlane(bv, u);
+          pm[u] = __builtin_amdgcn_readlane(mv, u);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks every load next to its use (load -> wait -> LN per row)
 #pragma unroll
@@ -707,6 +717,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_equi_pairs(Ctx c, int blk) 
       b0f[cc][i] = b0[f];
       w2f[cc][i] = (lane & 31) < 3 ? wp_at(w2, 32, f, lane & 31) : 0.0f;
     }
+  __builtin_amdgcn_s_setprio(0);
   __syncthreads();
   DS_STAMP(0);
   {

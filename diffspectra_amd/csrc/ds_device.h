@@ -46,9 +46,11 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 __device__ __forceinline__ float wave_sum(float v) {
   v = row16_sum(v);
-  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));   // xor 16 inside each 32-lane half
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) +
-         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  // rows 1,3 += row 0,2 (row_bcast:15, row_mask 0xA); rows 2,3 += lane 31 (row_bcast:31, row_mask 0xC): lane 63 then
+  // holds (r3 + r2) + (r1 + r0).  Pure VALU: no trip through the LDS pipe the MFMA waves' operand reads keep busy.
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // LayerNorm(no affine, eps 1e-6, biased variance) + modulate on register-resident rows.

@@ -15,18 +15,33 @@
 #define ADAC DS_ADA_COLS
 
 // Diagnostic build only (-DDS_STAMPS): per-phase shader-clock sums of wave 0 of every workgroup, accumulated into
-// the tail of ws.flags (64-bit counters at int32 index 16 + 2*phase).  Never compiled into the shipped library.
+// registers and flushed once at kernel exit to the tail of ws.flags (64-bit counters at int32 index 16 + 2*phase).  Never compiled into the shipped library.
 #ifdef DS_STAMPS
-#define DS_STAMP_INIT() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
+#define DS_STAMP_INIT()                                                                                 \
+  unsigned long long _sa[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                        \
+  unsigned long long _t0 = __builtin_amdgcn_s_memtime()
 #define DS_STAMP(i)                                                                                     \
   do {                                                                                                  \
     const unsigned long long _t1 = __builtin_amdgcn_s_memtime();                                        \
-    if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(c.ws.flags + 16) + (i), _t1 - _t0); \
+    _sa[i] += _t1 - _t0;                                                                                \
     _t0 = _t1;                                                                                          \
+  } while (0)
+#define DS_STAMP_W(i)                                                                                   \
+  do {                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
+    DS_STAMP(i);                                                                                        \
+  } while (0)
+#define DS_STAMP_FLUSH(t)                                                                               \
+  do {                                                                                                  \
+    if (threadIdx.x == (t))                                                                             \
+      for (int _i = 0; _i < 16; ++_i)                                                                   \
+        if (_sa[_i]) atomicAdd(reinterpret_cast<unsigned long long*>(c.ws.flags + 16) + _i, _sa[_i]);   \
   } while (0)
 #else
 #define DS_STAMP_INIT()
 #define DS_STAMP(i)
+#define DS_STAMP_W(i)
+#define DS_STAMP_FLUSH(t)
 #endif
 
 namespace {
@@ -639,139 +654,195 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
 // x = A_r + C_c + ed_{rc} -> LN -> modulate -> [256->256, SiLU] -> [256->3] -> tanh -> head mix -> CoorsNorm; the per-edge
 // translation vectors go to tr[2p + dir] and k_pos_update sums them per atom in the reference's edge order.
 // The 256->256 GEMM is computed TRANSPOSED (lane = edge row, registers = output features) so that its SiLU'd
-// accumulators are directly the B operand of the 256->3 MFMA: the hidden activations never touch LDS, X is the only
-// large LDS tile (66.5 kB -> two workgroups per CU overlap each other's gather/LN phases with MFMA work).
-template <int NW>
-__global__ __launch_bounds__(NW * 64, NW / 2) void k_equi_pairs(Ctx c, int blk) {
-  constexpr int T = 64, TP = 32, MT = 2, CPW = 8 / NW, PPW = TP / NW;   // rows, pairs, m-tiles, chunks / pairs per wave
-  __shared__ __attribute__((aligned(16))) float X[T][256 + DS_LDP];
-  __shared__ __attribute__((aligned(16))) float part[NW][T][4];
+// accumulators are directly the B operand of the 256->3 MFMA: the hidden activations never touch LDS.
+//
+// Warp-specialised and persistent: one 768-thread workgroup per CU loops over tiles.  Waves 8-11 (loaders, raised
+// priority, one per SIMD) gather + LayerNorm + modulate tile i+1 into the other half of a double-buffered LDS tile,
+// precompute its unit coordinate differences, and finish tile i-1's tail (tanh, head mix, CoorsNorm -> tr) while waves
+// 0-7 (two per SIMD, priority 0) run the MFMA chain on tile i, each owning 32 of the 256 hidden features.  One barrier
+// per tile.  Measured (tools/micro/): a wave that alternates gather and MFMA phases loses its memory issue
+// slots to a co-resident MFMA stream, and VALU work next to that stream issues about six times slower than alone, so the
+// roles are split, the loaders' four gather batches are software-pipelined behind their LayerNorm arithmetic, and one
+// MFMA wave's SiLU epilogue overlaps the other's MFMAs on the same SIMD.
+__global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
+  constexpr int T = 64, TP = 32, LD = 256 + DS_LDP, NC = 8;
+  __shared__ __attribute__((aligned(16))) float X[2][T][LD];         // 133,120 B
+  __shared__ __attribute__((aligned(16))) float part[2][NC][T][4];   //  16,384 B
+  __shared__ __attribute__((aligned(16))) float dirs[3][T][4];       //   3,072 B  (unit diff * coord_scale, adjacency bits)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5;
   const int Pp = c.L.Pp;
-  const int p0 = blockIdx.x * TP;
-  const int npairs = min(TP, Pp - p0);
-  // The co-resident workgroup is usually inside its MFMA phase; without a priority bump its always-ready MFMA stream wins
-  // the SIMD's issue arbitration and this workgroup's gather / LayerNorm phase crawls (57k cycles instead of 13k alone).
-  __builtin_amdgcn_s_setprio(3);
-  const BFrag pfc = bfrag_load(BW(c, blk, DS_BW_CM0_W), 256, wave * 32, 0, 32);   // coord_mlp.0 weights, ahead of everything
-  DS_STAMP_INIT();
-  {
-    const float* adq = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EQUI;
-    // A wave owns whole rows, so the pair-table entries are wave-uniform (scalar loads, SALU address math) and
-    // LayerNorm + modulate run in registers (DPP reductions) before the one LDS store: no second pass, no extra barrier.
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    constexpr int BATCH = PPW < 2 ? PPW : 2;
-    for (int b0 = 0; b0 < PPW; b0 += BATCH) {
-      float4 Aa[BATCH], Ca[BATCH], Ab[BATCH], Cb[BATCH], ve[BATCH], sh[BATCH], sc[BATCH];
-      int na[BATCH], nb[BATCH], pm[BATCH], pp[BATCH];
-      {   // pair-table entries: lane u fetches pair u's entries with VECTOR loads (3 loads in flight, one round trip) and
-          // readlane broadcasts them; wave-uniform scalar loads compile to s_load -> s_waitcnt -> s_load chains.
-        const int qv = wv + (b0 + (lane & (BATCH - 1))) * NW;
-        const int pv = qv < npairs ? p0 + qv : 0;                      // pairs past the end gather pair 0, zeroed below
-        const int av = c.L.pair_a[pv], bv = c.L.pair_b[pv], mv = c.L.pair_mol[pv];
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-          pp[u] = __builtin_amdgcn_readlane(pv, u);
-          na[u] = __builtin_amdgcn_readlane(av, u);
-          nb[u] = __builtin_amdgcn_readlane(bv, u);
-          pm[u] = __builtin_amdgcn_readlane(mv, u);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks every load next to its use (load -> wait -> LN per row)
-#pragma unroll
-      for (int u = 0; u < BATCH; ++u) {   // 7 independent 1-kB row loads per pair in flight
-        const float4* ra = reinterpret_cast<const float4*>(c.ws.ac + (size_t)na[u] * 512);
-        const float4* rb = reinterpret_cast<const float4*>(c.ws.ac + (size_t)nb[u] * 512);
-        Aa[u] = ra[lane]; Ca[u] = ra[64 + lane]; Ab[u] = rb[lane]; Cb[u] = rb[64 + lane];
-        ve[u] = reinterpret_cast<const float4*>(c.ws.ed + (size_t)pp[u] * 256)[lane];
-        sh[u] = reinterpret_cast<const float4*>(adq + (size_t)pm[u] * ADAC)[lane];          // shift (dmt.py:44)
-        sc[u] = reinterpret_cast<const float4*>(adq + (size_t)pm[u] * ADAC + 256)[lane];    // scale
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < BATCH; ++u) {
-        const int q = wv + (b0 + u) * NW;
-        float4 x1, x2;   // row a -> b: input_lin([h_a, h_b, e, d]);  row b -> a: input_lin([h_b, h_a, e, d])  (dmt.py:39,45)
-        x1.x = (Aa[u].x + Cb[u].x) + ve[u].x; x1.y = (Aa[u].y + Cb[u].y) + ve[u].y;
-        x1.z = (Aa[u].z + Cb[u].z) + ve[u].z; x1.w = (Aa[u].w + Cb[u].w) + ve[u].w;
-        x2.x = (Ab[u].x + Ca[u].x) + ve[u].x; x2.y = (Ab[u].y + Ca[u].y) + ve[u].y;
-        x2.z = (Ab[u].z + Ca[u].z) + ve[u].z; x2.w = (Ab[u].w + Ca[u].w) + ve[u].w;
-        x1 = ln_mod_reg256(x1, sh[u], sc[u]);
-        x2 = ln_mod_reg256(x2, sh[u], sc[u]);
-        if (q >= npairs) x1 = x2 = make_float4(0, 0, 0, 0);
-        reinterpret_cast<float4*>(&X[2 * q][0])[lane] = x1;
-        reinterpret_cast<float4*>(&X[2 * q + 1][0])[lane] = x2;
-      }
-    }
-  }
-  // per-lane constants of this wave's 32-feature chunks (coord_mlp.0 bias, coord_mlp.2 A-fragments), requested while the
-  // other waves finish their rows
-  const float* b0 = BW(c, blk, DS_BW_CM0_B);
-  const float* w2 = BW(c, blk, DS_BW_CM2_W);
-  float b0f[CPW][16], w2f[CPW][16];
-#pragma unroll
-  for (int cc = 0; cc < CPW; ++cc)
+  const int ntiles = (Pp + TP - 1) / TP;
+  const float* adq = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EQUI;
+  const bool consumer = wave < NC;
+  const float cscale = BW(c, blk, DS_BW_COORD_SCALE)[0];
+
+  float b0f[16], w2f[16];   // consumer constants: coord_mlp.0 bias and coord_mlp.2 A-fragments of its 32 features
+  if (consumer) {
+    __builtin_amdgcn_s_setprio(0);
+    const float* b0 = BW(c, blk, DS_BW_CM0_B);
+    const float* w2 = BW(c, blk, DS_BW_CM2_W);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int f = (wave + NW * cc) * 32 + acc_row(i, hh);
-      b0f[cc][i] = b0[f];
-      w2f[cc][i] = (lane & 31) < 3 ? wp_at(w2, 32, f, lane & 31) : 0.0f;
+      const int f = wave * 32 + acc_row(i, hh);
+      b0f[i] = b0[f];
+      w2f[i] = (lane & 31) < 3 ? wp_at(w2, 32, f, lane & 31) : 0.0f;
     }
-  __builtin_amdgcn_s_setprio(0);
-  __syncthreads();
-  DS_STAMP(0);
-  {
-    f32x16 acc2[MT];
-    acc_zero<MT>(acc2);
+  } else {
+    __builtin_amdgcn_s_setprio(3);
+  }
+
+  // loader wave lw owns pairs lw, lw+4, ... of a tile (8 pairs = 16 rows).  The pair-table entries of a tile are fetched
+  // one produce() early; the gathers run as four batches of two pairs, batch n+1 in flight while batch n is normalised
+  // (VALU issue is scarce next to the MFMA stream - tools/micro/ln_corun.hip - so latency must hide behind it, not add).
+  const int lw = __builtin_amdgcn_readfirstlane(wave - NC);
+  int pv_n = 0, av_n = 0, bv_n = 0, mv_n = 0, adj_n = 0;   // prefetched table entries, lane = (pair slot u8, direction)
+  auto fetch_idx = [&](int tile) {
+    const int p0 = tile * TP;
+    const int qv = lw + ((lane >> 1) & 7) * 4;
+    pv_n = qv < min(TP, Pp - p0) ? p0 + qv : 0;                        // pairs past the end gather pair 0, zeroed below
+    av_n = c.L.pair_a[pv_n]; bv_n = c.L.pair_b[pv_n]; mv_n = c.L.pair_mol[pv_n]; adj_n = c.ws.adj[pv_n];
+  };
+  auto produce = [&](int tile, int buf, int gen, int tile_after) {
+    const int p0 = tile * TP;
+    const int npairs = min(TP, Pp - p0);
+    int na[8], nb[8], pm[8], pp[8];
 #pragma unroll
-    for (int cc = 0; cc < CPW; ++cc) {
-      asm volatile("" ::: "memory");   // keep the A-fragment LDS reads inside each chunk (see tile_gemm)
-      f32x16 acc1[MT];
-      acc_zero<MT>(acc1);
-      wave_mma<MT, true>(&X[0][0], 256 + DS_LDP, BW(c, blk, DS_BW_CM0_W), 256, (wave + NW * cc) * 32, 0, 32, acc1, 0,
-                         cc == 0 ? &pfc : nullptr);
+    for (int u = 0; u < 8; ++u) {
+      pp[u] = __builtin_amdgcn_readlane(pv_n, 2 * u); na[u] = __builtin_amdgcn_readlane(av_n, 2 * u);
+      nb[u] = __builtin_amdgcn_readlane(bv_n, 2 * u); pm[u] = __builtin_amdgcn_readlane(mv_n, 2 * u);
+    }
+    const int dir = lane & 1, qd = lw + ((lane >> 1) & 7) * 4, bits = adj_n;
+    float4 pr = make_float4(0, 0, 0, 0), pc = pr;
+    if (lane < 16) {
+      pr = reinterpret_cast<const float4*>(c.ws.pos)[dir ? bv_n : av_n];   // row atom (edge_index[0])
+      pc = reinterpret_cast<const float4*>(c.ws.pos)[dir ? av_n : bv_n];
+    }
+    float4 Aa[2][2], Ca[2][2], Ab[2][2], Cb[2][2], ve[2][2], sh[2][2], sc[2][2];
+    auto load = [&](int bt) {
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int u = 0; u < 2; ++u) {
+        const int i = bt * 2 + u, s = bt & 1;
+        const float4* ra = reinterpret_cast<const float4*>(c.ws.ac + (size_t)na[i] * 512);
+        const float4* rb = reinterpret_cast<const float4*>(c.ws.ac + (size_t)nb[i] * 512);
+        Aa[s][u] = ra[lane]; Ca[s][u] = ra[64 + lane]; Ab[s][u] = rb[lane]; Cb[s][u] = rb[64 + lane];
+        ve[s][u] = reinterpret_cast<const float4*>(c.ws.ed + (size_t)pp[i] * 256)[lane];
+        sh[s][u] = reinterpret_cast<const float4*>(adq + (size_t)pm[i] * ADAC)[lane];          // shift (dmt.py:44)
+        sc[s][u] = reinterpret_cast<const float4*>(adq + (size_t)pm[i] * ADAC + 256)[lane];    // scale
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto process = [&](int bt) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int s = bt & 1, q = lw + (bt * 2 + u) * 4;
+        float4 x1, x2;   // row a -> b: input_lin([h_a, h_b, e, d]);  row b -> a: input_lin([h_b, h_a, e, d])  (dmt.py:39,45)
+        x1.x = (Aa[s][u].x + Cb[s][u].x) + ve[s][u].x; x1.y = (Aa[s][u].y + Cb[s][u].y) + ve[s][u].y;
+        x1.z = (Aa[s][u].z + Cb[s][u].z) + ve[s][u].z; x1.w = (Aa[s][u].w + Cb[s][u].w) + ve[s][u].w;
+        x2.x = (Ab[s][u].x + Ca[s][u].x) + ve[s][u].x; x2.y = (Ab[s][u].y + Ca[s][u].y) + ve[s][u].y;
+        x2.z = (Ab[s][u].z + Ca[s][u].z) + ve[s][u].z; x2.w = (Ab[s][u].w + Ca[s][u].w) + ve[s][u].w;
+        x1 = ln_mod_reg256(x1, sh[s][u], sc[s][u]);
+        x2 = ln_mod_reg256(x2, sh[s][u], sc[s][u]);
+        if (q >= npairs) x1 = x2 = make_float4(0, 0, 0, 0);
+        reinterpret_cast<float4*>(&X[buf][2 * q][0])[lane] = x1;
+        reinterpret_cast<float4*>(&X[buf][2 * q + 1][0])[lane] = x2;
+      }
+    };
+    load(0);
+    load(1);
+    if (tile_after < ntiles) fetch_idx(tile_after);
+    __builtin_amdgcn_sched_barrier(0);
+    if (lane < 16) {   // unit vector of pos[row] - pos[col], scaled (layers.py:345-346), + adjacency bits, for the tail
+      const float dx = pr.x - pc.x, dy = pr.y - pc.y, dz = pr.z - pc.z;
+      const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);
+      float4 d;
+      d.x = dx / nrm * cscale; d.y = dy / nrm * cscale; d.z = dz / nrm * cscale; d.w = __int_as_float(bits);
+      reinterpret_cast<float4*>(&dirs[gen][2 * qd + dir][0])[0] = d;
+    }
+    process(0);
+    load(2);
+    process(1);
+    load(3);
+    process(2);
+    process(3);
+  };
+
+  // first loader wave: tail of a finished tile, one lane per directed edge (row 2q+dir of the tile)
+  auto tail = [&](int tile, int pb, int gen) {
+    const int p0 = tile * TP;
+    const int npairs = min(TP, Pp - p0);
+    if ((lane >> 1) < npairs) {
+      float inv[3];
+#pragma unroll
+      for (int hI = 0; hI < 3; ++hI) {
+        float sacc = part[pb][0][lane][hI];
+#pragma unroll
+        for (int w = 1; w < NC; ++w) sacc += part[pb][w][lane][hI];
+        inv[hI] = tanhf(sacc);
+      }
+      const float4 d = reinterpret_cast<const float4*>(&dirs[gen][lane][0])[0];
+      const int bits = __float_as_int(d.w);
+      const float w = ((inv[0] + ((bits & 1) ? inv[1] : 0.0f)) + ((bits & 2) ? inv[2] : 0.0f)) / 3.0f;   // dmt.py:51-53
+      float4 t;
+      t.x = d.x * w; t.y = d.y * w; t.z = d.z * w; t.w = 0.0f;
+      reinterpret_cast<float4*>(c.ws.tr)[(size_t)p0 * 2 + lane] = t;   // coord_diff * inv (dmt.py:56)
+    }
+  };
+
+  // Two role loops with the same barrier count (one before the first tile, one per tile), kept apart so that neither
+  // role's registers stay live through the other's code.
+  const int first = blockIdx.x, stride = gridDim.x;
+  if (first >= ntiles) return;
+  DS_STAMP_INIT();
+  if (consumer) {
+    __syncthreads();
+    DS_STAMP(0);
+    int it = 0;
+    for (int tile = first; tile < ntiles; tile += stride, ++it) {
+      const int buf = it & 1;
+      f32x16 acc1[2], acc2[2];
+      acc_zero<2>(acc1);
+      acc_zero<2>(acc2);
+      wave_mma<2, true>(&X[buf][0][0], LD, BW(c, blk, DS_BW_CM0_W), 256, wave * 32, 0, 32, acc1);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float y = ds_silu(acc1[m][i] + b0f[cc][i]);                       // coord_mlp.0 + SiLU (dmt.py:32-33)
-          acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[cc][i], y, acc2[m], 0, 0, 0);   // coord_mlp.2 partial (dmt.py:34)
+          const float y = ds_silu(acc1[m][i] + b0f[i]);                                   // coord_mlp.0 + SiLU (dmt.py:32-33)
+          acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[i], y, acc2[m], 0, 0, 0);   // coord_mlp.2 partial (dmt.py:34)
         }
-    }
-    if (hh == 0) {   // out[j][row]: j = register 0..2 of the lower half, row = m*32 + lane
+      if (hh == 0) {   // out[j][row]: j = register 0..2 of the lower half, row = m*32 + lane
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        part[wave][m * 32 + lane][0] = acc2[m][0];
-        part[wave][m * 32 + lane][1] = acc2[m][1];
-        part[wave][m * 32 + lane][2] = acc2[m][2];
+        for (int m = 0; m < 2; ++m) {
+          float4 o;
+          o.x = acc2[m][0]; o.y = acc2[m][1]; o.z = acc2[m][2]; o.w = 0.0f;
+          reinterpret_cast<float4*>(&part[buf][wave][m * 32 + lane][0])[0] = o;
+        }
       }
+      DS_STAMP(1);
+      __syncthreads();
+      DS_STAMP(2);
     }
-  }
-  __syncthreads();
-  DS_STAMP(1);
-  if (tid < T && (tid >> 1) < npairs) {
-    const int p = p0 + (tid >> 1), dir = tid & 1;
-    const int na = c.L.pair_a[p], nb = c.L.pair_b[p];
-    const int bits = c.ws.adj[p];
-    float inv[3];
-#pragma unroll
-    for (int hI = 0; hI < 3; ++hI) {
-      float sacc = part[0][tid][hI];
-#pragma unroll
-      for (int w2i = 1; w2i < NW; ++w2i) sacc += part[w2i][tid][hI];
-      inv[hI] = tanhf(sacc);
+    DS_STAMP_FLUSH(0);
+  } else {
+    fetch_idx(first);
+    produce(first, 0, 0, first + stride);
+    __syncthreads();
+    DS_STAMP(4);
+    int it = 0, prev_tile = -1;
+    for (int tile = first; tile < ntiles; tile += stride, ++it) {
+      const int next = tile + stride, buf = it & 1;
+      if (next < ntiles) produce(next, buf ^ 1, (it + 1) % 3, next + stride);
+      DS_STAMP(5);
+      if (wave == NC && prev_tile >= 0) tail(prev_tile, buf ^ 1, (it + 2) % 3);   // part[buf^1]: written one interval ago
+      DS_STAMP(6);
+      __syncthreads();
+      DS_STAMP(7);
+      prev_tile = tile;
     }
-    const float w = ((inv[0] + ((bits & 1) ? inv[1] : 0.0f)) + ((bits & 2) ? inv[2] : 0.0f)) / 3.0f;   // dmt.py:51-53
-    const float* pr = c.ws.pos + (size_t)(dir ? nb : na) * 4;   // row atom (edge_index[0])
-    const float* pc = c.ws.pos + (size_t)(dir ? na : nb) * 4;
-    const float dx = pr[0] - pc[0], dy = pr[1] - pc[1], dz = pr[2] - pc[2];
-    const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);   // layers.py:345-346
-    const float cscale = BW(c, blk, DS_BW_COORD_SCALE)[0];
-    float4 t;
-    t.x = (dx / nrm * cscale) * w; t.y = (dy / nrm * cscale) * w; t.z = (dz / nrm * cscale) * w; t.w = 0.0f;
-    reinterpret_cast<float4*>(c.ws.tr)[(size_t)p * 2 + dir] = t;   // coord_diff * inv (dmt.py:56)
+    if (wave == NC) tail(prev_tile, (it + 1) & 1, (it + 2) % 3);
+    DS_STAMP_FLUSH(512);
   }
-  DS_STAMP(2);
 }
 
 // One wave per molecule: pos_r += sum_c trans(r -> c) in ascending c (the reference's scatter-add order, dmt.py:57-58),
@@ -1318,7 +1389,7 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   { ProfScope ps(6, s); hipLaunchKernelGGL(k_attn_agg, dim3(L->B), dim3(512), 0, s, c); }
   { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3((L->Pp + 127) / 128), dim3(256), 0, s, c, blk); }
-  if (pt > 0) { ProfScope ps(5, s); hipLaunchKernelGGL(k_equi_pairs<8>, dim3((L->Pp + 31) / 32), dim3(512), 0, s, c, blk); }
+  if (pt > 0) { ProfScope ps(5, s); { const int nt_ = (L->Pp + 31) / 32; hipLaunchKernelGGL(k_equi_pairs, dim3(nt_ < 256 ? nt_ : 256), dim3(768), 0, s, c, blk); } }
   hipLaunchKernelGGL(k_pos_update, dim3(L->B), dim3(64), 0, s, c, last);
   return launch_status();
 }

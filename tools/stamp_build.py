@@ -23,14 +23,15 @@ def stamp_kernel(s, name, base):
         out = out[:2] + "  DS_STAMP_INIT();\n" + out[2:]
     for i, pt in enumerate(parts[1:]):
         out += "  __syncthreads();\n  DS_STAMP(%d);\n" % (base + i) + pt
-    out += "\n  DS_STAMP(%d);" % (base + len(parts) - 1)
+    out += "\n  DS_STAMP(%d);\n  DS_STAMP_FLUSH(0);" % (base + len(parts) - 1)
     return s[:a] + out + s[b:], len(parts)
 
 
 def main():
     s = open(SRC).read()
     import re
-    s = re.sub(r"\n\s*DS_STAMP\(\d+\);", "", s)           # drop the in-tree stamps, re-insert uniformly
+    s = re.sub(r"\n\s*DS_STAMP(_W)?\(\d+\);", "", s)
+    s = re.sub(r"\n\s*DS_STAMP_FLUSH\(\d+\);", "", s)           # drop the in-tree stamps, re-insert uniformly
     s = s.replace("  DS_STAMP_INIT();\n", "")
     for spec in sys.argv[1:]:
         name, base = spec.split(":")

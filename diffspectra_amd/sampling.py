@@ -90,7 +90,9 @@ class AncestralSampler:
             noise_level.copy_(nl_dev[i].expand(B))
             cur = i & 1
             eng.forward(L, ws, x, edge_x, noise_level, cond_x, cond_edge_x, ctx, pred[cur], edge_pred[cur])
-            cond_x, cond_edge_x = pred[cur], edge_pred[cur]        # self_cond 'ori' (utils.py:135-136)
+            cond_x, cond_edge_x = pred[cur], edge_pred[cur]
+            if self.cond_process_fn is not None:                   # sampling.py:590 ('ori' identity, 'clamp' in place)
+                cond_x, cond_edge_x = self.cond_process_fn(cond_x, cond_edge_x)
             if self.noise_fn is not None:
                 raw = [r.to(dev, torch.float32).contiguous() for r in self.noise_fn(i)]
             else:                                                  # reference draw order/shapes (models/utils.py:69,78,102)

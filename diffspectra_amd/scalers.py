@@ -41,12 +41,24 @@ def get_data_inverse_scaler(config):
 
 
 def get_self_cond_fn(config):
-    """utils.py:108-150: 'ori' is the identity (every shipped config); 'clamp' is not on the HIP path."""
-    if config.model.self_cond_type != "ori":
-        raise ValueError("the MI355X sampler implements self_cond_type='ori' (identity), the shipped configuration")
+    """utils.py:108-150.  'ori' hands the prediction on unchanged; 'clamp' clamps the predicted atom-type and charge
+    channels IN PLACE (the clamped prediction therefore also enters the posterior mean, sampling.py:590,604-606) and
+    returns a clamped copy of the edge prediction.  Elementwise torch ops on the device tensors the HIP forward wrote."""
+    process_type = config.model.self_cond_type
+    atom_types, include_fc = config.data.atom_types, config.model.include_fc_charge
+    _, atom_norm, fc_norm, edge_norm = _factors(config)
+    lo, hi = (-1.0, 1.0) if config.data.centered else (0.0, 1.0)
+    fc_lo, fc_hi = (float(v) / fc_norm for v in config.data.fc_scale)
 
     def process_self_cond(cond_x, cond_edge_x):
-        return cond_x, cond_edge_x
+        if process_type == "ori":
+            return cond_x, cond_edge_x
+        if process_type == "clamp":
+            cond_x[:, :, 3:3 + atom_types].clamp_(lo / atom_norm, hi / atom_norm)
+            if include_fc:
+                cond_x[:, :, -1:].clamp_(fc_lo, fc_hi)
+            return cond_x, cond_edge_x.clamp(lo / edge_norm, hi / edge_norm)
+        raise ValueError("Self-condition data process error.")
 
     return process_self_cond
 

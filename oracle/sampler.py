@@ -33,9 +33,23 @@ def symmetric_edge_noise(raw, edge_mask):
     return z.permute(0, 2, 3, 1) * edge_mask.reshape(B, N, N, 1)
 
 
+def self_cond_ori(pred, edge_pred):
+    """utils.py:135-136."""
+    return pred, edge_pred
+
+
+def self_cond_clamp(pred, edge_pred, atom_types=5, norms=(1, 4, 4, 1), fc_scale=(-1.0, 1.0), centered=True):
+    """utils.py:113-148: clamp the predicted type and charge channels IN PLACE (so the clamped prediction also enters
+    the posterior mean that follows, sampling.py:604-606) and return a clamped copy of the edge prediction."""
+    lo, hi = (-1.0, 1.0) if centered else (0.0, 1.0)
+    pred[:, :, 3:3 + atom_types] = pred[:, :, 3:3 + atom_types].clamp(lo / norms[1], hi / norms[1])
+    pred[:, :, -1:] = pred[:, :, -1:].clamp(fc_scale[0] / norms[2], fc_scale[1] / norms[2])
+    return pred, edge_pred.clamp(lo / norms[3], hi / norms[3])
+
+
 @torch.no_grad()
 def ancestral_sampling(model_fn, z_T, node_mask, edge_mask, edge_z_T, steps, noise_fn, temperature=1.0,
-                       eps=1e-3):
+                       eps=1e-3, cond_process_fn=self_cond_ori):
     """sampling.py:565-631.  ``model_fn(x, edge_x, noise_level[B], cond_x, cond_edge_x) -> (pred, edge_pred)``;
     ``noise_fn(i) -> (raw_pos[B,N,3], raw_feat[B,N,6], raw_edge[B,2,N,N])`` replays the three randn draws of
     step ``i`` in the reference's order (``:611-612,623-624``)."""
@@ -47,7 +61,7 @@ def ancestral_sampling(model_fn, z_T, node_mask, edge_mask, edge_z_T, steps, noi
     for i in range(steps):
         noise_level = torch.ones(bs) * co["noise_level"][i]
         pred, edge_pred = model_fn(x, edge_x, noise_level, cond_x, cond_edge_x)
-        cond_x, cond_edge_x = pred, edge_pred                              # self_cond_type 'ori' (utils.py:135-136)
+        cond_x, cond_edge_x = cond_process_fn(pred, edge_pred)             # sampling.py:590
         raw_pos, raw_feat, raw_edge = noise_fn(i)
         x_mean = co["c_x"][i] * x + co["c_pred"][i] * pred
         x = x_mean + co["sigma"][i] * combined_noise(raw_pos, raw_feat, node_mask) * temperature

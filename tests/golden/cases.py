@@ -77,6 +77,19 @@ def block_inputs(n_atoms=RAGGED, salt: int = 0):
                 temb=temb, n_atoms=list(n_atoms), N=N, B=B, dense_index=(b, i, j))
 
 
+READOUT_GAIN_KEYS = ("node_pred_mlp.4.", "edge_type_mlp.4.", "edge_exist_mlp.4.")
+
+
+def readout_gain(state_dict, gain: float = 8.0):
+    """G8 only: multiply the last readout layers by ``gain`` so that predictions leave the self-conditioning clamp
+    range (random-init readouts stay inside it and the clamp would never act).  Works with or without ``module.``."""
+    out = dict(state_dict)
+    for k, v in state_dict.items():
+        if any(key in k for key in READOUT_GAIN_KEYS):
+            out[k] = v * gain
+    return out
+
+
 def config_for(version: str, steps: int = 1000):
     return qm9s_config(spectra_version=version, steps=steps)
 

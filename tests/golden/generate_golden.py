@@ -181,11 +181,14 @@ class _ReplayRandn:
         return t.clone()
 
 
-def g5_trajectory(mods, plan=(("allspectra", 5, None), ("ir", 50, None)), fname="g5_trajectory.npz"):
+def g5_trajectory(mods, plan=(("allspectra", 5, None), ("ir", 50, None)), fname="g5_trajectory.npz", self_cond_type="ori"):
     out = {}
     for version, steps, n_atoms in plan:
         cfg, model = ref_model(mods, version)
         cfg.sampling.steps = steps
+        cfg.model.self_cond_type = self_cond_type
+        if self_cond_type == "clamp":
+            model.load_state_dict(cases.readout_gain(model.state_dict()), strict=True)
         tr = cases.trajectory_inputs(version, steps) if n_atoms is None else cases.trajectory_inputs(version, steps, n_atoms)
         ns = mods.noise_schedule.NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0)
         time_steps = torch.linspace(ns.T, 1e-3, steps)
@@ -226,6 +229,11 @@ def g7_full_length(mods):
     g5_trajectory(mods, plan=(("ir", 1000, cases.FULL_LENGTH_ATOMS),), fname="g7_trajectory_1000.npz")
 
 
+def g8_clamp_self_cond(mods):
+    """self_cond_type='clamp' (utils.py:137-148): the in-place clamp of the predicted type/charge channels."""
+    g5_trajectory(mods, plan=(("ir", 8, None),), fname="g8_trajectory_clamp.npz", self_cond_type="clamp")
+
+
 def g6_post_process(mods):
     cfg = cases.config_for("ir")
     inv = mods.top_utils.get_data_inverse_scaler(cfg)
@@ -252,7 +260,7 @@ def main():
     torch.set_num_threads(8)
     mods = import_reference()
     todo = {"G0": g0_manifest, "G1": g1_schedule, "G2": g2_specformer, "G3": g3_components, "G4": g4_forward,
-            "G5": g5_trajectory, "G6": g6_post_process, "G7": g7_full_length}
+            "G5": g5_trajectory, "G6": g6_post_process, "G7": g7_full_length, "G8": g8_clamp_self_cond}
     only = [s for s in args.only.split(",") if s]
     for k, fn in todo.items():
         if not only or k in only:

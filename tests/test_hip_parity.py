@@ -262,6 +262,49 @@ def test_g5_trajectory_golden(gpu_device, version, steps):
         assert torch.equal(c, g[f"{tag}_mol{m}_fc"])
 
 
+def test_g8_clamp_self_cond_golden(gpu_device):
+    """self_cond_type='clamp' through the HIP sampler vs the reference trajectory (utils.py:137-148, sampling.py:590)."""
+    from diffspectra_amd import sampling as S
+    from diffspectra_amd.noise_schedule import NoiseScheduleVP
+    from diffspectra_amd.scalers import get_data_inverse_scaler
+    version, steps = "ir", 8
+    cfg, model = gpu_model(version, gpu_device)
+    cfg = cfg.clone()
+    cfg.sampling.steps = steps
+    cfg.model.self_cond_type = "clamp"
+    original = {k: v.clone() for k, v in model.state_dict().items()}
+    model.load_state_dict(cases.readout_gain(original), strict=True)   # the engine repacks on the version bump
+    try:
+        g = cases.load_npz("g8_trajectory_clamp.npz")
+        tr = cases.trajectory_inputs(version, steps)
+        d = gpu_device
+        z = oracle.combined_noise(*tr["raw0"][:2], tr["node_mask"])
+        ez = oracle.symmetric_edge_noise(tr["raw0"][2], tr["edge_mask"])
+
+        def run(c):
+            sampler = S._make_sampler(c, NoiseScheduleVP("cosine"), 1e-3, 1.0)
+            sampler.noise_fn = lambda i: tr["raws"][i]
+            return sampler.sampling(model, z.to(d), tr["node_mask"].to(d), tr["edge_mask"].to(d), ez.to(d),
+                                    to_dev(tr["context"], d))
+
+        x_mean, e_mean = run(cfg)
+        tag = f"{version}_S{steps}"
+        assert_close(x_mean, g[tag + "_x_mean"], TOL_TRAJ, tag + " x_mean (clamp)")
+        assert_close(e_mean, g[tag + "_edge_mean"], TOL_TRAJ, tag + " edge_mean (clamp)")
+        ori = cfg.clone()
+        ori.model.self_cond_type = "ori"
+        x_ori, _ = run(ori)
+        assert float((x_ori.cpu() - g[tag + "_x_mean"]).abs().max()) > 100 * TOL_TRAJ   # the clamp really acts here
+        eng = model.module.engine()
+        _, one_hot, fc, et = S.post_process(x_mean, 5, True, tr["node_mask"].to(d), get_data_inverse_scaler(cfg), e_mean,
+                                            tr["edge_mask"].to(d), True, engine=eng)
+        assert torch.equal(one_hot.argmax(-1).cpu(), g[tag + "_atom_type"])
+        assert torch.equal(fc.squeeze(-1).cpu(), g[tag + "_fc"].squeeze(-1).long())
+        assert torch.equal(et.cpu(), g[tag + "_edge_type"])
+    finally:
+        model.load_state_dict(original, strict=True)
+
+
 def test_g6_post_process_golden(gpu_device):
     from diffspectra_amd import filler
     cfg, model = gpu_model("ir", gpu_device)

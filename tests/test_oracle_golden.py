@@ -115,6 +115,35 @@ def test_g5_trajectory(version, steps):
         assert torch.equal(c, g[f"{tag}_mol{m}_fc"])
 
 
+def test_g8_clamp_self_cond():
+    """self_cond_type='clamp' (utils.py:137-148): oracle vs the reference trajectory, and the clamp must matter."""
+    version, steps = "ir", 8
+    cfg, sd = procedural_state_dict(version)
+    sd = cases.readout_gain(sd)
+    g = cases.load_npz("g8_trajectory_clamp.npz")
+    tr = cases.trajectory_inputs(version, steps)
+    ctx = oracle.context_embedding(sd, tr["context"], cfg)
+
+    def model_fn(x, edge_x, noise_level, cond_x, cond_edge_x):
+        return oracle.dmt_forward(sd, cfg, x, tr["node_mask"], tr["edge_mask"], edge_x, noise_level, cond_x,
+                                  cond_edge_x, context_emb=ctx)
+
+    z = oracle.combined_noise(tr["raw0"][0], tr["raw0"][1], tr["node_mask"])
+    ez = oracle.symmetric_edge_noise(tr["raw0"][2], tr["edge_mask"])
+    run = lambda fn: oracle.ancestral_sampling(model_fn, z, tr["node_mask"], tr["edge_mask"], ez, steps,
+                                               lambda i: tr["raws"][i], cond_process_fn=fn)
+    x_mean, e_mean = run(oracle.self_cond_clamp)
+    tag = f"{version}_S{steps}"
+    assert max_abs_diff(x_mean, g[tag + "_x_mean"]) <= TOL_TRAJ
+    assert max_abs_diff(e_mean, g[tag + "_edge_mean"]) <= TOL_TRAJ
+    x_ori, _ = run(oracle.self_cond_ori)
+    assert max_abs_diff(x_ori, g[tag + "_x_mean"]) > 100 * TOL_TRAJ      # the fixture really exercises the clamp
+    _, one_hot, fc, et = oracle.post_process(x_mean, tr["node_mask"], e_mean, tr["edge_mask"])
+    assert torch.equal(one_hot.argmax(-1), g[tag + "_atom_type"])
+    assert torch.equal(fc.to(g[tag + "_fc"].dtype), g[tag + "_fc"])
+    assert torch.equal(et, g[tag + "_edge_type"])
+
+
 def test_g6_post_process_thresholds():
     g = cases.load_npz("g6_post_process.npz")
     from diffspectra_amd import filler

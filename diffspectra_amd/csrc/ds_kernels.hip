@@ -102,7 +102,8 @@ __global__ void k_pair_flags(Ctx c, const float* __restrict__ cond_x, const floa
     const int lb = db - m * c.L.N;
     const float ce = cond_edge_x[((size_t)da * c.L.N + lb) * 2 + 0];
     bits = (ce >= c.edge_th ? 1 : 0) | (d2 <= c.cutoff ? 2 : 0);
-    if (d2 != 0.0f) atomicOr(&c.ws.flags[0], 1);
+    // one atomic per wave, not per pair: every pair of a batch hitting one address serialised the kernel at the L2
+    if (__ballot(d2 != 0.0f) != 0 && (threadIdx.x & 63) == __builtin_ctzll(__ballot(d2 != 0.0f))) atomicOr(&c.ws.flags[0], 1);
   }
   c.ws.adj[p] = bits;
 }
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(256) void k_pair_init(Ctx c, const float* __restric
       }
     }
     X[tid][0] = e0; X[tid][1] = e1; X[tid][2] = c0; X[tid][3] = c1;
+    X[tid][68] = 0.0f; X[tid][69] = 0.0f; X[tid][70] = 0.0f; X[tid][71] = 0.0f;   // K padded to the 8-wide k-group
     xs[tid] = x;
   }
   __syncthreads();
@@ -168,18 +170,18 @@ __global__ __launch_bounds__(256) void k_pair_init(Ctx c, const float* __restric
     X[row][4 + k] = v;
   }
   __syncthreads();
-  const float* W = GW(c, DS_GW_EDGE_EMB_W);
   const float* bias = GW(c, DS_GW_EDGE_EMB_B);
-  for (int idx = tid; idx < T * 64; idx += 256) {
-    const int row = idx >> 6, col = idx & 63;
+  const int Pp = c.L.Pp;
+  float* e = c.ws.e;
+  float* hid = c.ws.edge_hids;
+  tile_gemm<2, 1>(&X[0][0], 72 + DS_LDP, 72, GW(c, DS_GW_EDGE_EMB_W), 64, 2, [&](int row, int col, float v) {
     const int p = row0 + row;
-    if (p >= c.L.Pp) continue;
-    float acc = 0.0f;
-    for (int k = 0; k < 68; ++k) acc += X[row][k] * wp_at(W, 64, k, col);
-    acc += bias[col];
-    c.ws.e[(size_t)p * 64 + col] = acc;
-    c.ws.edge_hids[(size_t)p * 192 + col] = acc;
-  }
+    if (p < Pp) {
+      const float y = v + bias[col];
+      e[(size_t)p * 64 + col] = y;
+      hid[(size_t)p * 192 + col] = y;
+    }
+  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -255,19 +257,23 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
 }
 
 // Block stage B (nodes): LN -> modulate -> q|k|v projection (256 -> 768).  dmt.py:148; layers.py:147-149.
+// 64-row tiles, two row tiles per weight fragment (with one, the q|k|v weight stream alone asks the L2 for ~75 GB/s per
+// CU at full MFMA rate, the measured per-CU L2 ceiling); blockIdx.y picks one 384-column half of the projection so
+// that the launch keeps >= 4 workgroups per CU at bench sizes - the LayerNorm of the tile is simply done by both halves.
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_node_qkv(Ctx c, int blk) {
   constexpr int NT = NW * 64;
-  constexpr int T = 32;
+  constexpr int T = 64;
   __shared__ __attribute__((aligned(16))) float X[T][256 + DS_LDP];
   __shared__ int rmol[T];
-  const int tid = threadIdx.x, row0 = blockIdx.x * T;
+  const int tid = threadIdx.x, row0 = blockIdx.x * T, col0 = blockIdx.y * 384;
   if (tid < T) rmol[tid] = (row0 + tid < c.L.Nn) ? c.L.node_mol[row0 + tid] : 0;
-  const BFrag pfq = tile_first<1, 1>(BW(c, blk, DS_BW_QKV_W), 768, 256, 24);   // GEMM weights requested before the staging
+  const float* Wq = BW(c, blk, DS_BW_QKV_W) + (size_t)col0 * 4;   // packed Wp[K/8][2][768][4]: a column offset is +4 floats/col
+  const BFrag pfq = tile_first<2, 2>(Wq, 768, 256, 12);            // GEMM weights requested before the staging
   __syncthreads();
   {
     const float* adn = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
-    for (int it = 0; it < 512 / NT; ++it) {   // 32 rows x 64 float4; each wave holds whole rows -> LN + modulate in registers
+    for (int it = 0; it < T * 16 / NT; ++it) {   // 64 rows x 64 float4; each wave holds whole rows -> LN + modulate in registers
       float4 v[4], sh[4], sc[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -287,12 +293,12 @@ __global__ __launch_bounds__(NW * 64) void k_node_qkv(Ctx c, int blk) {
     }
   }
   __syncthreads();
-  const float* bias = BW(c, blk, DS_BW_QKV_B);
-  float* qkv = c.ws.qkv + (size_t)row0 * 768;
+  const float* bias = BW(c, blk, DS_BW_QKV_B) + col0;
+  float* qkv = c.ws.qkv + (size_t)row0 * 768 + col0;
   const int valid = c.L.Nn - row0;
-  tile_gemm_blk<1, 1>(&X[0][0], 256 + DS_LDP, 256, BW(c, blk, DS_BW_QKV_W), 768, 24, [&](int ch, int, const f32x16 (&acc)[1]) {
+  tile_gemm_blk<2, 2>(&X[0][0], 256 + DS_LDP, 256, Wq, 768, 12, [&](int ch, int, const f32x16 (&acc)[2]) {
     const float b = bias[ch * 32 + (threadIdx.x & 31)];
-    acc_store<1, 768>(acc, qkv + ch * 32, valid, [b](int, float v) { return v + b; });
+    acc_store<2, 768>(acc, qkv + ch * 32, valid, [b](int, float v) { return v + b; });
   }, &pfq);
 }
 
@@ -301,14 +307,17 @@ __global__ __launch_bounds__(NW * 64) void k_node_qkv(Ctx c, int blk) {
 // lg[p][0][h]: source a -> target b;  lg[p][1][h]: source b -> target a.  The molecule's q|k rows are staged in LDS once
 // (<= 58 kB) instead of being re-gathered from L2 for every 16 pairs; te0 streams through once.
 __global__ __launch_bounds__(256, 2) void k_attn_logits(Ctx c) {
-  __shared__ __attribute__((aligned(16))) float QK[DS_MAX_ATOMS * 512];
+  // row stride 544 floats: consecutive atoms sit 32 banks apart, so the two pairs of a half-wave - (lo, hi) and (lo, hi+1)
+  // in the molecule's pair order - read row hi / hi+1 segments from disjoint banks and row lo as a broadcast
+  constexpr int QS = 512 + 32;
+  __shared__ __attribute__((aligned(16))) float QK[DS_MAX_ATOMS * QS];
   const int m = blockIdx.x, tid = threadIdx.x;
   const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
   const int p0 = c.L.pair_off[m], P = c.L.pair_off[m + 1] - p0;
   if (P <= 0) return;
   for (int idx = tid; idx < n * 128; idx += 256) {   // q (256) | k (256) of every atom
     const int a = idx >> 7, k4 = idx & 127;
-    reinterpret_cast<float4*>(QK)[a * 128 + k4] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + a) * 768)[k4];
+    reinterpret_cast<float4*>(QK)[a * (QS / 4) + k4] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + a) * 768)[k4];
   }
   __syncthreads();
   for (int it = tid; it < P * 16; it += 256) {
@@ -325,10 +334,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_logits(Ctx c) {
     }
     const int a = c.L.pair_a[p] - n0, b = c.L.pair_b[p] - n0;
     const float2* t0 = reinterpret_cast<const float2*>(c.ws.te0 + (size_t)p * 256 + hs * 18);
-    const float2* qa = reinterpret_cast<const float2*>(QK + a * 512 + hs * 18);
-    const float2* qb = reinterpret_cast<const float2*>(QK + b * 512 + hs * 18);
-    const float2* ka = reinterpret_cast<const float2*>(QK + a * 512 + 256 + hs * 18);
-    const float2* kb = reinterpret_cast<const float2*>(QK + b * 512 + 256 + hs * 18);
+    const float2* qa = reinterpret_cast<const float2*>(QK + a * QS + hs * 18);
+    const float2* qb = reinterpret_cast<const float2*>(QK + b * QS + hs * 18);
+    const float2* ka = reinterpret_cast<const float2*>(QK + a * QS + 256 + hs * 18);
+    const float2* kb = reinterpret_cast<const float2*>(QK + b * QS + 256 + hs * 18);
     float s_ab = 0.0f, s_ba = 0.0f;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
@@ -391,14 +400,23 @@ __global__ __launch_bounds__(512, 2) void k_attn_agg(Ctx c) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     float4 acc = make_float4(0, 0, 0, 0);
-    for (int s = 0; s < n; ++s) {
-      if (s == t) continue;
-      const int lo = s < t ? s : t, hi = s < t ? t : s;
-      const int pl = lo * (2 * n - lo - 1) / 2 + (hi - lo - 1);
-      const float4 g = te1[(size_t)pl * 64];
-      const float4 v = reinterpret_cast<const float4*>(V)[s * 64 + lane];
-      const float a = al[wave][s][hd];
-      acc.x += (v.x * g.x) * a; acc.y += (v.y * g.y) * a; acc.z += (v.z * g.z) * a; acc.w += (v.w * g.w) * a;
+    for (int s0 = 0; s0 < n; s0 += 8) {   // eight te1 rows in flight per trip; accumulation stays in ascending source order
+      float4 g[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int s = min(s0 + j, n - 1), so = s == t ? (t ? 0 : 1) : s;   // the skipped source reads a valid row, unused
+        const int lo = so < t ? so : t, hi = so < t ? t : so;
+        g[j] = te1[(size_t)(lo * (2 * n - lo - 1) / 2 + (hi - lo - 1)) * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int s = s0 + j;
+        if (s < n && s != t) {
+          const float4 v = reinterpret_cast<const float4*>(V)[s * 64 + lane];
+          const float a = al[wave][s][hd];
+          acc.x += (v.x * g[j].x) * a; acc.y += (v.y * g[j].y) * a; acc.z += (v.z * g[j].z) * a; acc.w += (v.w * g[j].w) * a;
+        }
+      }
     }
     reinterpret_cast<float4*>(c.ws.attn + (size_t)(n0 + t) * 256)[lane] = acc;
     __builtin_amdgcn_wave_barrier();   // al[wave] is rewritten for the next target
@@ -1384,7 +1402,7 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   if (!make_ctx(c, w, L, ws, s) || blk < 0 || blk >= DS_NBLOCKS) return DS_ERR_ARG;
   const int pt = (L->Pp + 63) / 64, nt = (L->Nn + 31) / 32;
   if (pt > 0) { ProfScope ps(0, s); hipLaunchKernelGGL(k_edge_geom, dim3(pt), dim3(256), 0, s, c, blk); }
-  { ProfScope ps(1, s); hipLaunchKernelGGL(k_node_qkv<4>, dim3(nt), dim3(256), 0, s, c, blk); }
+  { ProfScope ps(1, s); hipLaunchKernelGGL(k_node_qkv<4>, dim3((L->Nn + 63) / 64, 2), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(2, s); hipLaunchKernelGGL(k_attn_logits, dim3(L->B), dim3(256), 0, s, c); }
   { ProfScope ps(6, s); hipLaunchKernelGGL(k_attn_agg, dim3(L->B), dim3(512), 0, s, c); }
   { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }

@@ -211,6 +211,19 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
     rmol[tid] = m;
   }
   __syncthreads();
+  // adaLN shift/scale of the LayerNorm further down, requested now (they only need rmol): wave w normalises rows
+  // 16w .. 16w+15 as four passes of four rows, one row per 16-lane DPP row, float4 per lane
+  float4 lsh[4], lsc[4];
+  {
+    const float* ade = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* am = ade + (size_t)rmol[16 * wv + 4 * j + (lane >> 4)] * ADAC;
+      lsh[j] = reinterpret_cast<const float4*>(am)[lane & 15];        // edge_shift_msa
+      lsc[j] = reinterpret_cast<const float4*>(am + 64)[lane & 15];   // edge_scale_msa
+    }
+  }
   {   // thread owns feature k of rows rb, rb+4, ...: its RBF centre/width are constants, the 16 e loads issue together
     const int k = tid & 63, rb = tid >> 6;
     const float mk = k ? BW(c, blk, DS_BW_RBF_MEAN)[k - 1] : 0.0f;
@@ -241,7 +254,14 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
   }
   const BFrag pf0 = tile_first<2, 2>(BW(c, blk, DS_BW_E0_W), 256, 64, 8);
   __syncthreads();
-  ln_mod_tile<64, 16, 4>(&Y[0][0], 64 + DS_LDP, rmol, c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE, ADAC, 0, 64);   // edge_shift_msa, edge_scale_msa
+  {
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4* yp = reinterpret_cast<float4*>(&Y[16 * wv + 4 * j + (lane >> 4)][0]) + (lane & 15);
+      *yp = ln_mod_reg64(*yp, lsh[j], lsc[j]);   // norm1_edge + modulate (dmt.py:149)
+    }
+  }
   __syncthreads();
   {
     float* te0 = c.ws.te0 + (size_t)row0 * 256;

@@ -1240,6 +1240,20 @@ bool make_ctx(Ctx& c, const ds_weights* w, const ds_layout* L, const ds_workspac
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? DS_OK : DS_ERR_LAUNCH; }
 
+// Compute units of the current device (256 on a full MI355X; fewer in a partitioned mode): the persistent
+// k_equi_pairs launches exactly one workgroup per CU.
+inline int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cus = n;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
 // Large plain GEMMs (the per-step adaLN table [B,1024] x [1024,19744] is 6 % of a denoising step): 128x128 output tile,
 // MT = 4 (each B fragment feeds 16 MFMAs), A double-buffered in LDS with the next K-chunk fetched into registers while
 // the current one is multiplied (one barrier per chunk), the next chunk's first B group requested ahead of that barrier.
@@ -1427,7 +1441,7 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   { ProfScope ps(6, s); hipLaunchKernelGGL(k_attn_agg, dim3(L->B), dim3(512), 0, s, c); }
   { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3((L->Pp + 127) / 128), dim3(256), 0, s, c, blk); }
-  if (pt > 0) { ProfScope ps(5, s); { const int nt_ = (L->Pp + 31) / 32; hipLaunchKernelGGL(k_equi_pairs, dim3(nt_ < 256 ? nt_ : 256), dim3(768), 0, s, c, blk); } }
+  if (pt > 0) { ProfScope ps(5, s); { const int nt_ = (L->Pp + 31) / 32, cu_ = device_cus(); hipLaunchKernelGGL(k_equi_pairs, dim3(nt_ < cu_ ? nt_ : cu_), dim3(768), 0, s, c, blk); } }
   hipLaunchKernelGGL(k_pos_update, dim3(L->B), dim3(64), 0, s, c, last);
   return launch_status();
 }

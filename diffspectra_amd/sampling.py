@@ -188,17 +188,22 @@ def _sampling_fn_factory(config, sampler, batch_size, n_samples, inverse_scaler,
             perm = torch.randperm(len(ds))
             for r in range(rounds):
                 ids = perm[r * batch_size:(r + 1) * batch_size]
-                items = [ds[int(i)] for i in ids]
-                n_nodes = [int(it.num_atom.item()) if hasattr(it.num_atom, "item") else int(it.num_atom) for it in items]
-                for it in items:
-                    gt_pos.append(it.pos)
-                    gt_mols.append(getattr(it, "rdmol", None))
-                stack = lambda name: torch.stack([getattr(it, name) for it in items])
-                if version == "allspectra":
-                    context = [stack("uv"), stack("ir"), stack("raman")]
-                else:
-                    context = stack(version)
-                bs = len(items)
+                if hasattr(ds, "batch"):                           # PackedSpectraTable: resident in HBM, no per-item Python
+                    context, n_nodes, pos_r, mols_r = ds.batch(ids, version)
+                    gt_pos += pos_r
+                    gt_mols += mols_r
+                else:                                              # the reference's per-item assembly (sampling.py:391-420)
+                    items = [ds[int(i)] for i in ids]
+                    n_nodes = [int(it.num_atom.item()) if hasattr(it.num_atom, "item") else int(it.num_atom) for it in items]
+                    for it in items:
+                        gt_pos.append(it.pos)
+                        gt_mols.append(getattr(it, "rdmol", None))
+                    stack = lambda name: torch.stack([getattr(it, name) for it in items])
+                    if version == "allspectra":
+                        context = [stack("uv"), stack("ir"), stack("raman")]
+                    else:
+                        context = stack(version)
+                bs = len(n_nodes)
                 node_mask, edge_mask = build_masks(n_nodes, bs, device)
                 max_n = node_mask.shape[1]
                 z, edge_z = initial_noise(bs, max_n, node_nf, edge_nf, node_mask, edge_mask)

@@ -498,6 +498,15 @@ def test_cond_sampling_eval_fn_end_to_end(gpu_device):
     for a, b in zip(mols, mols2):
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
         assert float((a[0] - b[0]).abs().max()) < 1e-5
+    # the HBM-resident conditioning table (N3) is a drop-in for the dataset: identical rounds, identical molecules
+    from diffspectra_amd.dataset_pack import PackedSpectraTable
+    tab = PackedSpectraTable.from_dataset(ds, "allspectra", device=gpu_device)
+    fn3 = S.get_cond_sampling_eval_fn(cfg, ns, 3, 5, get_data_inverse_scaler(cfg), tab)
+    mols3, gt_pos3, gt_mols3 = fn3(model)
+    assert gt_mols3 == gt_mols and all(torch.equal(p, q) for p, q in zip(gt_pos3, gt_pos))
+    for a, b in zip(mols, mols3):
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        assert float((a[0] - b[0]).abs().max()) < 1e-5
 
 
 def test_checkpoint_and_ema_roundtrip(gpu_device, tmp_path):

@@ -133,3 +133,32 @@ def test_sampler_surface():
     nm, em = S.build_masks([2, 3], 2, "cpu")
     want_nm, want_em = filler.masks_from_n_atoms([2, 3])
     assert torch.equal(nm, want_nm) and torch.equal(em, want_em)
+
+
+def test_packed_spectra_table():
+    """N3 (conditioning side): the HBM-resident table hands a round exactly what per-item assembly would."""
+    from types import SimpleNamespace
+    from diffspectra_amd.dataset_pack import PackedSpectraTable
+    M = 9
+    raw = [filler.uniform(f"pack.{n}", (M, 1, L)) * 50.0 for n, L in zip(("uv", "ir", "raman"), (701, 3501, 3501))]
+    n_atoms = filler.sample_n_atoms(M, seed=4).tolist()
+    ds = [SimpleNamespace(uv=raw[0][i], ir=raw[1][i], raman=raw[2][i], num_atom=torch.tensor(n_atoms[i]),
+                          pos=torch.full((n_atoms[i], 3), float(i)), rdmol=f"m{i}") for i in range(M)]
+    tab = PackedSpectraTable.from_dataset(ds, "allspectra", normalize=True)
+    assert len(tab) == M
+    ids = torch.tensor([7, 2, 2, 5])
+    ctx, n_nodes, pos, mols = tab.batch(ids, "allspectra")
+    assert n_nodes == [n_atoms[i] for i in ids.tolist()] and mols == ["m7", "m2", "m2", "m5"]
+    assert all(torch.equal(p, ds[i].pos) for p, i in zip(pos, ids.tolist()))
+    for k in range(3):      # log10(x + 1) of the reference transform (build_dataset.py:141-148), stacked like sampling.py:404-420
+        want = torch.stack([torch.log10(raw[k][i] + 1) for i in ids.tolist()])
+        assert ctx[k].shape == want.shape and torch.equal(ctx[k], want)
+    it = tab[5]             # dataset surface kept for code written against the reference's ds[i]
+    assert int(it.num_atom) == n_atoms[5] and it.rdmol == "m5" and torch.equal(it.ir, torch.log10(raw[1][5] + 1))
+    ir_only = PackedSpectraTable.from_dataset(ds, "ir")
+    c1, n1, _, _ = ir_only.batch([0, 8], "ir")
+    assert torch.equal(c1, torch.stack([raw[1][0], raw[1][8]])) and n1 == [n_atoms[0], n_atoms[8]]
+    with pytest.raises(ValueError):
+        ir_only.batch([0], "allspectra")
+    with pytest.raises(ValueError):
+        PackedSpectraTable([raw[0][:, :, :10], None, None], torch.tensor(n_atoms))

@@ -335,9 +335,18 @@ __global__ __launch_bounds__(256, 2) void k_attn_logits(Ctx c) {
   const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
   const int p0 = c.L.pair_off[m], P = c.L.pair_off[m + 1] - p0;
   if (P <= 0) return;
-  for (int idx = tid; idx < n * 128; idx += 256) {   // q (256) | k (256) of every atom
-    const int a = idx >> 7, k4 = idx & 127;
-    reinterpret_cast<float4*>(QK)[a * (QS / 4) + k4] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + a) * 768)[k4];
+  for (int i0 = tid; i0 < n * 128; i0 += 256 * 8) {   // q (256) | k (256) of every atom, eight loads in flight per thread
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = min(i0 + u * 256, n * 128 - 1);
+      v[u] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + (idx >> 7)) * 768)[idx & 127];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = i0 + u * 256;
+      if (idx < n * 128) reinterpret_cast<float4*>(QK)[(idx >> 7) * (QS / 4) + (idx & 127)] = v[u];
+    }
   }
   __syncthreads();
   for (int it = tid; it < P * 16; it += 256) {
@@ -382,9 +391,16 @@ __global__ __launch_bounds__(512, 2) void k_attn_agg(Ctx c) {
   const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
   const int p0 = c.L.pair_off[m];
   if (n <= 0) return;
-  for (int idx = tid; idx < n * 64; idx += 512) {
-    const int a = idx >> 6, k4 = idx & 63;
-    reinterpret_cast<float4*>(V)[a * 64 + k4] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + a) * 768 + 512)[k4];
+  {   // V rows of the molecule: n * 64 float4 <= 1856 = four per thread, requested together
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = min(tid + u * 512, n * 64 - 1);
+      v[u] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + (idx >> 6)) * 768 + 512)[idx & 63];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (tid + u * 512 < n * 64) reinterpret_cast<float4*>(V)[tid + u * 512] = v[u];
   }
   __syncthreads();
   const int h = lane & 15, sq = lane >> 4;          // softmax phase: lane = (source mod 4, head)
@@ -921,13 +937,22 @@ __global__ __launch_bounds__(256) void k_node_readout(Ctx c, float* __restrict__
   __shared__ __attribute__((aligned(16))) float X[T][768 + DS_LDP];
   __shared__ __attribute__((aligned(16))) float Y1[T][256 + DS_LDP];
   __shared__ __attribute__((aligned(16))) float Y2[T][128 + DS_LDP];
+  __shared__ int dn[T];   // dense output row of each tile row (-1 past the end)
   const int tid = threadIdx.x, row0 = blockIdx.x * T;
   const int Nn = c.L.Nn;
-  for (int idx = tid; idx < T * 192; idx += 256) {
-    const int row = idx / 192, k4 = idx - row * 192;
-    float4 v = make_float4(0, 0, 0, 0);
-    if (row0 + row < Nn) v = reinterpret_cast<const float4*>(c.ws.atom_hids + (size_t)(row0 + row) * 768)[k4];
-    reinterpret_cast<float4*>(&X[row][0])[k4] = v;
+  if (tid < T) dn[tid] = row0 + tid < Nn ? c.L.node_dense[row0 + tid] : -1;
+  for (int i0 = tid; i0 < T * 192; i0 += 256 * 8) {   // eight loads in flight per thread (a plain loop pays one trip per load)
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = i0 + u * 256, row = idx / 192, k4 = idx - row * 192;
+      v[u] = reinterpret_cast<const float4*>(c.ws.atom_hids + (size_t)min(row0 + row, Nn - 1) * 768)[k4];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = i0 + u * 256, row = idx / 192, k4 = idx - row * 192;
+      reinterpret_cast<float4*>(&X[row][0])[k4] = row0 + row < Nn ? v[u] : make_float4(0, 0, 0, 0);
+    }
   }
   __syncthreads();
   {
@@ -944,9 +969,9 @@ __global__ __launch_bounds__(256) void k_node_readout(Ctx c, float* __restrict__
   __syncthreads();
   {
     const float* b = GW(c, DS_GW_NP4_B);
-    const int* nd = c.L.node_dense;
+    const float bc = b[min((int)(threadIdx.x & 31), 5)];
     tile_gemm<1, 1>(&Y2[0][0], 128 + DS_LDP, 128, GW(c, DS_GW_NP4_W), 32, 1, [&](int row, int col, float v) {
-      if (row0 + row < Nn && col < 6) out_xh[(size_t)nd[row0 + row] * 9 + 3 + col] = v + b[col];
+      if (col < 6 && dn[row] >= 0) out_xh[(size_t)dn[row] * 9 + 3 + col] = v + bc;
     });
   }
 }
@@ -957,13 +982,32 @@ __global__ __launch_bounds__(256) void k_edge_readout(Ctx c, float* __restrict__
   __shared__ __attribute__((aligned(16))) float X[T][192 + DS_LDP];
   __shared__ __attribute__((aligned(16))) float Y1[T][64 + DS_LDP];
   __shared__ __attribute__((aligned(16))) float Y2[T][32 + DS_LDP];
+  __shared__ int oab[T], oba[T];   // dense output offsets of (a, b) and (b, a), resolved once per row (index chain of 2 trips)
   const int tid = threadIdx.x, row0 = blockIdx.x * T;
   const int Pp = c.L.Pp;
-  for (int idx = tid; idx < T * 48; idx += 256) {
-    const int row = idx / 48, k4 = idx - row * 48;
-    float4 v = make_float4(0, 0, 0, 0);
-    if (row0 + row < Pp) v = reinterpret_cast<const float4*>(c.ws.edge_hids + (size_t)(row0 + row) * 192)[k4];
-    reinterpret_cast<float4*>(&X[row][0])[k4] = v;
+  if (tid < T) {
+    const int p = row0 + tid;
+    int ab = -1, ba = -1;
+    if (p < Pp) {
+      const int da = c.L.node_dense[c.L.pair_a[p]], db = c.L.node_dense[c.L.pair_b[p]];
+      const int mN = c.L.pair_mol[p] * c.L.N;
+      ab = (da * c.L.N + (db - mN)) * 2;
+      ba = (db * c.L.N + (da - mN)) * 2;
+    }
+    oab[tid] = ab; oba[tid] = ba;
+  }
+  {   // 64 rows x 48 float4: all twelve loads of a thread in flight together
+    float4 v[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      const int idx = tid + u * 256, row = idx / 48, k4 = idx - row * 48;
+      v[u] = reinterpret_cast<const float4*>(c.ws.edge_hids + (size_t)min(row0 + row, Pp - 1) * 192)[k4];
+    }
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      const int idx = tid + u * 256, row = idx / 48, k4 = idx - row * 48;
+      reinterpret_cast<float4*>(&X[row][0])[k4] = row0 + row < Pp ? v[u] : make_float4(0, 0, 0, 0);
+    }
   }
   __syncthreads();
   for (int ch = 0; ch < 2; ++ch) {   // channel 0: edge_exist_mlp, channel 1: edge_type_mlp (dmt.py:394)
@@ -981,16 +1025,12 @@ __global__ __launch_bounds__(256) void k_edge_readout(Ctx c, float* __restrict__
     }
     __syncthreads();
     {
-      const float* b = GW(c, g0 + 5);
-      const ds_layout L = c.L;
+      const float b0 = GW(c, g0 + 5)[0];
       tile_gemm<2, 1>(&Y2[0][0], 32 + DS_LDP, 32, GW(c, g0 + 4), 32, 1, [&](int row, int col, float v) {
-        const int p = row0 + row;
-        if (p < Pp && col == 0) {
-          const int da = L.node_dense[L.pair_a[p]], db = L.node_dense[L.pair_b[p]];
-          const int mN = L.pair_mol[p] * L.N;
-          const float val = v + b[0];   // 0.5*(x + x) == x: the symmetrisation of dmt.py:399 is exact here
-          out_edge[((size_t)da * L.N + (db - mN)) * 2 + ch] = val;
-          out_edge[((size_t)db * L.N + (da - mN)) * 2 + ch] = val;
+        if (col == 0 && oab[row] >= 0) {
+          const float val = v + b0;   // 0.5*(x + x) == x: the symmetrisation of dmt.py:399 is exact here
+          out_edge[(size_t)oab[row] + ch] = val;
+          out_edge[(size_t)oba[row] + ch] = val;
         }
       });
     }

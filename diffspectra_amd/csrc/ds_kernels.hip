@@ -514,6 +514,16 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
     f32x16 acc2[2][1];
     acc_zero<1>(acc2[0]);
     acc_zero<1>(acc2[1]);
+    // node_gate_mlp (dmt.py:162) is per molecule: the gate columns of the tile's first / last molecule and the FF2 bias are
+    // requested here, a whole FF ahead of their use (fetched after it they cost the epilogue one exposed round trip)
+    const int mA = rmol[0], mB = rmol[T - 1];
+    const float* gsec = ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE + 1280;
+    float gAv[2], gBv[2], bbv[2];
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int col = (wave + 4 * cc) * 32 + (tid & 31);
+      gAv[cc] = gsec[(size_t)mA * ADAC + col]; gBv[cc] = gsec[(size_t)mB * ADAC + col]; bbv[cc] = BW(c, blk, DS_BW_FF2_B)[col];
+    }
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {   // this wave's two 32-column chunks of the 256-wide hidden half
@@ -532,15 +542,11 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
       }
       __syncthreads();
     }
-    const float* b2 = BW(c, blk, DS_BW_FF2_B);
     float* h = c.ws.h;
-    // node_gate_mlp (dmt.py:162) is per molecule: fetch the gate column of the tile's first / last molecule once per lane
-    const int mA = rmol[0], mB = rmol[T - 1];
-    const float* gsec = ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE + 1280;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
       const int col = (wave + 4 * cc) * 32 + (tid & 31);
-      const float gA = gsec[(size_t)mA * ADAC + col], gB = gsec[(size_t)mB * ADAC + col], bb = b2[col];
+      const float gA = gAv[cc], gB = gBv[cc], bb = bbv[cc];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = acc_row(i, (tid & 63) >> 5);

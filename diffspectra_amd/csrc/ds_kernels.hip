@@ -194,6 +194,15 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
   __shared__ __attribute__((aligned(16))) float xs[T];
   __shared__ int rmol[T];
   const int tid = threadIdx.x, row0 = blockIdx.x * T;
+  // Thread (k = feature, rb = row phase) of the RBF stage further down: its RBF centre/width and its 16 previous-block
+  // edge features depend on nothing computed here, so they are requested first and ride along with the index chain.
+  const int kf = tid & 63, rbp = tid >> 6;
+  const float mk = kf ? BW(c, blk, DS_BW_RBF_MEAN)[kf - 1] : 0.0f;
+  const float sk = kf ? BW(c, blk, DS_BW_RBF_STD)[kf - 1] : 1.0f;
+  const float ak = kf ? BW(c, blk, DS_BW_RBF_ASTD)[kf - 1] : 1.0f;
+  float ev[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) ev[j] = c.ws.e[(size_t)min(row0 + rbp + 4 * j, c.L.Pp - 1) * 64 + kf];
   if (tid < T) {
     const int p = row0 + tid;
     float x = 0.0f;
@@ -224,21 +233,16 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
       lsc[j] = reinterpret_cast<const float4*>(am + 64)[lane & 15];   // edge_scale_msa
     }
   }
-  {   // thread owns feature k of rows rb, rb+4, ...: its RBF centre/width are constants, the 16 e loads issue together
-    const int k = tid & 63, rb = tid >> 6;
-    const float mk = k ? BW(c, blk, DS_BW_RBF_MEAN)[k - 1] : 0.0f;
-    const float sk = k ? BW(c, blk, DS_BW_RBF_STD)[k - 1] : 1.0f;
-    const float ak = k ? BW(c, blk, DS_BW_RBF_ASTD)[k - 1] : 1.0f;
+  {   // thread owns feature k of rows rb, rb+4, ...
+    const int k = kf, rb = rbp;
+    const float rsk = __builtin_amdgcn_rcpf(sk), rak = __builtin_amdgcn_rcpf(ak);   // once per thread, not once per element
     const int Pp = c.L.Pp;
-    float ev[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) ev[j] = c.ws.e[(size_t)min(row0 + rb + 4 * j, Pp - 1) * 64 + k];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int row = rb + 4 * j, p = row0 + row;
       const float x = xs[row];
-      const float z = __fdividef(x - mk, sk);
-      float v = k ? __fdividef(__expf(-0.5f * (z * z)), ak) : x;   // layers.py:291-295,334 (k = 0 is the raw x')
+      const float z = (x - mk) * rsk;
+      float v = k ? __expf(-0.5f * (z * z)) * rak : x;             // layers.py:291-295,334 (k = 0 is the raw x')
       if (p >= Pp) { v = 0.0f; ev[j] = 0.0f; }
       X[row][k] = v;
       X[row][64 + k] = ev[j];

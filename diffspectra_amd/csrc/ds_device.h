@@ -23,6 +23,26 @@ __device__ __forceinline__ float ds_tanh(float x) {
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
+// Two at a time: the multiply, add and fma become packed-fp32 issues (v_pk_*), 7 VALU issues per 2 values instead of 10.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 ds_tanh2(f32x2 x) {
+  const f32x2 t = x * 2.8853900817779268f;
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+  const f32x2 d = e + 1.0f;
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+  return r * -2.0f + 1.0f;
+}
+__device__ __forceinline__ f32x2 ds_silu2(f32x2 x) {   // x / (1 + exp(-x)), 8 issues per 2 values instead of 10
+  const f32x2 t = x * -1.4426950408889634f;
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+  const f32x2 d = e + 1.0f;
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+  return x * r;
+}
 __device__ __forceinline__ float ds_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 template <int ACT>
@@ -50,8 +70,10 @@ __device__ __forceinline__ float wave_sum(float v) {
   v = row16_sum(v);
   // rows 1,3 += row 0,2 (row_bcast:15, row_mask 0xA); rows 2,3 += lane 31 (row_bcast:31, row_mask 0xC): lane 63 then
   // holds (r3 + r2) + (r1 + r0).  Pure VALU: no trip through the LDS pipe the MFMA waves' operand reads keep busy.
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));
+  // Written as the fused v_add_f32_dpp (rows outside row_mask keep their value): through the builtin the compiler emits
+  // v_mov 0 + v_mov_dpp + v_add per step, and VALU issue slots next to the MFMA stream are what the LayerNorms cost.
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa\n\ts_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc" : "+v"(v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
@@ -196,6 +218,38 @@ __device__ __forceinline__ void acc_store(const f32x16 (&acc)[MT], float* __rest
       for (int i = 0; i < 16; ++i) {
         const int row = m * 32 + (i & 3) + 8 * (i >> 2);
         if (row + 4 * hh < rows_valid) p[row * LD] = f(r, acc[m][i]);
+      }
+  }
+}
+
+// acc_store with a two-wide epilogue f2(f32x2) -> f32x2 (packed-fp32 arithmetic for activation epilogues).
+template <int MT, int LD, class F2>
+__device__ __forceinline__ void acc_store2(const f32x16 (&acc)[MT], float* __restrict__ dst, int rows_valid, F2 f2) {
+  const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+  float* p = dst + (size_t)(4 * hh) * LD + r;
+  if (rows_valid >= 32 * MT) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {   // i even: registers i, i+1 are two consecutive rows
+        f32x2 v;
+        v.x = acc[m][i]; v.y = acc[m][i + 1];
+        v = f2(v);
+        const int row0 = m * 32 + (i & 3) + 8 * (i >> 2);
+        p[row0 * LD] = v.x;
+        p[(row0 + 1) * LD] = v.y;
+      }
+  } else {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        f32x2 v;
+        v.x = acc[m][i]; v.y = acc[m][i + 1];
+        v = f2(v);
+        const int row0 = m * 32 + (i & 3) + 8 * (i >> 2);
+        if (row0 + 4 * hh < rows_valid) p[row0 * LD] = v.x;
+        if (row0 + 1 + 4 * hh < rows_valid) p[(row0 + 1) * LD] = v.y;
       }
   }
 }

@@ -272,10 +272,10 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
     float* te1 = c.ws.te1 + (size_t)row0 * 256;
     const int valid = c.L.Pp - row0;
     tile_gemm_blk<2, 2>(&Y[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_E0_W), 256, 8, [&](int ch, int, const f32x16 (&acc)[2]) {
-      acc_store<2, 256>(acc, te0 + ch * 32, valid, [](int, float v) { return ds_tanh(v); });   // layers.py:165-166
+      acc_store2<2, 256>(acc, te0 + ch * 32, valid, [](f32x2 v) { return ds_tanh2(v); });   // layers.py:165-166
     }, &pf0);
     tile_gemm_blk<2, 2>(&Y[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_E1_W), 256, 8, [&](int ch, int, const f32x16 (&acc)[2]) {
-      acc_store<2, 256>(acc, te1 + ch * 32, valid, [](int, float v) { return ds_tanh(v); });   // layers.py:183
+      acc_store2<2, 256>(acc, te1 + ch * 32, valid, [](f32x2 v) { return ds_tanh2(v); });   // layers.py:183
     });
   }
 }
@@ -536,7 +536,18 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
         f32x16 acc[1];
         acc_zero<1>(acc);
         wave_mma<1>(&H2[0][0], LD, W1, 512, (half * 8 + ch) * 32, 0, 32, acc, 0, (half == 0 && cc == 0) ? &pf1 : nullptr);
-        acc_foreach<1>(acc, 0, ch * 32, [&](int row, int col, float v) { B1[row][col] = ds_silu(v + b1[half * 256 + col]); });
+        {   // SiLU(FF1 + bias) -> hidden tile, two rows at a time (packed-fp32 epilogue)
+          const int colf = ch * 32 + (tid & 31), hhf = (tid & 63) >> 5;
+          const float bf = b1[half * 256 + colf];
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {
+            f32x2 v;
+            v.x = acc[0][i] + bf; v.y = acc[0][i + 1] + bf;
+            v = ds_silu2(v);
+            const int r0 = acc_row(i, hhf);
+            B1[r0][colf] = v.x; B1[r0 + 1][colf] = v.y;
+          }
+        }
       }
       __syncthreads();
 #pragma unroll
@@ -656,11 +667,18 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
         const int f0 = hc * 32 + 8 * q + 4 * hh;                       // registers 4q..4q+3 hold features f0..f0+3
         const float4 bb = *reinterpret_cast<const float4*>(b3 + f0);
         const float bs[4] = {bb.x, bb.y, bb.z, bb.w};
+        float ys[4];
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {   // packed-fp32 SiLU, two features at a time
+          f32x2 v;
+          v.x = a3[hc][0][4 * q + j] + bs[j]; v.y = a3[hc][0][4 * q + j + 1] + bs[j + 1];
+          v = ds_silu2(v);
+          ys[j] = v.x; ys[j + 1] = v.y;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float y = ds_silu(a3[hc][0][4 * q + j] + bs[j]);
-          a4[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp_at(W4, 64, f0 + j, r31), y, a4[0][0], 0, 0, 0);
-          a4[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp_at(W4, 64, f0 + j, 32 + r31), y, a4[1][0], 0, 0, 0);
+          a4[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp_at(W4, 64, f0 + j, r31), ys[j], a4[0][0], 0, 0, 0);
+          a4[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp_at(W4, 64, f0 + j, 32 + r31), ys[j], a4[1][0], 0, 0, 0);
         }
       }
   }
@@ -696,11 +714,12 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
     for (int ch = 0; ch < 8; ++ch) {
       asm volatile("" ::: "memory");
       f32x16 acc[1];
-      acc_zero<1>(acc);
+      const float b = bd[ch * 32 + r31];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] = b;   // accumulate onto the bias: no epilogue arithmetic left
       wave_mma<1>(&E2[0][0], LDW, Wd, 256, ch * 32, 0, 8, acc);
       wave_mma<1>(&D[0][0], LDW, Wd, 256, ch * 32, 8, 16, acc, 8);
-      const float b = bd[ch * 32 + r31];
-      acc_store<1, 256>(acc, ed + ch * 32, valid, [b](int, float v) { return v + b; });
+      acc_store<1, 256>(acc, ed + ch * 32, valid, [](int, float v) { return v; });
     }
     f32x16 acc[1];
     acc_zero<1>(acc);
@@ -865,15 +884,21 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
     for (int tile = first; tile < ntiles; tile += stride, ++it) {
       const int buf = it & 1;
       f32x16 acc1[2], acc2[2];
-      acc_zero<2>(acc1);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc1[m][i] = b0f[i];   // the MFMA chain accumulates onto the coord_mlp.0 bias
       acc_zero<2>(acc2);
       wave_mma<2, true>(&X[buf][0][0], LD, BW(c, blk, DS_BW_CM0_W), 256, wave * 32, 0, 32, acc1);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float y = ds_silu(acc1[m][i] + b0f[i]);                                   // coord_mlp.0 + SiLU (dmt.py:32-33)
-          acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[i], y, acc2[m], 0, 0, 0);   // coord_mlp.2 partial (dmt.py:34)
+        for (int i = 0; i < 16; i += 2) {
+          f32x2 y;   // SiLU of coord_mlp.0 (dmt.py:32-33), packed-fp32, two hidden features at a time
+          y.x = acc1[m][i]; y.y = acc1[m][i + 1];
+          y = ds_silu2(y);
+          acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[i], y.x, acc2[m], 0, 0, 0);       // coord_mlp.2 partial (dmt.py:34)
+          acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[i + 1], y.y, acc2[m], 0, 0, 0);
         }
       if (hh == 0) {   // out[j][row]: j = register 0..2 of the lower half, row = m*32 + lane
 #pragma unroll

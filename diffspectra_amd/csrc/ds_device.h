@@ -107,12 +107,38 @@ __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 *
 struct BFrag {
   float4 v[4];
 };
+
+// Weight stream through buffer loads: one 128-bit resource per matrix in SGPRs, the lane's position inside a k-group as a
+// 32-bit VGPR offset computed once per call, the k-group stride as an SGPR offset - no per-load 64-bit VALU address
+// arithmetic (two VALU issues per load otherwise, and VALU issue slots next to the MFMA stream are the scarce resource).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct WStream {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff;      // bytes: ((lane >> 5) * Npad + col0 + (lane & 31)) * 16
+  int kstride;   // bytes between k-groups: 2 * Npad * 16
+};
+__device__ __forceinline__ WStream wstream(const float* __restrict__ Wp, int Npad, int col0) {
+  const int lane = threadIdx.x & 63;
+  WStream w;
+  // the weight pointer is wave-uniform by construction; readfirstlane tells the compiler so (otherwise it wraps every
+  // buffer load in a waterfall loop over "possibly different" descriptors)
+  const unsigned long long pw = reinterpret_cast<unsigned long long>(Wp);
+  const unsigned long long pu = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<int>(pw >> 32))) << 32) |
+                                static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(pw)));
+  w.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(pu), 0, 0x7fffffff, 0x00020000);
+  w.voff = (((lane >> 5) * Npad + col0 + (lane & 31)) << 4);
+  w.kstride = Npad << 5;
+  return w;
+}
+__device__ __forceinline__ float4 wload(const WStream& w, int kg) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w.rsrc, w.voff, kg * w.kstride, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 __device__ __forceinline__ BFrag bfrag_load(const float* __restrict__ Wp, int Npad, int col0, int kg0, int kg1) {
-  const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-  const float4* wp = reinterpret_cast<const float4*>(Wp) + (size_t)hh * Npad + col0 + r;
+  const WStream w = wstream(Wp, Npad, col0);
   BFrag f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) f.v[j] = wp[(size_t)min(kg0 + j, kg1 - 1) * 2 * Npad];
+  for (int j = 0; j < 4; ++j) f.v[j] = wload(w, min(kg0 + j, kg1 - 1));
   return f;
 }
 
@@ -129,8 +155,7 @@ __device__ __forceinline__ void wave_mma(const float* X, int ldx, const float* _
                                          int kg0, int kg1, f32x16 (&acc)[MT], int xkg0 = 0, const BFrag* first = nullptr) {
   constexpr int G = 4;
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-  const float4* wp = reinterpret_cast<const float4*>(Wp) + (size_t)hh * Npad + col0 + r;
-  const size_t wstride = (size_t)2 * Npad;
+  const WStream ws = wstream(Wp, Npad, col0);
   const float* xr = X + r * ldx + 4 * hh - xkg0 * 8;
   float4 bc[G], bn[G];
   if (first) {
@@ -138,7 +163,7 @@ __device__ __forceinline__ void wave_mma(const float* X, int ldx, const float* _
     for (int j = 0; j < G; ++j) bc[j] = first->v[j];
   } else {
 #pragma unroll
-    for (int j = 0; j < G; ++j) bc[j] = wp[(size_t)min(kg0 + j, kg1 - 1) * wstride];
+    for (int j = 0; j < G; ++j) bc[j] = wload(ws, min(kg0 + j, kg1 - 1));
   }
   // A fragments are double-buffered one k-group ahead: hipcc otherwise issues each ds_read_b128 right in front of the
   // MFMA that consumes it and the LDS latency (~100 cycles per 512 cycles of MFMA) is exposed at 1-2 waves per SIMD.
@@ -148,7 +173,7 @@ __device__ __forceinline__ void wave_mma(const float* X, int ldx, const float* _
   for (int g = kg0; g < kg1; g += G) {
     if (g + G < kg1) {
 #pragma unroll
-      for (int j = 0; j < G; ++j) bn[j] = wp[(size_t)min(g + G + j, kg1 - 1) * wstride];
+      for (int j = 0; j < G; ++j) bn[j] = wload(ws, min(g + G + j, kg1 - 1));
     }
 #pragma unroll
     for (int j = 0; j < G; ++j) {

@@ -227,22 +227,42 @@ __device__ __forceinline__ void acc_foreach(const f32x16 (&acc)[MT], int row_bas
 // Store a lane's accumulator block to a row-major global matrix: dst points at element (tile row 0, col0) of the
 // destination, LD is its compile-time row stride.  One 64-bit base per lane; the 16*MT row offsets are immediates; full
 // tiles (rows_valid >= 32*MT) take a guard-free path.  f(col_in_chunk_lane, value) -> value applies bias / activation.
+// The stores are buffer stores: the (wave-uniform) destination in an SGPR resource, the lane's position in one VGPR
+// offset, the row as an SGPR offset - a global_store needs a 64-bit VALU address add per row beyond its 4 KB immediate.
+struct RowStore {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff;
+};
+template <int LD>
+__device__ __forceinline__ RowStore row_store(float* dst) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long pw = reinterpret_cast<unsigned long long>(dst);
+  const unsigned long long pu = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<int>(pw >> 32))) << 32) |
+                                static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(pw)));
+  RowStore s;
+  s.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(pu), 0, 0x7fffffff, 0x00020000);
+  s.voff = ((4 * (lane >> 5)) * LD + (lane & 31)) * 4;
+  return s;
+}
+__device__ __forceinline__ void row_put(const RowStore& s, int row_byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), s.rsrc, s.voff, row_byte_off, 0);
+}
 template <int MT, int LD, class F>
 __device__ __forceinline__ void acc_store(const f32x16 (&acc)[MT], float* __restrict__ dst, int rows_valid, F f) {
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-  float* p = dst + (size_t)(4 * hh) * LD + r;
+  const RowStore st = row_store<LD>(dst);
   if (rows_valid >= 32 * MT) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) p[(m * 32 + (i & 3) + 8 * (i >> 2)) * LD] = f(r, acc[m][i]);
+      for (int i = 0; i < 16; ++i) row_put(st, (m * 32 + (i & 3) + 8 * (i >> 2)) * LD * 4, f(r, acc[m][i]));
   } else {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = m * 32 + (i & 3) + 8 * (i >> 2);
-        if (row + 4 * hh < rows_valid) p[row * LD] = f(r, acc[m][i]);
+        if (row + 4 * hh < rows_valid) row_put(st, row * LD * 4, f(r, acc[m][i]));
       }
   }
 }
@@ -250,8 +270,8 @@ __device__ __forceinline__ void acc_store(const f32x16 (&acc)[MT], float* __rest
 // acc_store with a two-wide epilogue f2(f32x2) -> f32x2 (packed-fp32 arithmetic for activation epilogues).
 template <int MT, int LD, class F2>
 __device__ __forceinline__ void acc_store2(const f32x16 (&acc)[MT], float* __restrict__ dst, int rows_valid, F2 f2) {
-  const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-  float* p = dst + (size_t)(4 * hh) * LD + r;
+  const int hh = (threadIdx.x & 63) >> 5;
+  const RowStore st = row_store<LD>(dst);
   if (rows_valid >= 32 * MT) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -261,8 +281,8 @@ __device__ __forceinline__ void acc_store2(const f32x16 (&acc)[MT], float* __res
         v.x = acc[m][i]; v.y = acc[m][i + 1];
         v = f2(v);
         const int row0 = m * 32 + (i & 3) + 8 * (i >> 2);
-        p[row0 * LD] = v.x;
-        p[(row0 + 1) * LD] = v.y;
+        row_put(st, row0 * LD * 4, v.x);
+        row_put(st, (row0 + 1) * LD * 4, v.y);
       }
   } else {
 #pragma unroll
@@ -273,8 +293,8 @@ __device__ __forceinline__ void acc_store2(const f32x16 (&acc)[MT], float* __res
         v.x = acc[m][i]; v.y = acc[m][i + 1];
         v = f2(v);
         const int row0 = m * 32 + (i & 3) + 8 * (i >> 2);
-        if (row0 + 4 * hh < rows_valid) p[row0 * LD] = v.x;
-        if (row0 + 1 + 4 * hh < rows_valid) p[(row0 + 1) * LD] = v.y;
+        if (row0 + 4 * hh < rows_valid) row_put(st, row0 * LD * 4, v.x);
+        if (row0 + 1 + 4 * hh < rows_valid) row_put(st, (row0 + 1) * LD * 4, v.y);
       }
   }
 }

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
     acc_zero<1>(acc2[1]);
     // node_gate_mlp (dmt.py:162) is per molecule: the gate columns of the tile's first / last molecule and the FF2 bias are
     // requested here, a whole FF ahead of their use (fetched after it they cost the epilogue one exposed round trip)
-    const int mA = rmol[0], mB = rmol[T - 1];
+    const int mA = rmol[0], mB = rmol[min(T, Nn - row0) - 1];   // first / last VALID row (padded rows carry molecule 0)
     const float* gsec = ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE + 1280;
     float gAv[2], gBv[2], bbv[2];
 #pragma unroll
@@ -557,19 +557,27 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
       }
       __syncthreads();
     }
-    float* h = c.ws.h;
+    // which of the tile's molecules a row belongs to is decided once per row (the predicates live in SGPR lane masks),
+    // not once per element; rows are sorted by molecule, so a third molecule only occurs for tiny ones (uniform slow path)
+    const int hhl = (tid & 63) >> 5;
+    const bool two = mB - mA <= 1;
+    bool isB[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) isB[i] = rmol[acc_row(i, hhl)] != mA;
+    const int rows_here = Nn - row0;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
       const int col = (wave + 4 * cc) * 32 + (tid & 31);
       const float gA = gAv[cc], gB = gBv[cc], bb = bbv[cc];
+      const RowStore st = row_store<256>(c.ws.h + (size_t)row0 * 256 + (wave + 4 * cc) * 32);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int row = acc_row(i, (tid & 63) >> 5);
-        const int m = rmol[row];
-        const float g = m == mA ? gA : (m == mB ? gB : gsec[(size_t)m * ADAC + col]);
+        const int row = acc_row(i, hhl);
+        float g = isB[i] ? gB : gA;
+        if (!two) { const int m = rmol[row]; if (m != mA && m != mB) g = gsec[(size_t)m * ADAC + col]; }
         const float out = H2[row][col] + g * (acc2[cc][0][i] + bb);   // in place
         H2[row][col] = out;
-        if (row0 + row < Nn) h[(size_t)(row0 + row) * 256 + col] = out;
+        if (row < rows_here) row_put(st, ((i & 3) + 8 * (i >> 2)) * 256 * 4, out);
       }
     }
   }

@@ -1274,21 +1274,23 @@ __global__ __launch_bounds__(64) void k_spec_attention(const float* __restrict__
   if (i >= L) return;
   float q[DK];
   for (int d = 0; d < DK; ++d) q[d] = qkv[((size_t)b * L + i) * 3 * D + h * DK + d];
-  float* srow = scores + (((size_t)b * heads + h) * L + i) * L;
+  // residual scores are kept TRANSPOSED, [b][h][key j][query i]: the lanes of a wave are consecutive queries, so every
+  // access below is one contiguous 256-byte segment (query-major rows made each lane touch its own cache line)
+  float* scol = scores + ((size_t)b * heads + h) * L * L + i;
   float mx = -INFINITY;
   for (int j = 0; j < L; ++j) {
     float s = 0.0f;
 #pragma unroll
     for (int d = 0; d < DK; ++d) s += q[d] * Ks[j * DK + d];
     s *= scale;
-    if (has_prev) s += srow[j];
-    srow[j] = s;
+    if (has_prev) s += scol[(size_t)j * L];
+    scol[(size_t)j * L] = s;
     mx = fmaxf(mx, s);
   }
   float den = 0.0f, o[DK];
   for (int d = 0; d < DK; ++d) o[d] = 0.0f;
   for (int j = 0; j < L; ++j) {
-    const float p = expf(srow[j] - mx);
+    const float p = expf(scol[(size_t)j * L] - mx);
     den += p;
 #pragma unroll
     for (int d = 0; d < DK; ++d) o[d] += p * Vs[j * DK + d];

@@ -182,7 +182,9 @@ int ds_sampler_step(const ds_layout* L, float c_x, float c_pred, float sigma, fl
 int ds_post_process(const ds_layout* L, const float* xh, const float* edge_x,
                     float* pos_out, int32_t* atom_type, int32_t* fc, float* edge_type, void* stream);
 
-/* SpecFormer pieces that are not plain GEMMs (specformer.py:385-425 residual-score attention; :119 LayerNorm). */
+/* SpecFormer pieces that are not plain GEMMs (specformer.py:385-425 residual-score attention; :119 LayerNorm).
+ * qkv [B,L,3*heads*dk]; out [B,L,heads*dk]; scores: B*heads*L*L floats of caller-owned scratch that carries the
+ * pre-softmax scores from layer to layer (has_prev = 0 on the first layer); its layout ([b][h][key][query]) is private. */
 int ds_spec_attention(const float* qkv, float* scores, float* out, int B, int L, int heads, int dk, float scale,
                       int has_prev, void* stream);
 int ds_layernorm_affine(const float* x, const float* gamma, const float* beta, float* y, int rows, int cols,

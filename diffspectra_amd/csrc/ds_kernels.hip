@@ -1389,16 +1389,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm_big(GemmArgs g) {
     __syncthreads();
   }
   if (!active) return;
-  acc_foreach<4>(acc, 0, col0, [&](int row, int col, float v) {
-    const int gr = row0 + row;
-    if (gr < g.M && col < g.N) {
-      if (g.bias) v += g.bias[col];
-      v = ds_act<ACT>(v);
-      if (g.R) v += g.R[(size_t)(g.r_grp_rows > 0 ? gr % g.r_grp_rows : gr) * g.ldr + col];
-      if (g.cs) v = v * g.cs[col] + g.csh[col];
-      g.C[(size_t)gr * g.ldc + col] = v;
-    }
-  });
+  {   // epilogue: the lane's column constants are fetched once, rows go out as buffer stores with SGPR row offsets
+    const int lane = tid & 63, r = lane & 31, hh = lane >> 5, col = col0 + r;
+    const bool colok = col < g.N;
+    const float bcol = (g.bias && colok) ? g.bias[col] : 0.0f;
+    const float csc = (g.cs && colok) ? g.cs[col] : 1.0f, csh = (g.cs && colok) ? g.csh[col] : 0.0f;
+    const unsigned long long pw = reinterpret_cast<unsigned long long>(g.C + (size_t)row0 * g.ldc + col0);
+    const unsigned long long pu = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<int>(pw >> 32))) << 32) |
+                                  static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(pw)));
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(pu), 0, 0x7fffffff, 0x00020000);
+    const int voff = (4 * hh * g.ldc + r) * 4, rowb = g.ldc * 4;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = m * 32 + (i & 3) + 8 * (i >> 2), gr = row0 + row + 4 * hh;
+        if (gr < g.M && colok) {
+          float v = ds_act<ACT>(acc[m][i] + bcol);
+          if (g.R) v += g.R[(size_t)(g.r_grp_rows > 0 ? gr % g.r_grp_rows : gr) * g.ldr + col];
+          if (g.cs) v = v * csc + csh;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, voff, row * rowb, 0);
+        }
+      }
+  }
 }
 
 int gemm_dispatch(const GemmArgs& g, int act, hipStream_t s) {

@@ -215,6 +215,13 @@ def main():
     E._check(lib.ds_profile_read(C.byref(tot_ms), C.byref(samples)), "ds_profile_read")
     lib.ds_profile_config(C.c_int(-1), C.c_int(1), C.c_int(0))
     assert torch.isfinite(rec).all()
+    if rank == 0:   # the timed work must be the real computation: check invariants the reference guarantees on its outputs
+        pos_o, atom_o, _, et_o = shard.unpack_records(rec[:M], max_n)
+        nm = node_mask.squeeze(-1)
+        assert float((pos_o * nm.unsqueeze(-1)).sum(1).abs().max()) < 1e-3, "generated positions are not zero-CoM"
+        assert float((pos_o * (1 - nm).unsqueeze(-1)).abs().max()) == 0.0, "padded atoms carry positions"
+        assert int(atom_o.min()) >= 0 and int(atom_o.max()) < 5, "atom types out of range"
+        assert torch.equal(et_o, et_o.transpose(1, 2)) and float(et_o.max()) <= 3.0, "bond orders not symmetric in {0..3}"
     if world > 1:
         t = torch.tensor([elapsed], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -606,3 +606,18 @@ def test_g7_full_length_trajectory_golden(gpu_device):
     assert int((one_hot.argmax(-1).cpu() != g[tag + "_atom_type"]).sum()) == 0, "atom-type argmax mismatches after 1000 steps"
     assert torch.equal(fc.squeeze(-1).cpu(), g[tag + "_fc"].squeeze(-1).long()), "formal charges differ after 1000 steps"
     assert torch.equal(et.cpu(), g[tag + "_edge_type"]), "bond orders differ after 1000 steps"
+
+
+def test_batched_stability_on_device(gpu_device):
+    """N4: the batched stability check gives the same answer on the GPU tensors the sampler returns as on the CPU."""
+    from diffspectra_amd import filler
+    from diffspectra_amd.stability import check_stability_batch
+    n_atoms = filler.sample_n_atoms(64, seed=5).tolist()
+    x, _, node_mask, _ = filler.synthetic_state(n_atoms, "stab.x")
+    pos = x[:, :, :3] * 1.3
+    types = (filler.uniform("stab.t", (64, x.shape[1])) * 5).long().clamp(0, 4)
+    cpu = check_stability_batch(pos, types, node_mask)
+    dev = check_stability_batch(pos.to(gpu_device), types.to(gpu_device), node_mask.to(gpu_device))
+    for a, b in zip(cpu, dev):
+        assert torch.equal(a, b.cpu())
+    assert int(cpu[3].sum()) > 0                      # the fixture does contain bonds

@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define DS_LDP 4  // LDS row padding (floats)
 
@@ -24,7 +25,6 @@ __device__ __forceinline__ float ds_tanh(float x) {
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 // Two at a time: the multiply, add and fma become packed-fp32 issues (v_pk_*), 7 VALU issues per 2 values instead of 10.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 ds_tanh2(f32x2 x) {
   const f32x2 t = x * 2.8853900817779268f;
   f32x2 e;
@@ -96,6 +96,31 @@ __device__ __forceinline__ float4 ln_mod_reg64(float4 v, float4 sh, float4 sc) {
   v.x = v.x * rstd * (1.0f + sc.x) + sh.x; v.y = v.y * rstd * (1.0f + sc.y) + sh.y;
   v.z = v.z * rstd * (1.0f + sc.z) + sh.z; v.w = v.w * rstd * (1.0f + sc.w) + sh.w;
   return v;
+}
+
+// 256-wide rows, FOUR rows per wave pass: a row lives in one 16-lane DPP row, lane j of it holds the float4s at columns
+// 4j + 64u (u = 0..3).  Every lane works on every step and the row sum is four DPP steps with no broadcast/readlane tail:
+// ~15 VALU issues per row against ~55 for the one-row-per-wave form.  v[u], sh[u], sc[u]: the lane's four float4s.
+__device__ __forceinline__ void ln_mod_quad256(float4 (&v)[4], const float4 (&sh)[4], const float4 (&sc)[4]) {
+  f32x2 lo[4], hi[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { lo[u].x = v[u].x; lo[u].y = v[u].y; hi[u].x = v[u].z; hi[u].y = v[u].w; }
+  const f32x2 s2 = ((lo[0] + hi[0]) + (lo[1] + hi[1])) + ((lo[2] + hi[2]) + (lo[3] + hi[3]));
+  const float mean = row16_sum(s2.x + s2.y) * (1.0f / 256.0f);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { lo[u] -= mean; hi[u] -= mean; }
+  const f32x2 q2 = ((lo[0] * lo[0] + hi[0] * hi[0]) + (lo[1] * lo[1] + hi[1] * hi[1])) +
+                   ((lo[2] * lo[2] + hi[2] * hi[2]) + (lo[3] * lo[3] + hi[3] * hi[3]));
+  const float rstd = __builtin_amdgcn_rsqf(row16_sum(q2.x + q2.y) * (1.0f / 256.0f) + 1e-6f);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    f32x2 slo, shi, clo, chi;
+    slo.x = sh[u].x; slo.y = sh[u].y; shi.x = sh[u].z; shi.y = sh[u].w;
+    clo.x = sc[u].x; clo.y = sc[u].y; chi.x = sc[u].z; chi.y = sc[u].w;
+    lo[u] = (lo[u] * rstd) * (clo + 1.0f) + slo;
+    hi[u] = (hi[u] * rstd) * (chi + 1.0f) + shi;
+    v[u] = make_float4(lo[u].x, lo[u].y, hi[u].x, hi[u].y);
+  }
 }
 
 // Row of accumulator register `reg` (0..15) for a lane in half `hh` (lane>>5) of a 32x32 tile.

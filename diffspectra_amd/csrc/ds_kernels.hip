@@ -295,24 +295,32 @@ __global__ __launch_bounds__(NW * 64) void k_node_qkv(Ctx c, int blk) {
   const float* Wq = BW(c, blk, DS_BW_QKV_W) + (size_t)col0 * 4;   // packed Wp[K/8][2][768][4]: a column offset is +4 floats/col
   const BFrag pfq = tile_first<2, 2>(Wq, 768, 256, 12);            // GEMM weights requested before the staging
   __syncthreads();
-  {
+  {   // 64 rows: wave w normalises rows 16w .. 16w+15, four rows per pass (one per 16-lane DPP row), two passes in flight
     const float* adn = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
-    for (int it = 0; it < T * 16 / NT; ++it) {   // 64 rows x 64 float4; each wave holds whole rows -> LN + modulate in registers
-      float4 v[4], sh[4], sc[4];
+    const int lane = tid & 63, wv = tid >> 6, g = lane >> 4, j = lane & 15;
+    static_assert(NT == 256, "four waves x 16 rows");
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = tid + (it * 4 + u) * NT, row = idx >> 6, k4 = idx & 63;
-        v[u] = reinterpret_cast<const float4*>(c.ws.h + (size_t)min(row0 + row, c.L.Nn - 1) * 256)[k4];
-        sh[u] = reinterpret_cast<const float4*>(adn + (size_t)rmol[row] * ADAC)[k4];          // node_shift_msa
-        sc[u] = reinterpret_cast<const float4*>(adn + (size_t)rmol[row] * ADAC + 256)[k4];    // node_scale_msa
+    for (int half = 0; half < 2; ++half) {
+      float4 v[2][4], sh[2][4], sc[2][4];
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int row = 16 * wv + 8 * half + 4 * ps + g;
+        const float4* hp = reinterpret_cast<const float4*>(c.ws.h + (size_t)min(row0 + row, c.L.Nn - 1) * 256) + j;
+        const float4* ap = reinterpret_cast<const float4*>(adn + (size_t)rmol[row] * ADAC) + j;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          v[ps][u] = hp[16 * u];
+          sh[ps][u] = ap[16 * u];        // node_shift_msa
+          sc[ps][u] = ap[64 + 16 * u];   // node_scale_msa
+        }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = ln_mod_reg256(v[u], sh[u], sc[u]);   // dmt.py:148
+      for (int ps = 0; ps < 2; ++ps) {
+        const int row = 16 * wv + 8 * half + 4 * ps + g;
+        ln_mod_quad256(v[ps], sh[ps], sc[ps]);   // dmt.py:148
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = tid + (it * 4 + u) * NT, row = idx >> 6, k4 = idx & 63;
-        if (row0 + row >= c.L.Nn) v[u] = make_float4(0, 0, 0, 0);
-        reinterpret_cast<float4*>(&X[row][0])[k4] = v[u];
+        for (int u = 0; u < 4; ++u)
+          reinterpret_cast<float4*>(&X[row][0])[16 * u + j] = row0 + row < c.L.Nn ? v[ps][u] : make_float4(0, 0, 0, 0);
       }
     }
   }

@@ -485,29 +485,41 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
   const float* ada = c.ws.ada;
   if (tid < T) rmol[tid] = (row0 + tid < Nn) ? c.L.node_mol[row0 + tid] : 0;
   __syncthreads();
-  for (int it = 0; it < 2; ++it) {   // 32 rows x 64 float4; whole rows per wave -> residual, LN, modulate in registers
-    float4 va[4], vh[4], vg[4], sh[4], sc[4];
+  {   // 32 rows: wave w takes rows 8w .. 8w+7 as two passes of four rows (one row per 16-lane DPP row, lane j holds the
+      // float4s at columns 4j + 64u); residual, LayerNorm and modulate in registers
+    const int lane = tid & 63, g = lane >> 4, j = lane & 15;
+    float4 va[2][4], vh[2][4], vg[2][4], sh[2][4], sc[2][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + (it * 4 + u) * 256, row = idx >> 6, k4 = idx & 63;
+    for (int ps = 0; ps < 2; ++ps) {
+      const int row = 8 * wave + 4 * ps + g;
       const size_t gr = (size_t)min(row0 + row, Nn - 1);   // clamp instead of branching: loads stay batched
-      const float* ad = ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
-      va[u] = reinterpret_cast<const float4*>(c.ws.attn + gr * 256)[k4];
-      vh[u] = reinterpret_cast<const float4*>(c.ws.h + gr * 256)[k4];
-      vg[u] = reinterpret_cast<const float4*>(ad + 512)[k4];    // node_gate_msa
-      sh[u] = reinterpret_cast<const float4*>(ad + 768)[k4];    // node_shift_mlp
-      sc[u] = reinterpret_cast<const float4*>(ad + 1024)[k4];   // node_scale_mlp
+      const float4* ad = reinterpret_cast<const float4*>(ada + (size_t)rmol[row] * ADAC + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE) + j;
+      const float4* ap = reinterpret_cast<const float4*>(c.ws.attn + gr * 256) + j;
+      const float4* hp = reinterpret_cast<const float4*>(c.ws.h + gr * 256) + j;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        va[ps][u] = ap[16 * u];
+        vh[ps][u] = hp[16 * u];
+        vg[ps][u] = ad[128 + 16 * u];   // node_gate_msa   (+512 floats)
+        sh[ps][u] = ad[192 + 16 * u];   // node_shift_mlp  (+768)
+        sc[ps][u] = ad[256 + 16 * u];   // node_scale_mlp  (+1024)
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + (it * 4 + u) * 256, row = idx >> 6, k4 = idx & 63;
-      if (row0 + row >= Nn) va[u] = vh[u] = make_float4(0, 0, 0, 0);
-      reinterpret_cast<float4*>(&B1[row][0])[k4] = va[u];
-      float4 r;   // h_in + gate_msa * attn (dmt.py:159)
-      r.x = vh[u].x + vg[u].x * va[u].x; r.y = vh[u].y + vg[u].y * va[u].y;
-      r.z = vh[u].z + vg[u].z * va[u].z; r.w = vh[u].w + vg[u].w * va[u].w;
-      r = ln_mod_reg256(r, sh[u], sc[u]);   // norm2_node + modulate (dmt.py:160)
-      reinterpret_cast<float4*>(&H2[row][0])[k4] = r;
+    for (int ps = 0; ps < 2; ++ps) {
+      const int row = 8 * wave + 4 * ps + g;
+      float4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (row0 + row >= Nn) va[ps][u] = vh[ps][u] = make_float4(0, 0, 0, 0);
+        reinterpret_cast<float4*>(&B1[row][0])[16 * u + j] = va[ps][u];
+        // h_in + gate_msa * attn (dmt.py:159)
+        r[u].x = vh[ps][u].x + vg[ps][u].x * va[ps][u].x; r[u].y = vh[ps][u].y + vg[ps][u].y * va[ps][u].y;
+        r[u].z = vh[ps][u].z + vg[ps][u].z * va[ps][u].z; r[u].w = vh[ps][u].w + vg[ps][u].w * va[ps][u].w;
+      }
+      ln_mod_quad256(r, sh[ps], sc[ps]);   // norm2_node + modulate (dmt.py:160)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) reinterpret_cast<float4*>(&H2[row][0])[16 * u + j] = r[u];
     }
   }
   __syncthreads();

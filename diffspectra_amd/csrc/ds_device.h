@@ -374,82 +374,3 @@ __device__ __forceinline__ void tile_gemm(const float* X, int ldx, int K, const 
 __device__ __forceinline__ float wp_at(const float* __restrict__ Wp, int Npad, int k, int n) {
   return Wp[((size_t)((k >> 3) * 2 + ((k >> 2) & 1)) * Npad + n) * 4 + (k & 3)];
 }
-
-// LayerNorm (no affine, eps 1e-6, biased variance) + adaLN modulate of one LDS row by one wave.
-// W = 256: each lane owns 4 consecutive columns; W = 64: one column per lane.
-template <int W>
-__device__ __forceinline__ void ln_mod_row(float* row, const float* __restrict__ shift, const float* __restrict__ scale) {
-  const int lane = threadIdx.x & 63;
-  if (W == 256) {
-    float4 v = reinterpret_cast<float4*>(row)[lane];
-    const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
-    v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
-    const float var = wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 256.0f);
-    const float rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
-    const float4 sh = reinterpret_cast<const float4*>(shift)[lane];
-    const float4 sc = reinterpret_cast<const float4*>(scale)[lane];
-    v.x = v.x * rstd * (1.0f + sc.x) + sh.x;
-    v.y = v.y * rstd * (1.0f + sc.y) + sh.y;
-    v.z = v.z * rstd * (1.0f + sc.z) + sh.z;
-    v.w = v.w * rstd * (1.0f + sc.w) + sh.w;
-    reinterpret_cast<float4*>(row)[lane] = v;
-  } else {
-    float v = row[lane];
-    const float mean = wave_sum(v) * (1.0f / 64.0f);
-    v -= mean;
-    const float var = wave_sum(v * v) * (1.0f / 64.0f);
-    const float rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
-    row[lane] = v * rstd * (1.0f + scale[lane]) + shift[lane];
-  }
-}
-
-// LayerNorm + modulate of a whole LDS tile: wave w owns rows w, w+NWV, ...  The per-row adaLN shift/scale vectors live
-// in global memory (one row of the ada table per molecule); ALL of a wave's rows are requested before the first
-// reduction so the L2/HBM latency is paid once per tile instead of once per row (it was 28 % of the equivariant-update kernel).
-template <int W, int RPW, int NWV>
-__device__ __forceinline__ void ln_mod_tile(float* X, int ldx, const int* rmol, const float* __restrict__ ada, size_t ada_ld,
-                                            int shift_off, int scale_off) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (W == 256) {
-    float4 sh[RPW], sc[RPW];
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-      const float* a = ada + (size_t)rmol[wave + NWV * j] * ada_ld;
-      sh[j] = reinterpret_cast<const float4*>(a + shift_off)[lane];
-      sc[j] = reinterpret_cast<const float4*>(a + scale_off)[lane];
-    }
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-      float* row = X + (size_t)(wave + NWV * j) * ldx;
-      float4 v = reinterpret_cast<float4*>(row)[lane];
-      const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
-      v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
-      const float var = wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 256.0f);
-      const float rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
-      v.x = v.x * rstd * (1.0f + sc[j].x) + sh[j].x;
-      v.y = v.y * rstd * (1.0f + sc[j].y) + sh[j].y;
-      v.z = v.z * rstd * (1.0f + sc[j].z) + sh[j].z;
-      v.w = v.w * rstd * (1.0f + sc[j].w) + sh[j].w;
-      reinterpret_cast<float4*>(row)[lane] = v;
-    }
-  } else {
-    float sh[RPW], sc[RPW], v[RPW];
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-      const float* a = ada + (size_t)rmol[wave + NWV * j] * ada_ld;
-      sh[j] = a[shift_off + lane];
-      sc[j] = a[scale_off + lane];
-      v[j] = X[(size_t)(wave + NWV * j) * ldx + lane];
-    }
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {   // independent rows: the reductions of different rows interleave
-      const float mean = wave_sum(v[j]) * (1.0f / 64.0f);
-      v[j] -= mean;
-      const float var = wave_sum(v[j] * v[j]) * (1.0f / 64.0f);
-      const float rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
-      v[j] = v[j] * rstd * (1.0f + sc[j]) + sh[j];
-    }
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) X[(size_t)(wave + NWV * j) * ldx + lane] = v[j];
-  }
-}

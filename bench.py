@@ -1,9 +1,12 @@
 """Headline benchmark: molecules/sec for 1000-step QM9S all-spectra conditional sampling (BASELINE.json).
 
     python bench.py --gpus N --steps K --warmup W
-N>1 is launched by the driver through torch.distributed.run, one rank per GPU.  A *step* is one complete
-sampling pass over one micro-batch of ``--mols`` molecules per GPU: SpecFormer conditioning (once per molecule) +
-initial noise + ``--denoise-steps`` (1000) DMT evaluations with the fused ancestral update + post-processing.
+N>1 is launched by the driver through torch.distributed.run, one rank per GPU.  ``--mols`` molecules per GPU (4096) stay
+resident in HBM and are sampled in back-to-back complete passes: SpecFormer conditioning (once per molecule) + initial
+noise + ``--denoise-steps`` (1000) DMT evaluations with the fused ancestral update + post-processing + gather.  A bench
+*step* is one twentieth of such a pass: 50 denoise iterations over the resident batch (≈ 1.8 s), so the driver's
+``--steps 20 --warmup 5`` times exactly one complete 1000-step pass over 4096 molecules per GPU (pass-opening work lands
+in step 0, pass-closing work in step 19) and molecules/sec = molecules × (denoise iterations timed / 1000) / elapsed.
 Molecules are independent, so ranks own disjoint molecules (weak scaling) and the only collective is the final
 all_gather of the fixed-size result records over RCCL.
 
@@ -78,8 +81,19 @@ def pmc_traffic(kernel: str, mols: int):
         return None, None
 
 
-def cpu_baseline(version: str, denoise_steps: int, sample_mols: int = 64, sample_steps: int = 8):
-    """Time the CPU oracle (reference algorithm, SpecFormer re-encoded every step as the reference does) on the host."""
+def executed_macs(n_atoms) -> int:
+    """MACs the kernels actually issue: the edge-side GEMMs whose operands are symmetric in (a, b) run once per unordered
+    pair, only MultiCondEquiUpdate's coord_mlp (66 304 MACs) runs per directed edge."""
+    n = np.asarray(n_atoms, dtype=np.int64)
+    N, E, B = int(n.sum()), int((n * (n - 1)).sum()), len(n)
+    sym, directed = 157184 - EQUI_MACS_PER_DIRECTED_EDGE, EQUI_MACS_PER_DIRECTED_EDGE
+    return 8 * (620544 * N + (sym // 2 + directed) * E + 2492416 * B) + (233216 * N + (33088 // 2) * E + 1330176 * B)
+
+
+def cpu_baseline(version: str, denoise_steps: int, sample_mols: int = 64, sample_steps: int = 6, budget_s: float = 25.0):
+    """Time the CPU oracle (reference algorithm, SpecFormer re-encoded every step as the reference does) on the host.
+
+    Bounded: at most ``sample_steps`` timed denoise steps and ``budget_s`` seconds, so the JSON line is always emitted."""
     import oracle
     from diffspectra_amd import filler
     from diffspectra_amd.config import qm9s_config
@@ -96,24 +110,32 @@ def cpu_baseline(version: str, denoise_steps: int, sample_mols: int = 64, sample
     torch.set_num_threads(cores)                   # every core this process may run on (cgroup quota respected)
     cond = (None, None)
     times = []
+    t_begin = time.perf_counter()
     for i in range(sample_steps + 1):              # first iteration = warm-up (and first-step branch)
         t0 = time.perf_counter()
         out = oracle.dmt_forward(sd, cfg, x, node_mask, edge_mask, ex, nl, cond[0], cond[1], context=ctx)
         times.append(time.perf_counter() - t0)
         cond = out
+        if len(times) >= 3 and time.perf_counter() - t_begin > budget_s:
+            break
     per_step = float(np.mean(times[1:]))
     return {"value": sample_mols / (per_step * denoise_steps), "unit": "molecules/sec", "cores": int(cores), "kind": "port",
-            "sample": f"{sample_mols} molecules (QM9 size histogram, seed 0), {sample_steps} timed denoise steps of the "
+            "sample": f"{sample_mols} molecules (QM9 size histogram, seed 0), {len(times) - 1} timed denoise steps of the "
                       f"faithful CPU oracle ({per_step:.3f} s/step), extrapolated to {denoise_steps} steps"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mols", type=int, default=4096, help="molecules per GPU per step (one sampling micro-batch)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mols", type=int, default=4096, help="molecules resident per GPU (one sampling micro-batch)")
     ap.add_argument("--denoise-steps", type=int, default=1000)
+    ap.add_argument("--steps-per-pass", type=int, default=20,
+                    help="bench steps one complete sampling pass is cut into: a step = denoise_steps / this many denoise "
+                         "iterations over the resident micro-batch (20 steps = one complete 1000-step pass)")
+    ap.add_argument("--budget-s", type=float, default=300.0,
+                    help="wall-clock cap of the timed region: --steps is lowered (and reported) if it would not fit")
     ap.add_argument("--spectra", default="allspectra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse)")
@@ -178,57 +200,90 @@ def main():
                               cfg.eval.sampling_temperature)
     inv = get_data_inverse_scaler(cfg)
     torch.manual_seed(42 + rank)
-    if rank == 0:
-        def progress(i, n):
-            torch.cuda.synchronize()
-            log(f"  denoise step {i}/{n}")
-        sampler.progress_fn = progress if os.environ.get("BENCH_QUIET", "0") != "1" else None
+    spp = max(1, min(args.steps_per_pass, args.denoise_steps))
+    slice_len = -(-args.denoise_steps // spp)          # denoise iterations per bench step
 
-    def one_step():
-        z, edge_z = S.initial_noise(M, max_n, 6, 2, node_mask, edge_mask)
-        x_node, x_edge = sampler.sampling(model, z, node_mask, edge_mask, edge_z, None if args.unconditional else context)
-        pos, one_hot, fc, edge_types = S.post_process(x_node, 5, True, node_mask, inv, x_edge, edge_mask, True, engine=eng)
-        rec = shard.pack_records(pos, one_hot.argmax(-1), fc, edge_types)     # fixed-size record per molecule
-        return shard.gather_records(rec)                                # the only collective: final gather over xGMI
+    class Stream:
+        """Back-to-back sampling passes over the resident micro-batch, advanced one bench step (= slice_len denoise
+        iterations) at a time.  A pass opens with SpecFormer + initial noise and closes with post-processing and the
+        only collective of the path (the final gather of the result records)."""
+        def __init__(self):
+            self.st, self.rec, self.passes, self.iters = None, None, 0, 0
+
+        def step(self):
+            if self.st is None:
+                z, edge_z = S.initial_noise(M, max_n, 6, 2, node_mask, edge_mask)
+                self.st = sampler.begin(model, z, node_mask, edge_mask, edge_z, None if args.unconditional else context)
+            before = self.st.i
+            done = sampler.advance(self.st, slice_len)
+            self.iters += self.st.i - before
+            if done:
+                pos, one_hot, fc, edge_types = S.post_process(self.st.x_mean, 5, True, node_mask, inv, self.st.edge_mean,
+                                                              edge_mask, True, engine=eng)
+                rec = shard.pack_records(pos, one_hot.argmax(-1), fc, edge_types)   # fixed-size record per molecule
+                self.rec = shard.gather_records(rec)                               # final gather over xGMI
+                self.st = None
+                self.passes += 1
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(v: float) -> float:
+        if world == 1:
+            return v
+        t = torch.tensor([v], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- warm-up: W steps of a throwaway pass (code paths, allocator, layout cache, clocks); the last one is timed to
+    # size the timed region against the wall-clock budget
+    warm = Stream()
+    t_step = 0.0
     for w in range(args.warmup):
-        one_step()
+        sync()
+        t0 = time.perf_counter()
+        warm.step()
+        sync()
+        t_step = max_over_ranks(time.perf_counter() - t0)
         if rank == 0:
-            log(f"warmup step {w + 1}/{args.warmup} done")
-    sampler.progress_fn = None                       # no host syncs inside the timed region
-    every = max(1, (args.steps * args.denoise_steps * 8) // 2000)
+            log(f"warmup step {w + 1}/{args.warmup} done ({t_step * 1e3:.0f} ms, {slice_len} denoise iterations x {M} molecules)")
+    del warm
+    steps = args.steps
+    if t_step > 0 and steps * t_step > args.budget_s:
+        steps = max(1, int(args.budget_s / t_step))
+        if rank == 0:
+            log(f"--steps {args.steps} would take ~{args.steps * t_step:.0f} s; running {steps} steps to stay inside {args.budget_s:.0f} s")
+
+    every = max(1, (steps * slice_len * 8) // 2000)
     E._check(lib.ds_profile_config(C.c_int(args.profile_kernel), C.c_int(every), C.c_int(4096)), "ds_profile_config")
+    run = Stream()
     sync()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        rec = one_step()
-        if rank == 0:
-            log(f"timed step {k + 1}/{args.steps} enqueued")
+    for k in range(steps):
+        run.step()
     sync()
-    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     tot_ms, samples = C.c_double(0.0), C.c_int64(0)
     E._check(lib.ds_profile_read(C.byref(tot_ms), C.byref(samples)), "ds_profile_read")
     lib.ds_profile_config(C.c_int(-1), C.c_int(1), C.c_int(0))
-    assert torch.isfinite(rec).all()
-    if rank == 0:   # the timed work must be the real computation: check invariants the reference guarantees on its outputs
-        pos_o, atom_o, _, et_o = shard.unpack_records(rec[:M], max_n)
+    # the timed work must be the real computation: check invariants the reference guarantees on its outputs
+    if run.rec is not None:
+        rec = run.rec
+        assert torch.isfinite(rec).all()
+        pos_o, atom_o, _, et_o = shard.unpack_records(rec[rank * M:(rank + 1) * M], max_n)
         nm = node_mask.squeeze(-1)
         assert float((pos_o * nm.unsqueeze(-1)).sum(1).abs().max()) < 1e-3, "generated positions are not zero-CoM"
         assert float((pos_o * (1 - nm).unsqueeze(-1)).abs().max()) == 0.0, "padded atoms carry positions"
         assert int(atom_o.min()) >= 0 and int(atom_o.max()) < 5, "atom types out of range"
         assert torch.equal(et_o, et_o.transpose(1, 2)) and float(et_o.max()) <= 3.0, "bond orders not symmetric in {0..3}"
-    if world > 1:
-        t = torch.tensor([elapsed], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    else:
+        assert torch.isfinite(run.st.x).all() and torch.isfinite(run.st.edge_x).all()
 
     if rank == 0:
-        value = world * M * args.steps / elapsed
+        mol_passes = world * M * run.iters / args.denoise_steps       # molecules x fraction of their 1000 steps done
+        value = mol_passes / elapsed
         n = np.asarray(n_atoms, dtype=np.int64)
         E_dir = int((n * (n - 1)).sum())
         kern_ms = tot_ms.value / max(1, samples.value)
@@ -248,23 +303,36 @@ def main():
                         "launches_timed": int(samples.value), "achieved": None, "peak": PEAK_FP32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": None, "traffic": None}
         fwd_flop = 2.0 * algorithmic_macs(n_atoms)
-        whole = fwd_flop * args.denoise_steps * args.steps / elapsed / 1e12
+        exe_flop = 2.0 * executed_macs(n_atoms)
+        whole = fwd_flop * run.iters / elapsed / 1e12
+        whole_exe = exe_flop * run.iters / elapsed / 1e12
         line = {
             "metric": "molecules/sec, 1000-step QM9S all-spectra sampling", "value": value, "unit": "molecules/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("QM9S unconditional (zero context embedding), DMT only" if args.unconditional else
                                     f"QM9S {args.spectra}, DMT + SpecFormer (no pretrain)") + ", random-init procedural weights, "
-                                   f"{args.denoise_steps} denoise steps, {M} molecules per GPU per step "
-                                   f"(n_atoms ~ qm9_second_half histogram, mean {float(n.mean()):.2f})",
-                       "molecules_per_gpu_per_step": M, "denoise_steps": args.denoise_steps, "parallelism": f"dp{world} (molecule shards)"},
+                                   f"{args.denoise_steps} denoise steps per molecule, {M} molecules resident per GPU "
+                                   f"(n_atoms ~ qm9_second_half histogram, mean {float(n.mean()):.2f}); one bench step = "
+                                   f"{slice_len} denoise iterations over the resident batch, {spp} steps = one complete "
+                                   f"{args.denoise_steps}-step sampling pass incl. SpecFormer, initial noise, post-processing "
+                                   "and the final gather",
+                       "molecules_per_gpu": M, "denoise_steps": args.denoise_steps, "denoise_iterations_per_step": slice_len,
+                       "steps_per_pass": spp, "passes_completed": run.passes, "denoise_iterations_timed": run.iters,
+                       "steps_requested": args.steps, "parallelism": f"dp{world} (molecule shards)"},
             "roofline": roofline,
             "whole_path": {"algorithmic_tflops_per_gpu": whole, "frac_of_fp32_mfma_peak": whole / PEAK_FP32_MFMA_TFLOPS,
-                           "algorithmic_gflop_per_molecule_step": fwd_flop / M / 1e9},
+                           "executed_tflops_per_gpu": whole_exe, "executed_frac": whole_exe / PEAK_FP32_MFMA_TFLOPS,
+                           "algorithmic_gflop_per_molecule_step": fwd_flop / M / 1e9,
+                           "executed_gflop_per_molecule_step": exe_flop / M / 1e9},
         }
-        log(f"GPU timing done: {value:.2f} molecules/sec; timing CPU baseline")
+        log(f"GPU timing done: {value:.2f} molecules/sec ({elapsed:.1f} s for {steps} steps); timing CPU baseline")
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.spectra, args.denoise_steps)
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.spectra, args.denoise_steps)
+            except Exception as exc:   # the GPU line must not be lost to a host-side problem
+                line["cpu_baseline"] = {"value": None, "unit": "molecules/sec", "cores": usable_cores(), "kind": "port",
+                                        "sample": f"failed: {type(exc).__name__}: {exc}"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -67,42 +67,66 @@ class AncestralSampler:
         return self._table
 
     @torch.no_grad()
-    def sampling(self, model, z_T, node_mask, edge_mask, edge_z_T=None, context=None):
+    def begin(self, model, z_T, node_mask, edge_mask, edge_z_T=None, context=None):
+        """State of one sampling pass before its first denoise step: noisy tensors cloned onto the GPU, the (hoisted,
+        loop-invariant) spectra embedding, the per-step coefficient table.  ``advance`` runs denoise steps on it."""
         m = _hip_model(model)
         eng = m.engine()
         dev = eng.device
         L, ws = eng.layout_for(node_mask, edge_mask, validate=True)
         B, N = L.B, L.N
-        x = z_T.detach().to(dev, torch.float32).contiguous().clone()
-        edge_x = edge_z_T.detach().to(dev, torch.float32).contiguous().clone()
-        ctx = eng.context_embedding(context)                      # hoisted: loop-invariant
+        st = _Pass()
+        st.eng, st.L, st.ws, st.i = eng, L, ws, 0
+        st.x = z_T.detach().to(dev, torch.float32).contiguous().clone()
+        st.edge_x = edge_z_T.detach().to(dev, torch.float32).contiguous().clone()
+        st.ctx = eng.context_embedding(context)                      # hoisted: loop-invariant
         tab = self.coefficient_table()
-        coef = tab.tolist()
-        nl_dev = tab[:, 3].to(dev)
+        st.coef = tab.tolist()
+        st.nl_rows = tab[:, 3].to(dev).reshape(-1, 1).expand(-1, B).contiguous()   # [S, B]: row i = noise level of step i
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        pred, edge_pred = [f(B, N, 9), f(B, N, 9)], [f(B, N, N, 2), f(B, N, N, 2)]
-        x_mean, edge_mean = torch.zeros(B, N, 9, device=dev), torch.zeros(B, N, N, 2, device=dev)
-        noise_level = f(B)
-        cond_x = cond_edge_x = None
+        st.pred, st.edge_pred = [f(B, N, 9), f(B, N, 9)], [f(B, N, N, 2), f(B, N, N, 2)]
+        st.x_mean, st.edge_mean = torch.zeros(B, N, 9, device=dev), torch.zeros(B, N, N, 2, device=dev)
+        st.cond_x = st.cond_edge_x = None
+        return st
+
+    @torch.no_grad()
+    def advance(self, st, n_steps=None):
+        """Run the next ``n_steps`` denoise steps of the pass (all remaining ones by default); True when it is complete."""
+        eng, L, ws = st.eng, st.L, st.ws
+        dev = eng.device
+        B, N = L.B, L.N
         temp = float(self.sampling_temperature)
-        for i in range(len(coef)):
-            c_x, c_pred, sigma, _ = coef[i]
-            noise_level.copy_(nl_dev[i].expand(B))
+        end = len(st.coef) if n_steps is None else min(len(st.coef), st.i + int(n_steps))
+        for i in range(st.i, end):
+            c_x, c_pred, sigma, _ = st.coef[i]
             cur = i & 1
-            eng.forward(L, ws, x, edge_x, noise_level, cond_x, cond_edge_x, ctx, pred[cur], edge_pred[cur])
-            cond_x, cond_edge_x = pred[cur], edge_pred[cur]
+            eng.forward(L, ws, st.x, st.edge_x, st.nl_rows[i], st.cond_x, st.cond_edge_x, st.ctx, st.pred[cur], st.edge_pred[cur])
+            st.cond_x, st.cond_edge_x = st.pred[cur], st.edge_pred[cur]
             if self.cond_process_fn is not None:                   # sampling.py:590 ('ori' identity, 'clamp' in place)
-                cond_x, cond_edge_x = self.cond_process_fn(cond_x, cond_edge_x)
+                st.cond_x, st.cond_edge_x = self.cond_process_fn(st.cond_x, st.cond_edge_x)
             if self.noise_fn is not None:
                 raw = [r.to(dev, torch.float32).contiguous() for r in self.noise_fn(i)]
             else:                                                  # reference draw order/shapes (models/utils.py:69,78,102)
                 raw = [torch.randn((B, N, 3), device=dev), torch.randn((B, N, 6), device=dev),
                        torch.randn((B, 2, N, N), device=dev)]
-            eng.sampler_step(L, c_x, c_pred, sigma, temp, x, edge_x, pred[cur], edge_pred[cur], raw[0], raw[1], raw[2],
-                             x_mean, edge_mean)
+            eng.sampler_step(L, c_x, c_pred, sigma, temp, st.x, st.edge_x, st.pred[cur], st.edge_pred[cur], raw[0], raw[1],
+                             raw[2], st.x_mean, st.edge_mean)
             if self.progress_fn is not None and (i + 1) % 100 == 0:
-                self.progress_fn(i + 1, len(coef))
-        return x_mean, edge_mean
+                self.progress_fn(i + 1, len(st.coef))
+        st.i = end
+        return end >= len(st.coef)
+
+    @torch.no_grad()
+    def sampling(self, model, z_T, node_mask, edge_mask, edge_z_T=None, context=None):
+        st = self.begin(model, z_T, node_mask, edge_mask, edge_z_T, context)
+        self.advance(st)
+        return st.x_mean, st.edge_mean
+
+
+class _Pass:
+    """Mutable state of one in-flight sampling pass (``AncestralSampler.begin`` / ``advance``)."""
+    __slots__ = ("eng", "L", "ws", "i", "x", "edge_x", "ctx", "coef", "nl_rows", "pred", "edge_pred", "x_mean", "edge_mean",
+                 "cond_x", "cond_edge_x")
 
 
 def post_process(xh, atom_types, include_charge, node_mask, inverse_scaler, edge_x=None, edge_mask=None,

@@ -199,7 +199,9 @@ def main():
                                                    continuous_beta_1=cfg.sde.continuous_beta_1), 1e-3,
                               cfg.eval.sampling_temperature)
     inv = get_data_inverse_scaler(cfg)
-    torch.manual_seed(42 + rank)
+    # noise: the product's per-molecule Philox streams keyed on (seed 42, global molecule id) - generated inside the fused
+    # update kernel, identical molecules for any number of ranks
+    mol_ids = torch.arange(rank * M, (rank + 1) * M, dtype=torch.int64, device=device)
     spp = max(1, min(args.steps_per_pass, args.denoise_steps))
     slice_len = -(-args.denoise_steps // spp)          # denoise iterations per bench step
 
@@ -212,16 +214,16 @@ def main():
 
         def step(self):
             if self.st is None:
-                z, edge_z = S.initial_noise(M, max_n, 6, 2, node_mask, edge_mask)
-                self.st = sampler.begin(model, z, node_mask, edge_mask, edge_z, None if args.unconditional else context)
+                self.st = sampler.begin(model, None, node_mask, edge_mask, None, None if args.unconditional else context,
+                                        mol_ids=mol_ids, seed=42)
             before = self.st.i
             done = sampler.advance(self.st, slice_len)
             self.iters += self.st.i - before
             if done:
                 pos, one_hot, fc, edge_types = S.post_process(self.st.x_mean, 5, True, node_mask, inv, self.st.edge_mean,
                                                               edge_mask, True, engine=eng)
-                rec = shard.pack_records(pos, one_hot.argmax(-1), fc, edge_types)   # fixed-size record per molecule
-                self.rec = shard.gather_records(rec)                               # final gather over xGMI
+                rec = shard.pack_records_u8(pos, one_hot.argmax(-1), fc, edge_types)   # 1 248-byte record per molecule
+                self.rec = shard.gather_records(rec)                                  # final gather over xGMI
                 self.st = None
                 self.passes += 1
 
@@ -271,8 +273,9 @@ def main():
     # the timed work must be the real computation: check invariants the reference guarantees on its outputs
     if run.rec is not None:
         rec = run.rec
-        assert torch.isfinite(rec).all()
-        pos_o, atom_o, _, et_o = shard.unpack_records(rec[rank * M:(rank + 1) * M], max_n)
+        pos_o, atom_o, _, et_o = shard.unpack_records_u8(rec[rank * M:(rank + 1) * M])
+        pos_o, atom_o, et_o = pos_o[:, :max_n], atom_o[:, :max_n], et_o[:, :max_n, :max_n]
+        assert torch.isfinite(pos_o).all()
         nm = node_mask.squeeze(-1)
         assert float((pos_o * nm.unsqueeze(-1)).sum(1).abs().max()) < 1e-3, "generated positions are not zero-CoM"
         assert float((pos_o * (1 - nm).unsqueeze(-1)).abs().max()) == 0.0, "padded atoms carry positions"

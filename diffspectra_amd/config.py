@@ -38,7 +38,7 @@ def qm9s_config(spectra_version: str = "allspectra", device="cpu", steps: int = 
         pretrained_specformer_path="", patch_len=[20, 50, 50], stride=[10, 25, 25],
     )
     sde = Config(schedule="cosine", continuous_beta_0=0.1, continuous_beta_1=20.0)
-    sampling = Config(method="ancestral", steps=steps)
+    sampling = Config(method="ancestral", steps=steps, noise_source="philox", seed=42)
     evaluate = Config(batch_size=batch_size, num_samples=num_samples, sampling_temperature=1.0, enable_sampling=True,
                       begin_ckpt=40, end_ckpt=40, ckpts="")
     return Config(

@@ -773,8 +773,12 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
 // 0-7 (two per SIMD, priority 0) run the MFMA chain on tile i, each owning 32 of the 256 hidden features.  One barrier
 // per tile.  Measured (tools/micro/): a wave that alternates gather and MFMA phases loses its memory issue
 // slots to a co-resident MFMA stream, and VALU work next to that stream issues about six times slower than alone, so the
-// roles are split, the loaders' four gather batches are software-pipelined behind their LayerNorm arithmetic, and one
-// MFMA wave's SiLU epilogue overlaps the other's MFMAs on the same SIMD.
+// roles are split and one MFMA wave's SiLU epilogue overlaps the other's MFMAs on the same SIMD.  Round-2 measurements
+// (profiles/r02_equi_roles.md): with the loaders idle the kernel takes 1.36 ms per launch (4096 molecules; the MFMA
+// pipes are then 92 % busy), with the consumers idle 0.45 ms, together 1.57 ms - the loaders' ~950 instructions per tile
+// issue ~4x slower beside two MFMA waves per SIMD whatever the priorities, and the consumers wait ~11 % at the barrier.
+// Hence the loaders' diet: the HBM-latency stream (`ed` rows) goes by LDS-DMA into the X rows, the LayerNorm runs four rows
+// per pass (one per DPP row), the ac / adaLN gathers of the next pass fly behind the current pass's arithmetic.
 __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
   constexpr int T = 64, TP = 32, LD = 256 + DS_LDP, NC = 8;
   __shared__ __attribute__((aligned(16))) float X[2][T][LD];         // 133,120 B
@@ -786,6 +790,7 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
   const float* adq = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EQUI;
   const bool consumer = wave < NC;
   const float cscale = BW(c, blk, DS_BW_COORD_SCALE)[0];
+  DS_STAMP_INIT();
 
   float b0f[16], w2f[16];   // consumer constants: coord_mlp.0 bias and coord_mlp.2 A-fragments of its 32 features
   if (consumer) {
@@ -828,54 +833,89 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
       pr = reinterpret_cast<const float4*>(c.ws.pos)[dir ? bv_n : av_n];   // row atom (edge_index[0])
       pc = reinterpret_cast<const float4*>(c.ws.pos)[dir ? av_n : bv_n];
     }
-    float4 Aa[2][2], Ca[2][2], Ab[2][2], Cb[2][2], ve[2][2], sh[2][2], sc[2][2];
-    auto load = [&](int bt) {
-      __builtin_amdgcn_sched_barrier(0);
+    // Four tile rows per pass (both directions of two pairs), one row per 16-lane DPP row, lane j of it holding the float4s at
+    // columns 4j + 64u: the LayerNorm sums are four DPP steps with every lane busy - ~15 VALU issues per row against ~55
+    // for the row-per-wave form.  VALU issue slots are what a loader is short of next to two MFMA waves per SIMD
+    // (tools/micro/ln_corun.hip: ~27 cycles per VALU instruction there); halving the gather instructions instead (ac / adaLN
+    // rows carried over in registers) was measured and changed nothing.
+    const int g = lane >> 4, j = lane & 15, up = g >> 1, gdir = g & 1;
+    const float4* ac4 = reinterpret_cast<const float4*>(c.ws.ac);
+    const float4* ed4 = reinterpret_cast<const float4*>(c.ws.ed);
+    // The pair rows `ed` are the one HBM-latency stream of the kernel (written by k_edge_update just before, 0.66 GB per
+    // launch): stamps showed the loaders parked on them for ~47 % of their time with one pass of register gathers in flight.
+    // They now travel by LDS-DMA straight into the X row they are consumed from (row 2q; both directions read it before
+    // either overwrites it), all eight rows of the wave's pairs requested up front: no registers, one exposed latency per tile.
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int i = bt * 2 + u, s = bt & 1;
-        const float4* ra = reinterpret_cast<const float4*>(c.ws.ac + (size_t)na[i] * 512);
-        const float4* rb = reinterpret_cast<const float4*>(c.ws.ac + (size_t)nb[i] * 512);
-        Aa[s][u] = ra[lane]; Ca[s][u] = ra[64 + lane]; Ab[s][u] = rb[lane]; Cb[s][u] = rb[64 + lane];
-        ve[s][u] = reinterpret_cast<const float4*>(c.ws.ed + (size_t)pp[i] * 256)[lane];
-        sh[s][u] = reinterpret_cast<const float4*>(adq + (size_t)pm[i] * ADAC)[lane];          // shift (dmt.py:44)
-        sc[s][u] = reinterpret_cast<const float4*>(adq + (size_t)pm[i] * ADAC + 256)[lane];    // scale
-      }
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ed4 + (size_t)pp[i] * 64 + lane),
+                                       (__attribute__((address_space(3))) void*)&X[buf][2 * (lw + 4 * i)][0], 16, 0, 0);
+    float4 A[4], Cc[4], sh[4], sc[4];
+    int cur_m = -1;
+    auto issue = [&](int bt) {   // gathers of pass bt: rows of pairs 2bt (DPP rows 0, 1) and 2bt + 1 (DPP rows 2, 3)
+      __builtin_amdgcn_sched_barrier(0);
+      const int i0 = 2 * bt, i1 = 2 * bt + 1;
+      const int ra = up ? na[i1] : na[i0], rb = up ? nb[i1] : nb[i0];
+      const float4* pa = ac4 + (size_t)(gdir ? rb : ra) * 128 + j;          // row atom (edge_index[0]): input_lin h_row part
+      const float4* pcol = ac4 + (size_t)(gdir ? ra : rb) * 128 + 64 + j;   // column atom: h_col part
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { A[u] = pa[16 * u]; Cc[u] = pcol[16 * u]; }
       __builtin_amdgcn_sched_barrier(0);
     };
-    auto process = [&](int bt) {
+    auto modulation = [&](int bt) {   // adaLN rows of pass bt's molecule; they change once per ~160 pairs
+      const int m = up ? pm[2 * bt + 1] : pm[2 * bt];
+      if (m != cur_m) {
+        const float4* ps = reinterpret_cast<const float4*>(adq + (size_t)m * ADAC) + j;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int s = bt & 1, q = lw + (bt * 2 + u) * 4;
-        float4 x1, x2;   // row a -> b: input_lin([h_a, h_b, e, d]);  row b -> a: input_lin([h_b, h_a, e, d])  (dmt.py:39,45)
-        x1.x = (Aa[s][u].x + Cb[s][u].x) + ve[s][u].x; x1.y = (Aa[s][u].y + Cb[s][u].y) + ve[s][u].y;
-        x1.z = (Aa[s][u].z + Cb[s][u].z) + ve[s][u].z; x1.w = (Aa[s][u].w + Cb[s][u].w) + ve[s][u].w;
-        x2.x = (Ab[s][u].x + Ca[s][u].x) + ve[s][u].x; x2.y = (Ab[s][u].y + Ca[s][u].y) + ve[s][u].y;
-        x2.z = (Ab[s][u].z + Ca[s][u].z) + ve[s][u].z; x2.w = (Ab[s][u].w + Ca[s][u].w) + ve[s][u].w;
-        x1 = ln_mod_reg256(x1, sh[s][u], sc[s][u]);
-        x2 = ln_mod_reg256(x2, sh[s][u], sc[s][u]);
-        if (q >= npairs) x1 = x2 = make_float4(0, 0, 0, 0);
-        reinterpret_cast<float4*>(&X[buf][2 * q][0])[lane] = x1;
-        reinterpret_cast<float4*>(&X[buf][2 * q + 1][0])[lane] = x2;
+        for (int u = 0; u < 4; ++u) { sh[u] = ps[16 * u]; sc[u] = ps[64 + 16 * u]; }   // shift, scale (dmt.py:44)
+        cur_m = m;
       }
     };
-    load(0);
-    load(1);
+    issue(0);
+    modulation(0);
     if (tile_after < ntiles) fetch_idx(tile_after);
     __builtin_amdgcn_sched_barrier(0);
     if (lane < 16) {   // unit vector of pos[row] - pos[col], scaled (layers.py:345-346), + adjacency bits, for the tail
       const float dx = pr.x - pc.x, dy = pr.y - pc.y, dz = pr.z - pc.z;
-      const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);
+      const float nrm = fmaxf(__builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);
+      const float sn = cscale * __builtin_amdgcn_rcpf(nrm);   // hardware sqrt / rcp (1 ulp): loader VALU issues are the scarce resource
       float4 d;
-      d.x = dx / nrm * cscale; d.y = dy / nrm * cscale; d.z = dz / nrm * cscale; d.w = __int_as_float(bits);
+      d.x = dx * sn; d.y = dy * sn; d.z = dz * sn; d.w = __int_as_float(bits);
       reinterpret_cast<float4*>(&dirs[gen][2 * qd + dir][0])[0] = d;
     }
-    process(0);
-    load(2);
-    process(1);
-    load(3);
-    process(2);
-    process(3);
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) {
+      if (bt == 0) {   // the DMA'd rows must have landed before they are read back (and nothing may be hoisted above this)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      DS_STAMP_W(8 + bt);
+      const int q = lw + (2 * bt + up) * 4;
+      float4 x[4];   // a -> b: input_lin([h_a, h_b, e, d]);  b -> a: input_lin([h_b, h_a, e, d])  (dmt.py:39,45)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 e = reinterpret_cast<const float4*>(&X[buf][2 * q][0])[16 * u + j];
+        x[u].x = (A[u].x + Cc[u].x) + e.x; x[u].y = (A[u].y + Cc[u].y) + e.y;
+        x[u].z = (A[u].z + Cc[u].z) + e.z; x[u].w = (A[u].w + Cc[u].w) + e.w;
+      }
+      DS_STAMP(12);
+      if (bt < 3) issue(bt + 1);   // next pass's gathers fly behind this pass's LayerNorm
+      DS_STAMP(13);
+      ln_mod_quad256(x, sh, sc);
+      float* xr = &X[buf][2 * q + gdir][0];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) reinterpret_cast<float4*>(xr)[16 * u + j] = x[u];
+      if (bt < 3) modulation(bt + 1);
+      DS_STAMP(14);
+    }
+    if (npairs < TP) {   // last tile only: rows of the pairs past the end (they were computed from pair 0) become zero rows
+      for (int i = 0; i < 8; ++i) {
+        const int qz = lw + 4 * i;
+        if (qz >= npairs) {
+          reinterpret_cast<float4*>(&X[buf][2 * qz][0])[lane] = make_float4(0, 0, 0, 0);
+          reinterpret_cast<float4*>(&X[buf][2 * qz + 1][0])[lane] = make_float4(0, 0, 0, 0);
+        }
+      }
+    }
   };
 
   // first loader wave: tail of a finished tile, one lane per directed edge (row 2q+dir of the tile)
@@ -883,17 +923,16 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
     const int p0 = tile * TP;
     const int npairs = min(TP, Pp - p0);
     if ((lane >> 1) < npairs) {
-      float inv[3];
+      float4 sacc = reinterpret_cast<const float4*>(&part[pb][0][lane][0])[0];
 #pragma unroll
-      for (int hI = 0; hI < 3; ++hI) {
-        float sacc = part[pb][0][lane][hI];
-#pragma unroll
-        for (int w = 1; w < NC; ++w) sacc += part[pb][w][lane][hI];
-        inv[hI] = tanhf(sacc);
+      for (int w = 1; w < NC; ++w) {   // the eight consumers' partial sums, in wave order
+        const float4 pw = reinterpret_cast<const float4*>(&part[pb][w][lane][0])[0];
+        sacc.x += pw.x; sacc.y += pw.y; sacc.z += pw.z;
       }
+      const float inv[3] = {ds_tanh(sacc.x), ds_tanh(sacc.y), ds_tanh(sacc.z)};
       const float4 d = reinterpret_cast<const float4*>(&dirs[gen][lane][0])[0];
       const int bits = __float_as_int(d.w);
-      const float w = ((inv[0] + ((bits & 1) ? inv[1] : 0.0f)) + ((bits & 2) ? inv[2] : 0.0f)) / 3.0f;   // dmt.py:51-53
+      const float w = ((inv[0] + ((bits & 1) ? inv[1] : 0.0f)) + ((bits & 2) ? inv[2] : 0.0f)) * (1.0f / 3.0f);   // dmt.py:51-53
       float4 t;
       t.x = d.x * w; t.y = d.y * w; t.z = d.z * w; t.w = 0.0f;
       reinterpret_cast<float4*>(c.ws.tr)[(size_t)p0 * 2 + lane] = t;   // coord_diff * inv (dmt.py:56)
@@ -904,7 +943,6 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
   // role's registers stay live through the other's code.
   const int first = blockIdx.x, stride = gridDim.x;
   if (first >= ntiles) return;
-  DS_STAMP_INIT();
   if (consumer) {
     __syncthreads();
     DS_STAMP(0);
@@ -1235,6 +1273,101 @@ __global__ __launch_bounds__(256) void k_sampler_step(ds_layout L, float c_x, fl
     const float em = c_x * edge_x[o] + c_pred * edge_pred[o];
     edge_mean[o] = em;
     edge_x[o] = em + (sigma * nz) * temp;
+  }
+}
+
+// ---- in-kernel noise: Philox4x32-10 (Salmon et al., SC'11; the generator torch/curand use) + Box-Muller ----
+struct Philox4 { unsigned int x, y, z, w; };
+__device__ __forceinline__ Philox4 philox4x32_10(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3,
+                                                 unsigned int k0, unsigned int k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned int hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned int hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const unsigned int n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox4{c0, c1, c2, c3};
+}
+// u = (x + 0.5) / 2^32 in (0, 1]; (z0, z1) = sqrt(-2 ln u0) * (cos, sin)(2 pi u1)
+__device__ __forceinline__ float2 box_muller(unsigned int a, unsigned int b) {
+  const float u0 = __fmaf_rn((float)a, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+  const float u1 = __fmaf_rn((float)b, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+  const float r = sqrtf(-2.0f * logf(u0));
+  const float th = 6.283185307179586f * u1;
+  return make_float2(r * cosf(th), r * sinf(th));
+}
+__device__ __forceinline__ float4 philox_normal4(unsigned int elem, unsigned int draw, unsigned long long mol, unsigned int kind,
+                                                 unsigned long long seed) {
+  // counter words: (element, draw, mol_id low 32 bits, kind | mol_id high bits << 1)
+  const Philox4 p = philox4x32_10(elem, draw, (unsigned int)mol, kind | ((unsigned int)(mol >> 32) << 1),
+                                  (unsigned int)seed, (unsigned int)(seed >> 32));
+  const float2 a = box_muller(p.x, p.y), b = box_muller(p.z, p.w);
+  return make_float4(a.x, a.y, b.x, b.y);
+}
+
+// One workgroup per molecule.  MODE 0: initial noise (x, edge_x := noise; masked entries were zeroed by the caller's
+// memset).  MODE 1: ancestral update with in-kernel noise (the Philox twin of k_sampler_step).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_noise_step(ds_layout L, float c_x, float c_pred, float sigma, float temp,
+                                                    unsigned long long seed, unsigned int draw, const int64_t* __restrict__ mol_id,
+                                                    float* __restrict__ x, float* __restrict__ edge_x,
+                                                    const float* __restrict__ pred, const float* __restrict__ edge_pred,
+                                                    float* __restrict__ x_mean, float* __restrict__ edge_mean) {
+  __shared__ __attribute__((aligned(16))) float nz[32][12];
+  __shared__ float mean[3];
+  __shared__ int dn[32];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0;
+  if (n <= 0) return;
+  const unsigned long long mol = (unsigned long long)mol_id[m];
+  if (tid < n) dn[tid] = L.node_dense[n0 + tid];
+  if (tid < n * 3) {
+    const int a = tid / 3, j = tid - a * 3;
+    const float4 v = philox_normal4((unsigned int)tid, draw, mol, 0u, seed);
+    reinterpret_cast<float4*>(&nz[a][4 * j])[0] = v;
+  }
+  __syncthreads();
+  if (tid < 3) {   // CoM projection of the position noise (models/utils.py:38-45,88-93), atoms in ascending order
+    float s = 0.0f;
+    for (int a = 0; a < n; ++a) s += nz[a][tid];
+    mean[tid] = s / (float)n;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n * 9; idx += 256) {
+    const int a = idx / 9, ch = idx - a * 9;
+    const size_t d = (size_t)dn[a];
+    const float v = ch < 3 ? nz[a][ch] - mean[ch] : nz[a][ch];
+    if (MODE == 0) {
+      x[d * 9 + ch] = v;
+    } else {
+      const float xm = c_x * x[d * 9 + ch] + c_pred * pred[d * 9 + ch];
+      x_mean[d * 9 + ch] = xm;
+      x[d * 9 + ch] = xm + (sigma * v) * temp;
+    }
+  }
+  const int N = L.N, P = n * (n - 1) / 2;
+  for (int p = tid; p < P; p += 256) {   // unordered pair lo < hi: p = hi(hi-1)/2 + lo, independent of n and of padding
+    int hi = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+    while (hi * (hi - 1) / 2 > p) --hi;
+    while ((hi + 1) * hi / 2 <= p) ++hi;
+    const int lo = p - hi * (hi - 1) / 2;
+    const float4 v = philox_normal4((unsigned int)p, draw, mol, 1u, seed);
+    const int la = dn[lo] - m * N, lb = dn[hi] - m * N;
+    const size_t o1 = ((size_t)dn[lo] * N + lb) * 2, o2 = ((size_t)dn[hi] * N + la) * 2;
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const float nzv = ch ? v.y : v.x;
+      if (MODE == 0) {
+        edge_x[o1 + ch] = nzv; edge_x[o2 + ch] = nzv;
+      } else {
+        const float em1 = c_x * edge_x[o1 + ch] + c_pred * edge_pred[o1 + ch];
+        const float em2 = c_x * edge_x[o2 + ch] + c_pred * edge_pred[o2 + ch];
+        edge_mean[o1 + ch] = em1; edge_mean[o2 + ch] = em2;
+        edge_x[o1 + ch] = em1 + (sigma * nzv) * temp; edge_x[o2 + ch] = em2 + (sigma * nzv) * temp;
+      }
+    }
   }
 }
 
@@ -1595,14 +1728,38 @@ int ds_sampler_step(const ds_layout* L, float c_x, float c_pred, float sigma, fl
                      const float* pred, const float* edge_pred, const float* raw_pos, const float* raw_feat,
                      const float* raw_edge, float* x_mean, float* edge_mean, void* stream) {
   if (!L || !x || !edge_x || !pred || !edge_pred || !raw_pos || !raw_feat || !raw_edge || !x_mean || !edge_mean) return DS_ERR_ARG;
+  if (L->B <= 0 || L->max_n > DS_MAX_ATOMS || L->max_n > L->N) return DS_ERR_ARG;   // k_sampler_step stages <= 32 node indices in LDS
   hipLaunchKernelGGL(k_sampler_step, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, c_x, c_pred, sigma, temperature, x,
                      edge_x, pred, edge_pred, raw_pos, raw_feat, raw_edge, x_mean, edge_mean);
+  return launch_status();
+}
+
+int ds_initial_noise(const ds_layout* L, uint64_t seed, const int64_t* mol_id, float* x, float* edge_x, void* stream) {
+  if (!L || !mol_id || !x || !edge_x) return DS_ERR_ARG;
+  if (L->B <= 0 || L->max_n > DS_MAX_ATOMS || L->max_n > L->N) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t nb = (size_t)L->B * L->N;
+  if (hipMemsetAsync(x, 0, nb * 9 * sizeof(float), s) != hipSuccess) return DS_ERR_LAUNCH;
+  if (hipMemsetAsync(edge_x, 0, nb * L->N * 2 * sizeof(float), s) != hipSuccess) return DS_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_noise_step<0>, dim3(L->B), dim3(256), 0, s, *L, 0.0f, 0.0f, 0.0f, 0.0f, (unsigned long long)seed, 0u, mol_id,
+                     x, edge_x, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+  return launch_status();
+}
+
+int ds_sampler_step_philox(const ds_layout* L, float c_x, float c_pred, float sigma, float temperature, uint64_t seed, int32_t step,
+                           const int64_t* mol_id, float* x, float* edge_x, const float* pred, const float* edge_pred,
+                           float* x_mean, float* edge_mean, void* stream) {
+  if (!L || !mol_id || !x || !edge_x || !pred || !edge_pred || !x_mean || !edge_mean || step < 0) return DS_ERR_ARG;
+  if (L->B <= 0 || L->max_n > DS_MAX_ATOMS || L->max_n > L->N) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_noise_step<1>, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, c_x, c_pred, sigma, temperature,
+                     (unsigned long long)seed, (unsigned int)step + 1u, mol_id, x, edge_x, pred, edge_pred, x_mean, edge_mean);
   return launch_status();
 }
 
 int ds_post_process(const ds_layout* L, const float* xh, const float* edge_x, float* pos_out, int32_t* atom_type, int32_t* fc,
                     float* edge_type, void* stream) {
   if (!L || !xh || !edge_x || !pos_out || !atom_type || !fc || !edge_type) return DS_ERR_ARG;
+  if (L->B <= 0 || L->max_n > DS_MAX_ATOMS || L->max_n > L->N) return DS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const size_t nb = (size_t)L->B * L->N;
   if (hipMemsetAsync(pos_out, 0, nb * 3 * sizeof(float), s) != hipSuccess) return DS_ERR_LAUNCH;

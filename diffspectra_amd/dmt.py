@@ -67,12 +67,27 @@ class DMT(nn.Module):
         return matched
 
     def _weights_key(self):
-        dev = next(self.parameters()).device
-        return (str(dev), sum(int(p._version) for p in self.parameters()) + sum(int(b._version) for b in self.buffers()),
-                tuple(p.data_ptr() for p in list(self.parameters())[:4]))
+        """Fingerprint of the current weights: device + the 1- and 2-norm of every floating-point parameter and buffer.
+
+        ``Tensor._version`` is not enough: both EMA implementations write with ``p.data.copy_(...)`` (reference
+        models/ema.py:55,77), which leaves the version counter untouched.  Two fused multi-tensor reductions and one
+        small device->host copy per ``engine()`` call (once per sampling pass / per drop-in ``forward``)."""
+        ts = [t.detach() for t in list(self.parameters()) + list(self.buffers()) if t.is_floating_point()]
+        dev = ts[0].device
+        if dev.type != "cuda":
+            return (str(dev),)
+        with torch.no_grad():
+            fp = torch.stack(torch._foreach_norm(ts, 1) + torch._foreach_norm(ts, 2)).double().cpu()
+        return (str(dev), tuple(t.data_ptr() for t in ts[:4]), fp.numpy().tobytes())
+
+    def invalidate_engine(self):
+        """Drop the packed weights; the next call re-packs from the current parameters."""
+        self._engine = None
+        self._engine_key = None
 
     def engine(self):
-        """Packed-weight HIP engine for the current parameters (re-packed when they change, e.g. ``ema.copy_to``)."""
+        """Packed-weight HIP engine for the current parameters (re-packed whenever their values change: ``load_state_dict``,
+        ``ema.copy_to`` / ``ema.restore``, in-place edits)."""
         from .engine import DmtEngine
         dev = next(self.parameters()).device
         if dev.type != "cuda":
@@ -91,6 +106,11 @@ class DMT(nn.Module):
         noise_level = kwargs["noise_level"]
         eng = self.engine()
         L, ws = eng.layout_for(node_mask, edge_mask, validate=True)
+        # the kernels keep edge features once per unordered pair (the sampler's edge tensors are symmetric by
+        # construction, models/utils.py:100-106); the reference reads both directed entries, so refuse anything else
+        L.check_edge_symmetry(edge_x, "edge_x")
+        if cond_edge_x is not None:
+            L.check_edge_symmetry(cond_edge_x, "cond_edge_x")
         if context is None:
             # reference: `time_mlp(noise_level) + None` raises TypeError (dmt.py:354); keep that behaviour explicit
             raise TypeError("DMT.forward needs `context` (spectra); pass context_emb to the engine for a zero context")

@@ -306,6 +306,16 @@ class Layout:
             raise ValueError("edge_mask is not node_mask ⊗ node_mask minus the diagonal; unsupported graph structure")
 
 
+    def check_edge_symmetry(self, edge: torch.Tensor, name: str = "edge_x"):
+        """The pair layout stores one value per unordered pair: ``edge[b,i,j,:] == edge[b,j,i,:]`` must hold on valid pairs."""
+        e = edge.detach().reshape(self.B, self.N, self.N, -1)
+        v = torch.from_numpy(self.valid).to(e.device)
+        m = (v.unsqueeze(1) & v.unsqueeze(2)).unsqueeze(-1)
+        if bool(((e != e.transpose(1, 2)) & m).any()):
+            raise ValueError(f"{name} is not symmetric in its two atom indices; the MI355X path stores edge features per "
+                             "unordered pair and does not support directed edge inputs")
+
+
 class Workspace:
     def __init__(self, L: Layout, device):
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
@@ -403,6 +413,22 @@ class DmtEngine:
                                       _ptr(raw_pos), _ptr(raw_feat), _ptr(raw_edge), _ptr(x_mean), _ptr(edge_mean),
                                       _stream())
         _check(st, "ds_sampler_step")
+
+    def initial_noise_philox(self, L, seed: int, mol_id: torch.Tensor):
+        """z_T, edge_z_T of sampling.py:442-447 from the per-molecule Philox streams (``ds_initial_noise``)."""
+        dev = self.device
+        x = torch.empty(L.B, L.N, 9, dtype=torch.float32, device=dev)
+        edge_x = torch.empty(L.B, L.N, L.N, 2, dtype=torch.float32, device=dev)
+        _check(self.lib.ds_initial_noise(C.byref(L.c), C.c_uint64(seed), _ptr(mol_id), _ptr(x), _ptr(edge_x), _stream()),
+               "ds_initial_noise")
+        return x, edge_x
+
+    def sampler_step_philox(self, L, c_x, c_pred, sigma, temperature, seed: int, step: int, mol_id, x, edge_x, pred, edge_pred,
+                            x_mean, edge_mean):
+        st = self.lib.ds_sampler_step_philox(C.byref(L.c), C.c_float(c_x), C.c_float(c_pred), C.c_float(sigma),
+                                             C.c_float(temperature), C.c_uint64(seed), C.c_int32(step), _ptr(mol_id), _ptr(x),
+                                             _ptr(edge_x), _ptr(pred), _ptr(edge_pred), _ptr(x_mean), _ptr(edge_mean), _stream())
+        _check(st, "ds_sampler_step_philox")
 
     def post_process(self, L, xh, edge_x):
         dev = self.device

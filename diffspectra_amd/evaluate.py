@@ -23,43 +23,33 @@ from .scalers import get_data_inverse_scaler
 
 
 class ExponentialMovingAverage:
-    """Shadow copy of the trainable parameters, state layout identical to reference ``models/ema.py``."""
+    """Inference-side holder of a checkpoint's EMA weights.
 
-    def __init__(self, parameters: Iterable[torch.nn.Parameter], decay: float, use_num_updates: bool = True):
+    Only what evaluation needs of reference ``models/ema.py``: the checkpoint state layout (``decay``, ``num_updates``,
+    ``shadow_params`` = list in ``parameters()`` order of the trainable tensors, ``ema.py:79-85``) and ``copy_to``
+    (``ema.py:44-55``).  The training-side half (``update`` / ``store`` / ``restore``) belongs to the training step
+     and is not part of this path."""
+
+    def __init__(self, parameters: Iterable[torch.nn.Parameter], decay: float):
         if not 0.0 <= decay <= 1.0:
             raise ValueError("Decay must be between 0 and 1")
-        self.decay = decay
-        self.num_updates = 0 if use_num_updates else None
-        self.shadow_params = [p.clone().detach() for p in parameters if p.requires_grad]
-        self.collected_params = []
-
-    def update(self, parameters):
-        decay = self.decay
-        if self.num_updates is not None:
-            self.num_updates += 1
-            decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
-        with torch.no_grad():
-            for s, p in zip(self.shadow_params, [p for p in parameters if p.requires_grad]):
-                s.sub_((1.0 - decay) * (s - p))
-
-    def copy_to(self, parameters):
-        for s, p in zip(self.shadow_params, [p for p in parameters if p.requires_grad]):
-            p.data.copy_(s.data)
-
-    def store(self, parameters):
-        self.collected_params = [p.clone() for p in parameters]
-
-    def restore(self, parameters):
-        for c, p in zip(self.collected_params, parameters):
-            p.data.copy_(c.data)
-
-    def state_dict(self):
-        return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)
+        self.decay, self.num_updates = decay, 0
+        self.shadow_params = [p.detach().clone() for p in parameters if p.requires_grad]
 
     def load_state_dict(self, state_dict):
-        self.decay = state_dict["decay"]
-        self.num_updates = state_dict["num_updates"]
+        self.decay, self.num_updates = state_dict["decay"], state_dict["num_updates"]
         self.shadow_params = state_dict["shadow_params"]
+
+    def state_dict(self):
+        return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": self.shadow_params}
+
+    @torch.no_grad()
+    def copy_to(self, parameters):
+        trainable = [p for p in parameters if p.requires_grad]
+        if len(trainable) != len(self.shadow_params):
+            raise ValueError(f"EMA holds {len(self.shadow_params)} tensors, the model has {len(trainable)} trainable ones")
+        for shadow, p in zip(self.shadow_params, trainable):
+            p.copy_(shadow.to(p.device))
 
 
 def restore_checkpoint(ckpt_path: str, state: Dict, device) -> Dict:

@@ -37,10 +37,12 @@ class SingleDeviceParallel(nn.Module):
 
 
 def get_model(name: str):
+    if name not in _MODELS:
+        from . import dmt  # noqa: F401  (the shipped model registers itself on import, as models/__init__.py does upstream)
     return _MODELS[name]
 
 
 def create_model(config):
-    model = _MODELS[config.model.name](config)
+    model = get_model(config.model.name)(config)
     model = model.to(config.device)
     return SingleDeviceParallel(model)

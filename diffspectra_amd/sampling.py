@@ -46,6 +46,7 @@ class AncestralSampler:
         self.sampling_temperature = sampling_temperature
         self.noise_fn: Optional[Callable] = None     # noise_fn(i) -> (raw_pos, raw_feat, raw_edge): injected randn draws
         self.progress_fn: Optional[Callable] = None  # progress_fn(i, n_steps), called every 100 steps (long runs)
+        self.philox_seed = 42                        # key of the per-molecule noise streams (begin(..., mol_ids=...))
         self._table = None
 
     def coefficient_table(self):
@@ -67,9 +68,13 @@ class AncestralSampler:
         return self._table
 
     @torch.no_grad()
-    def begin(self, model, z_T, node_mask, edge_mask, edge_z_T=None, context=None):
+    def begin(self, model, z_T, node_mask, edge_mask, edge_z_T=None, context=None, mol_ids=None, seed=None):
         """State of one sampling pass before its first denoise step: noisy tensors cloned onto the GPU, the (hoisted,
-        loop-invariant) spectra embedding, the per-step coefficient table.  ``advance`` runs denoise steps on it."""
+        loop-invariant) spectra embedding, the per-step coefficient table.  ``advance`` runs denoise steps on it.
+
+        ``mol_ids`` (int64 [B]) + ``seed`` select the in-kernel noise: every molecule then has its own Philox stream keyed
+        on (seed, mol_id), so its trajectory does not depend on the batch or rank it is sampled in.  ``z_T=None`` draws
+        the initial noise from the same streams."""
         m = _hip_model(model)
         eng = m.engine()
         dev = eng.device
@@ -77,8 +82,19 @@ class AncestralSampler:
         B, N = L.B, L.N
         st = _Pass()
         st.eng, st.L, st.ws, st.i = eng, L, ws, 0
-        st.x = z_T.detach().to(dev, torch.float32).contiguous().clone()
-        st.edge_x = edge_z_T.detach().to(dev, torch.float32).contiguous().clone()
+        st.mol_ids, st.seed = None, 0
+        if mol_ids is not None:
+            st.mol_ids = torch.as_tensor(mol_ids, dtype=torch.int64).to(dev).contiguous()
+            st.seed = int(self.philox_seed if seed is None else seed)
+            if st.mol_ids.numel() != B:
+                raise ValueError("mol_ids must hold one id per molecule of the batch")
+        if z_T is None:
+            if st.mol_ids is None:
+                raise ValueError("z_T=None needs mol_ids (in-kernel initial noise)")
+            st.x, st.edge_x = eng.initial_noise_philox(L, st.seed, st.mol_ids)
+        else:
+            st.x = z_T.detach().to(dev, torch.float32).contiguous().clone()
+            st.edge_x = edge_z_T.detach().to(dev, torch.float32).contiguous().clone()
         st.ctx = eng.context_embedding(context)                      # hoisted: loop-invariant
         tab = self.coefficient_table()
         st.coef = tab.tolist()
@@ -104,21 +120,25 @@ class AncestralSampler:
             st.cond_x, st.cond_edge_x = st.pred[cur], st.edge_pred[cur]
             if self.cond_process_fn is not None:                   # sampling.py:590 ('ori' identity, 'clamp' in place)
                 st.cond_x, st.cond_edge_x = self.cond_process_fn(st.cond_x, st.cond_edge_x)
-            if self.noise_fn is not None:
-                raw = [r.to(dev, torch.float32).contiguous() for r in self.noise_fn(i)]
-            else:                                                  # reference draw order/shapes (models/utils.py:69,78,102)
-                raw = [torch.randn((B, N, 3), device=dev), torch.randn((B, N, 6), device=dev),
-                       torch.randn((B, 2, N, N), device=dev)]
-            eng.sampler_step(L, c_x, c_pred, sigma, temp, st.x, st.edge_x, st.pred[cur], st.edge_pred[cur], raw[0], raw[1],
-                             raw[2], st.x_mean, st.edge_mean)
+            if st.mol_ids is not None and self.noise_fn is None:   # per-molecule Philox streams, generated in the kernel
+                eng.sampler_step_philox(L, c_x, c_pred, sigma, temp, st.seed, i, st.mol_ids, st.x, st.edge_x, st.pred[cur],
+                                        st.edge_pred[cur], st.x_mean, st.edge_mean)
+            else:
+                if self.noise_fn is not None:
+                    raw = [r.to(dev, torch.float32).contiguous() for r in self.noise_fn(i)]
+                else:                                              # reference draw order/shapes (models/utils.py:69,78,102)
+                    raw = [torch.randn((B, N, 3), device=dev), torch.randn((B, N, 6), device=dev),
+                           torch.randn((B, 2, N, N), device=dev)]
+                eng.sampler_step(L, c_x, c_pred, sigma, temp, st.x, st.edge_x, st.pred[cur], st.edge_pred[cur], raw[0], raw[1],
+                                 raw[2], st.x_mean, st.edge_mean)
             if self.progress_fn is not None and (i + 1) % 100 == 0:
                 self.progress_fn(i + 1, len(st.coef))
         st.i = end
         return end >= len(st.coef)
 
     @torch.no_grad()
-    def sampling(self, model, z_T, node_mask, edge_mask, edge_z_T=None, context=None):
-        st = self.begin(model, z_T, node_mask, edge_mask, edge_z_T, context)
+    def sampling(self, model, z_T, node_mask, edge_mask, edge_z_T=None, context=None, mol_ids=None, seed=None):
+        st = self.begin(model, z_T, node_mask, edge_mask, edge_z_T, context, mol_ids=mol_ids, seed=seed)
         self.advance(st)
         return st.x_mean, st.edge_mean
 
@@ -126,7 +146,7 @@ class AncestralSampler:
 class _Pass:
     """Mutable state of one in-flight sampling pass (``AncestralSampler.begin`` / ``advance``)."""
     __slots__ = ("eng", "L", "ws", "i", "x", "edge_x", "ctx", "coef", "nl_rows", "pred", "edge_pred", "x_mean", "edge_mean",
-                 "cond_x", "cond_edge_x")
+                 "cond_x", "cond_edge_x", "mol_ids", "seed")
 
 
 def post_process(xh, atom_types, include_charge, node_mask, inverse_scaler, edge_x=None, edge_mask=None,
@@ -191,60 +211,141 @@ def _make_sampler(config, noise_scheduler, eps, temperature):
                             get_self_cond_fn(config), sampling_temperature=temperature)
 
 
-def _sampling_fn_factory(config, sampler, batch_size, n_samples, inverse_scaler, ds, fixed_seed):
+def _assemble(ds, ids, version):
+    """Context, n_nodes, ground-truth positions / molecules of the dataset items ``ids`` (sampling.py:391-420)."""
+    if hasattr(ds, "batch"):                                   # PackedSpectraTable: resident in HBM, no per-item Python
+        return ds.batch(ids, version)
+    items = [ds[int(i)] for i in ids]
+    n_nodes = [int(it.num_atom.item()) if hasattr(it.num_atom, "item") else int(it.num_atom) for it in items]
+    stack = lambda name: torch.stack([getattr(it, name) for it in items])
+    context = [stack("uv"), stack("ir"), stack("raman")] if version == "allspectra" else stack(version)
+    return context, n_nodes, [it.pos for it in items], [getattr(it, "rdmol", None) for it in items]
+
+
+def _ground_truth(ds, ids):
+    """(gt_pos, gt_rdmols) of the dataset items ``ids`` without touching their spectra."""
+    idl = [int(i) for i in ids]
+    if hasattr(ds, "pos") and hasattr(ds, "rdmol") and isinstance(getattr(ds, "pos"), list):
+        return [ds.pos[i] for i in idl], [ds.rdmol[i] for i in idl]
+    items = [ds[i] for i in idl]
+    return [it.pos for it in items], [getattr(it, "rdmol", None) for it in items]
+
+
+def _num_atoms(ds, ids):
+    if hasattr(ds, "num_atom") and torch.is_tensor(getattr(ds, "num_atom")):
+        return ds.num_atom[torch.as_tensor(ids, dtype=torch.int64)].tolist()
+    out = []
+    for i in ids:
+        na = ds[int(i)].num_atom
+        out.append(int(na.item()) if hasattr(na, "item") else int(na))
+    return out
+
+
+def _sampling_fn_factory(config, sampler, batch_size, n_samples, inverse_scaler, ds, fixed_seed, top_k=1):
+    """``sampling_fn(model) -> (processed_mols, gt_pos, gt_rdmols)`` of sampling.py:378-468 in two noise modes
+    (``config.sampling.noise_source``):
+
+    ``'philox'`` (default): sample slot k (= k-th entry of the seed-42 permutation; with ``top_k`` = K every spectrum owns
+    K consecutive slots) has its own noise stream keyed on ``(config.sampling.seed, k)``.  Slots are dealt to the ranks of
+    the initialised process group by size (``shard.assign_slots``), sampled in n-bucketed micro-batches of ``batch_size``
+    with no collective in the loop, and the 1 248-byte result records are all-gathered once at the end (RCCL over xGMI),
+    so every rank returns the full lists, in slot order, and the molecules are the same for any number of ranks and any
+    batch size.
+    ``'torch'``: the reference's own draw order - ``torch.randn`` of the padded batch shapes on the model device, full
+    rounds of ``batch_size`` (sampling.py:442-447,611-612,623-624); single process; what the G11 golden replays."""
+    from . import shard
     atom_types = config.data.atom_types
     include_fc = config.model.include_fc_charge
     node_nf = atom_types + int(include_fc)
     edge_nf = config.model.edge_ch
     version = config.data.spectra_version
-    rounds = int(np.ceil(n_samples / batch_size))
+    noise_source = getattr(config.sampling, "noise_source", "philox")
+    if noise_source not in ("philox", "torch"):
+        raise ValueError("config.sampling.noise_source must be 'philox' or 'torch'")
+    if top_k < 1:
+        raise ValueError("top_k must be >= 1")
     if not hip_post_process_supported(config):
         raise ValueError("ds_post_process implements the shipped scaling configuration only")
+
+    def reference_order(model, eng, perm):
+        device = eng.device
+        processed, gt_pos, gt_mols = [], [], []
+        for r in range(int(np.ceil(n_samples * top_k / batch_size))):
+            ids = perm[r * batch_size:(r + 1) * batch_size]
+            context, n_nodes, pos_r, mols_r = _assemble(ds, ids, version)
+            gt_pos += pos_r
+            gt_mols += mols_r
+            bs = len(n_nodes)
+            node_mask, edge_mask = build_masks(n_nodes, bs, device)
+            max_n = node_mask.shape[1]
+            z, edge_z = initial_noise(bs, max_n, node_nf, edge_nf, node_mask, edge_mask)
+            x_node, x_edge = sampler.sampling(model, z, node_mask, edge_mask, edge_z, context)
+            pos, one_hot, fc, edge_types = post_process(x_node, atom_types, include_fc, node_mask, inverse_scaler,
+                                                        x_edge, edge_mask, config.data.compress_edge, engine=eng)
+            processed += mol_process(one_hot, pos, fc, n_nodes, edge_types)
+            print("Generate {}, Total {}.".format(len(processed), n_samples))
+        return processed[:n_samples * top_k], gt_pos[:n_samples * top_k], gt_mols[:n_samples * top_k]
+
+    def sharded(model, eng, perm):
+        device = eng.device
+        rank, world = shard.world_info()
+        slot_ds = perm[:n_samples].repeat_interleave(top_k)         # dataset item of every sample slot
+        n_slots = slot_ds.numel()
+        n_atoms = _num_atoms(ds, slot_ds.tolist())
+        mine = shard.assign_slots(n_atoms, rank, world)
+        seed = int(getattr(config.sampling, "seed", 42))
+        recs = []
+        for lo in range(0, mine.numel(), batch_size):
+            slots = mine[lo:lo + batch_size]
+            context, n_nodes, _, _ = _assemble(ds, slot_ds[slots], version)
+            bs = len(n_nodes)
+            node_mask, edge_mask = build_masks(n_nodes, bs, device)
+            x_node, x_edge = sampler.sampling(model, None, node_mask, edge_mask, None, context, mol_ids=slots, seed=seed)
+            pos, one_hot, fc, edge_types = post_process(x_node, atom_types, include_fc, node_mask, inverse_scaler,
+                                                        x_edge, edge_mask, config.data.compress_edge, engine=eng)
+            recs.append(shard.pack_records_u8(pos, one_hot.argmax(-1), fc, edge_types))
+        rec = torch.cat(recs) if recs else torch.zeros(0, shard.RECORD_BYTES, dtype=torch.uint8, device=device)
+        counts = [shard.assign_slots(n_atoms, r, world).numel() for r in range(world)]
+        allrec = shard.gather_records(rec, counts)                   # the only collective of the path
+        owner_order = torch.cat([shard.assign_slots(n_atoms, r, world) for r in range(world)])
+        by_slot = torch.empty_like(allrec)
+        by_slot[owner_order.to(allrec.device)] = allrec
+        pos, atom, fc, et = (t.cpu() for t in shard.unpack_records_u8(by_slot))     # ONE device->host copy per tensor
+        processed = []
+        for k in range(n_slots):
+            n = n_atoms[k]
+            processed.append((pos[k, :n].clone(), atom[k, :n].clone(), et[k, :n, :n].clone(), fc[k, :n].clone()))
+        gt_pos, gt_mols = _ground_truth(ds, slot_ds.tolist())
+        if rank == 0:
+            print("Generate {}, Total {}.".format(len(processed), n_samples * top_k))
+        return processed, gt_pos, gt_mols
 
     def sampling_fn(model):
         model.eval()
         eng = _hip_model(model).engine()
-        device = eng.device
-        processed, gt_pos, gt_mols = [], [], []
         with torch.no_grad():
             if fixed_seed:
                 torch.manual_seed(42)                              # sampling.py:387
             perm = torch.randperm(len(ds))
-            for r in range(rounds):
-                ids = perm[r * batch_size:(r + 1) * batch_size]
-                if hasattr(ds, "batch"):                           # PackedSpectraTable: resident in HBM, no per-item Python
-                    context, n_nodes, pos_r, mols_r = ds.batch(ids, version)
-                    gt_pos += pos_r
-                    gt_mols += mols_r
-                else:                                              # the reference's per-item assembly (sampling.py:391-420)
-                    items = [ds[int(i)] for i in ids]
-                    n_nodes = [int(it.num_atom.item()) if hasattr(it.num_atom, "item") else int(it.num_atom) for it in items]
-                    for it in items:
-                        gt_pos.append(it.pos)
-                        gt_mols.append(getattr(it, "rdmol", None))
-                    stack = lambda name: torch.stack([getattr(it, name) for it in items])
-                    if version == "allspectra":
-                        context = [stack("uv"), stack("ir"), stack("raman")]
-                    else:
-                        context = stack(version)
-                bs = len(n_nodes)
-                node_mask, edge_mask = build_masks(n_nodes, bs, device)
-                max_n = node_mask.shape[1]
-                z, edge_z = initial_noise(bs, max_n, node_nf, edge_nf, node_mask, edge_mask)
-                x_node, x_edge = sampler.sampling(model, z, node_mask, edge_mask, edge_z, context)
-                pos, one_hot, fc, edge_types = post_process(x_node, atom_types, include_fc, node_mask, inverse_scaler,
-                                                            x_edge, edge_mask, config.data.compress_edge, engine=eng)
-                processed += mol_process(one_hot, pos, fc, n_nodes, edge_types)
-                print("Generate {}, Total {}.".format(len(processed), n_samples))
-        return processed[:n_samples], gt_pos[:n_samples], gt_mols[:n_samples]
+            from .shard import world_info, broadcast_from_rank0
+            if not fixed_seed:
+                perm = broadcast_from_rank0(perm, eng.device)      # an unseeded permutation must still be ONE permutation
+            if noise_source == "torch":
+                if world_info()[1] != 1:
+                    raise RuntimeError("noise_source='torch' reproduces the reference's single-process draw order; "
+                                       "multi-rank sampling needs noise_source='philox'")
+                return reference_order(model, eng, perm)
+            return sharded(model, eng, perm)
 
     return sampling_fn
 
 
-def get_cond_sampling_eval_fn(config, noise_scheduler, batch_size, n_samples, inverse_scaler, test_ds, eps=1e-3):
-    """sampling.py:353-468 (fixed seed-42 permutation of the test set, eval temperature)."""
+def get_cond_sampling_eval_fn(config, noise_scheduler, batch_size, n_samples, inverse_scaler, test_ds, eps=1e-3, top_k=1):
+    """sampling.py:353-468 (fixed seed-42 permutation of the test set, eval temperature).  ``top_k`` = K draws K molecules
+    per test spectrum (the reference's Top-K accuracy protocol, assets/3_performance.png panel c) in the same batched run:
+    ``processed_mols[i*K:(i+1)*K]`` are the K candidates of the i-th spectrum."""
     sampler = _make_sampler(config, noise_scheduler, eps, config.eval.sampling_temperature)
-    return _sampling_fn_factory(config, sampler, batch_size, n_samples, inverse_scaler, test_ds, fixed_seed=True)
+    return _sampling_fn_factory(config, sampler, batch_size, n_samples, inverse_scaler, test_ds, fixed_seed=True, top_k=top_k)
 
 
 def get_sampling_fn(config, noise_scheduler, batch_size, n_samples, inverse_scaler, val_ds, eps=1e-3):

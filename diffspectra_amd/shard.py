@@ -36,6 +36,71 @@ def unpack_records(rec: torch.Tensor, N: int):
     return pos, atom, fc, et
 
 
+RECORD_ATOMS = 29          # DS_MAX_ATOMS: records have one width whatever the padded width of the batch they came from
+RECORD_BYTES = 1248        # 29*3 f32 (348) + 29 u8 atom types + 29 i8 charges + 29*29 u8 bond orders (841) = 1247, padded to 16
+
+
+def pack_records_u8(pos, atom_type, fc, edge_type) -> torch.Tensor:
+    """One 1 248-byte record per molecule: positions stay fp32, the integer outputs travel as bytes.
+    ``pos [B,N,3]`` f32, ``atom_type [B,N]`` in 0..4, ``fc [B,N]`` (or ``[B,N,1]``) in -128..127, ``edge_type [B,N,N]`` in 0..3;
+    N <= 29, padded entries zero."""
+    B, N = pos.shape[0], pos.shape[1]
+    if N > RECORD_ATOMS:
+        raise ValueError(f"records hold at most {RECORD_ATOMS} atoms")
+    W, dev = RECORD_ATOMS, pos.device
+    p = torch.zeros(B, W, 3, dtype=torch.float32, device=dev)
+    p[:, :N] = pos.float()
+    a = torch.zeros(B, W, dtype=torch.uint8, device=dev)
+    a[:, :N] = atom_type.reshape(B, N).to(torch.uint8)
+    c = torch.zeros(B, W, dtype=torch.int8, device=dev)
+    c[:, :N] = fc.reshape(B, N).to(torch.int8)
+    e = torch.zeros(B, W, W, dtype=torch.uint8, device=dev)
+    e[:, :N, :N] = edge_type.to(torch.uint8)
+    rec = torch.zeros(B, RECORD_BYTES, dtype=torch.uint8, device=dev)
+    rec[:, :348] = p.reshape(B, -1).view(torch.uint8)
+    rec[:, 348:377] = a
+    rec[:, 377:406] = c.view(torch.uint8)
+    rec[:, 406:1247] = e.reshape(B, -1)
+    return rec
+
+
+def unpack_records_u8(rec: torch.Tensor):
+    """→ ``(pos [M,29,3] f32, atom_type [M,29] i64, fc [M,29] i64, edge_type [M,29,29] f32)``."""
+    M = rec.shape[0]
+    pos = rec[:, :348].contiguous().view(torch.float32).reshape(M, RECORD_ATOMS, 3)
+    atom = rec[:, 348:377].long()
+    fc = rec[:, 377:406].contiguous().view(torch.int8).long()
+    et = rec[:, 406:1247].reshape(M, RECORD_ATOMS, RECORD_ATOMS).float()
+    return pos, atom, fc, et
+
+
+def assign_slots(n_atoms, rank: int, world: int):
+    """Sample slots owned by ``rank``: slots sorted by molecule size (largest first, stable) and dealt round-robin, so every
+    rank gets the same mix of sizes (cost grows as n(n-1)) and its own list is size-sorted, i.e. its micro-batches are
+    n-bucketed.  Returns an int64 tensor of slot indices."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    n = torch.as_tensor(n_atoms, dtype=torch.int64).reshape(-1)
+    order = torch.argsort(-n, stable=True)
+    return order[rank::world]
+
+
+def world_info():
+    """(rank, world) of the initialised default process group, (0, 1) without one."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def broadcast_from_rank0(t: torch.Tensor, device) -> torch.Tensor:
+    """Every rank gets rank 0's ``t`` (a small host tensor: permutations, seeds); identity without a process group."""
+    if world_info()[1] == 1:
+        return t
+    buf = t.clone() if dist.get_backend() == "gloo" else t.to(device)
+    dist.broadcast(buf, src=0)
+    return buf.cpu()
+
+
 def gather_records(rec: torch.Tensor, counts=None) -> torch.Tensor:
     """all_gather of per-rank record blocks → [sum(counts), record] on every rank, in rank order.
 

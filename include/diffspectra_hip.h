@@ -16,6 +16,8 @@
  *                         CondGaussianLayer / gaussian        models/layers.py:291-295,328-334
  *                         LearnedSinusodialposEmb + time_mlp  models/layers.py:283-288, dmt.py:249-257,353-357
  *   ds_sampler_step       AncestralSampler.sampling loop body sampling.py:604-624 + models/utils.py:67-106
+ *   ds_initial_noise /    sample_combined_position_feature_noise, sample_symmetric_edge_feature_noise
+ *   ds_sampler_step_philox                                    models/utils.py:67-106 (+ sampling.py:442-447,604-624)
  *   ds_post_process       post_process + inverse scaler       sampling.py:53-97, utils.py:88-103
  *   ds_gemm / ds_spec_*   SpecFormer.forward                  models/specformer.py:77-120,167-200,279-309,345-425,457-470
  *
@@ -176,6 +178,23 @@ int ds_sampler_step(const ds_layout* L, float c_x, float c_pred, float sigma, fl
                     float* x, float* edge_x, const float* pred, const float* edge_pred,
                     const float* raw_pos, const float* raw_feat, const float* raw_edge,
                     float* x_mean, float* edge_mean, void* stream);
+
+/* The same two operations with the noise generated IN the kernel: counter-based Philox4x32-10 + Box-Muller, one stream per
+ * molecule keyed on (seed, mol_id[m]) and indexed by (draw, atom / unordered atom pair) - never by the molecule's position
+ * in the batch, the batch's padded width or the rank that owns it.  A sampling run therefore produces the same molecules
+ * however it is cut into micro-batches and ranks, and the three randn launches + raw-noise tensors of the
+ * reference's draw order disappear from the step.  Same distributions as models/utils.py:67-106: masked N(0,1), position
+ * noise CoM-projected per molecule, edge noise one draw per unordered pair and channel written to both (i,j) and (j,i).
+ *   draw 0           : ds_initial_noise  (z_T, edge_z_T of sampling.py:442-447)
+ *   draw 1 + step    : ds_sampler_step_philox for denoise step `step` (sampling.py:611-612,623-624)
+ * Philox counter = (element, draw, mol_id, kind) with kind 0: atom a, word block j -> element 3a + j (12 normals per atom,
+ * 9 used: xyz, 5 type channels, charge); kind 1: pair lo < hi -> element hi(hi-1)/2 + lo (4 normals, 2 used).  Key = seed.
+ * mol_id: device int64 [B].  x [B,N,9] / edge_x [B,N,N,2] are fully written by ds_initial_noise (masked entries 0). */
+int ds_initial_noise(const ds_layout* L, uint64_t seed, const int64_t* mol_id, float* x, float* edge_x, void* stream);
+int ds_sampler_step_philox(const ds_layout* L, float c_x, float c_pred, float sigma, float temperature,
+                           uint64_t seed, int32_t step, const int64_t* mol_id,
+                           float* x, float* edge_x, const float* pred, const float* edge_pred,
+                           float* x_mean, float* edge_mean, void* stream);
 
 /* post_process (sampling.py:53-97, compress_edge=True, centered=True, normalize_factors 1,4,4,1):
  * pos_out [B,N,3] f32, atom_type [B,N] i32 (argmax), fc [B,N] i32 (round(4*x)), edge_type [B,N,N] f32 in {0,1,2,3}. */

@@ -23,3 +23,4 @@ from .specformer import specformer_forward  # noqa: F401
 from .dmt import dmt_forward, context_embedding  # noqa: F401
 from .sampler import (ancestral_sampling, combined_noise, symmetric_edge_noise, post_process,  # noqa: F401
                       mol_process, inverse_scale, self_cond_ori, self_cond_clamp)
+from . import philox  # noqa: F401,E402

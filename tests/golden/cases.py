@@ -90,6 +90,110 @@ def readout_gain(state_dict, gain: float = 8.0):
     return out
 
 
+# ---- 'diverse readout' perturbation of the trajectory goldens (see calibrate_diverse.py) ----
+NODE_GAIN = (8.0, 8.0, 8.0, 8.0, 8.0, 24.0)     # rows of node_pred_mlp.4.weight: 5 atom-type logits, formal charge
+EDGE_GAIN = (16.0, 64.0)                        # edge_exist_mlp.4.weight, edge_type_mlp.4.weight
+NODE_BIAS0 = (0.06, -0.09, 0.02, 0.10, 0.28, -0.37)   # starting point of the per-case calibration
+EDGE_BIAS0 = (-0.19, -0.71)
+ALLSPECTRA_FULL_ATOMS = [5, 9, 12]              # molecules of the all-spectra 1000-step golden trajectory (G9)
+DIVERSE_CASES = {                               # tag -> (spectra version, denoise steps, n_atoms)
+    "allspectra_S5": ("allspectra", 5, RAGGED),
+    "ir_S50": ("ir", 50, RAGGED),
+    "ir_S1000": ("ir", 1000, FULL_LENGTH_ATOMS),
+    "allspectra_S1000": ("allspectra", 1000, ALLSPECTRA_FULL_ATOMS),
+}
+
+
+def apply_readout(state_dict, node_bias, edge_bias):
+    """Scale the last layer of the three readout MLPs by NODE_GAIN / EDGE_GAIN and replace its bias (works with or
+    without the ``module.`` prefix; returns a new dict)."""
+    out = dict(state_dict)
+    for k, v in state_dict.items():
+        if k.endswith("node_pred_mlp.4.weight"):
+            out[k] = v * torch.tensor(NODE_GAIN, dtype=v.dtype, device=v.device).reshape(-1, 1)
+        elif k.endswith("node_pred_mlp.4.bias"):
+            out[k] = torch.tensor(node_bias, dtype=v.dtype, device=v.device)
+        elif k.endswith("edge_exist_mlp.4.weight"):
+            out[k] = v * EDGE_GAIN[0]
+        elif k.endswith("edge_type_mlp.4.weight"):
+            out[k] = v * EDGE_GAIN[1]
+        elif k.endswith("edge_exist_mlp.4.bias"):
+            out[k] = torch.tensor([edge_bias[0]], dtype=v.dtype, device=v.device)
+        elif k.endswith("edge_type_mlp.4.bias"):
+            out[k] = torch.tensor([edge_bias[1]], dtype=v.dtype, device=v.device)
+    return out
+
+
+def readout_diverse(state_dict, tag: str):
+    """The calibrated perturbation of golden case ``tag`` (``diverse_readout.json``): atom types, charges and bond
+    orders of the sampled molecules then cover their whole range, with decisions close to the thresholds."""
+    import json
+    with open(fixture_path("diverse_readout.json")) as f:
+        rec = json.load(f)[tag]
+    return apply_readout(state_dict, rec["node_bias"], rec["edge_bias"])
+
+
+def pretrained_specformer_ckpt(encoder_state, variant: str):
+    """A Lightning-style SpecFormer pre-training checkpoint for the key mapping of reference dmt.py:268-303.
+
+    ``variant='spec_model'``: encoder under ``model.representation_spec_model.*`` (the first prefix the loader tries) while
+    ``out_norm`` lives under ``model.representation_model.out_norm.*`` (the loader's special case); one entry has a
+    mismatched shape and one is absent (both must keep their current values); unrelated keys are ignored.
+    ``variant='plain_model'``: everything under ``model.representation_model.*``.
+    Values: the procedural filler with salt 11, so they differ from the model's own salt-0 weights."""
+    prefix = {"spec_model": "model.representation_spec_model", "plain_model": "model.representation_model"}[variant]
+    sd = {}
+    for k, v in encoder_state.items():
+        val = filler.fill_tensor("cond_encoder." + k, v.shape, like=v, salt=11)
+        if k in ("out_norm.weight", "out_norm.bias"):
+            sd[f"model.representation_model.{k}"] = val
+            if variant == "spec_model":     # a decoy under the tried prefix that the special case must NOT read
+                sd[f"{prefix}.{k}"] = torch.full_like(val, 123.0)
+            continue
+        if variant == "spec_model" and k == "backbone.W_P.1.bias":
+            continue                                                        # absent from the checkpoint
+        if variant == "spec_model" and k == "backbone.W_pos_ir":
+            val = torch.zeros(v.shape[0] + 1, v.shape[1])                   # wrong shape: skipped by the loader
+        sd[f"{prefix}.{k}"] = val
+    sd["model.some_other_head.weight"] = torch.ones(3, 3)
+    sd["optimizer_like_entry"] = torch.zeros(1)
+    return {"state_dict": sd, "epoch": 3}
+
+
+def sampling_fn_case():
+    """Inputs of the outer-loop golden (G11): 7-item dataset, rounds of 3, 6 molecules kept, 5 denoise steps."""
+    count, batch_size, n_samples, steps = 7, 3, 6, 5
+    n_atoms = [5, 9, 3, 12, 7, 4, 10]
+    return dict(count=count, batch_size=batch_size, n_samples=n_samples, steps=steps, temperature=0.9, n_atoms=n_atoms,
+                spectra=spectra_for("allspectra", count, salt=5))
+
+
+def sampling_fn_noise_queue(case, perm):
+    """Every randn draw of ``sampling_fn`` in call order (sampling.py:442-447 then :611-612,:623-624 per step), for the
+    rounds the seed-42 permutation ``perm`` produces.  The generator replays it into the reference; the GPU test replays
+    it into the HIP sampling function."""
+    queue = []
+    bs, rounds = case["batch_size"], -(-case["n_samples"] // case["batch_size"])
+    for r in range(rounds):
+        ids = perm[r * bs:(r + 1) * bs]
+        N = max(case["n_atoms"][i] for i in ids)
+        B = bs
+        queue += [filler.normal(f"g11.r{r}.init.pos", (B, N, 3)), filler.normal(f"g11.r{r}.init.feat", (B, N, 6)),
+                  filler.normal(f"g11.r{r}.init.edge", (B, 2, N, N))]
+        for i in range(case["steps"]):
+            queue += [filler.normal(f"g11.r{r}.s{i}.pos", (B, N, 3)), filler.normal(f"g11.r{r}.s{i}.feat", (B, N, 6)),
+                      filler.normal(f"g11.r{r}.s{i}.edge", (B, 2, N, N))]
+    return queue
+
+
+def bond_distance_sweep():
+    """Distances (Angstrom) for the bond-order golden (G12): a 1 pm grid over 0.5-2.0 A plus points 1e-4 A either side of
+    every integer-picometre threshold in that range, so each ``<`` comparison is exercised on both sides."""
+    grid = np.arange(50, 201, dtype=np.float64) / 100.0
+    near = np.concatenate([grid - 1e-4, grid + 1e-4])
+    return np.sort(np.concatenate([grid, near]))
+
+
 def config_for(version: str, steps: int = 1000):
     return qm9s_config(spectra_version=version, steps=steps)
 
@@ -100,4 +204,4 @@ def save_npz(name: str, **arrays):
 
 def load_npz(name: str):
     with np.load(fixture_path(name)) as z:
-        return {k: torch.from_numpy(z[k]) for k in z.files}
+        return {k: (str(z[k]) if z[k].dtype.kind in "US" else torch.from_numpy(z[k])) for k in z.files}

@@ -189,6 +189,8 @@ def g5_trajectory(mods, plan=(("allspectra", 5, None), ("ir", 50, None)), fname=
         cfg.model.self_cond_type = self_cond_type
         if self_cond_type == "clamp":
             model.load_state_dict(cases.readout_gain(model.state_dict()), strict=True)
+        else:   # de-trivialised integer outputs: calibrated readout perturbation of this case (calibrate_diverse.py)
+            model.load_state_dict(cases.readout_diverse(model.state_dict(), f"{version}_S{steps}"), strict=True)
         tr = cases.trajectory_inputs(version, steps) if n_atoms is None else cases.trajectory_inputs(version, steps, n_atoms)
         ns = mods.noise_schedule.NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0)
         time_steps = torch.linspace(ns.T, 1e-3, steps)
@@ -220,13 +222,22 @@ def g5_trajectory(mods, plan=(("allspectra", 5, None), ("ir", 50, None)), fname=
         for m, (p, at, e, c) in enumerate(mols):
             out[f"{tag}_mol{m}_pos"], out[f"{tag}_mol{m}_atom"] = p.numpy(), at.numpy()
             out[f"{tag}_mol{m}_edge"], out[f"{tag}_mol{m}_fc"] = e.numpy(), c.numpy()
-        print("G5", tag, float(x_mean.abs().max()))
+        nmv = tr["node_mask"].squeeze(-1).bool()
+        emv = tr["edge_mask"].reshape(et.shape).bool()
+        print("G5", tag, float(x_mean.abs().max()), "atom types", np.bincount(one_hot.argmax(-1)[nmv].numpy(), minlength=5),
+              "bond orders", np.bincount(et[emv].long().numpy(), minlength=4),
+              "charges", np.unique(fc.squeeze(-1)[nmv].numpy(), return_counts=True))
     cases.save_npz(fname, **out)
 
 
 def g7_full_length(mods):
     """The metric's own step count: 1000 ancestral steps with injected noise on three small molecules."""
     g5_trajectory(mods, plan=(("ir", 1000, cases.FULL_LENGTH_ATOMS),), fname="g7_trajectory_1000.npz")
+
+
+def g9_full_length_allspectra(mods):
+    """1000 steps on the headline configuration (all-spectra, SpecFormer conditioning) with injected noise."""
+    g5_trajectory(mods, plan=(("allspectra", 1000, cases.ALLSPECTRA_FULL_ATOMS),), fname="g9_trajectory_1000_allspectra.npz")
 
 
 def g8_clamp_self_cond(mods):
@@ -253,15 +264,107 @@ def g6_post_process(mods):
     print("G6 done")
 
 
+def g10_pretrained_specformer(mods):
+    """BASELINE config 3: the reference's own ``load_pretrained_specformer`` (models/dmt.py:268-303) on a Lightning-style
+    checkpoint built by the filler (``cases.pretrained_specformer_ckpt``): which keys it takes, and the resulting
+    conditioning embedding."""
+    import tempfile
+    out = {}
+    for variant in ("spec_model", "plain_model"):
+        cfg, model = ref_model(mods, "allspectra")
+        enc = model.module.cond_encoder
+        before = {k: v.clone() for k, v in enc.state_dict().items()}
+        ckpt = cases.pretrained_specformer_ckpt(before, variant)
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "pretrained_specformer.ckpt")
+            torch.save(ckpt, path)
+            model.module.load_pretrained_specformer(path)
+        after = enc.state_dict()
+        changed = [k for k in after if not torch.equal(after[k], before[k])]
+        ctx = cases.spectra_for("allspectra", 4)
+        with torch.no_grad():
+            z = enc(ctx)
+            out[f"{variant}_z"] = z.numpy()
+            out[f"{variant}_ctx"] = model.module.cond_lin(z).numpy()
+        out[f"{variant}_changed_keys"] = np.array(json.dumps(changed))
+        out[f"{variant}_checksums"] = np.array([float(after[k].double().sum()) for k in after])
+        print("G10", variant, len(changed), "of", len(after), "entries replaced")
+    cases.save_npz("g10_pretrained_specformer.npz", **out)
+
+
+class _DsItem:
+    def __init__(self, i, n, specs):
+        self.num_atom = torch.tensor(n)
+        self.pos = torch.full((n, 3), float(i))
+        self.rdmol = f"mol{i}"
+        self.uv, self.ir, self.raman = specs
+
+
+def g11_sampling_fn(mods):
+    """The OUTER loop: the reference's ``get_cond_sampling_eval_fn(...)(model)`` (sampling.py:353-468) on an in-memory
+    dataset with every ``torch.randn`` replayed from the filler (``cases.sampling_fn_case``): seed-42 permutation, rounds,
+    masks, initial noise, sampler, post-processing, ``mol_process``."""
+    c = cases.sampling_fn_case()
+    cfg, model = ref_model(mods, "allspectra")
+    cfg.sampling.steps = c["steps"]
+    cfg.eval.sampling_temperature = c["temperature"]
+    model.load_state_dict(cases.readout_diverse(model.state_dict(), "allspectra_S5"), strict=True)
+    ds = [_DsItem(i, c["n_atoms"][i], (c["spectra"][0][i], c["spectra"][1][i], c["spectra"][2][i])) for i in range(c["count"])]
+    ns = mods.noise_schedule.NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0)
+    inv = mods.top_utils.get_data_inverse_scaler(cfg)
+    fn = mods.sampling.get_cond_sampling_eval_fn(cfg, ns, c["batch_size"], c["n_samples"], inv, ds)
+    torch.manual_seed(42)
+    perm = torch.randperm(c["count"])
+    replay = _ReplayRandn(cases.sampling_fn_noise_queue(c, perm.tolist()))
+    real_randn = torch.randn
+    mods.model_utils.torch.randn = replay
+    try:
+        mols, gt_pos, gt_mols = fn(model)
+    finally:
+        torch.randn = real_randn
+    assert not replay.queue
+    out = {"perm": perm.numpy(), "gt_mols": np.array(json.dumps(gt_mols)),
+           "gt_pos0": np.array([float(p[0, 0]) for p in gt_pos])}
+    for m, (p, at, e, ch) in enumerate(mols):
+        out[f"mol{m}_pos"], out[f"mol{m}_atom"], out[f"mol{m}_edge"], out[f"mol{m}_fc"] = p.numpy(), at.numpy(), e.numpy(), ch.numpy()
+    print("G11", len(mols), "molecules; atom types", np.bincount(np.concatenate([m[1].numpy() for m in mols]), minlength=5))
+    cases.save_npz("g11_sampling_fn.npz", **out)
+
+
+def g12_bond_orders():
+    """evaluation/bond_analyze.py (pure Python, no dependencies; imported by file path because ``evaluation/__init__``
+    pulls RDKit): ``get_bond_order`` on every QM9 atom pair over a distance sweep that brackets every threshold, and
+    the ``allowed_bonds`` valences.  Pins oracle/stability.py and the product's batched stability check."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_bond_analyze", os.path.join(REF, "evaluation", "bond_analyze.py"))
+    ba = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ba)
+    atoms = ["H", "C", "N", "O", "F"]
+    dist = cases.bond_distance_sweep()
+    orders = np.zeros((5, 5, len(dist)), dtype=np.int64)
+    for i, a in enumerate(atoms):
+        for j, b in enumerate(atoms):
+            for k, d in enumerate(dist.tolist()):
+                orders[i, j, k] = ba.get_bond_order(a, b, d)
+    valence = np.array([ba.allowed_bonds[a] for a in atoms], dtype=np.int64)
+    cases.save_npz("g12_bond_orders.npz", orders=orders, valence=valence)
+    print("G12 bond-order histogram", np.bincount(orders.reshape(-1), minlength=4), "valence", valence)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     torch.set_num_threads(8)
+    only = [s for s in args.only.split(",") if s]
+    if not only or "G12" in only:
+        g12_bond_orders()
+    if only == ["G12"]:
+        return
     mods = import_reference()
     todo = {"G0": g0_manifest, "G1": g1_schedule, "G2": g2_specformer, "G3": g3_components, "G4": g4_forward,
-            "G5": g5_trajectory, "G6": g6_post_process, "G7": g7_full_length, "G8": g8_clamp_self_cond}
-    only = [s for s in args.only.split(",") if s]
+            "G5": g5_trajectory, "G6": g6_post_process, "G7": g7_full_length, "G8": g8_clamp_self_cond,
+            "G9": g9_full_length_allspectra, "G10": g10_pretrained_specformer, "G11": g11_sampling_fn}
     for k, fn in todo.items():
         if not only or k in only:
             fn(mods)

@@ -37,6 +37,69 @@ def _worker(rank, world, port, total, ret):
         dist.destroy_process_group()
 
 
+def _worker_u8(rank, world, port, n_atoms, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert shard.world_info() == (rank, world)
+        mine = shard.assign_slots(n_atoms, rank, world)
+        N = 6
+        ids = mine.float()
+        pos = ids.view(-1, 1, 1).expand(-1, N, 3) * 0.5 - 1.25
+        atom = (mine.view(-1, 1).expand(-1, N) % 5)
+        fc = (mine.view(-1, 1).expand(-1, N) % 5) - 2
+        et = (mine.view(-1, 1, 1).expand(-1, N, N) % 4).float()
+        rec = shard.pack_records_u8(pos, atom, fc, et)
+        counts = [shard.assign_slots(n_atoms, r, world).numel() for r in range(world)]
+        allrec = shard.gather_records(rec, counts)
+        order = torch.cat([shard.assign_slots(n_atoms, r, world) for r in range(world)])
+        by_slot = torch.empty_like(allrec)
+        by_slot[order] = allrec
+        p2, a2, f2, e2 = shard.unpack_records_u8(by_slot)
+        k = torch.arange(len(n_atoms))
+        ok = (torch.equal(p2[:, 0, 0], k.float() * 0.5 - 1.25) and torch.equal(a2[:, 0], k % 5) and torch.equal(f2[:, 3], k % 5 - 2)
+              and torch.equal(e2[:, 1, 2], (k % 4).float()) and float(p2[:, N:].abs().max()) == 0.0 and int(e2[:, N:].abs().max()) == 0)
+        perm = shard.broadcast_from_rank0(torch.randperm(11, generator=torch.Generator().manual_seed(100 + rank)), "cpu")
+        ret[rank] = (bool(ok), perm.tolist())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_u8_records_and_slot_assignment():
+    n_atoms = [9, 29, 3, 18, 18, 12, 21, 5, 16]
+    parts = [shard.assign_slots(n_atoms, r, 3) for r in range(3)]
+    assert sorted(torch.cat(parts).tolist()) == list(range(9))                      # a partition of the slots
+    for part in parts:
+        sizes = [n_atoms[i] for i in part.tolist()]
+        assert sizes == sorted(sizes, reverse=True)                                 # n-bucketed inside a rank
+    cost = [sum(n_atoms[i] * (n_atoms[i] - 1) for i in p.tolist()) for p in parts]
+    assert max(cost) - min(cost) <= 29 * 28                                          # balanced to within one molecule
+    assert shard.assign_slots(n_atoms, 0, 1).tolist() == torch.argsort(-torch.tensor(n_atoms), stable=True).tolist()
+    assert shard.world_info() == (0, 1)
+    g = torch.Generator().manual_seed(0)
+    B, N = 5, 7
+    pos = torch.randn(B, N, 3, generator=g)
+    atom = torch.randint(0, 5, (B, N), generator=g)
+    fc = torch.randint(-3, 4, (B, N, 1), generator=g)
+    et = torch.randint(0, 4, (B, N, N), generator=g).float()
+    rec = shard.pack_records_u8(pos, atom, fc, et)
+    assert rec.shape == (B, shard.RECORD_BYTES) and rec.dtype == torch.uint8 and shard.RECORD_BYTES == 1248
+    p2, a2, f2, e2 = shard.unpack_records_u8(rec)
+    assert torch.equal(p2[:, :N], pos) and torch.equal(a2[:, :N], atom) and torch.equal(f2[:, :N], fc.squeeze(-1))
+    assert torch.equal(e2[:, :N, :N], et) and float(p2[:, N:].abs().max()) == 0.0
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_u8, args=(r, 2, port, n_atoms, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret[0][0] and ret[1][0]
+    assert ret[0][1] == ret[1][1] == torch.randperm(11, generator=torch.Generator().manual_seed(100)).tolist()
+
+
 def test_two_rank_shard_and_gather():
     world, total = 2, 7                      # uneven split: 4 + 3
     assert [shard.shard_bounds(total, r, world) for r in range(world)] == [(0, 4), (4, 7)]

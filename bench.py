@@ -69,16 +69,18 @@ def algorithmic_macs(n_atoms) -> int:
 
 
 def pmc_traffic(kernel: str, mols: int):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json).
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json).
 
     bench.py cannot run the profiler on itself; the counters are collected with `rocprofv3 --pmc FETCH_SIZE` and
     `--pmc WRITE_SIZE` in separate passes of this same workload (tools/pmc_report.py) and scaled per molecule."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        rec = json.load(open(path))[kernel]
-        return rec["bytes_per_launch_per_molecule"] * mols, os.path.relpath(path, ROOT)
-    except (OSError, KeyError, ValueError):
-        return None, None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            rec = json.load(open(path))[kernel]
+            return rec["bytes_per_launch_per_molecule"] * mols, os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def executed_macs(n_atoms) -> int:
@@ -143,6 +145,8 @@ def main():
     ap.add_argument("--unconditional", action="store_true",
                     help="BASELINE config 4: zero context embedding, SpecFormer skipped (build extension, DESIGN.md §7)")
     ap.add_argument("--profile-kernel", type=int, default=5, help="block-stage kernel timed with HIP events (5 = k_equi_pairs)")
+    ap.add_argument("--graph", default="off", choices=["auto", "on", "off"],
+                    help="hipGraph replay of the denoise iteration (measured: no gain at any batch size, so off by default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,6 +206,10 @@ def main():
     # noise: the product's per-molecule Philox streams keyed on (seed 42, global molecule id) - generated inside the fused
     # update kernel, identical molecules for any number of ranks
     mol_ids = torch.arange(rank * M, (rank + 1) * M, dtype=torch.int64, device=device)
+    sampler.use_graph = {"auto": "auto", "on": True, "off": False}[args.graph]
+    graphed = sampler.use_graph is True or (sampler.use_graph == "auto" and eng.layout_for(node_mask, edge_mask)[0].Pp <= sampler.graph_max_pairs)
+    if graphed:
+        args.profile_kernel = -1          # HIP-event sampling brackets eager launches; a replayed graph has none
     spp = max(1, min(args.steps_per_pass, args.denoise_steps))
     slice_len = -(-args.denoise_steps // spp)          # denoise iterations per bench step
 
@@ -259,7 +267,8 @@ def main():
             log(f"--steps {args.steps} would take ~{args.steps * t_step:.0f} s; running {steps} steps to stay inside {args.budget_s:.0f} s")
 
     every = max(1, (steps * slice_len * 8) // 2000)
-    E._check(lib.ds_profile_config(C.c_int(args.profile_kernel), C.c_int(every), C.c_int(4096)), "ds_profile_config")
+    if args.profile_kernel >= 0:
+        E._check(lib.ds_profile_config(C.c_int(args.profile_kernel), C.c_int(every), C.c_int(4096)), "ds_profile_config")
     run = Stream()
     sync()
     t0 = time.perf_counter()
@@ -322,7 +331,8 @@ def main():
                                    "and the final gather",
                        "molecules_per_gpu": M, "denoise_steps": args.denoise_steps, "denoise_iterations_per_step": slice_len,
                        "steps_per_pass": spp, "passes_completed": run.passes, "denoise_iterations_timed": run.iters,
-                       "steps_requested": args.steps, "parallelism": f"dp{world} (molecule shards)"},
+                       "steps_requested": args.steps, "parallelism": f"dp{world} (molecule shards)",
+                       "launch_mode": "hipGraph replay per denoise iteration" if graphed else "eager launches"},
             "roofline": roofline,
             "whole_path": {"algorithmic_tflops_per_gpu": whole, "frac_of_fp32_mfma_peak": whole / PEAK_FP32_MFMA_TFLOPS,
                            "executed_tflops_per_gpu": whole_exe, "executed_frac": whole_exe / PEAK_FP32_MFMA_TFLOPS,

@@ -1309,18 +1309,25 @@ __device__ __forceinline__ float4 philox_normal4(unsigned int elem, unsigned int
 
 // One workgroup per molecule.  MODE 0: initial noise (x, edge_x := noise; masked entries were zeroed by the caller's
 // memset).  MODE 1: ancestral update with in-kernel noise (the Philox twin of k_sampler_step).
+// MODE 2: as MODE 1 with (c_x, c_pred, sigma) and the draw index read from device memory (graph replay).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_noise_step(ds_layout L, float c_x, float c_pred, float sigma, float temp,
                                                     unsigned long long seed, unsigned int draw, const int64_t* __restrict__ mol_id,
                                                     float* __restrict__ x, float* __restrict__ edge_x,
                                                     const float* __restrict__ pred, const float* __restrict__ edge_pred,
-                                                    float* __restrict__ x_mean, float* __restrict__ edge_mean) {
+                                                    float* __restrict__ x_mean, float* __restrict__ edge_mean,
+                                                    const float* __restrict__ table, const int32_t* __restrict__ step) {
   __shared__ __attribute__((aligned(16))) float nz[32][12];
   __shared__ float mean[3];
   __shared__ int dn[32];
   const int m = blockIdx.x, tid = threadIdx.x;
   const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0;
   if (n <= 0) return;
+  if (MODE == 2) {
+    const int i = *step;
+    c_x = table[4 * i]; c_pred = table[4 * i + 1]; sigma = table[4 * i + 2];
+    draw = (unsigned int)i + 1u;
+  }
   const unsigned long long mol = (unsigned long long)mol_id[m];
   if (tid < n) dn[tid] = L.node_dense[n0 + tid];
   if (tid < n * 3) {
@@ -1341,7 +1348,7 @@ __global__ __launch_bounds__(256) void k_noise_step(ds_layout L, float c_x, floa
     const float v = ch < 3 ? nz[a][ch] - mean[ch] : nz[a][ch];
     if (MODE == 0) {
       x[d * 9 + ch] = v;
-    } else {
+    } else {   // MODE 1, 2
       const float xm = c_x * x[d * 9 + ch] + c_pred * pred[d * 9 + ch];
       x_mean[d * 9 + ch] = xm;
       x[d * 9 + ch] = xm + (sigma * v) * temp;
@@ -1369,6 +1376,20 @@ __global__ __launch_bounds__(256) void k_noise_step(ds_layout L, float c_x, floa
       }
     }
   }
+}
+
+// Opens a graph-replayable denoise iteration: ++*step, noise_level[b] = table[*step][3] (one workgroup).
+__global__ __launch_bounds__(256) void k_step_begin(const float* __restrict__ table, int n_steps, int32_t* __restrict__ step, int B,
+                                                    float* __restrict__ noise_level) {
+  __shared__ int cur;
+  if (threadIdx.x == 0) {
+    const int i = min(*step + 1, n_steps - 1);
+    *step = i;
+    cur = i;
+  }
+  __syncthreads();
+  const float nl = table[4 * cur + 3];
+  for (int b = threadIdx.x; b < B; b += 256) noise_level[b] = nl;
 }
 
 // post_process (sampling.py:53-97) with the inverse scaler of utils.py:88-103 (norms 1,4,4,1; centered).
@@ -1742,7 +1763,8 @@ int ds_initial_noise(const ds_layout* L, uint64_t seed, const int64_t* mol_id, f
   if (hipMemsetAsync(x, 0, nb * 9 * sizeof(float), s) != hipSuccess) return DS_ERR_LAUNCH;
   if (hipMemsetAsync(edge_x, 0, nb * L->N * 2 * sizeof(float), s) != hipSuccess) return DS_ERR_LAUNCH;
   hipLaunchKernelGGL(k_noise_step<0>, dim3(L->B), dim3(256), 0, s, *L, 0.0f, 0.0f, 0.0f, 0.0f, (unsigned long long)seed, 0u, mol_id,
-                     x, edge_x, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                     x, edge_x, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                     (const float*)nullptr, (const int32_t*)nullptr);
   return launch_status();
 }
 
@@ -1752,7 +1774,24 @@ int ds_sampler_step_philox(const ds_layout* L, float c_x, float c_pred, float si
   if (!L || !mol_id || !x || !edge_x || !pred || !edge_pred || !x_mean || !edge_mean || step < 0) return DS_ERR_ARG;
   if (L->B <= 0 || L->max_n > DS_MAX_ATOMS || L->max_n > L->N) return DS_ERR_ARG;
   hipLaunchKernelGGL(k_noise_step<1>, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, c_x, c_pred, sigma, temperature,
-                     (unsigned long long)seed, (unsigned int)step + 1u, mol_id, x, edge_x, pred, edge_pred, x_mean, edge_mean);
+                     (unsigned long long)seed, (unsigned int)step + 1u, mol_id, x, edge_x, pred, edge_pred, x_mean, edge_mean,
+                     (const float*)nullptr, (const int32_t*)nullptr);
+  return launch_status();
+}
+
+int ds_step_begin(const float* table, int32_t n_steps, int32_t* step, int32_t B, float* noise_level, void* stream) {
+  if (!table || !step || !noise_level || B <= 0 || n_steps <= 0) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(256), 0, (hipStream_t)stream, table, n_steps, step, B, noise_level);
+  return launch_status();
+}
+
+int ds_sampler_step_philox_dev(const ds_layout* L, const float* table, const int32_t* step, float temperature, uint64_t seed,
+                               const int64_t* mol_id, float* x, float* edge_x, const float* pred, const float* edge_pred,
+                               float* x_mean, float* edge_mean, void* stream) {
+  if (!L || !table || !step || !mol_id || !x || !edge_x || !pred || !edge_pred || !x_mean || !edge_mean) return DS_ERR_ARG;
+  if (L->B <= 0 || L->max_n > DS_MAX_ATOMS || L->max_n > L->N) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_noise_step<2>, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, 0.0f, 0.0f, 0.0f, temperature,
+                     (unsigned long long)seed, 0u, mol_id, x, edge_x, pred, edge_pred, x_mean, edge_mean, table, step);
   return launch_status();
 }
 

@@ -430,6 +430,17 @@ class DmtEngine:
                                              _ptr(edge_x), _ptr(pred), _ptr(edge_pred), _ptr(x_mean), _ptr(edge_mean), _stream())
         _check(st, "ds_sampler_step_philox")
 
+    def step_begin(self, table, n_steps: int, step_dev, B: int, noise_level):
+        _check(self.lib.ds_step_begin(_ptr(table), C.c_int32(n_steps), _ptr(step_dev), C.c_int32(B), _ptr(noise_level), _stream()),
+               "ds_step_begin")
+
+    def sampler_step_philox_dev(self, L, table, step_dev, temperature, seed: int, mol_id, x, edge_x, pred, edge_pred, x_mean,
+                                edge_mean):
+        st = self.lib.ds_sampler_step_philox_dev(C.byref(L.c), _ptr(table), _ptr(step_dev), C.c_float(temperature),
+                                                 C.c_uint64(seed), _ptr(mol_id), _ptr(x), _ptr(edge_x), _ptr(pred),
+                                                 _ptr(edge_pred), _ptr(x_mean), _ptr(edge_mean), _stream())
+        _check(st, "ds_sampler_step_philox_dev")
+
     def post_process(self, L, xh, edge_x):
         dev = self.device
         pos = torch.empty(L.B, L.N, 3, dtype=torch.float32, device=dev)

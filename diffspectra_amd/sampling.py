@@ -47,6 +47,13 @@ class AncestralSampler:
         self.noise_fn: Optional[Callable] = None     # noise_fn(i) -> (raw_pos, raw_feat, raw_edge): injected randn draws
         self.progress_fn: Optional[Callable] = None  # progress_fn(i, n_steps), called every 100 steps (long runs)
         self.philox_seed = 42                        # key of the per-molecule noise streams (begin(..., mol_ids=...))
+        # hipGraph replay of the denoise iteration.  Off by default: measured on the MI355X
+        # (profiles/r02_throughput_vs_batch.jsonl) a replayed iteration takes the same time as ~90 eager launches at every
+        # batch size from 64 to 2048 molecules (2.66 ms vs 2.66 ms at 64) - small batches are bound by the latency of the
+        # dependent kernel chain on a mostly empty chip, not by host launch work.  True forces it, 'auto' applies it below
+        # graph_max_pairs packed pair rows; results are bit-identical either way (tests/test_hip_parity.py).
+        self.use_graph = False
+        self.graph_max_pairs = 120_000
         self._table = None
 
     def coefficient_table(self):
@@ -103,7 +110,59 @@ class AncestralSampler:
         st.pred, st.edge_pred = [f(B, N, 9), f(B, N, 9)], [f(B, N, N, 2), f(B, N, N, 2)]
         st.x_mean, st.edge_mean = torch.zeros(B, N, 9, device=dev), torch.zeros(B, N, N, 2, device=dev)
         st.cond_x = st.cond_edge_x = None
+        st.graph = None
         return st
+
+    # ------------------------------------------------------------------ hipGraph replay of one denoise iteration
+    def _graph_wanted(self, st):
+        if st.mol_ids is None or self.noise_fn is not None or self.progress_fn is not None:
+            return False                     # needs the in-kernel noise; injected noise / progress callbacks stay eager
+        if self.cond_process_fn is not None and getattr(self.cond_process_fn, "in_place_clamp", False):
+            return False                     # the 'clamp' hook allocates per call
+        if self.use_graph == "auto":
+            return st.L.Pp <= self.graph_max_pairs
+        return bool(self.use_graph)
+
+    def _graph_body(self, st):
+        """One iteration with constant launch arguments: the step index lives in device memory (ds_step_begin), the
+        prediction is written in place over the self-conditioning input (ds_stage_init has consumed it by then)."""
+        eng, L, ws, g = st.eng, st.L, st.ws, st.graph
+        eng.step_begin(g["table"], len(st.coef), g["step"], L.B, g["nl"])
+        eng.forward(L, ws, st.x, st.edge_x, g["nl"], g["pred"], g["edge_pred"], st.ctx, g["pred"], g["edge_pred"])
+        eng.sampler_step_philox_dev(L, g["table"], g["step"], float(self.sampling_temperature), st.seed, st.mol_ids, st.x,
+                                    st.edge_x, g["pred"], g["edge_pred"], st.x_mean, st.edge_mean)
+
+    def _graph_advance(self, st, end):
+        """Iterations st.i .. end-1 by graph replay (st.i >= 1: the first iteration takes the no-conditioning branch)."""
+        eng, dev = st.eng, st.eng.device
+        if st.graph is None:
+            tab = self.coefficient_table().to(dev).contiguous()
+            g = dict(table=tab, step=torch.zeros(1, dtype=torch.int32, device=dev), nl=torch.empty(st.L.B, device=dev),
+                     pred=st.cond_x, edge_pred=st.cond_edge_x, graph=None)
+            st.graph = g
+            g["step"].fill_(st.i - 1)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                self._graph_body(st)                              # a real iteration, eagerly, on the capture stream
+            torch.cuda.current_stream(dev).wait_stream(side)
+            st.i += 1
+            if st.i >= end:
+                return
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                self._graph_body(st)
+            g["graph"] = graph
+        g = st.graph
+        g["step"].fill_(st.i - 1)
+        if g["graph"] is None:                                    # captured lazily when only one iteration was asked for
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._graph_body(st)
+            g["graph"] = graph
+        for _ in range(st.i, end):
+            g["graph"].replay()
+        st.i = end
 
     @torch.no_grad()
     def advance(self, st, n_steps=None):
@@ -113,7 +172,13 @@ class AncestralSampler:
         B, N = L.B, L.N
         temp = float(self.sampling_temperature)
         end = len(st.coef) if n_steps is None else min(len(st.coef), st.i + int(n_steps))
-        for i in range(st.i, end):
+        if st.i >= 1 and st.i < end and self._graph_wanted(st):
+            self._graph_advance(st, end)
+            return end >= len(st.coef)
+        stop_eager = end
+        if st.i == 0 and end > 1 and self._graph_wanted(st):
+            stop_eager = 1                                         # first iteration eagerly, the rest by graph replay
+        for i in range(st.i, stop_eager):
             c_x, c_pred, sigma, _ = st.coef[i]
             cur = i & 1
             eng.forward(L, ws, st.x, st.edge_x, st.nl_rows[i], st.cond_x, st.cond_edge_x, st.ctx, st.pred[cur], st.edge_pred[cur])
@@ -133,7 +198,9 @@ class AncestralSampler:
                                  raw[2], st.x_mean, st.edge_mean)
             if self.progress_fn is not None and (i + 1) % 100 == 0:
                 self.progress_fn(i + 1, len(st.coef))
-        st.i = end
+        st.i = stop_eager
+        if stop_eager < end:
+            self._graph_advance(st, end)
         return end >= len(st.coef)
 
     @torch.no_grad()
@@ -146,7 +213,7 @@ class AncestralSampler:
 class _Pass:
     """Mutable state of one in-flight sampling pass (``AncestralSampler.begin`` / ``advance``)."""
     __slots__ = ("eng", "L", "ws", "i", "x", "edge_x", "ctx", "coef", "nl_rows", "pred", "edge_pred", "x_mean", "edge_mean",
-                 "cond_x", "cond_edge_x", "mol_ids", "seed")
+                 "cond_x", "cond_edge_x", "mol_ids", "seed", "graph")
 
 
 def post_process(xh, atom_types, include_charge, node_mask, inverse_scaler, edge_x=None, edge_mask=None,

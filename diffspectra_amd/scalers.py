@@ -60,6 +60,7 @@ def get_self_cond_fn(config):
             return cond_x, cond_edge_x.clamp(lo / edge_norm, hi / edge_norm)
         raise ValueError("Self-condition data process error.")
 
+    process_self_cond.in_place_clamp = process_type != "ori"    # the sampler keeps such hooks out of graph replay
     return process_self_cond
 
 

@@ -196,6 +196,17 @@ int ds_sampler_step_philox(const ds_layout* L, float c_x, float c_pred, float si
                            float* x, float* edge_x, const float* pred, const float* edge_pred,
                            float* x_mean, float* edge_mean, void* stream);
 
+/* Graph-replayable form of one denoise iteration: everything that changes from one iteration to the next
+ * is read from device memory, so the launch sequence [ds_step_begin, ds_forward, ds_sampler_step_philox_dev] has constant
+ * arguments and can be captured once (hipGraph) and replayed - small batches are otherwise bound by host launch work.
+ *   table [S,4] device: (c_x, c_pred, sigma, noise_level) per step (sampling.py:572-584,604-606);
+ *   step  device int32: ds_step_begin increments it (so it must hold i-1 before iteration i) and fills noise_level[0..B)
+ *         with table[*step][3]; ds_sampler_step_philox_dev reads the coefficients and the Philox draw index from *step. */
+int ds_step_begin(const float* table, int32_t n_steps, int32_t* step, int32_t B, float* noise_level, void* stream);
+int ds_sampler_step_philox_dev(const ds_layout* L, const float* table, const int32_t* step, float temperature,
+                               uint64_t seed, const int64_t* mol_id, float* x, float* edge_x, const float* pred,
+                               const float* edge_pred, float* x_mean, float* edge_mean, void* stream);
+
 /* post_process (sampling.py:53-97, compress_edge=True, centered=True, normalize_factors 1,4,4,1):
  * pos_out [B,N,3] f32, atom_type [B,N] i32 (argmax), fc [B,N] i32 (round(4*x)), edge_type [B,N,N] f32 in {0,1,2,3}. */
 int ds_post_process(const ds_layout* L, const float* xh, const float* edge_x,

@@ -738,6 +738,40 @@ def test_philox_sampling_is_batch_independent_and_topk(gpu_device):
     assert torch.equal(k3[0][0], a[0][0])                                # slot 0 is slot 0 in both runs
 
 
+def test_graph_replay_equals_eager(gpu_device):
+    """hipGraph replay of the denoise iteration (device-side step index, in-place self-conditioning buffer) gives the
+    eager launch sequence's result bit for bit, also when a pass is advanced in slices."""
+    from diffspectra_amd import filler, sampling as S
+    from diffspectra_amd.noise_schedule import NoiseScheduleVP
+    cfg, model = gpu_model("allspectra", gpu_device)
+    cfg = cfg.clone()
+    cfg.sampling.steps = 13
+    d = gpu_device
+    n_atoms = [5, 29, 2, 17, 9, 1, 12]
+    node_mask, edge_mask = filler.masks_from_n_atoms(n_atoms)
+    ctx = to_dev(cases.spectra_for("allspectra", len(n_atoms), salt=9), d)
+    ids = torch.arange(100, 100 + len(n_atoms))
+    outs = {}
+    with swapped_weights(model, lambda sd: cases.readout_diverse(sd, "allspectra_S5")):
+        for mode, slices in (("eager", [13]), ("graph", [13]), ("graph_sliced", [1, 1, 4, 7]), ("graph_late", [3, 10])):
+            sampler = S._make_sampler(cfg, NoiseScheduleVP("cosine"), 1e-3, 0.9)
+            sampler.use_graph = mode != "eager"
+            st = sampler.begin(model, None, node_mask.to(d), edge_mask.to(d), None, ctx, mol_ids=ids, seed=7)
+            if mode == "graph_late":
+                sampler.use_graph = False                     # first slice eager (ping-pong buffers), then switch
+            for k, n in enumerate(slices):
+                if mode == "graph_late" and k == 1:
+                    sampler.use_graph = True
+                done = sampler.advance(st, n)
+            assert done and st.i == 13
+            assert (st.graph is not None) == (mode != "eager")
+            outs[mode] = (st.x_mean.clone(), st.edge_mean.clone(), st.x.clone())
+    for mode in ("graph", "graph_sliced", "graph_late"):
+        for a, b in zip(outs["eager"], outs[mode]):
+            assert torch.equal(a, b), f"{mode} differs from the eager launch sequence"
+    assert float(outs["eager"][0].abs().max()) > 0.1
+
+
 def _rank_worker(rank, world, port, out_path):
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -1425,6 +1425,54 @@ __global__ void k_post_process(ds_layout L, const float* __restrict__ xh, const 
   }
 }
 
+// Stability check, one workgroup per molecule (evaluation/stability.py:40-73; tables of evaluation/bond_analyze.py:5-45 for
+// H, C, N, O, F; 0 = no such bond).  Thread a walks the other atoms of its molecule.
+__constant__ int c_bond1[5][5] = {{74, 109, 101, 96, 92}, {109, 154, 147, 143, 135}, {101, 147, 145, 140, 136},
+                                  {96, 143, 140, 148, 142}, {92, 135, 136, 142, 142}};
+__constant__ int c_bond2[5][5] = {{0, 0, 0, 0, 0}, {0, 134, 129, 120, 0}, {0, 129, 125, 121, 0}, {0, 120, 121, 121, 0}, {0, 0, 0, 0, 0}};
+__constant__ int c_bond3[5][5] = {{0, 0, 0, 0, 0}, {0, 120, 116, 113, 0}, {0, 116, 110, 0, 0}, {0, 113, 0, 0, 0}, {0, 0, 0, 0, 0}};
+__constant__ int c_valence[5] = {1, 4, 3, 2, 1};
+__global__ __launch_bounds__(64) void k_check_stability(ds_layout L, const float* __restrict__ pos, const int32_t* __restrict__ atom_type,
+                                                        int32_t* __restrict__ bond_order, int32_t* __restrict__ nr_stable,
+                                                        int32_t* __restrict__ mol_stable) {
+  __shared__ float px[32], py[32], pz[32];
+  __shared__ int ty[32], dn[32];
+  const int m = blockIdx.x, a = threadIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0;
+  if (n <= 0) { if (a == 0) { nr_stable[m] = 0; mol_stable[m] = 1; } return; }
+  if (a < n) {
+    const int d = L.node_dense[n0 + a];
+    dn[a] = d;
+    px[a] = pos[(size_t)d * 3]; py[a] = pos[(size_t)d * 3 + 1]; pz[a] = pos[(size_t)d * 3 + 2];
+    ty[a] = min(max(atom_type[d], 0), 4);
+  }
+  __syncthreads();
+  int ok = 0;
+  if (a < n) {
+    int bonds = 0;
+    const int ta = ty[a], N = L.N;
+    for (int b = 0; b < n; ++b) {
+      if (b == a) continue;
+      const float dx = px[a] - px[b], dy = py[a] - py[b], dz = pz[a] - pz[b];
+      const float d = __fmul_rn(__fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz))), 100.0f);
+      const int tb = ty[b];
+      int order = 0;
+      if (d < (float)(c_bond1[ta][tb] + 10)) {
+        order = 1;
+        if (c_bond2[ta][tb] != 0 && d < (float)(c_bond2[ta][tb] + 5)) {
+          order = 2;
+          if (c_bond3[ta][tb] != 0 && d < (float)(c_bond3[ta][tb] + 3)) order = 3;
+        }
+      }
+      bonds += order;
+      if (bond_order) bond_order[(size_t)dn[a] * N + (dn[b] - m * N)] = order;
+    }
+    ok = bonds == c_valence[ta] ? 1 : 0;
+  }
+  const int cnt = __popcll(__ballot(ok != 0));
+  if (a == 0) { nr_stable[m] = cnt; mol_stable[m] = cnt == n ? 1 : 0; }
+}
+
 // SpecFormer residual-score attention (specformer.py:401-424): one workgroup per (molecule, head, 64-query tile).
 // qkv [B, L, 3*heads*dk] (q | k | v); scores [B, heads, L, L] holds prev on entry (if has_prev) and the new
 // pre-softmax scores on exit; out [B, L, heads*dk].
@@ -1806,6 +1854,16 @@ int ds_post_process(const ds_layout* L, const float* xh, const float* edge_x, fl
   if (hipMemsetAsync(fc, 0, nb * sizeof(int32_t), s) != hipSuccess) return DS_ERR_LAUNCH;
   if (hipMemsetAsync(edge_type, 0, nb * L->N * sizeof(float), s) != hipSuccess) return DS_ERR_LAUNCH;
   hipLaunchKernelGGL(k_post_process, dim3(L->B), dim3(128), 0, s, *L, xh, edge_x, pos_out, atom_type, fc, edge_type);
+  return launch_status();
+}
+
+int ds_check_stability(const ds_layout* L, const float* pos, const int32_t* atom_type, int32_t* bond_order, int32_t* nr_stable,
+                       int32_t* mol_stable, void* stream) {
+  if (!L || !pos || !atom_type || !nr_stable || !mol_stable) return DS_ERR_ARG;
+  if (L->B <= 0 || L->max_n > DS_MAX_ATOMS || L->max_n > L->N) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (bond_order && hipMemsetAsync(bond_order, 0, (size_t)L->B * L->N * L->N * sizeof(int32_t), s) != hipSuccess) return DS_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_check_stability, dim3(L->B), dim3(64), 0, s, *L, pos, atom_type, bond_order, nr_stable, mol_stable);
   return launch_status();
 }
 

@@ -441,6 +441,20 @@ class DmtEngine:
                                                  _ptr(edge_pred), _ptr(x_mean), _ptr(edge_mean), _stream())
         _check(st, "ds_sampler_step_philox_dev")
 
+    def check_stability(self, L, pos, atom_type, want_orders: bool = True):
+        """``ds_check_stability`` on the tensors ``post_process`` left on the GPU: (mol_stable [B] bool, nr_stable [B],
+        n_atoms [B], bond_order [B,N,N] int64 or None)."""
+        dev = self.device
+        pos = _f32c(pos, dev)
+        at = atom_type.detach().to(device=dev, dtype=torch.int32).contiguous()
+        order = torch.empty(L.B, L.N, L.N, dtype=torch.int32, device=dev) if want_orders else None
+        nr = torch.empty(L.B, dtype=torch.int32, device=dev)
+        ok = torch.empty(L.B, dtype=torch.int32, device=dev)
+        _check(self.lib.ds_check_stability(C.byref(L.c), _ptr(pos), _ptr(at), _ptr(order), _ptr(nr), _ptr(ok), _stream()),
+               "ds_check_stability")
+        n_atoms = torch.as_tensor(L.n_atoms, device=dev)
+        return ok.bool(), nr.long(), n_atoms, (order.long() if want_orders else None)
+
     def post_process(self, L, xh, edge_x):
         dev = self.device
         pos = torch.empty(L.B, L.N, 3, dtype=torch.float32, device=dev)

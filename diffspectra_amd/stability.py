@@ -54,9 +54,16 @@ def bond_orders(pos: torch.Tensor, atom_type: torch.Tensor, node_mask: torch.Ten
     return order * pair_ok.long()
 
 
-def check_stability_batch(pos: torch.Tensor, atom_type: torch.Tensor, node_mask: torch.Tensor):
+def check_stability_batch(pos: torch.Tensor, atom_type: torch.Tensor, node_mask: torch.Tensor, engine=None):
     """-> ``(molecule_stable [B] bool, nr_stable_atoms [B], n_atoms [B], order [B,N,N])`` - the first three values of
-    ``check_stability`` (``stability.py:58-73``) for every molecule of the batch."""
+    ``check_stability`` (``stability.py:58-73``) for every molecule of the batch.
+
+    With ``engine`` (``model.engine()``) the decision runs in the HIP library (``ds_check_stability``, one workgroup per
+    molecule) on the tensors the sampler left on the GPU; without it, as tensor operations on whatever device the inputs
+    live on (host-side analytics, where the reference runs its Python loops)."""
+    if engine is not None:
+        L, _ = engine.layout_for(node_mask)
+        return engine.check_stability(L, pos, atom_type)
     order = bond_orders(pos, atom_type, node_mask)
     mask = node_mask.reshape(pos.shape[0], pos.shape[1]).bool()
     valence = torch.tensor(_VALENCE, dtype=torch.long, device=pos.device)[atom_type.long()]

@@ -19,6 +19,7 @@
  *   ds_initial_noise /    sample_combined_position_feature_noise, sample_symmetric_edge_feature_noise
  *   ds_sampler_step_philox                                    models/utils.py:67-106 (+ sampling.py:442-447,604-624)
  *   ds_post_process       post_process + inverse scaler       sampling.py:53-97, utils.py:88-103
+ *   ds_check_stability    check_stability (distance half)     evaluation/stability.py:40-73, evaluation/bond_analyze.py:108-133
  *   ds_gemm / ds_spec_*   SpecFormer.forward                  models/specformer.py:77-120,167-200,279-309,345-425,457-470
  *
  * Data layout ("packed-ragged", symmetric pair storage — DESIGN.md §3):
@@ -211,6 +212,14 @@ int ds_sampler_step_philox_dev(const ds_layout* L, const float* table, const int
  * pos_out [B,N,3] f32, atom_type [B,N] i32 (argmax), fc [B,N] i32 (round(4*x)), edge_type [B,N,N] f32 in {0,1,2,3}. */
 int ds_post_process(const ds_layout* L, const float* xh, const float* edge_x,
                     float* pos_out, int32_t* atom_type, int32_t* fc, float* edge_type, void* stream);
+
+/* 3-D stability check of generated molecules (evaluation/stability.py:40-73 with evaluation/bond_analyze.py:5-45,85,90,
+ * 108-133; QM9 atom set H, C, N, O, F): bond order of every atom pair from its distance in picometres (single if
+ * 100 d < L1 + 10, then double if a double-bond length exists and 100 d < L2 + 5, then triple if 100 d < L3 + 3), valence
+ * of every atom against allowed_bonds.  pos [B,N,3] Angstrom, atom_type [B,N] in 0..4 (the argmax ds_post_process wrote).
+ * bond_order [B,N,N] i32 (may be NULL), nr_stable [B] = atoms with the right valence, mol_stable [B] = 1 if all are. */
+int ds_check_stability(const ds_layout* L, const float* pos, const int32_t* atom_type, int32_t* bond_order,
+                       int32_t* nr_stable, int32_t* mol_stable, void* stream);
 
 /* SpecFormer pieces that are not plain GEMMs (specformer.py:385-425 residual-score attention; :119 LayerNorm).
  * qkv [B,L,3*heads*dk]; out [B,L,heads*dk]; scores: B*heads*L*L floats of caller-owned scratch that carries the

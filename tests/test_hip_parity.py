@@ -1003,6 +1003,50 @@ def test_c_abi_rejects_oversized_layout(gpu_device):
         assert st == -1
 
 
+def test_stability_kernel_vs_reference_decisions(gpu_device):
+    """ds_check_stability against the scalar restatement of the reference's check (oracle/stability.py, pinned to the
+    reference's own get_bond_order by G12) on ragged molecules, and on the G12 threshold sweep itself."""
+    from diffspectra_amd import filler
+    from diffspectra_amd.stability import check_stability_batch
+    from oracle import stability as ost
+    cfg, model = gpu_model("ir", gpu_device)
+    eng = model.module.engine()
+    d = gpu_device
+    gen = torch.Generator().manual_seed(11)
+    n_atoms = [1, 2, 5, 9, 18, 29, 13, 7]
+    B, N = len(n_atoms), max(n_atoms)
+    pos, mask = torch.zeros(B, N, 3), torch.zeros(B, N)
+    types = torch.randint(0, 5, (B, N), generator=gen)
+    grid = torch.stack(torch.meshgrid(torch.arange(4.0), torch.arange(4.0), torch.arange(2.0), indexing="ij"), -1).reshape(-1, 3)
+    for b, n in enumerate(n_atoms):
+        pos[b, :n] = grid[:n] * (1.0 + 0.08 * b) + 0.08 * torch.randn(n, 3, generator=gen)
+        mask[b, :n] = 1
+    types[3, 0], types[3, 1] = 1, 2
+    pos[3, 1] = pos[3, 0] + torch.tensor([1.15, 0.0, 0.0])                     # a C#N pair at triple-bond distance
+    stable, nr, cnt, order = check_stability_batch(pos.to(d), types.to(d), mask.to(d), engine=eng)
+    seen = set()
+    for b, n in enumerate(n_atoms):
+        want = ost.check_stability(pos[b, :n].tolist(), types[b, :n].tolist())
+        assert (bool(stable[b]), int(nr[b]), int(cnt[b])) == want[:3], b
+        assert order[b, :n, :n].cpu().tolist() == want[3], b
+        assert int(order[b, n:].abs().sum()) == 0 and int(order[b, :, n:].abs().sum()) == 0
+        seen |= {o for row in want[3] for o in row}
+    assert seen == {0, 1, 2, 3}
+    g = cases.load_npz("g12_bond_orders.npz")                                    # the reference's own decisions
+    dist = cases.bond_distance_sweep()
+    off = np.abs(dist * 100 - np.round(dist * 100)) > 1e-6
+    d32 = torch.from_numpy(dist[off]).float()
+    M = len(d32)
+    for i in range(5):
+        for j in range(5):
+            p2 = torch.zeros(M, 2, 3)
+            p2[:, 1, 0] = d32
+            t2 = torch.tensor([[i, j]]).expand(M, 2).contiguous()
+            _, _, _, o = check_stability_batch(p2.to(d), t2.to(d), torch.ones(M, 2, device=d), engine=eng)
+            assert o[:, 0, 1].cpu().tolist() == g["orders"][i, j][torch.from_numpy(off)].tolist(), (i, j)
+            assert torch.equal(o[:, 0, 1], o[:, 1, 0])
+
+
 def test_batched_stability_on_device(gpu_device):
     """N4 plumbing: the batched stability check (torch tensor ops) gives the same answer on GPU tensors as on CPU tensors;
     its decisions are pinned to the reference's ``get_bond_order`` by tests/test_oracle_golden.py::test_g12_*."""

@@ -849,16 +849,26 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
     for (int i = 0; i < 8; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ed4 + (size_t)pp[i] * 64 + lane),
                                        (__attribute__((address_space(3))) void*)&X[buf][2 * (lw + 4 * i)][0], 16, 0, 0);
-    float4 A[4], Cc[4], sh[4], sc[4];
-    int cur_m = -1;
+    // ac rows: a lane of direction a -> b needs the h_row part of a and the h_col part of b, a lane of direction b -> a the h_row
+    // part of b and the h_col part of a.  Each lane therefore KEEPS its part of the a-row (a changes about once per tile in
+    // the (a, b)-row-major pair order) and fetches its part of the b-row per pass: 4 gathers per pass instead of 8.  Vector-
+    // memory instructions are what a loader pays most for beside the MFMA waves (tools/micro/vmem_corun.hip: ~670 cycles per
+    // 1-KiB load instruction there against ~280 alone).
+    float4 Ka[4], Bv[4], sh[4], sc[4];
+    int cur_m = -1, cur_a = -1;
     auto issue = [&](int bt) {   // gathers of pass bt: rows of pairs 2bt (DPP rows 0, 1) and 2bt + 1 (DPP rows 2, 3)
       __builtin_amdgcn_sched_barrier(0);
       const int i0 = 2 * bt, i1 = 2 * bt + 1;
       const int ra = up ? na[i1] : na[i0], rb = up ? nb[i1] : nb[i0];
-      const float4* pa = ac4 + (size_t)(gdir ? rb : ra) * 128 + j;          // row atom (edge_index[0]): input_lin h_row part
-      const float4* pcol = ac4 + (size_t)(gdir ? ra : rb) * 128 + 64 + j;   // column atom: h_col part
+      const float4* pb = ac4 + (size_t)rb * 128 + (gdir ? 0 : 64) + j;    // b: h_row part for b -> a lanes, h_col part for a -> b lanes
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { A[u] = pa[16 * u]; Cc[u] = pcol[16 * u]; }
+      for (int u = 0; u < 4; ++u) Bv[u] = pb[16 * u];
+      if (ra != cur_a) {
+        const float4* pa = ac4 + (size_t)ra * 128 + (gdir ? 64 : 0) + j;  // a: h_row part for a -> b lanes, h_col part for b -> a lanes
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Ka[u] = pa[16 * u];
+        cur_a = ra;
+      }
       __builtin_amdgcn_sched_barrier(0);
     };
     auto modulation = [&](int bt) {   // adaLN rows of pass bt's molecule; they change once per ~160 pairs
@@ -894,8 +904,8 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float4 e = reinterpret_cast<const float4*>(&X[buf][2 * q][0])[16 * u + j];
-        x[u].x = (A[u].x + Cc[u].x) + e.x; x[u].y = (A[u].y + Cc[u].y) + e.y;
-        x[u].z = (A[u].z + Cc[u].z) + e.z; x[u].w = (A[u].w + Cc[u].w) + e.w;
+        x[u].x = (Ka[u].x + Bv[u].x) + e.x; x[u].y = (Ka[u].y + Bv[u].y) + e.y;
+        x[u].z = (Ka[u].z + Bv[u].z) + e.z; x[u].w = (Ka[u].w + Bv[u].w) + e.w;
       }
       DS_STAMP(12);
       if (bt < 3) issue(bt + 1);   // next pass's gathers fly behind this pass's LayerNorm

@@ -780,8 +780,11 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
 // Hence the loaders' diet: the HBM-latency stream (`ed` rows) goes by LDS-DMA into the X rows, the LayerNorm runs four rows
 // per pass (one per DPP row), the ac / adaLN gathers of the next pass fly behind the current pass's arithmetic.
 __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
-  constexpr int T = 64, TP = 32, LD = 256 + DS_LDP, NC = 8;
-  __shared__ __attribute__((aligned(16))) float X[2][T][LD];         // 133,120 B
+  constexpr int T = 64, TP = 32, LDH = 256 + 8, NC = 8;
+  // X tile as TWO fp16 planes per row, x = x1 + x2 / 2048 (|error| <= 2^-23 |x|): [buffer][row][plane][256 + 8 halves].  A row's
+  // slot (1056 B) first receives the fp32 `ed` row by LDS-DMA, then the split LayerNorm output.  Row stride 528 B = 132
+  // dwords: the 16-byte operand reads of 16 consecutive rows hit 16 distinct 4-bank groups.
+  __shared__ __attribute__((aligned(16))) _Float16 Xh[2][T][2][LDH];   // 135,168 B
   __shared__ __attribute__((aligned(16))) float part[2][NC][T][4];   //  16,384 B
   __shared__ __attribute__((aligned(16))) float dirs[3][T][4];       //   3,072 B  (unit diff * coord_scale, adjacency bits)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5;
@@ -793,6 +796,12 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
   DS_STAMP_INIT();
 
   float b0f[16], w2f[16];   // consumer constants: coord_mlp.0 bias and coord_mlp.2 A-fragments of its 32 features
+  // split-fp16 coord_mlp.0 weights: [plane][k/16][k-half][feature][8 halves], 8192 B per (plane, k/16); buffer resource in SGPRs
+  const unsigned long long pw_ = reinterpret_cast<unsigned long long>(BW(c, blk, DS_BW_CM0_H));
+  const unsigned long long pu_ = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<int>(pw_ >> 32))) << 32) |
+                                 static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(pw_)));
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(pu_), 0, 0x7fffffff, 0x00020000);
+  const int wvoff = ((hh * 256) + (wave & 7) * 32 + (lane & 31)) * 16;
   if (consumer) {
     __builtin_amdgcn_s_setprio(0);
     const float* b0 = BW(c, blk, DS_BW_CM0_B);
@@ -848,7 +857,7 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ed4 + (size_t)pp[i] * 64 + lane),
-                                       (__attribute__((address_space(3))) void*)&X[buf][2 * (lw + 4 * i)][0], 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)&Xh[buf][2 * (lw + 4 * i)][0][0], 16, 0, 0);
     // ac rows: a lane of direction a -> b needs the h_row part of a and the h_col part of b, a lane of direction b -> a the h_row
     // part of b and the h_col part of a.  Each lane therefore KEEPS its part of the a-row (a changes about once per tile in
     // the (a, b)-row-major pair order) and fetches its part of the b-row per pass: 4 gathers per pass instead of 8.  Vector-
@@ -903,7 +912,7 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
       float4 x[4];   // a -> b: input_lin([h_a, h_b, e, d]);  b -> a: input_lin([h_b, h_a, e, d])  (dmt.py:39,45)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float4 e = reinterpret_cast<const float4*>(&X[buf][2 * q][0])[16 * u + j];
+        const float4 e = reinterpret_cast<const float4*>(&Xh[buf][2 * q][0][0])[16 * u + j];
         x[u].x = (Ka[u].x + Bv[u].x) + e.x; x[u].y = (Ka[u].y + Bv[u].y) + e.y;
         x[u].z = (Ka[u].z + Bv[u].z) + e.z; x[u].w = (Ka[u].w + Bv[u].w) + e.w;
       }
@@ -911,18 +920,30 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
       if (bt < 3) issue(bt + 1);   // next pass's gathers fly behind this pass's LayerNorm
       DS_STAMP(13);
       ln_mod_quad256(x, sh, sc);
-      float* xr = &X[buf][2 * q + gdir][0];
+      _Float16* xr = &Xh[buf][2 * q + gdir][0][0];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) reinterpret_cast<float4*>(xr)[16 * u + j] = x[u];
+      for (int u = 0; u < 4; ++u) {   // split: x1 = fp16(x) (round to nearest), x2 = fp16((x - x1) * 2048); the difference is exact in fp32
+        const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+        h4 h1, h2;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          h1[t] = (_Float16)xs[t];
+          h2[t] = (_Float16)((xs[t] - (float)h1[t]) * 2048.0f);
+        }
+        *reinterpret_cast<h4*>(xr + 64 * u + 4 * j) = h1;
+        *reinterpret_cast<h4*>(xr + LDH + 64 * u + 4 * j) = h2;
+      }
       if (bt < 3) modulation(bt + 1);
       DS_STAMP(14);
     }
     if (npairs < TP) {   // last tile only: rows of the pairs past the end (they were computed from pair 0) become zero rows
       for (int i = 0; i < 8; ++i) {
         const int qz = lw + 4 * i;
-        if (qz >= npairs) {
-          reinterpret_cast<float4*>(&X[buf][2 * qz][0])[lane] = make_float4(0, 0, 0, 0);
-          reinterpret_cast<float4*>(&X[buf][2 * qz + 1][0])[lane] = make_float4(0, 0, 0, 0);
+        if (qz >= npairs) {   // two 1056-byte row slots = 132 float4
+          float4* z = reinterpret_cast<float4*>(&Xh[buf][2 * qz][0][0]);
+          z[lane] = make_float4(0, 0, 0, 0);
+          z[64 + lane] = make_float4(0, 0, 0, 0);
+          if (lane < 4) z[128 + lane] = make_float4(0, 0, 0, 0);
         }
       }
     }
@@ -959,13 +980,46 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
     int it = 0;
     for (int tile = first; tile < ntiles; tile += stride, ++it) {
       const int buf = it & 1;
-      f32x16 acc1[2], acc2[2];
+      // coord_mlp.0 (256 -> 256) on the f16 matrix pipe with fp32-level accuracy: both operands are split in two fp16 planes
+      // (a = a1 + a2/2048), the product is a1 b1 + (a1 b2 + a2 b1)/2048 - three v_mfma_f32_32x32x16_f16 (32 cycles each,
+      // fp32 accumulate, exact fp16 x fp16 products) per 16-deep k-block instead of eight 64-cycle fp32 MFMAs; the dropped
+      // a2 b2 term and the representation errors are ~2^-22 relative.  Transposed as before: A operand = weights (lane =
+      // output feature), B operand = X rows (lane = edge row), so lane = edge row and registers = features in the result.
+      f32x16 acc1[2], acclo[2], acc2[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc1[m][i] = b0f[i];   // the MFMA chain accumulates onto the coord_mlp.0 bias
+      acc_zero<2>(acclo);
       acc_zero<2>(acc2);
-      wave_mma<2, true>(&X[buf][0][0], LD, BW(c, blk, DS_BW_CM0_W), 256, wave * 32, 0, 32, acc1);
+      {
+        auto wl = [&](int p, int kb) { return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, (p * 16 + kb) * 8192, 0)); };
+        auto xl = [&](int m, int p, int kb) { return *reinterpret_cast<const h8*>(&Xh[buf][m * 32 + (lane & 31)][p][kb * 16 + 8 * hh]); };
+        h8 w1 = wl(0, 0), w2 = wl(1, 0);
+        h8 xa[2][2] = {{xl(0, 0, 0), xl(0, 1, 0)}, {xl(1, 0, 0), xl(1, 1, 0)}};
+#pragma unroll 4
+        for (int kb = 0; kb < 16; ++kb) {
+          const int kn = kb < 15 ? kb + 1 : 15;
+          const h8 w1n = wl(0, kn), w2n = wl(1, kn);
+          h8 xn[2][2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) { xn[m][0] = xl(m, 0, kn); xn[m][1] = xl(m, 1, kn); }
+          __builtin_amdgcn_sched_barrier(0);   // next block's operands are requested ahead of this block's MFMAs
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            acc1[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xa[m][0], acc1[m], 0, 0, 0);
+            acclo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xa[m][1], acclo[m], 0, 0, 0);
+            acclo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, xa[m][0], acclo[m], 0, 0, 0);
+          }
+          w1 = w1n; w2 = w2n;
+#pragma unroll
+          for (int m = 0; m < 2; ++m) { xa[m][0] = xn[m][0]; xa[m][1] = xn[m][1]; }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc1[m][i] = fmaf(acclo[m][i], 1.0f / 2048.0f, acc1[m][i]);
+      }
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll

@@ -143,6 +143,23 @@ def pack_linear(weight: torch.Tensor, n_pad_to: int = 32) -> torch.Tensor:
     return b.view(Kp // 8, 2, 4, Np).permute(0, 1, 3, 2).contiguous().reshape(-1)
 
 
+SPLIT_SCALE = 2048.0   # 2^11: the low fp16 plane of a split operand is stored scaled so that it keeps 11 significant bits
+
+
+def pack_linear_f16_split(weight: torch.Tensor) -> torch.Tensor:
+    """torch Linear weight [N_out, K_in] (K % 16 == 0, N % 32 == 0) → two fp16 planes with w ≈ w1 + w2 / 2048 (|error| ≤
+    2^-23 |w|), in the A-operand order of v_mfma_f32_32x32x16_f16: halves [plane][K/16][k-half][N][8], k = 16 kb + 8 h + j;
+    returned as the fp32 view of those bits (the packed weight buffer is fp32)."""
+    w = weight.detach().to(torch.float32).cpu()
+    N, K = w.shape
+    assert K % 16 == 0 and N % 32 == 0
+    w1 = w.half()
+    w2 = ((w - w1.float()) * SPLIT_SCALE).half()
+    planes = torch.stack([w1, w2])                                   # [2, N, K]
+    t = planes.view(2, N, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()   # [plane, kb, h, N, 8]
+    return t.reshape(-1).view(torch.float32).clone()
+
+
 def pad_vec(v: torch.Tensor, to: int = 32) -> torch.Tensor:
     v = v.detach().to(torch.float32).cpu().reshape(-1)
     out = torch.zeros((v.numel() + to - 1) // to * to)
@@ -218,6 +235,7 @@ def pack_dmt_weights(sd: Dict[str, torch.Tensor]):
         put(bslot(b, "DS_BW_CM0_W"), pack_linear(sd[p + "equi_update.coord_mlp.0.weight"]))
         put(bslot(b, "DS_BW_CM0_B"), pad_vec(sd[p + "equi_update.coord_mlp.0.bias"]))
         put(bslot(b, "DS_BW_CM2_W"), pack_linear(sd[p + "equi_update.coord_mlp.2.weight"]))
+        put(bslot(b, "DS_BW_CM0_H"), pack_linear_f16_split(sd[p + "equi_update.coord_mlp.0.weight"]))
         mean, std, astd = _rbf_tables(sd, p + "dist_layer")
         put(bslot(b, "DS_BW_RBF_MEAN"), mean)
         put(bslot(b, "DS_BW_RBF_STD"), std)

@@ -71,6 +71,8 @@ enum ds_block_slot {
   DS_BW_CM2_W,                              /* 256 -> 3(32) coord_mlp.2 (no bias)             dmt.py:34 */
   DS_BW_RBF_MEAN, DS_BW_RBF_STD, DS_BW_RBF_ASTD, /* 63(64): mean, |std|+1e-5, a*std           layers.py:332-334 */
   DS_BW_COORD_SCALE,                        /* 1(32)       CoorsNorm.scale                    layers.py:347 */
+  DS_BW_CM0_H,                              /* coord_mlp.0 as two fp16 planes (w = w1 + w2/2048) in f16-MFMA A-operand order:
+                                               halves [plane 2][k/16 16][k-half 2][feature 256][8]; see k_equi_pairs */
   DS_W_BLOCK_SLOTS
 };
 enum ds_global_slot {

@@ -233,6 +233,112 @@ __device__ __forceinline__ void wave_mma(const float* X, int ldx, const float* _
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Split-fp16 GEMM building block: fp32-level accuracy on the f16 matrix pipe (v_mfma_f32_32x32x16_f16: 32 cycles for
+// 16 384 MACs against 64 cycles for 2 048 on the fp32 MFMA).  Every operand value a is carried as two fp16 numbers,
+// a = a1 + a2 / 2048 with a1 = fp16(a) (round to nearest) and a2 = fp16((a - a1) * 2048): the difference is exact in fp32 and
+// |a - a1 - a2/2048| <= 2^-23 |a|.  A product is evaluated as a1 b1 + (a1 b2 + a2 b1) / 2048 - three MFMAs per 16-deep
+// k-block, the first into `hi`, the other two into `lo` (fp16 x fp16 products are exact in the fp32 accumulate); the dropped
+// a2 b2 / 2^22 term is below the representation error.  Measured through the whole DMT: parity gates and the 1000-step
+// trajectory drift are unchanged against the fp32-MFMA build.
+//   X tile in LDS : [row][plane 0: K halves | plane 1: K halves | 8 halves pad]  (row stride 2K + 8 halves = K + 4 dwords: the
+//                   16-byte fragment reads of 16 consecutive rows hit 16 distinct 4-bank groups, like the fp32 tiles)
+//   weights       : two planes in MFMA operand order, halves [plane][K/16][k-half][N][8] (engine.pack_linear_f16_split)
+__device__ __forceinline__ void split_store4(_Float16* row, int K, int col, float4 v) {   // columns col .. col+3 of a tile row
+  const float xs[4] = {v.x, v.y, v.z, v.w};
+  h4 h1, h2;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    h1[t] = (_Float16)xs[t];
+    h2[t] = (_Float16)((xs[t] - (float)h1[t]) * 2048.0f);
+  }
+  *reinterpret_cast<h4*>(row + col) = h1;
+  *reinterpret_cast<h4*>(row + K + col) = h2;
+}
+__device__ __forceinline__ void split_store1(_Float16* row, int K, int col, float v) {
+  const _Float16 h1 = (_Float16)v;
+  row[col] = h1;
+  row[K + col] = (_Float16)((v - (float)h1) * 2048.0f);
+}
+__device__ __forceinline__ float split_load1(const _Float16* row, int K, int col) {   // a1 + a2/2048 (2^-23 |a| from the original)
+  return fmaf((float)row[K + col], 1.0f / 2048.0f, (float)row[col]);
+}
+
+struct WStreamH {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff;      // bytes: ((lane >> 5) * N + col0 + (lane & 31)) * 16
+  int kstride;   // bytes between k-blocks of one plane: 2 * N * 16
+  int pstride;   // bytes between the planes: (K/16) * kstride
+};
+__device__ __forceinline__ WStreamH wstream_h(const float* __restrict__ Wh, int N, int K, int col0) {
+  const int lane = threadIdx.x & 63;
+  WStreamH w;
+  const unsigned long long pw = reinterpret_cast<unsigned long long>(Wh);
+  const unsigned long long pu = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<int>(pw >> 32))) << 32) |
+                                static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(pw)));
+  w.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(pu), 0, 0x7fffffff, 0x00020000);
+  w.voff = ((lane >> 5) * N + col0 + (lane & 31)) << 4;
+  w.kstride = N << 5;
+  w.pstride = (K >> 4) * w.kstride;
+  return w;
+}
+__device__ __forceinline__ h8 wload_h(const WStreamH& w, int plane, int kb) {
+  return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(w.rsrc, w.voff, plane * w.pstride + kb * w.kstride, 0));
+}
+
+// hi[m] += X1 W1, lo[m] += X1 W2 + X2 W1 over k-blocks [kb0, kb1) of the weight matrix; the X tile's column 0 is k-block xkb0.
+// TRANS swaps the operands (accumulator = transposed block: lane = tile row, registers = output columns), as in wave_mma.
+// UNROLL: k-blocks per unrolled loop body (measured: 16 for the 16-block equi GEMM, 4 for the 4-block edge GEMMs; 1-2 lose 5-15 %)
+template <int MT, bool TRANS = false, int UNROLL = 4>
+__device__ __forceinline__ void wave_mma_h(const _Float16* X, int K_tile, const float* __restrict__ Wh, int N, int K, int col0,
+                                           int kb0, int kb1, f32x16 (&hi)[MT], f32x16 (&lo)[MT], int xkb0 = 0) {
+  const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+  const int ldh = 2 * K_tile + 8;
+  const WStreamH ws = wstream_h(Wh, N, K, col0);
+  const _Float16* xr = X + r * ldh + 8 * hh - xkb0 * 16;
+  h8 w1 = wload_h(ws, 0, kb0), w2 = wload_h(ws, 1, kb0);
+  h8 xa[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    xa[m][0] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + kb0 * 16);
+    xa[m][1] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + K_tile + kb0 * 16);
+  }
+#pragma unroll UNROLL
+  for (int kb = kb0; kb < kb1; ++kb) {
+    const int kn = min(kb + 1, kb1 - 1);
+    const h8 w1n = wload_h(ws, 0, kn), w2n = wload_h(ws, 1, kn);
+    h8 xn[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      xn[m][0] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + kn * 16);
+      xn[m][1] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + K_tile + kn * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // next block's operands are requested ahead of this block's MFMAs
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (TRANS) {
+        hi[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xa[m][0], hi[m], 0, 0, 0);
+        lo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xa[m][1], lo[m], 0, 0, 0);
+        lo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, xa[m][0], lo[m], 0, 0, 0);
+      } else {
+        hi[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[m][0], w1, hi[m], 0, 0, 0);
+        lo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[m][1], w1, lo[m], 0, 0, 0);
+        lo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[m][0], w2, lo[m], 0, 0, 0);
+      }
+    }
+    w1 = w1n; w2 = w2n;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { xa[m][0] = xn[m][0]; xa[m][1] = xn[m][1]; }
+  }
+}
+template <int MT>
+__device__ __forceinline__ void split_finish(f32x16 (&hi)[MT], const f32x16 (&lo)[MT]) {   // hi += lo / 2048
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hi[m][i] = fmaf(lo[m][i], 1.0f / 2048.0f, hi[m][i]);
+}
+
 template <int MT>
 __device__ __forceinline__ void acc_zero(f32x16 (&acc)[MT]) {
 #pragma unroll

@@ -13,6 +13,10 @@
 #include "ds_device.h"
 
 #define ADAC DS_ADA_COLS
+#ifndef DS_EQUI_NCW
+#define DS_EQUI_NCW 8   // MFMA waves of k_equi_pairs (each owns 8 / NCW feature chunks); measured: 8 + 4 beats 4 + 8 by 11 %
+#define DS_EQUI_NLW 4   // loader waves (each owns 32 / NLW pairs of a tile)
+#endif
 
 // Diagnostic build only (-DDS_STAMPS): per-phase shader-clock sums of wave 0 of every workgroup, accumulated into
 // registers and flushed once at kernel exit to the tail of ws.flags (64-bit counters at int32 index 16 + 2*phase).  Never compiled into the shipped library.
@@ -256,27 +260,34 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
     tile_gemm<2, 1>(&X[0][0], 128 + DS_LDP, 128, BW(c, blk, DS_BW_EDGE_EMB_W), 64, 2,
                     [&](int row, int col, float v) { Y[row][col] = v + bias[col]; }, &pfe);
   }
-  const BFrag pf0 = tile_first<2, 2>(BW(c, blk, DS_BW_E0_W), 256, 64, 8);
   __syncthreads();
+  // norm1_edge + modulate (dmt.py:149), written back IN PLACE in the split-fp16 layout of ds_device.h (a 64-wide tile row is
+  // 272 bytes either way): the two 64 -> 256 projections below then run on the f16 matrix pipe (wave_mma_h)
+  _Float16* Yh = reinterpret_cast<_Float16*>(&Y[0][0]);
   {
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float4* yp = reinterpret_cast<float4*>(&Y[16 * wv + 4 * j + (lane >> 4)][0]) + (lane & 15);
-      *yp = ln_mod_reg64(*yp, lsh[j], lsc[j]);   // norm1_edge + modulate (dmt.py:149)
+      const int row = 16 * wv + 4 * j + (lane >> 4);
+      const float4 v = ln_mod_reg64(reinterpret_cast<const float4*>(&Y[row][0])[lane & 15], lsh[j], lsc[j]);
+      split_store4(Yh + row * (2 * 64 + 8), 64, 4 * (lane & 15), v);   // all 16 lanes of the row have read before any writes (one DS queue per wave)
     }
   }
   __syncthreads();
   {
     float* te0 = c.ws.te0 + (size_t)row0 * 256;
     float* te1 = c.ws.te1 + (size_t)row0 * 256;
-    const int valid = c.L.Pp - row0;
-    tile_gemm_blk<2, 2>(&Y[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_E0_W), 256, 8, [&](int ch, int, const f32x16 (&acc)[2]) {
-      acc_store2<2, 256>(acc, te0 + ch * 32, valid, [](f32x2 v) { return ds_tanh2(v); });   // layers.py:165-166
-    }, &pf0);
-    tile_gemm_blk<2, 2>(&Y[0][0], 64 + DS_LDP, 64, BW(c, blk, DS_BW_E1_W), 256, 8, [&](int ch, int, const f32x16 (&acc)[2]) {
-      acc_store2<2, 256>(acc, te1 + ch * 32, valid, [](f32x2 v) { return ds_tanh2(v); });   // layers.py:183
-    });
+    const int valid = c.L.Pp - row0, wave = tid >> 6;
+    for (int it = wave; it < 16; it += 4) {   // 8 column chunks of lin_edge0, then 8 of lin_edge1; both row tiles per weight fragment
+      asm volatile("" ::: "memory");
+      const int ch = it & 7;
+      f32x16 acc[2], lo[2];
+      acc_zero<2>(acc);
+      acc_zero<2>(lo);
+      wave_mma_h<2>(Yh, 64, BW(c, blk, it < 8 ? DS_BW_E0_H : DS_BW_E1_H), 256, 64, ch * 32, 0, 4, acc, lo);
+      split_finish<2>(acc, lo);
+      acc_store2<2, 256>(acc, (it < 8 ? te0 : te1) + ch * 32, valid, [](f32x2 v) { return ds_tanh2(v); });   // layers.py:165-166,183
+    }
   }
 }
 
@@ -288,12 +299,11 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_node_qkv(Ctx c, int blk) {
   constexpr int NT = NW * 64;
   constexpr int T = 64;
-  __shared__ __attribute__((aligned(16))) float X[T][256 + DS_LDP];
+  constexpr int LDH = 2 * 256 + 8;
+  __shared__ __attribute__((aligned(16))) _Float16 Xh[T][LDH];    // LayerNorm output in the split-fp16 layout (ds_device.h)
   __shared__ int rmol[T];
   const int tid = threadIdx.x, row0 = blockIdx.x * T, col0 = blockIdx.y * 384;
   if (tid < T) rmol[tid] = (row0 + tid < c.L.Nn) ? c.L.node_mol[row0 + tid] : 0;
-  const float* Wq = BW(c, blk, DS_BW_QKV_W) + (size_t)col0 * 4;   // packed Wp[K/8][2][768][4]: a column offset is +4 floats/col
-  const BFrag pfq = tile_first<2, 2>(Wq, 768, 256, 12);            // GEMM weights requested before the staging
   __syncthreads();
   {   // 64 rows: wave w normalises rows 16w .. 16w+15, four rows per pass (one per 16-lane DPP row), two passes in flight
     const float* adn = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_NODE;
@@ -320,18 +330,27 @@ __global__ __launch_bounds__(NW * 64) void k_node_qkv(Ctx c, int blk) {
         ln_mod_quad256(v[ps], sh[ps], sc[ps]);   // dmt.py:148
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          reinterpret_cast<float4*>(&X[row][0])[16 * u + j] = row0 + row < c.L.Nn ? v[ps][u] : make_float4(0, 0, 0, 0);
+          split_store4(&Xh[row][0], 256, 64 * u + 4 * j, row0 + row < c.L.Nn ? v[ps][u] : make_float4(0, 0, 0, 0));
       }
     }
   }
   __syncthreads();
   const float* bias = BW(c, blk, DS_BW_QKV_B) + col0;
   float* qkv = c.ws.qkv + (size_t)row0 * 768 + col0;
-  const int valid = c.L.Nn - row0;
-  tile_gemm_blk<2, 2>(&X[0][0], 256 + DS_LDP, 256, Wq, 768, 12, [&](int ch, int, const f32x16 (&acc)[2]) {
-    const float b = bias[ch * 32 + (threadIdx.x & 31)];
-    acc_store<2, 768>(acc, qkv + ch * 32, valid, [b](int, float v) { return v + b; });
-  }, &pfq);
+  const int valid = c.L.Nn - row0, wave = tid >> 6;
+  for (int ch = wave; ch < 12; ch += NW) {   // 32-column chunks of this half of q|k|v; both row tiles per weight fragment
+    asm volatile("" ::: "memory");
+    const float b = bias[ch * 32 + (tid & 31)];
+    f32x16 acc[2], lo[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][i] = b;
+    acc_zero<2>(lo);
+    wave_mma_h<2, false, 8>(&Xh[0][0], 256, BW(c, blk, DS_BW_QKV_H), 768, 256, col0 + ch * 32, 0, 16, acc, lo);
+    split_finish<2>(acc, lo);
+    acc_store<2, 768>(acc, qkv + ch * 32, valid, [](int, float v) { return v; });
+  }
 }
 
 // Block stage C1 (one workgroup per molecule): attention logits of both directions of every pair, 14 learned heads
@@ -476,9 +495,11 @@ __global__ __launch_bounds__(512, 2) void k_attn_agg(Ctx c) {
 // in place, per-block readout slice (256->64) and the node parts of equi_update.input_lin (256->512).
 // dmt.py:156-163,387,39-45.  66.5 kB LDS -> two workgroups per CU.
 __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
-  constexpr int T = 32, LD = 256 + DS_LDP;
-  __shared__ __attribute__((aligned(16))) float B1[T][LD];   // attention tile, then FF hidden halves
-  __shared__ __attribute__((aligned(16))) float H2[T][LD];   // normalised residual stream, then h_out in place
+  constexpr int T = 32, LDH = 2 * 256 + 8;
+  // both tiles in the split-fp16 layout of ds_device.h (every use is an MFMA operand; the one fp32 re-read - the residual of
+  // the FF - reconstructs x1 + x2/2048, 2^-23 relative from the original); same bytes as the fp32 tiles they replace
+  __shared__ __attribute__((aligned(16))) _Float16 B1[T][LDH];   // attention tile, then FF hidden halves
+  __shared__ __attribute__((aligned(16))) _Float16 H2[T][LDH];   // normalised residual stream, then h_out in place
   __shared__ int rmol[T];
   const int tid = threadIdx.x, wave = tid >> 6, row0 = blockIdx.x * T;
   const int Nn = c.L.Nn;
@@ -512,32 +533,33 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (row0 + row >= Nn) va[ps][u] = vh[ps][u] = make_float4(0, 0, 0, 0);
-        reinterpret_cast<float4*>(&B1[row][0])[16 * u + j] = va[ps][u];
+        split_store4(&B1[row][0], 256, 64 * u + 4 * j, va[ps][u]);
         // h_in + gate_msa * attn (dmt.py:159)
         r[u].x = vh[ps][u].x + vg[ps][u].x * va[ps][u].x; r[u].y = vh[ps][u].y + vg[ps][u].y * va[ps][u].y;
         r[u].z = vh[ps][u].z + vg[ps][u].z * va[ps][u].z; r[u].w = vh[ps][u].w + vg[ps][u].w * va[ps][u].w;
       }
       ln_mod_quad256(r, sh[ps], sc[ps]);   // norm2_node + modulate (dmt.py:160)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) reinterpret_cast<float4*>(&H2[row][0])[16 * u + j] = r[u];
+      for (int u = 0; u < 4; ++u) split_store4(&H2[row][0], 256, 64 * u + 4 * j, r[u]);
     }
   }
   __syncthreads();
-  {
-    float* u = c.ws.u + (size_t)row0 * 64;
-    tile_gemm_blk<1, 1>(&B1[0][0], LD, 256, BW(c, blk, DS_BW_N2E_W), 64, 2, [&](int ch, int, const f32x16 (&acc)[1]) {
-      acc_store<1, 64>(acc, u + ch * 32, Nn - row0, [](int, float v) { return v; });
-    });
+  if (wave < 2) {   // node2edge_lin applied per node (256 -> 64): two 32-column chunks
+    f32x16 acc[1], lo[1];
+    acc_zero<1>(acc);
+    acc_zero<1>(lo);
+    wave_mma_h<1, false, 8>(&B1[0][0], 256, BW(c, blk, DS_BW_N2E_H), 64, 256, wave * 32, 0, 16, acc, lo);
+    split_finish<1>(acc, lo);
+    acc_store<1, 64>(acc, c.ws.u + (size_t)row0 * 64 + wave * 32, Nn - row0, [](int, float v) { return v; });
   }
-  const BFrag pf1 = bfrag_load(BW(c, blk, DS_BW_FF1_W), 512, wave * 32, 0, 32);   // FF1 weights, ahead of the barrier
   __syncthreads();   // H2 normalised; every wave is done reading B1 (node2edge)
   {
     const float* b1 = BW(c, blk, DS_BW_FF1_B);
-    const float* W1 = BW(c, blk, DS_BW_FF1_W);
-    const float* W2 = BW(c, blk, DS_BW_FF2_W);
-    f32x16 acc2[2][1];
-    acc_zero<1>(acc2[0]);
-    acc_zero<1>(acc2[1]);
+    const float* W1 = BW(c, blk, DS_BW_FF1_H);
+    const float* W2 = BW(c, blk, DS_BW_FF2_H);
+    f32x16 acc2[2][1], lo2[2][1];
+    acc_zero<1>(acc2[0]); acc_zero<1>(acc2[1]);
+    acc_zero<1>(lo2[0]); acc_zero<1>(lo2[1]);
     // node_gate_mlp (dmt.py:162) is per molecule: the gate columns of the tile's first / last molecule and the FF2 bias are
     // requested here, a whole FF ahead of their use (fetched after it they cost the epilogue one exposed round trip)
     const int mA = rmol[0], mB = rmol[min(T, Nn - row0) - 1];   // first / last VALID row (padded rows carry molecule 0)
@@ -553,30 +575,35 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
       for (int cc = 0; cc < 2; ++cc) {   // this wave's two 32-column chunks of the 256-wide hidden half
         asm volatile("" ::: "memory");
         const int ch = wave + 4 * cc;
-        f32x16 acc[1];
-        acc_zero<1>(acc);
-        wave_mma<1>(&H2[0][0], LD, W1, 512, (half * 8 + ch) * 32, 0, 32, acc, 0, (half == 0 && cc == 0) ? &pf1 : nullptr);
-        {   // SiLU(FF1 + bias) -> hidden tile, two rows at a time (packed-fp32 epilogue)
-          const int colf = ch * 32 + (tid & 31), hhf = (tid & 63) >> 5;
-          const float bf = b1[half * 256 + colf];
+        const int colf = ch * 32 + (tid & 31), hhf = (tid & 63) >> 5;
+        const float bf = b1[half * 256 + colf];
+        f32x16 acc[1], lo[1];
 #pragma unroll
-          for (int i = 0; i < 16; i += 2) {
-            f32x2 v;
-            v.x = acc[0][i] + bf; v.y = acc[0][i + 1] + bf;
-            v = ds_silu2(v);
-            const int r0 = acc_row(i, hhf);
-            B1[r0][colf] = v.x; B1[r0 + 1][colf] = v.y;
-          }
+        for (int i = 0; i < 16; ++i) acc[0][i] = bf;
+        acc_zero<1>(lo);
+        wave_mma_h<1, false, 8>(&H2[0][0], 256, W1, 512, 256, (half * 8 + ch) * 32, 0, 16, acc, lo);
+        split_finish<1>(acc, lo);
+        // SiLU(FF1 + bias) -> hidden tile, two rows at a time (packed-fp32 epilogue)
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          f32x2 v;
+          v.x = acc[0][i]; v.y = acc[0][i + 1];
+          v = ds_silu2(v);
+          const int r0 = acc_row(i, hhf);
+          split_store1(&B1[r0][0], 256, colf, v.x);
+          split_store1(&B1[r0 + 1][0], 256, colf, v.y);
         }
       }
       __syncthreads();
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
         asm volatile("" ::: "memory");
-        wave_mma<1>(&B1[0][0], LD, W2, 256, (wave + 4 * cc) * 32, half * 32, half * 32 + 32, acc2[cc], half * 32);
+        wave_mma_h<1, false, 8>(&B1[0][0], 256, W2, 256, 512, (wave + 4 * cc) * 32, half * 16, half * 16 + 16, acc2[cc], lo2[cc], half * 16);
       }
       __syncthreads();
     }
+    split_finish<1>(acc2[0], lo2[0]);
+    split_finish<1>(acc2[1], lo2[1]);
     // which of the tile's molecules a row belongs to is decided once per row (the predicates live in SGPR lane masks),
     // not once per element; rows are sorted by molecule, so a third molecule only occurs for tiny ones (uniform slow path)
     const int hhl = (tid & 63) >> 5;
@@ -595,24 +622,34 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
         const int row = acc_row(i, hhl);
         float g = isB[i] ? gB : gA;
         if (!two) { const int m = rmol[row]; if (m != mA && m != mB) g = gsec[(size_t)m * ADAC + col]; }
-        const float out = H2[row][col] + g * (acc2[cc][0][i] + bb);   // in place
-        H2[row][col] = out;
+        const float out = split_load1(&H2[row][0], 256, col) + g * (acc2[cc][0][i] + bb);   // in place
+        split_store1(&H2[row][0], 256, col, out);
         if (row < rows_here) row_put(st, ((i & 3) + 8 * (i >> 2)) * 256 * 4, out);
       }
     }
   }
   __syncthreads();
-  {
+  {   // per-block readout slice (256 -> 64) and the node parts of equi_update.input_lin (256 -> 512): 18 chunks over 4 waves
     const float* br = BW(c, blk, DS_BW_NODE_RO_B);
-    float* ah = c.ws.atom_hids;
-    float* ac = c.ws.ac;
-    tile_gemm_blk<1, 1>(&H2[0][0], LD, 256, BW(c, blk, DS_BW_NODE_RO_W), 64, 2, [&](int ch, int, const f32x16 (&acc)[1]) {
-      const float b = br[ch * 32 + (threadIdx.x & 31)];
-      acc_store<1, 768>(acc, ah + (size_t)row0 * 768 + 256 + 64 * blk + ch * 32, Nn - row0, [b](int, float v) { return v + b; });
-    });
-    tile_gemm_blk<1, 1>(&H2[0][0], LD, 256, BW(c, blk, DS_BW_AC_W), 512, 16, [&](int ch, int, const f32x16 (&acc)[1]) {
-      acc_store<1, 512>(acc, ac + (size_t)row0 * 512 + ch * 32, Nn - row0, [](int, float v) { return v; });
-    });
+    for (int it = wave; it < 18; it += 4) {
+      asm volatile("" ::: "memory");
+      f32x16 acc[1], lo[1];
+      acc_zero<1>(lo);
+      if (it < 2) {
+        const float b = br[it * 32 + (tid & 31)];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][i] = b;
+        wave_mma_h<1, false, 8>(&H2[0][0], 256, BW(c, blk, DS_BW_NODE_RO_H), 64, 256, it * 32, 0, 16, acc, lo);
+        split_finish<1>(acc, lo);
+        acc_store<1, 768>(acc, c.ws.atom_hids + (size_t)row0 * 768 + 256 + 64 * blk + it * 32, Nn - row0, [](int, float v) { return v; });
+      } else {
+        const int ch = it - 2;
+        acc_zero<1>(acc);
+        wave_mma_h<1, false, 8>(&H2[0][0], 256, BW(c, blk, DS_BW_AC_H), 512, 256, ch * 32, 0, 16, acc, lo);
+        split_finish<1>(acc, lo);
+        acc_store<1, 512>(acc, c.ws.ac + (size_t)row0 * 512 + ch * 32, Nn - row0, [](int, float v) { return v; });
+      }
+    }
   }
 }
 
@@ -628,8 +665,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
   __shared__ __attribute__((aligned(16))) float Ds[4][R][LDW];    // CondGaussian features of this block
   __shared__ int idx_s[4][3][R];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5, r31 = lane & 31;
+  constexpr int LDW2 = 2 * 64 + 8;                       // split-fp16 row: 272 bytes, as an fp32 row of 64 + 4
   float(*E2)[LDW] = E2s[wave];
-  float(*D)[LDW] = Ds[wave];
+  _Float16* Dh = reinterpret_cast<_Float16*>(&Ds[wave][0][0]);
   int* rmol = idx_s[wave][0];
   int* rpa = idx_s[wave][1];
   int* rpb = idx_s[wave][2];
@@ -670,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
         r = ln_mod_reg64(r, sh[u], sc[u]);   // norm2_edge + modulate (dmt.py:166)
         if (row >= valid) { r = make_float4(0, 0, 0, 0); vd[u] = r; }
         reinterpret_cast<float4*>(&E2[row][0])[k4] = r;
-        reinterpret_cast<float4*>(&D[row][0])[k4] = vd[u];
+        split_store4(Dh + row * LDW2, 64, 4 * k4, vd[u]);   // CondGaussian features: only ever an MFMA operand -> split-fp16 layout
       }
     }
   }
@@ -734,27 +772,42 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
     const float4 v = reinterpret_cast<const float4*>(&E2[row][0])[k4];
     if (row < valid) reinterpret_cast<float4*>(c.ws.e + (size_t)(row0 + row) * 64)[k4] = v;
   }
-  // ---- [e_out | dist] (128) -> 256 (input_lin edge part + bias) and the 64 -> 16 readout slice
+  // ---- the 64 -> 16 readout slice (fp32 MFMA on the fp32 tile), then [e_out | dist] (128) -> 256 (input_lin edge part +
+  //      bias) on the f16 matrix pipe: e_out is re-written in place in the split-fp16 layout first
   {
-    const float* bd = BW(c, blk, DS_BW_ED_B);
-    const float* Wd = BW(c, blk, DS_BW_ED_W);
-    float* ed = c.ws.ed + (size_t)row0 * 256;
-    for (int ch = 0; ch < 8; ++ch) {
-      asm volatile("" ::: "memory");
-      f32x16 acc[1];
-      const float b = bd[ch * 32 + r31];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[0][i] = b;   // accumulate onto the bias: no epilogue arithmetic left
-      wave_mma<1>(&E2[0][0], LDW, Wd, 256, ch * 32, 0, 8, acc);
-      wave_mma<1>(&D[0][0], LDW, Wd, 256, ch * 32, 8, 16, acc, 8);
-      acc_store<1, 256>(acc, ed + ch * 32, valid, [](int, float v) { return v; });
-    }
     f32x16 acc[1];
     acc_zero<1>(acc);
     wave_mma<1>(&E2[0][0], LDW, BW(c, blk, DS_BW_EDGE_RO_W), 32, 0, 0, 8, acc);
     if (r31 < 16) {
       const float b = BW(c, blk, DS_BW_EDGE_RO_B)[r31];
       acc_store<1, 192>(acc, c.ws.edge_hids + (size_t)row0 * 192 + 64 + 16 * blk, valid, [b](int, float v) { return v + b; });
+    }
+  }
+  _Float16* E2h = reinterpret_cast<_Float16*>(&E2[0][0]);
+  {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(&E2[(lane + u * 64) >> 4][0])[lane & 15];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // every read of the fp32 tile (MFMA fragments above included) before any write
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) split_store4(E2h + ((lane + u * 64) >> 4) * LDW2, 64, 4 * (lane & 15), v[u]);
+  }
+  {
+    const float* bd = BW(c, blk, DS_BW_ED_B);
+    const float* Wd = BW(c, blk, DS_BW_ED_H);
+    float* ed = c.ws.ed + (size_t)row0 * 256;
+    for (int ch = 0; ch < 8; ++ch) {
+      asm volatile("" ::: "memory");
+      f32x16 acc[1], lo[1];
+      const float b = bd[ch * 32 + r31];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] = b;   // accumulate onto the bias: no epilogue arithmetic left
+      acc_zero<1>(lo);
+      wave_mma_h<1>(E2h, 64, Wd, 256, 128, ch * 32, 0, 4, acc, lo);
+      wave_mma_h<1>(Dh, 64, Wd, 256, 128, ch * 32, 4, 8, acc, lo, 4);
+      split_finish<1>(acc, lo);
+      acc_store<1, 256>(acc, ed + ch * 32, valid, [](int, float v) { return v; });
     }
   }
 }
@@ -779,90 +832,81 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
 // issue ~4x slower beside two MFMA waves per SIMD whatever the priorities, and the consumers wait ~11 % at the barrier.
 // Hence the loaders' diet: the HBM-latency stream (`ed` rows) goes by LDS-DMA into the X rows, the LayerNorm runs four rows
 // per pass (one per DPP row), the ac / adaLN gathers of the next pass fly behind the current pass's arithmetic.
-__global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
-  constexpr int T = 64, TP = 32, LDH = 256 + 8, NC = 8;
-  // X tile as TWO fp16 planes per row, x = x1 + x2 / 2048 (|error| <= 2^-23 |x|): [buffer][row][plane][256 + 8 halves].  A row's
-  // slot (1056 B) first receives the fp32 `ed` row by LDS-DMA, then the split LayerNorm output.  Row stride 528 B = 132
-  // dwords: the 16-byte operand reads of 16 consecutive rows hit 16 distinct 4-bank groups.
-  __shared__ __attribute__((aligned(16))) _Float16 Xh[2][T][2][LDH];   // 135,168 B
-  __shared__ __attribute__((aligned(16))) float part[2][NC][T][4];   //  16,384 B
-  __shared__ __attribute__((aligned(16))) float dirs[3][T][4];       //   3,072 B  (unit diff * coord_scale, adjacency bits)
+template <int NCW, int NLW>
+__global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk) {
+  constexpr int T = 64, TP = 32, LDH = 2 * 256 + 8, NCH = 8;
+  constexpr int CPW = NCH / NCW;     // 32-feature chunks of the hidden layer per consumer wave
+  constexpr int PPW = TP / NLW;      // pairs per loader wave and tile
+  constexpr int NPASS = PPW / 2;     // LayerNorm passes (two pairs = four rows each)
+  static_assert(NCH % NCW == 0 && TP % NLW == 0 && PPW % 2 == 0, "role split");
+  // X tile in the split-fp16 layout of ds_device.h (x = x1 + x2 / 2048): [buffer][row][plane 0 | plane 1 | pad].  A row's
+  // 1040-byte slot first receives the fp32 `ed` row by LDS-DMA, then the split LayerNorm output.
+  __shared__ __attribute__((aligned(16))) _Float16 Xh[2][T][LDH];      // 133,120 B
+  __shared__ __attribute__((aligned(16))) float part[2][NCH][T][4];   //  16,384 B
+  __shared__ __attribute__((aligned(16))) float dirs[3][T][4];        //   3,072 B  (unit diff * coord_scale, adjacency bits)
+  __shared__ __attribute__((aligned(16))) float cb0[NCH][2][16];      //   1,024 B  coord_mlp.0 bias in accumulator order [chunk][lane half][reg]
+  __shared__ __attribute__((aligned(16))) float cw2[NCH][2][4][16];   //   4,096 B  coord_mlp.2 A-fragments [chunk][lane half][output 0..2][reg]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5;
   const int Pp = c.L.Pp;
   const int ntiles = (Pp + TP - 1) / TP;
   const float* adq = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EQUI;
-  const bool consumer = wave < NC;
+  const bool consumer = wave < NCW;
   const float cscale = BW(c, blk, DS_BW_COORD_SCALE)[0];
   DS_STAMP_INIT();
-
-  float b0f[16], w2f[16];   // consumer constants: coord_mlp.0 bias and coord_mlp.2 A-fragments of its 32 features
-  // split-fp16 coord_mlp.0 weights: [plane][k/16][k-half][feature][8 halves], 8192 B per (plane, k/16); buffer resource in SGPRs
-  const unsigned long long pw_ = reinterpret_cast<unsigned long long>(BW(c, blk, DS_BW_CM0_H));
-  const unsigned long long pu_ = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<int>(pw_ >> 32))) << 32) |
-                                 static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(pw_)));
-  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(pu_), 0, 0x7fffffff, 0x00020000);
-  const int wvoff = ((hh * 256) + (wave & 7) * 32 + (lane & 31)) * 16;
-  if (consumer) {
-    __builtin_amdgcn_s_setprio(0);
+  {   // per-block constants of the consumers, laid out so that a lane reads its 16 values as four 16-byte LDS loads
     const float* b0 = BW(c, blk, DS_BW_CM0_B);
     const float* w2 = BW(c, blk, DS_BW_CM2_W);
+    for (int idx = tid; idx < NCH * 2 * 16; idx += (NCW + NLW) * 64) {
+      const int ch = idx >> 5, h = (idx >> 4) & 1, i = idx & 15, f = ch * 32 + acc_row(i, h);
+      cb0[ch][h][i] = b0[f];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int f = wave * 32 + acc_row(i, hh);
-      b0f[i] = b0[f];
-      w2f[i] = (lane & 31) < 3 ? wp_at(w2, 32, f, lane & 31) : 0.0f;
+      for (int o = 0; o < 3; ++o) cw2[ch][h][o][i] = wp_at(w2, 32, f, o);
+      cw2[ch][h][3][i] = 0.0f;
     }
-  } else {
-    __builtin_amdgcn_s_setprio(3);
   }
+  if (consumer) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
 
-  // loader wave lw owns pairs lw, lw+4, ... of a tile (8 pairs = 16 rows).  The pair-table entries of a tile are fetched
-  // one produce() early; the gathers run as four batches of two pairs, batch n+1 in flight while batch n is normalised
-  // (VALU issue is scarce next to the MFMA stream - tools/micro/ln_corun.hip - so latency must hide behind it, not add).
-  const int lw = __builtin_amdgcn_readfirstlane(wave - NC);
-  int pv_n = 0, av_n = 0, bv_n = 0, mv_n = 0, adj_n = 0;   // prefetched table entries, lane = (pair slot u8, direction)
+  // Loader wave lw owns pairs lw, lw + NLW, ... of a tile (PPW pairs = 2 PPW rows).  The pair-table entries of a tile are
+  // fetched one produce() early.
+  const int lw = __builtin_amdgcn_readfirstlane(wave - NCW);
+  int pv_n = 0, av_n = 0, bv_n = 0, mv_n = 0, adj_n = 0;   // prefetched table entries, lane = (pair slot, direction)
   auto fetch_idx = [&](int tile) {
     const int p0 = tile * TP;
-    const int qv = lw + ((lane >> 1) & 7) * 4;
+    const int qv = lw + ((lane >> 1) & (PPW - 1)) * NLW;
     pv_n = qv < min(TP, Pp - p0) ? p0 + qv : 0;                        // pairs past the end gather pair 0, zeroed below
     av_n = c.L.pair_a[pv_n]; bv_n = c.L.pair_b[pv_n]; mv_n = c.L.pair_mol[pv_n]; adj_n = c.ws.adj[pv_n];
   };
   auto produce = [&](int tile, int buf, int gen, int tile_after) {
     const int p0 = tile * TP;
     const int npairs = min(TP, Pp - p0);
-    int na[8], nb[8], pm[8], pp[8];
+    int na[PPW], nb[PPW], pm[PPW], pp[PPW];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < PPW; ++u) {
       pp[u] = __builtin_amdgcn_readlane(pv_n, 2 * u); na[u] = __builtin_amdgcn_readlane(av_n, 2 * u);
       nb[u] = __builtin_amdgcn_readlane(bv_n, 2 * u); pm[u] = __builtin_amdgcn_readlane(mv_n, 2 * u);
     }
-    const int dir = lane & 1, qd = lw + ((lane >> 1) & 7) * 4, bits = adj_n;
+    const int dir = lane & 1, qd = lw + ((lane >> 1) & (PPW - 1)) * NLW, bits = adj_n;
     float4 pr = make_float4(0, 0, 0, 0), pc = pr;
-    if (lane < 16) {
+    if (lane < 2 * PPW) {
       pr = reinterpret_cast<const float4*>(c.ws.pos)[dir ? bv_n : av_n];   // row atom (edge_index[0])
       pc = reinterpret_cast<const float4*>(c.ws.pos)[dir ? av_n : bv_n];
     }
     // Four tile rows per pass (both directions of two pairs), one row per 16-lane DPP row, lane j of it holding the float4s at
     // columns 4j + 64u: the LayerNorm sums are four DPP steps with every lane busy - ~15 VALU issues per row against ~55
-    // for the row-per-wave form.  VALU issue slots are what a loader is short of next to two MFMA waves per SIMD
-    // (tools/micro/ln_corun.hip: ~27 cycles per VALU instruction there); halving the gather instructions instead (ac / adaLN
-    // rows carried over in registers) was measured and changed nothing.
+    // for the row-per-wave form.
     const int g = lane >> 4, j = lane & 15, up = g >> 1, gdir = g & 1;
     const float4* ac4 = reinterpret_cast<const float4*>(c.ws.ac);
     const float4* ed4 = reinterpret_cast<const float4*>(c.ws.ed);
     // The pair rows `ed` are the one HBM-latency stream of the kernel (written by k_edge_update just before, 0.66 GB per
-    // launch): stamps showed the loaders parked on them for ~47 % of their time with one pass of register gathers in flight.
-    // They now travel by LDS-DMA straight into the X row they are consumed from (row 2q; both directions read it before
-    // either overwrites it), all eight rows of the wave's pairs requested up front: no registers, one exposed latency per tile.
+    // launch).  They travel by LDS-DMA straight into the X row slot they are consumed from (row 2q; both directions read it
+    // before either overwrites it), all rows of the wave's pairs requested up front: no registers, one exposed latency per tile.
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < PPW; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ed4 + (size_t)pp[i] * 64 + lane),
-                                       (__attribute__((address_space(3))) void*)&Xh[buf][2 * (lw + 4 * i)][0][0], 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)&Xh[buf][2 * (lw + NLW * i)][0], 16, 0, 0);
     // ac rows: a lane of direction a -> b needs the h_row part of a and the h_col part of b, a lane of direction b -> a the h_row
-    // part of b and the h_col part of a.  Each lane therefore KEEPS its part of the a-row (a changes about once per tile in
-    // the (a, b)-row-major pair order) and fetches its part of the b-row per pass: 4 gathers per pass instead of 8.  Vector-
-    // memory instructions are what a loader pays most for beside the MFMA waves (tools/micro/vmem_corun.hip: ~670 cycles per
-    // 1-KiB load instruction there against ~280 alone).
+    // part of b and the h_col part of a.  Each lane KEEPS its part of the a-row (a changes about once per tile in the
+    // (a, b)-row-major pair order) and fetches its part of the b-row per pass: 4 gathers per pass instead of 8.
     float4 Ka[4], Bv[4], sh[4], sc[4];
     int cur_m = -1, cur_a = -1;
     auto issue = [&](int bt) {   // gathers of pass bt: rows of pairs 2bt (DPP rows 0, 1) and 2bt + 1 (DPP rows 2, 3)
@@ -893,7 +937,7 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
     modulation(0);
     if (tile_after < ntiles) fetch_idx(tile_after);
     __builtin_amdgcn_sched_barrier(0);
-    if (lane < 16) {   // unit vector of pos[row] - pos[col], scaled (layers.py:345-346), + adjacency bits, for the tail
+    if (lane < 2 * PPW) {   // unit vector of pos[row] - pos[col], scaled (layers.py:345-346), + adjacency bits, for the tail
       const float dx = pr.x - pc.x, dy = pr.y - pc.y, dz = pr.z - pc.z;
       const float nrm = fmaxf(__builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);
       const float sn = cscale * __builtin_amdgcn_rcpf(nrm);   // hardware sqrt / rcp (1 ulp): loader VALU issues are the scarce resource
@@ -902,48 +946,38 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
       reinterpret_cast<float4*>(&dirs[gen][2 * qd + dir][0])[0] = d;
     }
 #pragma unroll
-    for (int bt = 0; bt < 4; ++bt) {
+    for (int bt = 0; bt < NPASS; ++bt) {
       if (bt == 0) {   // the DMA'd rows must have landed before they are read back (and nothing may be hoisted above this)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
       }
-      DS_STAMP_W(8 + bt);
-      const int q = lw + (2 * bt + up) * 4;
+      DS_STAMP_W(8);
+      const int q = lw + (2 * bt + up) * NLW;
       float4 x[4];   // a -> b: input_lin([h_a, h_b, e, d]);  b -> a: input_lin([h_b, h_a, e, d])  (dmt.py:39,45)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float4 e = reinterpret_cast<const float4*>(&Xh[buf][2 * q][0][0])[16 * u + j];
+        const float4 e = reinterpret_cast<const float4*>(&Xh[buf][2 * q][0])[16 * u + j];
         x[u].x = (Ka[u].x + Bv[u].x) + e.x; x[u].y = (Ka[u].y + Bv[u].y) + e.y;
         x[u].z = (Ka[u].z + Bv[u].z) + e.z; x[u].w = (Ka[u].w + Bv[u].w) + e.w;
       }
       DS_STAMP(12);
-      if (bt < 3) issue(bt + 1);   // next pass's gathers fly behind this pass's LayerNorm
+      if (bt + 1 < NPASS) issue(bt + 1);   // next pass's gathers fly behind this pass's LayerNorm
       DS_STAMP(13);
       ln_mod_quad256(x, sh, sc);
-      _Float16* xr = &Xh[buf][2 * q + gdir][0][0];
+      _Float16* xr = &Xh[buf][2 * q + gdir][0];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {   // split: x1 = fp16(x) (round to nearest), x2 = fp16((x - x1) * 2048); the difference is exact in fp32
-        const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
-        h4 h1, h2;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          h1[t] = (_Float16)xs[t];
-          h2[t] = (_Float16)((xs[t] - (float)h1[t]) * 2048.0f);
-        }
-        *reinterpret_cast<h4*>(xr + 64 * u + 4 * j) = h1;
-        *reinterpret_cast<h4*>(xr + LDH + 64 * u + 4 * j) = h2;
-      }
-      if (bt < 3) modulation(bt + 1);
+      for (int u = 0; u < 4; ++u) split_store4(xr, 256, 64 * u + 4 * j, x[u]);
+      if (bt + 1 < NPASS) modulation(bt + 1);
       DS_STAMP(14);
     }
     if (npairs < TP) {   // last tile only: rows of the pairs past the end (they were computed from pair 0) become zero rows
-      for (int i = 0; i < 8; ++i) {
-        const int qz = lw + 4 * i;
-        if (qz >= npairs) {   // two 1056-byte row slots = 132 float4
-          float4* z = reinterpret_cast<float4*>(&Xh[buf][2 * qz][0][0]);
+      for (int i = 0; i < PPW; ++i) {
+        const int qz = lw + NLW * i;
+        if (qz >= npairs) {   // two 1040-byte row slots = 130 float4
+          float4* z = reinterpret_cast<float4*>(&Xh[buf][2 * qz][0]);
           z[lane] = make_float4(0, 0, 0, 0);
           z[64 + lane] = make_float4(0, 0, 0, 0);
-          if (lane < 4) z[128 + lane] = make_float4(0, 0, 0, 0);
+          if (lane < 2) z[128 + lane] = make_float4(0, 0, 0, 0);
         }
       }
     }
@@ -956,7 +990,7 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
     if ((lane >> 1) < npairs) {
       float4 sacc = reinterpret_cast<const float4*>(&part[pb][0][lane][0])[0];
 #pragma unroll
-      for (int w = 1; w < NC; ++w) {   // the eight consumers' partial sums, in wave order
+      for (int w = 1; w < NCH; ++w) {   // the eight feature chunks' partial sums, in chunk order
         const float4 pw = reinterpret_cast<const float4*>(&part[pb][w][lane][0])[0];
         sacc.x += pw.x; sacc.y += pw.y; sacc.z += pw.z;
       }
@@ -980,62 +1014,52 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
     int it = 0;
     for (int tile = first; tile < ntiles; tile += stride, ++it) {
       const int buf = it & 1;
-      // coord_mlp.0 (256 -> 256) on the f16 matrix pipe with fp32-level accuracy: both operands are split in two fp16 planes
-      // (a = a1 + a2/2048), the product is a1 b1 + (a1 b2 + a2 b1)/2048 - three v_mfma_f32_32x32x16_f16 (32 cycles each,
-      // fp32 accumulate, exact fp16 x fp16 products) per 16-deep k-block instead of eight 64-cycle fp32 MFMAs; the dropped
-      // a2 b2 term and the representation errors are ~2^-22 relative.  Transposed as before: A operand = weights (lane =
-      // output feature), B operand = X rows (lane = edge row), so lane = edge row and registers = features in the result.
-      f32x16 acc1[2], acclo[2], acc2[2];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int cc = 0; cc < CPW; ++cc) {
+        const int ch = wave + NCW * cc;
+        // coord_mlp.0 (256 -> 256) on the f16 matrix pipe with split operands (ds_device.h, wave_mma_h), transposed as before:
+        // lane = edge row, registers = the chunk's 32 output features.
+        f32x16 acc1[2], acclo[2], acc2[2];
+        {
+          const float4* bp = reinterpret_cast<const float4*>(&cb0[ch][hh][0]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc1[m][i] = b0f[i];   // the MFMA chain accumulates onto the coord_mlp.0 bias
-      acc_zero<2>(acclo);
-      acc_zero<2>(acc2);
-      {
-        auto wl = [&](int p, int kb) { return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, (p * 16 + kb) * 8192, 0)); };
-        auto xl = [&](int m, int p, int kb) { return *reinterpret_cast<const h8*>(&Xh[buf][m * 32 + (lane & 31)][p][kb * 16 + 8 * hh]); };
-        h8 w1 = wl(0, 0), w2 = wl(1, 0);
-        h8 xa[2][2] = {{xl(0, 0, 0), xl(0, 1, 0)}, {xl(1, 0, 0), xl(1, 1, 0)}};
-#pragma unroll 4
-        for (int kb = 0; kb < 16; ++kb) {
-          const int kn = kb < 15 ? kb + 1 : 15;
-          const h8 w1n = wl(0, kn), w2n = wl(1, kn);
-          h8 xn[2][2];
+          for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int m = 0; m < 2; ++m) { xn[m][0] = xl(m, 0, kn); xn[m][1] = xl(m, 1, kn); }
-          __builtin_amdgcn_sched_barrier(0);   // next block's operands are requested ahead of this block's MFMAs
+            for (int q4 = 0; q4 < 4; ++q4) {   // the MFMA chain accumulates onto the coord_mlp.0 bias
+              const float4 bv = bp[q4];
+              acc1[m][4 * q4] = bv.x; acc1[m][4 * q4 + 1] = bv.y; acc1[m][4 * q4 + 2] = bv.z; acc1[m][4 * q4 + 3] = bv.w;
+            }
+        }
+        acc_zero<2>(acclo);
+        acc_zero<2>(acc2);
+        wave_mma_h<2, true, 16>(&Xh[buf][0][0], 256, BW(c, blk, DS_BW_CM0_H), 256, 256, ch * 32, 0, 16, acc1, acclo);
+        split_finish<2>(acc1, acclo);
+        float w2f[16];
+        {
+          const float4* wp = reinterpret_cast<const float4*>(&cw2[ch][hh][min(lane & 31, 3)][0]);   // outputs >= 3: the zero row
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            acc1[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xa[m][0], acc1[m], 0, 0, 0);
-            acclo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xa[m][1], acclo[m], 0, 0, 0);
-            acclo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, xa[m][0], acclo[m], 0, 0, 0);
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 wv = wp[q4];
+            w2f[4 * q4] = wv.x; w2f[4 * q4 + 1] = wv.y; w2f[4 * q4 + 2] = wv.z; w2f[4 * q4 + 3] = wv.w;
           }
-          w1 = w1n; w2 = w2n;
-#pragma unroll
-          for (int m = 0; m < 2; ++m) { xa[m][0] = xn[m][0]; xa[m][1] = xn[m][1]; }
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc1[m][i] = fmaf(acclo[m][i], 1.0f / 2048.0f, acc1[m][i]);
-      }
+          for (int i = 0; i < 16; i += 2) {
+            f32x2 y;   // SiLU of coord_mlp.0 (dmt.py:32-33), packed-fp32, two hidden features at a time
+            y.x = acc1[m][i]; y.y = acc1[m][i + 1];
+            y = ds_silu2(y);
+            acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[i], y.x, acc2[m], 0, 0, 0);       // coord_mlp.2 partial (dmt.py:34)
+            acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[i + 1], y.y, acc2[m], 0, 0, 0);
+          }
+        if (hh == 0) {   // out[j][row]: j = register 0..2 of the lower half, row = m*32 + lane
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          f32x2 y;   // SiLU of coord_mlp.0 (dmt.py:32-33), packed-fp32, two hidden features at a time
-          y.x = acc1[m][i]; y.y = acc1[m][i + 1];
-          y = ds_silu2(y);
-          acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[i], y.x, acc2[m], 0, 0, 0);       // coord_mlp.2 partial (dmt.py:34)
-          acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[i + 1], y.y, acc2[m], 0, 0, 0);
-        }
-      if (hh == 0) {   // out[j][row]: j = register 0..2 of the lower half, row = m*32 + lane
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          float4 o;
-          o.x = acc2[m][0]; o.y = acc2[m][1]; o.z = acc2[m][2]; o.w = 0.0f;
-          reinterpret_cast<float4*>(&part[buf][wave][m * 32 + lane][0])[0] = o;
+          for (int m = 0; m < 2; ++m) {
+            float4 o;
+            o.x = acc2[m][0]; o.y = acc2[m][1]; o.z = acc2[m][2]; o.w = 0.0f;
+            reinterpret_cast<float4*>(&part[buf][ch][m * 32 + lane][0])[0] = o;
+          }
         }
       }
       DS_STAMP(1);
@@ -1053,14 +1077,14 @@ __global__ __launch_bounds__(768) void k_equi_pairs(Ctx c, int blk) {
       const int next = tile + stride, buf = it & 1;
       if (next < ntiles) produce(next, buf ^ 1, (it + 1) % 3, next + stride);
       DS_STAMP(5);
-      if (wave == NC && prev_tile >= 0) tail(prev_tile, buf ^ 1, (it + 2) % 3);   // part[buf^1]: written one interval ago
+      if (wave == NCW && prev_tile >= 0) tail(prev_tile, buf ^ 1, (it + 2) % 3);   // part[buf^1]: written one interval ago
       DS_STAMP(6);
       __syncthreads();
       DS_STAMP(7);
       prev_tile = tile;
     }
-    if (wave == NC) tail(prev_tile, (it + 1) & 1, (it + 2) % 3);
-    DS_STAMP_FLUSH(512);
+    if (wave == NCW) tail(prev_tile, (it + 1) & 1, (it + 2) % 3);
+    DS_STAMP_FLUSH(NCW * 64);
   }
 }
 
@@ -1825,7 +1849,7 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   { ProfScope ps(6, s); hipLaunchKernelGGL(k_attn_agg, dim3(L->B), dim3(512), 0, s, c); }
   { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3((L->Pp + 127) / 128), dim3(256), 0, s, c, blk); }
-  if (pt > 0) { ProfScope ps(5, s); { const int nt_ = (L->Pp + 31) / 32, cu_ = device_cus(); hipLaunchKernelGGL(k_equi_pairs, dim3(nt_ < cu_ ? nt_ : cu_), dim3(768), 0, s, c, blk); } }
+  if (pt > 0) { ProfScope ps(5, s); { const int nt_ = (L->Pp + 31) / 32, cu_ = device_cus(); hipLaunchKernelGGL((k_equi_pairs<DS_EQUI_NCW, DS_EQUI_NLW>), dim3(nt_ < cu_ ? nt_ : cu_), dim3((DS_EQUI_NCW + DS_EQUI_NLW) * 64), 0, s, c, blk); } }
   hipLaunchKernelGGL(k_pos_update, dim3(L->B), dim3(64), 0, s, c, last);
   return launch_status();
 }

@@ -151,8 +151,10 @@ def pack_linear_f16_split(weight: torch.Tensor) -> torch.Tensor:
     2^-23 |w|), in the A-operand order of v_mfma_f32_32x32x16_f16: halves [plane][K/16][k-half][N][8], k = 16 kb + 8 h + j;
     returned as the fp32 view of those bits (the packed weight buffer is fp32)."""
     w = weight.detach().to(torch.float32).cpu()
+    if w.shape[0] % 32:                                               # zero rows up to the MFMA tile width
+        w = torch.cat([w, torch.zeros(32 - w.shape[0] % 32, w.shape[1])], 0)
     N, K = w.shape
-    assert K % 16 == 0 and N % 32 == 0
+    assert K % 16 == 0
     w1 = w.half()
     w2 = ((w - w1.float()) * SPLIT_SCALE).half()
     planes = torch.stack([w1, w2])                                   # [2, N, K]
@@ -218,6 +220,7 @@ def pack_dmt_weights(sd: Dict[str, torch.Tensor]):
         wq, wk, wv = (sd[p + f"attn_mpnn.lin_{n}.weight"] for n in ("query", "key", "value"))
         bq, bk, bv = (sd[p + f"attn_mpnn.lin_{n}.bias"] for n in ("query", "key", "value"))
         put(bslot(b, "DS_BW_QKV_W"), pack_linear(cat_pad_rows([wq, wk, wv], [256, 256, 256])))
+        put(bslot(b, "DS_BW_QKV_H"), pack_linear_f16_split(cat_pad_rows([wq, wk, wv], [256, 256, 256])))
         put(bslot(b, "DS_BW_QKV_B"), torch.cat([pad_vec(bq, 256), pad_vec(bk, 256), pad_vec(bv, 256)]))
         put(bslot(b, "DS_BW_N2E_W"), pack_linear(sd[p + "node2edge_lin.weight"]))
         put(bslot(b, "DS_BW_N2E_B"), pad_vec(sd[p + "node2edge_lin.bias"]))
@@ -236,6 +239,14 @@ def pack_dmt_weights(sd: Dict[str, torch.Tensor]):
         put(bslot(b, "DS_BW_CM0_B"), pad_vec(sd[p + "equi_update.coord_mlp.0.bias"]))
         put(bslot(b, "DS_BW_CM2_W"), pack_linear(sd[p + "equi_update.coord_mlp.2.weight"]))
         put(bslot(b, "DS_BW_CM0_H"), pack_linear_f16_split(sd[p + "equi_update.coord_mlp.0.weight"]))
+        put(bslot(b, "DS_BW_N2E_H"), pack_linear_f16_split(sd[p + "node2edge_lin.weight"]))
+        put(bslot(b, "DS_BW_FF1_H"), pack_linear_f16_split(sd[p + "ff_linear1.weight"]))
+        put(bslot(b, "DS_BW_FF2_H"), pack_linear_f16_split(sd[p + "ff_linear2.weight"]))
+        put(bslot(b, "DS_BW_NODE_RO_H"), pack_linear_f16_split(sd[f"node_{b}.weight"]))
+        put(bslot(b, "DS_BW_AC_H"), pack_linear_f16_split(torch.cat([win[:, 0:256], win[:, 256:512]], 0)))
+        put(bslot(b, "DS_BW_E0_H"), pack_linear_f16_split(sd[p + "attn_mpnn.lin_edge0.weight"]))
+        put(bslot(b, "DS_BW_E1_H"), pack_linear_f16_split(sd[p + "attn_mpnn.lin_edge1.weight"]))
+        put(bslot(b, "DS_BW_ED_H"), pack_linear_f16_split(win[:, 512:640]))
         mean, std, astd = _rbf_tables(sd, p + "dist_layer")
         put(bslot(b, "DS_BW_RBF_MEAN"), mean)
         put(bslot(b, "DS_BW_RBF_STD"), std)

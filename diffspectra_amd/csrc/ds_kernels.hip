@@ -1254,7 +1254,68 @@ __global__ void k_temb_finish(Ctx c, const float* __restrict__ tm3, int tm3_rows
   const size_t b = i >> 10, col = i & 1023;
   float v = tm3[(tm3_rows == 1 ? 0 : b) * 1024 + col];
   if (ctx) v += ctx[i];
-  c.ws.temb_silu[i] = ds_silu(v);
+  // the adaLN GEMM's A operand, written once in the split-fp16 layout (two planes per row) instead of re-split per tile
+  split_store1(reinterpret_cast<_Float16*>(c.ws.temb_silu) + b * 2048, 1024, (int)col, ds_silu(v));
+}
+
+// The per-step adaLN table GEMM ada[M, N] = temb_silu[M, 1024] * W + bias on the f16 matrix pipe with split operands
+// (ds_device.h).  A arrives pre-split from k_temb_finish (halves [M][2][K]); 128 x 128 output tile per workgroup, each wave 128
+// rows x 32 columns (MT = 4: a weight fragment feeds 12 MFMAs), A chunks of 64 k double-buffered in LDS with the next chunk
+// fetched into registers while the current one is multiplied.
+__global__ __launch_bounds__(256, 2) void k_gemm_ada(const _Float16* __restrict__ A, const float* __restrict__ Wh, const float* __restrict__ bias,
+                                                     float* __restrict__ C, int ldc, int M, int K, int N) {
+  constexpr int T = 128, KC = 64, LDH = 2 * KC + 8;
+  __shared__ __attribute__((aligned(16))) _Float16 X[2][T][LDH];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int row0 = blockIdx.x * T;
+  const int col0 = (blockIdx.y * 4 + wave) * 32;
+  const bool active = col0 < N;
+  const int nchunks = K / KC;
+  uint4 st[8];
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + u * 256, row = idx >> 4, piece = idx & 15, plane = piece >> 3;
+      const size_t gr = (size_t)min(row0 + row, M - 1);
+      st[u] = *reinterpret_cast<const uint4*>(A + gr * 2 * K + (size_t)plane * K + kc * KC + (piece & 7) * 8);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + u * 256, row = idx >> 4, piece = idx & 15;
+      *reinterpret_cast<uint4*>(&X[buf][row][piece * 8]) = st[u];   // planes are adjacent in a tile row: piece 0..7 plane 0, 8..15 plane 1
+    }
+  };
+  f32x16 acc[4], lo[4];
+  acc_zero<4>(acc);
+  acc_zero<4>(lo);
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int cur = kc & 1;
+    if (kc + 1 < nchunks) fetch(kc + 1);
+    if (active) wave_mma_h<4, false, 4>(&X[cur][0][0], KC, Wh, N, K, col0, kc * 4, kc * 4 + 4, acc, lo, kc * 4);
+    if (kc + 1 < nchunks) stash(cur ^ 1);
+    __syncthreads();
+  }
+  if (!active) return;
+  split_finish<4>(acc, lo);
+  const int lane = tid & 63, r = lane & 31, hh = lane >> 5, col = col0 + r;
+  const float bcol = bias ? bias[col] : 0.0f;
+  const unsigned long long pw = reinterpret_cast<unsigned long long>(C + (size_t)row0 * ldc + col0);
+  const unsigned long long pu = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<int>(pw >> 32))) << 32) |
+                                static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(pw)));
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(pu), 0, 0x7fffffff, 0x00020000);
+  const int voff = (4 * hh * ldc + r) * 4, rowb = ldc * 4;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = m * 32 + (i & 3) + 8 * (i >> 2);
+      if (row0 + row + 4 * hh < M) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][i] + bcol), rc, voff, row * rowb, 0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1822,8 +1883,10 @@ int ds_stage_time(const ds_weights* w, const ds_layout* L, ds_workspace* ws, con
   const size_t tot = (size_t)B * 1024;
   hipLaunchKernelGGL(k_temb_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, c, (const float*)tm3, B, ctx_emb);
   // every *time_mlp Linear of the model in one GEMM: [B,1024] x [1024, DS_ADA_COLS]
-  st = gemm_simple(ws->temb_silu, 1024, w->base + off[DS_GW_ADA_W], w->base + off[DS_GW_ADA_B], ws->ada, ADAC, B, 1024, ADAC, 0, 0, s);
-  return st ? st : launch_status();
+  static_assert(ADAC % 32 == 0, "adaLN table width");
+  hipLaunchKernelGGL(k_gemm_ada, dim3((B + 127) / 128, (ADAC + 127) / 128), dim3(256), 0, s, reinterpret_cast<const _Float16*>(ws->temb_silu),
+                     w->base + off[DS_GW_ADA_W], w->base + off[DS_GW_ADA_B], ws->ada, (int)ADAC, B, 1024, (int)ADAC);
+  return launch_status();
 }
 
 int ds_stage_init(const ds_weights* w, const ds_layout* L, ds_workspace* ws, const float* xh, const float* edge_x,

@@ -267,7 +267,7 @@ def pack_dmt_weights(sd: Dict[str, torch.Tensor]):
     put(gslot("DS_GW_TM1_B"), pad_vec(sd["time_mlp.1.bias"]))
     put(gslot("DS_GW_TM3_W"), pack_linear(sd["time_mlp.3.weight"]))
     put(gslot("DS_GW_TM3_B"), pad_vec(sd["time_mlp.3.bias"]))
-    put(gslot("DS_GW_ADA_W"), pack_linear(ada_w))
+    put(gslot("DS_GW_ADA_W"), pack_linear_f16_split(ada_w))
     put(gslot("DS_GW_ADA_B"), ada_b)
     put(gslot("DS_GW_NODE_EMB_W"), pack_linear(sd["node_emb.weight"]))
     put(gslot("DS_GW_NODE_EMB_B"), pad_vec(sd["node_emb.bias"]))

@@ -83,7 +83,8 @@ enum ds_global_slot {
   DS_GW_SIN_W = 0,                          /* 8(32)       time_mlp.0.weights                 layers.py:285 */
   DS_GW_TM1_W, DS_GW_TM1_B,                 /* 17(24) -> 1024                                 dmt.py:254 */
   DS_GW_TM3_W, DS_GW_TM3_B,                 /* 1024 -> 1024                                   dmt.py:256 */
-  DS_GW_ADA_W, DS_GW_ADA_B,                 /* 1024 -> DS_ADA_COLS, all *time_mlp Linears     dmt.py:23-26,102-109; layers.py:321-324 */
+  DS_GW_ADA_W, DS_GW_ADA_B,                 /* 1024 -> DS_ADA_COLS, all *time_mlp Linears (dmt.py:23-26,102-109; layers.py:321-324);
+                                               the weight in the split-fp16 layout of DS_BW_CM0_H: halves [2][64][2][DS_ADA_COLS][8] */
   DS_GW_NODE_EMB_W, DS_GW_NODE_EMB_B,       /* 12(16) -> 256                                  dmt.py:376 */
   DS_GW_EDGE_EMB_W, DS_GW_EDGE_EMB_B,       /* 68(72) -> 64  rows [edge_x2, cond_edge_x2, dist64]  dmt.py:373,377 */
   DS_GW_RBF_MEAN, DS_GW_RBF_STD, DS_GW_RBF_ASTD,
@@ -125,7 +126,7 @@ typedef struct ds_workspace {        /* all device fp32 unless noted; sizes in f
   float* edge_hids;  /* [Pp,192] */
   float* tfeat;      /* [B,24]   sinusoid features (17 used) */
   float* tmid;       /* [B,1024] */
-  float* temb_silu;  /* [B,1024] SiLU(time_mlp(noise_level) + ctx) */
+  float* temb_silu;  /* [B,1024 floats]: SiLU(time_mlp(noise_level) + ctx) as two fp16 planes per row, halves [B][2][1024] (a = a1 + a2/2048) */
   float* ada;        /* [B,DS_ADA_COLS] */
   float* qkv;        /* [Nn,768] */
   float* te0;        /* [Pp,256] tanh(lin_edge0 e) (252 used) */

@@ -254,7 +254,8 @@ def test_stages_vs_oracle(gpu_device, first):
     eng.stage_time(L, ws, nl, ctx)
     temb = odmt.time_embedding(sd, a["noise_level"]) + ctx_cpu
     silu = torch.nn.functional.silu(temb)
-    assert_close(ws.t["temb_silu"], silu, TOL_KERNEL, "SiLU(time_emb)")
+    planes = ws.t["temb_silu"].view(torch.float16).reshape(-1, 2, 1024).float()      # split-fp16 layout: a = a1 + a2 / 2048
+    assert_close(planes[:, 0] + planes[:, 1] / 2048.0, silu, TOL_KERNEL, "SiLU(time_emb)")
     from diffspectra_amd import engine as E
     ada = ws.t["ada"].cpu()
     for blk in (0, 7):

@@ -261,32 +261,17 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
                     [&](int row, int col, float v) { Y[row][col] = v + bias[col]; }, &pfe);
   }
   __syncthreads();
-  // norm1_edge + modulate (dmt.py:149), written back IN PLACE in the split-fp16 layout of ds_device.h (a 64-wide tile row is
-  // 272 bytes either way): the two 64 -> 256 projections below then run on the f16 matrix pipe (wave_mma_h)
-  _Float16* Yh = reinterpret_cast<_Float16*>(&Y[0][0]);
+  // norm1_edge + modulate (dmt.py:149) -> ws.ye in the split-fp16 layout (two 64-half planes per pair row).  The two 64 -> 256
+  // projections lin_edge0 / lin_edge1 and their tanh are NOT evaluated here any more: k_attn_fused recomputes them per molecule
+  // on the f16 matrix pipe from these 256-byte rows, so the 2 x 1 kB per pair of round 1's te0 / te1 never travel through HBM.
   {
     const int lane = tid & 63, wv = tid >> 6;
+    _Float16* ye = reinterpret_cast<_Float16*>(c.ws.ye);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = 16 * wv + 4 * j + (lane >> 4);
       const float4 v = ln_mod_reg64(reinterpret_cast<const float4*>(&Y[row][0])[lane & 15], lsh[j], lsc[j]);
-      split_store4(Yh + row * (2 * 64 + 8), 64, 4 * (lane & 15), v);   // all 16 lanes of the row have read before any writes (one DS queue per wave)
-    }
-  }
-  __syncthreads();
-  {
-    float* te0 = c.ws.te0 + (size_t)row0 * 256;
-    float* te1 = c.ws.te1 + (size_t)row0 * 256;
-    const int valid = c.L.Pp - row0, wave = tid >> 6;
-    for (int it = wave; it < 16; it += 4) {   // 8 column chunks of lin_edge0, then 8 of lin_edge1; both row tiles per weight fragment
-      asm volatile("" ::: "memory");
-      const int ch = it & 7;
-      f32x16 acc[2], lo[2];
-      acc_zero<2>(acc);
-      acc_zero<2>(lo);
-      wave_mma_h<2>(Yh, 64, BW(c, blk, it < 8 ? DS_BW_E0_H : DS_BW_E1_H), 256, 64, ch * 32, 0, 4, acc, lo);
-      split_finish<2>(acc, lo);
-      acc_store2<2, 256>(acc, (it < 8 ? te0 : te1) + ch * 32, valid, [](f32x2 v) { return ds_tanh2(v); });   // layers.py:165-166,183
+      if (row0 + row < c.L.Pp) split_store4(ye + (size_t)(row0 + row) * 128, 64, 4 * (lane & 15), v);
     }
   }
 }
@@ -353,140 +338,235 @@ __global__ __launch_bounds__(NW * 64) void k_node_qkv(Ctx c, int blk) {
   }
 }
 
-// Block stage C1 (one workgroup per molecule): attention logits of both directions of every pair, 14 learned heads
-// (q_t . k_s . tanh(e0) over 18 channels, / sqrt(16)) + the 2 adjacency heads (0 -> -1e10).  layers.py:165-174.
-// lg[p][0][h]: source a -> target b;  lg[p][1][h]: source b -> target a.  The molecule's q|k rows are staged in LDS once
-// (<= 58 kB) instead of being re-gathered from L2 for every 16 pairs; te0 streams through once.
-__global__ __launch_bounds__(256, 2) void k_attn_logits(Ctx c) {
-  // row stride 544 floats: consecutive atoms sit 32 banks apart, so the two pairs of a half-wave - (lo, hi) and (lo, hi+1)
-  // in the molecule's pair order - read row hi / hi+1 segments from disjoint banks and row lo as a broadcast
-  constexpr int QS = 512 + 32;
-  __shared__ __attribute__((aligned(16))) float QK[DS_MAX_ATOMS * QS];
-  const int m = blockIdx.x, tid = threadIdx.x;
+// Block stage C (one 1024-thread workgroup per molecule): the whole edge-modulated attention of TransMixLayer
+// (layers.py:131-186 + PyG propagate / softmax) with tanh(lin_edge0 e) and tanh(lin_edge1 e) recomputed on chip.
+//   phase 1, per chunk of 64 pair rows: ye rows -> LDS, te0 = tanh(ye . lin_edge0) on the f16 matrix pipe (one 32-column chunk per
+//            and row tile per wave) -> LDS tile, logits of both directions of every pair:
+//            lg[p][0][h] source a -> target b, lg[p][1][h] source b -> target a; 14 learned heads (q_t . k_s . te0 over 18
+//            channels, / sqrt(16)) + the 2 adjacency heads (0 -> -1e10; layers.py:165-174)
+//   phase 2a: segment softmax over the sources of every target (PyG softmax: max-shift, exp, / (sum + 1e-16)), one wave per
+//            target, written back over the logits
+//   phase 2b, per chunk: te1 = tanh(ye . lin_edge1) -> LDS tile; out[t] += (v_s * te1) * alpha, every wave accumulating its own
+//            targets (t = wave, wave + 16) in registers, rows visited in pair order = ascending source order, as the
+//            reference's scatter-add (layers.py:178-186)
+// q|k of the molecule's atoms are staged in LDS for phase 1, V takes their place for phase 2.
+__global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
+  constexpr int NW = 16, NT = NW * 64, QS = 512 + 32, LDT = 256 + 4, LDY = 2 * 64 + 8;
+  __shared__ __attribute__((aligned(16))) float QK[DS_MAX_ATOMS * QS];       // 63,104 B; phase 2: V [n][256]
+  __shared__ __attribute__((aligned(16))) float Tt[64][LDT];                 // 66,560 B  tanh(te0 / te1) of the chunk
+  __shared__ __attribute__((aligned(16))) _Float16 Yc[64][LDY];              // 17,408 B  ye rows of the chunk (split-fp16 layout)
+  __shared__ __attribute__((aligned(16))) float AL[64][32];                  //  8,192 B  alpha of the chunk's pairs, both directions
+  __shared__ int pab[64];                                                    // (a << 8) | b, local atom indices of the chunk's pairs
+  const int m = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5;
   const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
   const int p0 = c.L.pair_off[m], P = c.L.pair_off[m + 1] - p0;
-  if (P <= 0) return;
-  for (int i0 = tid; i0 < n * 128; i0 += 256 * 8) {   // q (256) | k (256) of every atom, eight loads in flight per thread
-    float4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = min(i0 + u * 256, n * 128 - 1);
-      v[u] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + (idx >> 7)) * 768)[idx & 127];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = i0 + u * 256;
-      if (idx < n * 128) reinterpret_cast<float4*>(QK)[(idx >> 7) * (QS / 4) + (idx & 127)] = v[u];
-    }
-  }
-  __syncthreads();
-  for (int it = tid; it < P * 16; it += 256) {
-    const int pl = it >> 4, hs = it & 15;
-    const int p = p0 + pl;
-    float* out = c.ws.lg + (size_t)p * 32;
-    if (hs >= 14) {
-      if (hs == 14) {
-        const int bits = c.ws.adj[p];
-        const float h0 = (bits & 1) ? 1.0f : -1e10f, h1 = (bits & 2) ? 1.0f : -1e10f;   // layers.py:171-174
-        out[0] = h0; out[1] = h1; out[16] = h0; out[17] = h1;
-      }
-      continue;
-    }
-    const int a = c.L.pair_a[p] - n0, b = c.L.pair_b[p] - n0;
-    const float2* t0 = reinterpret_cast<const float2*>(c.ws.te0 + (size_t)p * 256 + hs * 18);
-    const float2* qa = reinterpret_cast<const float2*>(QK + a * QS + hs * 18);
-    const float2* qb = reinterpret_cast<const float2*>(QK + b * QS + hs * 18);
-    const float2* ka = reinterpret_cast<const float2*>(QK + a * QS + 256 + hs * 18);
-    const float2* kb = reinterpret_cast<const float2*>(QK + b * QS + 256 + hs * 18);
-    float s_ab = 0.0f, s_ba = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const float2 e = t0[j], xa = qa[j], xb = qb[j], ya = ka[j], yb = kb[j];
-      s_ab += (xb.x * ya.x) * e.x; s_ab += (xb.y * ya.y) * e.y;
-      s_ba += (xa.x * yb.x) * e.x; s_ba += (xa.y * yb.y) * e.y;
-    }
-    out[2 + hs] = s_ab / 4.0f;        // / sqrt(out_channels = 16) (layers.py:167)
-    out[16 + 2 + hs] = s_ba / 4.0f;
-  }
-}
-
-// Block stage C2 (one workgroup per molecule, one WAVE per target atom): segment softmax over the sources (PyG softmax:
-// max-shift, exp, / (sum + 1e-16)) and out[t] = sum_s (v_s * tanh(e1)_{st}) * alpha, sources in ascending order as the
-// reference's scatter-add visits them.  layers.py:178-186.  V is staged in LDS once per molecule; both readers of a te1
-// row (targets a and b) are waves of the same workgroup, so the second read is served on-chip.
-__global__ __launch_bounds__(512, 2) void k_attn_agg(Ctx c) {
-  constexpr int NW = 8;
-  __shared__ __attribute__((aligned(16))) float V[DS_MAX_ATOMS * 256];
-  __shared__ float al[NW][32][16];
-  const int m = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
-  const int p0 = c.L.pair_off[m];
   if (n <= 0) return;
-  {   // V rows of the molecule: n * 64 float4 <= 1856 = four per thread, requested together
+  if (P <= 0) {   // single atom: no message reaches it
+    for (int i = tid; i < 256; i += NT) c.ws.attn[(size_t)n0 * 256 + i] = 0.0f;
+    return;
+  }
+  const int nchunks = (P + 63) >> 6;
+  const uint4* ye4 = reinterpret_cast<const uint4*>(c.ws.ye) + (size_t)p0 * 16;   // 16 x 16 bytes per pair row
+  // A chunk's global reads are issued one chunk ahead into registers (fetch) and land in LDS at the top of the chunk (commit):
+  // with one workgroup per CU nothing else hides their latency.
+  uint4 yv;
+  float4 av = make_float4(0, 0, 0, 0);
+  int abv = 0;
+  auto fetch = [&](int ck, bool with_alpha) {
+    {   // 64 rows x 16 pieces of 16 bytes: one per thread
+      const int pl = ck * 64 + (tid >> 4);
+      yv = pl < P ? ye4[(size_t)pl * 16 + (tid & 15)] : make_uint4(0, 0, 0, 0);
+    }
+    if (with_alpha && tid < 512) {
+      const int pl = ck * 64 + (tid >> 3);
+      av = pl < P ? reinterpret_cast<const float4*>(c.ws.lg + (size_t)(p0 + pl) * 32)[tid & 7] : make_float4(0, 0, 0, 0);
+    }
+    if (tid < 64) {
+      const int pl = ck * 64 + tid;
+      abv = pl < P ? ((c.L.pair_a[p0 + pl] - n0) << 8) | (c.L.pair_b[p0 + pl] - n0) : 0;
+    }
+  };
+  auto commit = [&](bool with_alpha) {
+    *reinterpret_cast<uint4*>(&Yc[tid >> 4][(tid & 15) * 8]) = yv;
+    if (with_alpha && tid < 512) reinterpret_cast<float4*>(&AL[tid >> 3][0])[tid & 7] = av;
+    if (tid < 64) pab[tid] = abv;
+  };
+  // wave w owns output columns 32 (w & 7) .. +31 of row tile w >> 3; its lin_edge0 / lin_edge1 fragments (64 -> 256, split-fp16
+  // planes) live in registers for a whole phase: 8 x 16 bytes
+  h8 wf[2][4];
+  auto load_weights = [&](int slot) {
+    const WStreamH ws_ = wstream_h(BW(c, blk, slot), 256, 64, (wave & 7) * 32);
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) wf[pl][kb] = wload_h(ws_, pl, kb);
+  };
+  auto project = [&]() {   // Tt = tanh(Yc . W): this wave's 32 rows x 32 columns
+    f32x16 acc[1], lo[1];
+    acc_zero<1>(acc);
+    acc_zero<1>(lo);
+    const int mt = wave >> 3;
+    const _Float16* xr = &Yc[mt * 32 + (lane & 31)][8 * hh];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const h8 x1 = *reinterpret_cast<const h8*>(xr + kb * 16);
+      const h8 x2 = *reinterpret_cast<const h8*>(xr + 64 + kb * 16);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1, wf[0][kb], acc[0], 0, 0, 0);
+      lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x2, wf[0][kb], lo[0], 0, 0, 0);
+      lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1, wf[1][kb], lo[0], 0, 0, 0);
+    }
+    split_finish<1>(acc, lo);
+    const int col = (wave & 7) * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      f32x2 v;
+      v.x = acc[0][i]; v.y = acc[0][i + 1];
+      v = ds_tanh2(v);                                   // layers.py:165-166,183
+      const int r0 = mt * 32 + acc_row(i, hh);
+      Tt[r0][col] = v.x; Tt[r0 + 1][col] = v.y;
+    }
+  };
+
+  load_weights(DS_BW_E0_H);
+  fetch(0, false);
+  // ---- phase 0: q (256) | k (256) of every atom -> LDS
+  for (int i0 = tid; i0 < n * 128; i0 += NT * 4) {
     float4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int idx = min(tid + u * 512, n * 64 - 1);
-      v[u] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + (idx >> 6)) * 768 + 512)[idx & 63];
+      const int idx = min(i0 + u * NT, n * 128 - 1);
+      v[u] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + (idx >> 7)) * 768)[idx & 127];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (tid + u * 512 < n * 64) reinterpret_cast<float4*>(V)[tid + u * 512] = v[u];
+    for (int u = 0; u < 4; ++u) {
+      const int idx = i0 + u * NT;
+      if (idx < n * 128) reinterpret_cast<float4*>(QK)[(idx >> 7) * (QS / 4) + (idx & 127)] = v[u];
+    }
   }
-  __syncthreads();
-  const int h = lane & 15, sq = lane >> 4;          // softmax phase: lane = (source mod 4, head)
-  const int hd = lane >> 2;                         // aggregation phase: lane owns channels 4*lane .. 4*lane+3 of head lane/4
-  const float4* te1 = reinterpret_cast<const float4*>(c.ws.te1) + (size_t)p0 * 64 + lane;
-  for (int t = wave; t < n; t += NW) {
-    float x[8];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int s = sq + 4 * j;
-      x[j] = -INFINITY;
-      if (s < n && s != t) {
-        const int lo = s < t ? s : t, hi = s < t ? t : s;
-        const int pl = lo * (2 * n - lo - 1) / 2 + (hi - lo - 1);
-        x[j] = c.ws.lg[(size_t)(p0 + pl) * 32 + (s < t ? 0 : 16) + h];
+  // ---- phase 1: logits
+  for (int ck = 0; ck < nchunks; ++ck) {
+    commit(false);
+    __syncthreads();                       // Yc / pab of this chunk (and, first time, QK) visible; every reader of the previous Tt is past it
+    if (ck + 1 < nchunks) fetch(ck + 1, false);
+    project();
+    __syncthreads();
+    for (int it = tid; it < 64 * 16; it += NT) {
+      const int row = it >> 4, hs = it & 15, pl = ck * 64 + row;
+      if (pl >= P) continue;
+      float* out = c.ws.lg + (size_t)(p0 + pl) * 32;
+      if (hs >= 14) {
+        if (hs == 14) {
+          const int bits = c.ws.adj[p0 + pl];
+          const float h0 = (bits & 1) ? 1.0f : -1e10f, h1 = (bits & 2) ? 1.0f : -1e10f;   // layers.py:171-174
+          out[0] = h0; out[1] = h1; out[16] = h0; out[17] = h1;
+        }
+        continue;
       }
-      mx = fmaxf(mx, x[j]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.0f;
+      const int a = pab[row] >> 8, b = pab[row] & 255;
+      const float2* t0 = reinterpret_cast<const float2*>(&Tt[row][hs * 18]);
+      const float2* qa = reinterpret_cast<const float2*>(QK + a * QS + hs * 18);
+      const float2* qb = reinterpret_cast<const float2*>(QK + b * QS + hs * 18);
+      const float2* ka = reinterpret_cast<const float2*>(QK + a * QS + 256 + hs * 18);
+      const float2* kb = reinterpret_cast<const float2*>(QK + b * QS + 256 + hs * 18);
+      float s_ab = 0.0f, s_ba = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      x[j] = (sq + 4 * j < n && sq + 4 * j != t) ? expf(x[j] - mx) : 0.0f;
-      sum += x[j];
+      for (int j = 0; j < 9; ++j) {
+        const float2 e = t0[j], xa = qa[j], xb = qb[j], ya = ka[j], yb = kb[j];
+        s_ab += (xb.x * ya.x) * e.x; s_ab += (xb.y * ya.y) * e.y;
+        s_ba += (xa.x * yb.x) * e.x; s_ba += (xa.y * yb.y) * e.y;
+      }
+      out[2 + hs] = s_ab / 4.0f;        // / sqrt(out_channels = 16) (layers.py:167)
+      out[16 + 2 + hs] = s_ba / 4.0f;
     }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float den = sum + 1e-16f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) al[wave][sq + 4 * j][h] = x[j] / den;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    float4 acc = make_float4(0, 0, 0, 0);
-    for (int s0 = 0; s0 < n; s0 += 8) {   // eight te1 rows in flight per trip; accumulation stays in ascending source order
-      float4 g[8];
+  }
+  load_weights(DS_BW_E1_H);               // lin_edge1 fragments fly during the softmax
+  __threadfence_block();
+  __syncthreads();                         // all logits written (and visible to this workgroup); QK is dead from here
+  // ---- phase 2a: V -> LDS (over QK), softmax per target written back over the logits
+  float* V = QK;
+  for (int i0 = tid; i0 < n * 64; i0 += NT) reinterpret_cast<float4*>(V)[i0] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + (i0 >> 6)) * 768 + 512)[i0 & 63];
+  {
+    const int h = lane & 15, sq = lane >> 4;          // lane = (source mod 4, head)
+    for (int t = wave; t < n; t += NW) {
+      float x[8];
+      float mx = -INFINITY;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int s = min(s0 + j, n - 1), so = s == t ? (t ? 0 : 1) : s;   // the skipped source reads a valid row, unused
-        const int lo = so < t ? so : t, hi = so < t ? t : so;
-        g[j] = te1[(size_t)(lo * (2 * n - lo - 1) / 2 + (hi - lo - 1)) * 64];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int s = s0 + j;
+        const int s = sq + 4 * j;
+        x[j] = -INFINITY;
         if (s < n && s != t) {
-          const float4 v = reinterpret_cast<const float4*>(V)[s * 64 + lane];
-          const float a = al[wave][s][hd];
-          acc.x += (v.x * g[j].x) * a; acc.y += (v.y * g[j].y) * a; acc.z += (v.z * g[j].z) * a; acc.w += (v.w * g[j].w) * a;
+          const int lo_ = s < t ? s : t, hi_ = s < t ? t : s;
+          const int pl = lo_ * (2 * n - lo_ - 1) / 2 + (hi_ - lo_ - 1);
+          x[j] = c.ws.lg[(size_t)(p0 + pl) * 32 + (s < t ? 0 : 16) + h];
+        }
+        mx = fmaxf(mx, x[j]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        x[j] = (sq + 4 * j < n && sq + 4 * j != t) ? expf(x[j] - mx) : 0.0f;
+        sum += x[j];
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float den = sum + 1e-16f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int s = sq + 4 * j;
+        if (s < n && s != t) {
+          const int lo_ = s < t ? s : t, hi_ = s < t ? t : s;
+          const int pl = lo_ * (2 * n - lo_ - 1) / 2 + (hi_ - lo_ - 1);
+          c.ws.lg[(size_t)(p0 + pl) * 32 + (s < t ? 0 : 16) + h] = x[j] / den;
         }
       }
     }
-    reinterpret_cast<float4*>(c.ws.attn + (size_t)(n0 + t) * 256)[lane] = acc;
-    __builtin_amdgcn_wave_barrier();   // al[wave] is rewritten for the next target
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- phase 2b: aggregation; wave w owns targets w and w + 16 (lane = channels 4 lane .. 4 lane + 3, head lane / 4)
+  float4 acc[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) acc[k] = make_float4(0, 0, 0, 0);
+  const int hd = lane >> 2;
+  fetch(0, true);
+  for (int ck = 0; ck < nchunks; ++ck) {
+    commit(true);
+    __syncthreads();
+    if (ck + 1 < nchunks) fetch(ck + 1, true);
+    project();
+    __syncthreads();
+    const int rows = min(64, P - ck * 64);
+    const int my_ab = pab[lane];           // the chunk's 64 (a, b) pairs, one per lane
+    // rows in which this wave owns a target, as a lane mask: the loop visits only those (~16 of 64), in ascending row order
+    unsigned long long todo = __ballot(lane < rows && ((((my_ab >> 8) & 15) == wave) || ((my_ab & 15) == wave)));
+    while (todo) {
+      const int row = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const int ab = __builtin_amdgcn_readlane(my_ab, row), a = ab >> 8, b = ab & 255;
+      const bool mine_b = (b & 15) == wave, mine_a = (a & 15) == wave;     // wave-uniform
+      const float4 g = reinterpret_cast<const float4*>(&Tt[row][0])[lane];
+      const float4 va = reinterpret_cast<const float4*>(V)[a * 64 + lane];
+      const float4 vb = reinterpret_cast<const float4*>(V)[b * 64 + lane];
+      const float al_ab = AL[row][hd], al_ba = AL[row][16 + hd];
+      if (mine_b) {   // source a -> target b
+#pragma unroll
+        for (int k = 0; k < 2; ++k)   // the slot is wave-uniform: a branch, not a dynamic register index
+          if ((b >> 4) == k) { acc[k].x += (va.x * g.x) * al_ab; acc[k].y += (va.y * g.y) * al_ab; acc[k].z += (va.z * g.z) * al_ab; acc[k].w += (va.w * g.w) * al_ab; }
+      }
+      if (mine_a) {   // source b -> target a
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if ((a >> 4) == k) { acc[k].x += (vb.x * g.x) * al_ba; acc[k].y += (vb.y * g.y) * al_ba; acc[k].z += (vb.z * g.z) * al_ba; acc[k].w += (vb.w * g.w) * al_ba; }
+      }
+    }
+    __syncthreads();                       // Tt / AL / pab are rewritten by the next chunk
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int t = wave + 16 * k;
+    if (t < n) reinterpret_cast<float4*>(c.ws.attn + (size_t)(n0 + t) * 256)[lane] = acc[k];
   }
 }
 
@@ -1908,8 +1988,7 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   const int pt = (L->Pp + 63) / 64, nt = (L->Nn + 31) / 32;
   if (pt > 0) { ProfScope ps(0, s); hipLaunchKernelGGL(k_edge_geom, dim3(pt), dim3(256), 0, s, c, blk); }
   { ProfScope ps(1, s); hipLaunchKernelGGL(k_node_qkv<4>, dim3((L->Nn + 63) / 64, 2), dim3(256), 0, s, c, blk); }
-  if (pt > 0) { ProfScope ps(2, s); hipLaunchKernelGGL(k_attn_logits, dim3(L->B), dim3(256), 0, s, c); }
-  { ProfScope ps(6, s); hipLaunchKernelGGL(k_attn_agg, dim3(L->B), dim3(512), 0, s, c); }
+  { ProfScope ps(2, s); hipLaunchKernelGGL(k_attn_fused, dim3(L->B), dim3(1024), 0, s, c, blk); }
   { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3((L->Pp + 127) / 128), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(5, s); { const int nt_ = (L->Pp + 31) / 32, cu_ = device_cus(); hipLaunchKernelGGL((k_equi_pairs<DS_EQUI_NCW, DS_EQUI_NLW>), dim3(nt_ < cu_ ? nt_ : cu_), dim3((DS_EQUI_NCW + DS_EQUI_NLW) * 64), 0, s, c, blk); } }

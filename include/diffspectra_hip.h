@@ -129,8 +129,9 @@ typedef struct ds_workspace {        /* all device fp32 unless noted; sizes in f
   float* temb_silu;  /* [B,1024 floats]: SiLU(time_mlp(noise_level) + ctx) as two fp16 planes per row, halves [B][2][1024] (a = a1 + a2/2048) */
   float* ada;        /* [B,DS_ADA_COLS] */
   float* qkv;        /* [Nn,768] */
-  float* te0;        /* [Pp,256] tanh(lin_edge0 e) (252 used) */
-  float* te1;        /* [Pp,256] tanh(lin_edge1 e) */
+  float* ye;         /* [Pp,64 floats]: LayerNorm'd + modulated edge features of the current block (dmt.py:149) as two fp16 planes per
+                        row, halves [Pp][2][64] (a = a1 + a2/2048): the MFMA operand from which k_attn_fused recomputes
+                        tanh(lin_edge0 e) / tanh(lin_edge1 e) per molecule instead of streaming them through HBM */
   float* dist;       /* [Pp,64]  CondGaussian features of the current block */
   float* attn;       /* [Nn,256] */
   float* u;          /* [Nn,64]  node2edge_lin weight applied per node (no bias) */

@@ -25,7 +25,7 @@ def main():
     nl = torch.full((M,), 0.5)
     ctx = filler.normal("bb.ctx", (M, 1024)) * 0.5
     L, ws = eng.layout_for(node_mask, edge_mask)
-    print(f"molecules {M}: Nn {L.Nn} Pp {L.Pp}; te0 bytes {L.Pp * 1024 / 2**30:.2f} GiB", flush=True)
+    print(f"molecules {M}: Nn {L.Nn} Pp {L.Pp}; ed bytes {L.Pp * 1024 / 2**30:.2f} GiB", flush=True)
     out, oute = eng.forward(L, ws, x.to(d), ex.to(d), nl.to(d), cx.to(d), cex.to(d), ctx.to(d))
     out, oute = out.cpu(), oute.cpu()
     worst = 0.0

@@ -55,9 +55,9 @@ def main():
         torch.cuda.synchronize()
         print(f"  SpecFormer + cond_lin for {B} molecules: {(time.perf_counter() - t1) * 1e3:.1f} ms (once per 1000 steps)")
     import ctypes as C
-    names = ["edge_geom", "node_qkv", "attn_logits", "node_update", "edge_update", "equi_pairs", "attn_agg"]
+    names = ["edge_geom", "node_qkv", "attn_fused", "node_update", "edge_update", "equi_pairs"]
     per = []
-    for kid in range(7):
+    for kid in range(6):
         eng.lib.ds_profile_config(C.c_int(kid), C.c_int(1), C.c_int(256))
         for _ in range(3):
             eng.forward(L, ws, x, ex, nl, cx, cex, ctx, out, oute)

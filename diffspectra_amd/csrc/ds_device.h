@@ -289,7 +289,8 @@ __device__ __forceinline__ h8 wload_h(const WStreamH& w, int plane, int kb) {
 // hi[m] += X1 W1, lo[m] += X1 W2 + X2 W1 over k-blocks [kb0, kb1) of the weight matrix; the X tile's column 0 is k-block xkb0.
 // TRANS swaps the operands (accumulator = transposed block: lane = tile row, registers = output columns), as in wave_mma.
 // UNROLL: k-blocks per unrolled loop body (measured: 16 for the 16-block equi GEMM, 4 for the 4-block edge GEMMs; 1-2 lose 5-15 %)
-template <int MT, bool TRANS = false, int UNROLL = 4>
+// XPF: request the next k-block's X fragments ahead of this block's MFMAs (costs 8 MT registers; off for MT = 4).
+template <int MT, bool TRANS = false, int UNROLL = 4, bool XPF = true>
 __device__ __forceinline__ void wave_mma_h(const _Float16* X, int K_tile, const float* __restrict__ Wh, int N, int K, int col0,
                                            int kb0, int kb1, f32x16 (&hi)[MT], f32x16 (&lo)[MT], int xkb0 = 0) {
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
@@ -308,10 +309,12 @@ __device__ __forceinline__ void wave_mma_h(const _Float16* X, int K_tile, const 
     const int kn = min(kb + 1, kb1 - 1);
     const h8 w1n = wload_h(ws, 0, kn), w2n = wload_h(ws, 1, kn);
     h8 xn[MT][2];
+    if (XPF) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      xn[m][0] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + kn * 16);
-      xn[m][1] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + K_tile + kn * 16);
+      for (int m = 0; m < MT; ++m) {
+        xn[m][0] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + kn * 16);
+        xn[m][1] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + K_tile + kn * 16);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);   // next block's operands are requested ahead of this block's MFMAs
 #pragma unroll
@@ -328,7 +331,13 @@ __device__ __forceinline__ void wave_mma_h(const _Float16* X, int K_tile, const 
     }
     w1 = w1n; w2 = w2n;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) { xa[m][0] = xn[m][0]; xa[m][1] = xn[m][1]; }
+    for (int m = 0; m < MT; ++m) {
+      if (XPF) { xa[m][0] = xn[m][0]; xa[m][1] = xn[m][1]; }
+      else {
+        xa[m][0] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + kn * 16);
+        xa[m][1] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + K_tile + kn * 16);
+      }
+    }
   }
 }
 template <int MT>

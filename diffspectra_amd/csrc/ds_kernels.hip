@@ -1339,49 +1339,50 @@ __global__ void k_temb_finish(Ctx c, const float* __restrict__ tm3, int tm3_rows
 }
 
 // The per-step adaLN table GEMM ada[M, N] = temb_silu[M, 1024] * W + bias on the f16 matrix pipe with split operands
-// (ds_device.h).  A arrives pre-split from k_temb_finish (halves [M][2][K]); 128 x 128 output tile per workgroup, each wave 128
-// rows x 32 columns (MT = 4: a weight fragment feeds 12 MFMAs), A chunks of 64 k double-buffered in LDS with the next chunk
-// fetched into registers while the current one is multiplied.
-__global__ __launch_bounds__(256, 2) void k_gemm_ada(const _Float16* __restrict__ A, const float* __restrict__ Wh, const float* __restrict__ bias,
-                                                     float* __restrict__ C, int ldc, int M, int K, int N) {
-  constexpr int T = 128, KC = 64, LDH = 2 * KC + 8;
+// (ds_device.h).  A arrives pre-split from k_temb_finish (halves [M][2][K]); 64 x 128 output tile per workgroup, each wave 64
+// rows x 32 columns (a weight fragment feeds 6 MFMAs; 128-row tiles spilled their staging registers), A chunks of 64 k
+// double-buffered in LDS with the next chunk fetched into registers while the current one is multiplied.
+__global__ __launch_bounds__(256) void k_gemm_ada(const _Float16* __restrict__ A, const float* __restrict__ Wh, const float* __restrict__ bias,
+                                                  float* __restrict__ C, int ldc, int M, int K, int N) {
+  constexpr int T = 64, KC = 64, LDH = 2 * KC + 8, MT = T / 32;
   __shared__ __attribute__((aligned(16))) _Float16 X[2][T][LDH];
   const int tid = threadIdx.x, wave = tid >> 6;
   const int row0 = blockIdx.x * T;
   const int col0 = (blockIdx.y * 4 + wave) * 32;
   const bool active = col0 < N;
   const int nchunks = K / KC;
-  uint4 st[8];
+  // staging registers as four named values (an array here ended up in scratch memory)
+  float4 st0, st1, st2, st3;
+  const int srow = tid >> 4, spiece = tid & 15;               // thread's piece of rows srow, srow + 16, srow + 32, srow + 48
+  const size_t scol = (size_t)(spiece >> 3) * K + (spiece & 7) * 8;
   auto fetch = [&](int kc) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = tid + u * 256, row = idx >> 4, piece = idx & 15, plane = piece >> 3;
-      const size_t gr = (size_t)min(row0 + row, M - 1);
-      st[u] = *reinterpret_cast<const uint4*>(A + gr * 2 * K + (size_t)plane * K + kc * KC + (piece & 7) * 8);
-    }
+    const _Float16* base = A + scol + kc * KC;
+    st0 = *reinterpret_cast<const float4*>(base + (size_t)min(row0 + srow, M - 1) * 2 * K);
+    st1 = *reinterpret_cast<const float4*>(base + (size_t)min(row0 + srow + 16, M - 1) * 2 * K);
+    st2 = *reinterpret_cast<const float4*>(base + (size_t)min(row0 + srow + 32, M - 1) * 2 * K);
+    st3 = *reinterpret_cast<const float4*>(base + (size_t)min(row0 + srow + 48, M - 1) * 2 * K);
   };
-  auto stash = [&](int buf) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = tid + u * 256, row = idx >> 4, piece = idx & 15;
-      *reinterpret_cast<uint4*>(&X[buf][row][piece * 8]) = st[u];   // planes are adjacent in a tile row: piece 0..7 plane 0, 8..15 plane 1
-    }
+  auto stash = [&](int buf) {   // planes are adjacent in a tile row: piece 0..7 plane 0, 8..15 plane 1
+    *reinterpret_cast<float4*>(&X[buf][srow][spiece * 8]) = st0;
+    *reinterpret_cast<float4*>(&X[buf][srow + 16][spiece * 8]) = st1;
+    *reinterpret_cast<float4*>(&X[buf][srow + 32][spiece * 8]) = st2;
+    *reinterpret_cast<float4*>(&X[buf][srow + 48][spiece * 8]) = st3;
   };
-  f32x16 acc[4], lo[4];
-  acc_zero<4>(acc);
-  acc_zero<4>(lo);
+  f32x16 acc[MT], lo[MT];
+  acc_zero<MT>(acc);
+  acc_zero<MT>(lo);
   fetch(0);
   stash(0);
   __syncthreads();
   for (int kc = 0; kc < nchunks; ++kc) {
     const int cur = kc & 1;
     if (kc + 1 < nchunks) fetch(kc + 1);
-    if (active) wave_mma_h<4, false, 4>(&X[cur][0][0], KC, Wh, N, K, col0, kc * 4, kc * 4 + 4, acc, lo, kc * 4);
+    if (active) wave_mma_h<MT, false, 4>(&X[cur][0][0], KC, Wh, N, K, col0, kc * 4, kc * 4 + 4, acc, lo, kc * 4);
     if (kc + 1 < nchunks) stash(cur ^ 1);
     __syncthreads();
   }
   if (!active) return;
-  split_finish<4>(acc, lo);
+  split_finish<MT>(acc, lo);
   const int lane = tid & 63, r = lane & 31, hh = lane >> 5, col = col0 + r;
   const float bcol = bias ? bias[col] : 0.0f;
   const unsigned long long pw = reinterpret_cast<unsigned long long>(C + (size_t)row0 * ldc + col0);
@@ -1390,7 +1391,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_ada(const _Float16* __restrict_
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(pu), 0, 0x7fffffff, 0x00020000);
   const int voff = (4 * hh * ldc + r) * 4, rowb = ldc * 4;
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = m * 32 + (i & 3) + 8 * (i >> 2);
@@ -1964,7 +1965,7 @@ int ds_stage_time(const ds_weights* w, const ds_layout* L, ds_workspace* ws, con
   hipLaunchKernelGGL(k_temb_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, c, (const float*)tm3, B, ctx_emb);
   // every *time_mlp Linear of the model in one GEMM: [B,1024] x [1024, DS_ADA_COLS]
   static_assert(ADAC % 32 == 0, "adaLN table width");
-  hipLaunchKernelGGL(k_gemm_ada, dim3((B + 127) / 128, (ADAC + 127) / 128), dim3(256), 0, s, reinterpret_cast<const _Float16*>(ws->temb_silu),
+  hipLaunchKernelGGL(k_gemm_ada, dim3((B + 63) / 64, (ADAC + 127) / 128), dim3(256), 0, s, reinterpret_cast<const _Float16*>(ws->temb_silu),
                      w->base + off[DS_GW_ADA_W], w->base + off[DS_GW_ADA_B], ws->ada, (int)ADAC, B, 1024, (int)ADAC);
   return launch_status();
 }

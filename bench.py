@@ -11,7 +11,7 @@ Molecules are independent, so ranks own disjoint molecules (weak scaling) and th
 all_gather of the fixed-size result records over RCCL.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     live HIP-event timing of the dominant kernel (k_equi_pairs) vs the fp32-MFMA peak,
+  "roofline":     live HIP-event timing of the dominant kernel (k_equi_pairs) vs the ceiling of its arithmetic (f16 MFMA peak / 3),
   "cpu_baseline": the CPU oracle (faithful restatement of the reference path) timed on this host on a bounded sample.
 """
 from __future__ import annotations
@@ -32,6 +32,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (155 measured)
+PEAK_F16_MFMA_TFLOPS = 2516.6      # dense f16/bf16 MFMA peak (16x the fp32 MFMA rate; MI355X_MICROARCH.md "~2.5 PF dense")
+SPLIT_MFMAS_PER_PRODUCT = 3        # split-fp16 arithmetic: a*b = a1*b1 + (a1*b2 + a2*b1)/2048 -> three f16 MFMAs per fp32-accurate product
+PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / SPLIT_MFMAS_PER_PRODUCT   # ceiling of an fp32-accurate GEMM on the f16 matrix pipe
 EQUI_MACS_PER_DIRECTED_EDGE = 256 * 256 + 256 * 3   # coord_mlp.0 + coord_mlp.2 (SURVEY §8d constants)
 
 
@@ -305,8 +308,11 @@ def main():
             flop = 2.0 * EQUI_MACS_PER_DIRECTED_EDGE * E_dir
             ach = flop / (kern_ms * 1e-3) / 1e12
             traffic, traffic_src = pmc_traffic("k_equi_pairs", M)
-            roofline = {"bound": "mfma", "kernel": "k_equi_pairs", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+            roofline = {"bound": "mfma", "kernel": "k_equi_pairs", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
+                        "peak_note": "dense f16 MFMA peak (2516.6 TFLOP/s) / 3: the kernel evaluates its fp32-accurate 256x256 GEMM as three "
+                                     "f16 MFMAs per product (split operands, fp32 accumulate); algorithmic FLOPs counted once",
+                        "vs_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                         "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 PMC, separate passes)",
                         "traffic_source": traffic_src, "avg_launch_ms": kern_ms, "launches_timed": int(samples.value),
                         "algorithmic_flop_per_launch": flop}
@@ -321,7 +327,8 @@ def main():
         line = {
             "metric": "molecules/sec, 1000-step QM9S all-spectra sampling", "value": value, "unit": "molecules/sec",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (GEMMs as split-fp16 x3 MFMA with fp32 accumulate; fp32-level accuracy, parity gates unchanged)", "data": "synthetic",
             "config": {"workload": ("QM9S unconditional (zero context embedding), DMT only" if args.unconditional else
                                     f"QM9S {args.spectra}, DMT + SpecFormer (no pretrain)") + ", random-init procedural weights, "
                                    f"{args.denoise_steps} denoise steps per molecule, {M} molecules resident per GPU "
@@ -334,8 +341,10 @@ def main():
                        "steps_requested": args.steps, "parallelism": f"dp{world} (molecule shards)",
                        "launch_mode": "hipGraph replay per denoise iteration" if graphed else "eager launches"},
             "roofline": roofline,
-            "whole_path": {"algorithmic_tflops_per_gpu": whole, "frac_of_fp32_mfma_peak": whole / PEAK_FP32_MFMA_TFLOPS,
-                           "executed_tflops_per_gpu": whole_exe, "executed_frac": whole_exe / PEAK_FP32_MFMA_TFLOPS,
+            "whole_path": {"algorithmic_tflops_per_gpu": whole, "vs_fp32_mfma_peak": whole / PEAK_FP32_MFMA_TFLOPS,
+                           "frac_of_split_f16_ceiling": whole / PEAK_SPLIT_TFLOPS,
+                           "executed_tflops_per_gpu": whole_exe, "executed_vs_fp32_mfma_peak": whole_exe / PEAK_FP32_MFMA_TFLOPS,
+                           "executed_frac_of_split_f16_ceiling": whole_exe / PEAK_SPLIT_TFLOPS,
                            "algorithmic_gflop_per_molecule_step": fwd_flop / M / 1e9,
                            "executed_gflop_per_molecule_step": exe_flop / M / 1e9},
         }

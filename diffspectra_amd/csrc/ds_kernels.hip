@@ -1947,6 +1947,14 @@ int ds_gemm(const ds_gemm_args* a, void* stream) {
   return gemm_dispatch(g, a->act, (hipStream_t)stream);
 }
 
+int ds_gemm_split(const void* A_split, const float* W_split, const float* bias, float* C, int64_t ldc, int32_t M, int32_t K,
+                  int32_t N, void* stream) {
+  if (!A_split || !W_split || !C || M <= 0 || K <= 0 || N <= 0 || K % 64 != 0 || N % 32 != 0 || ldc < N) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_gemm_ada, dim3((M + 63) / 64, (N + 127) / 128), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const _Float16*>(A_split), W_split, bias, C, (int)ldc, M, K, N);
+  return launch_status();
+}
+
 int ds_stage_time(const ds_weights* w, const ds_layout* L, ds_workspace* ws, const float* noise_level, const float* ctx_emb,
                   void* stream) {
   hipStream_t s = (hipStream_t)stream;

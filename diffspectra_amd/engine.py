@@ -162,6 +162,20 @@ def pack_linear_f16_split(weight: torch.Tensor) -> torch.Tensor:
     return t.reshape(-1).view(torch.float32).clone()
 
 
+def split_rows_f16(a: torch.Tensor) -> torch.Tensor:
+    """fp32 [M, K] → the A-operand layout of ``ds_gemm_split``: halves [M][2][K] (a = a1 + a2/2048), returned as float16."""
+    a = a.detach().to(torch.float32)
+    a1 = a.half()
+    a2 = ((a - a1.float()) * SPLIT_SCALE).half()
+    return torch.stack([a1, a2], dim=1).contiguous()
+
+
+def gemm_split(lib, a_split: torch.Tensor, w_split: torch.Tensor, bias, out: torch.Tensor, M: int, K: int, N: int):
+    """C = A W + bias through ``ds_gemm_split`` (operands prepared by ``split_rows_f16`` / ``pack_linear_f16_split``)."""
+    _check(lib.ds_gemm_split(_ptr(a_split), _ptr(w_split), _ptr(bias), _ptr(out), C.c_int64(out.stride(0)), C.c_int32(M), C.c_int32(K),
+                             C.c_int32(N), _stream()), "ds_gemm_split")
+
+
 def pad_vec(v: torch.Tensor, to: int = 32) -> torch.Tensor:
     v = v.detach().to(torch.float32).cpu().reshape(-1)
     out = torch.zeros((v.numel() + to - 1) // to * to)

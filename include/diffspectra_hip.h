@@ -162,6 +162,15 @@ typedef struct ds_gemm_args {
 } ds_gemm_args;
 int ds_gemm(const ds_gemm_args* args, void* stream);
 
+/* The split-fp16 GEMM that the block kernels are built from, as a stand-alone entry point (the per-step adaLN table GEMM uses
+ * it; tests measure its accuracy against fp64 through it): C[M, N] = A * W + bias with fp32-level accuracy on the f16 matrix pipe.
+ * Every operand value a travels as two fp16 numbers, a = a1 + a2/2048 (a1 = fp16(a) round-to-nearest, a2 = fp16((a - a1)*2048)),
+ * the product is a1 b1 + (a1 b2 + a2 b1)/2048: three v_mfma_f32_32x32x16_f16 per 16-deep k-block, fp32 accumulate.
+ *   A_split : device, halves [M][2][K] (plane 0 | plane 1 per row), K % 64 == 0
+ *   W_split : device, the layout of engine.pack_linear_f16_split: halves [2][K/16][2][N][8], N % 32 == 0, as float* */
+int ds_gemm_split(const void* A_split, const float* W_split, const float* bias, float* C, int64_t ldc, int32_t M, int32_t K,
+                  int32_t N, void* stream);
+
 /* One DMT evaluation (dmt.py:306-412).  xh [B,N,9], edge_x [B,N,N,2] dense; cond_x/cond_edge_x may be NULL
  * (first step, dmt.py:332-335); noise_level [B]; ctx_emb [B,1024] = cond_lin(SpecFormer(context)) (dmt.py:348-350),
  * NULL means zero context embedding.  out_xh [B,N,9], out_edge [B,N,N,2] are fully written (masked entries 0). */

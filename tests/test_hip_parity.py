@@ -185,6 +185,37 @@ def test_gemm_vs_torch(gpu_device, M, K, N, act):
     assert_close(out2, ref2, 4e-5, f"gemm+residual+affine {M}x{K}x{N}", rtol=4e-5)
 
 
+def test_split_fp16_gemm_accuracy(gpu_device):
+    """The arithmetic every block GEMM now uses (ds_device.h wave_mma_h): operands split in two fp16 planes, three f16 MFMAs
+    per product, fp32 accumulate.  Against an fp64 reference its error must be at the level of the fp32-MFMA GEMM's own
+    rounding error (both measured here), over magnitudes from 1e-4 to 50 and K up to 1024 - and exact on small integers."""
+    from diffspectra_amd import engine as E
+    lib = E.load_library()
+    d = gpu_device
+    g = torch.Generator().manual_seed(123)
+    for M, K, N, scale in ((200, 256, 96, 1.0), (64, 1024, 160, 1.0), (130, 64, 256, 50.0), (77, 128, 64, 1e-4)):
+        A = torch.randn(M, K, generator=g) * scale
+        A[:, ::7] *= 1e-3                                               # mixed magnitudes inside a row
+        W = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g)
+        ref = A.double() @ W.double().t() + b.double()
+        out = torch.full((M, N), float("nan"), device=d)
+        E.gemm_split(lib, E.split_rows_f16(A).to(d), E.pack_linear_f16_split(W).to(d), b.to(d), out, M, K, N)
+        out32 = torch.full((M, N), float("nan"), device=d)
+        E.gemm(lib, A.to(d), K, E.pack_linear(W).to(d), E.pad_vec(b).to(d), out32, N, M, K, N)
+        norm = (A.double().abs() @ W.double().abs().t() + b.double().abs())   # scale of the terms that were summed
+        e_split = float(((out.cpu().double() - ref).abs() / norm).max())
+        e_fp32 = float(((out32.cpu().double() - ref).abs() / norm).max())
+        print(f"[split-gemm {M}x{K}x{N} scale {scale:g}] max error / sum|terms|: split-fp16 {e_split:.2e}, fp32 MFMA {e_fp32:.2e}")
+        assert e_split < 4e-7, e_split                                  # ~2^-22 (representation + dropped a2 b2) .. 2^-21
+        assert e_split < 8 * max(e_fp32, 2e-8)
+    A = torch.randint(-8, 9, (64, 64), generator=g).float()             # exact: integers are representable in one fp16 plane
+    W = torch.randint(-8, 9, (32, 64), generator=g).float()
+    out = torch.zeros(64, 32, device=d)
+    E.gemm_split(lib, E.split_rows_f16(A).to(d), E.pack_linear_f16_split(W).to(d), None, out, 64, 64, 32)
+    assert torch.equal(out.cpu(), A @ W.t())
+
+
 def test_gemm_identity_asymmetric(gpu_device):
     """A = I with an asymmetric B: catches a transposed C/D fragment map (cdna guide §3)."""
     from diffspectra_amd import engine as E

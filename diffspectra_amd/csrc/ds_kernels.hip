@@ -746,7 +746,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
   __shared__ int idx_s[4][3][R];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5, r31 = lane & 31;
   constexpr int LDW2 = 2 * 64 + 8;                       // split-fp16 row: 272 bytes, as an fp32 row of 64 + 4
-  float(*E2)[LDW] = E2s[wave];
+  float(*E2)[LDW] = E2s[wave];                             // fp32 view of the tile (e_out, from the gated residual on)
+  _Float16* E2h = reinterpret_cast<_Float16*>(&E2s[wave][0][0]);   // split-fp16 view of the same bytes
   _Float16* Dh = reinterpret_cast<_Float16*>(&Ds[wave][0][0]);
   int* rmol = idx_s[wave][0];
   int* rpa = idx_s[wave][1];
@@ -787,51 +788,62 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
         r.z = ve[u].z + vg[u].z * ((ua[u].z + ub[u].z) + b.z); r.w = ve[u].w + vg[u].w * ((ua[u].w + ub[u].w) + b.w);
         r = ln_mod_reg64(r, sh[u], sc[u]);   // norm2_edge + modulate (dmt.py:166)
         if (row >= valid) { r = make_float4(0, 0, 0, 0); vd[u] = r; }
-        reinterpret_cast<float4*>(&E2[row][0])[k4] = r;
+        split_store4(E2h + row * LDW2, 64, 4 * k4, r);      // the FF input: an MFMA operand and (reconstructed) the residual
         split_store4(Dh + row * LDW2, 64, 4 * k4, vd[u]);   // CondGaussian features: only ever an MFMA operand -> split-fp16 layout
       }
     }
   }
-  // ---- FF3 transposed: a3[hc][i] = hidden feature hc*32 + acc_row(i, hh) of row r31            (dmt.py:118-119)
-  f32x16 a3[4][1];
-#pragma unroll
-  for (int hc = 0; hc < 4; ++hc) {
-    acc_zero<1>(a3[hc]);
-    wave_mma<1, true>(&E2[0][0], LDW, BW(c, blk, DS_BW_FF3_W), 128, hc * 32, 0, 8, a3[hc]);
-  }
-  // ---- SiLU in registers, FF4 as MFMAs whose B operand is the hidden activation                (dmt.py:119-120)
-  f32x16 a4[2][1];
-  acc_zero<1>(a4[0]);
-  acc_zero<1>(a4[1]);
+  // ---- FF (dmt.py:118-120) on the f16 matrix pipe, chained in registers.  ff_linear3 is computed transposed, 32 hidden features
+  //      at a time (lane = row, register i = hidden feature hc*32 + acc_row(i, hh)); SiLU; the accumulator registers 8s .. 8s+7,
+  //      split in two fp16 planes, ARE the B fragment of the ff_linear4 MFMAs (weights pre-permuted to that k order: DS_BW_FF4_C)
+  f32x16 a4[2][1], a4lo[2][1];
+  acc_zero<1>(a4[0]); acc_zero<1>(a4[1]);
+  acc_zero<1>(a4lo[0]); acc_zero<1>(a4lo[1]);
   {
     const float* b3 = BW(c, blk, DS_BW_FF3_B);
-    const float* W4 = BW(c, blk, DS_BW_FF4_W);
+    const float* W3 = BW(c, blk, DS_BW_FF3_H);
+    const uint4* W4 = reinterpret_cast<const uint4*>(BW(c, blk, DS_BW_FF4_C)) + lane;   // [plane][hc][s][ft][lane]
 #pragma unroll
-    for (int hc = 0; hc < 4; ++hc)
+    for (int hc = 0; hc < 4; ++hc) {
+      f32x16 a3[1], a3lo[1];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f0 = hc * 32 + 8 * q + 4 * hh;                       // registers 4q..4q+3 hold features f0..f0+3
-        const float4 bb = *reinterpret_cast<const float4*>(b3 + f0);
-        const float bs[4] = {bb.x, bb.y, bb.z, bb.w};
-        float ys[4];
+      for (int q = 0; q < 4; ++q) {   // accumulate onto the bias: registers 4q .. 4q+3 are features hc*32 + 8q + 4hh ..
+        const float4 bb = *reinterpret_cast<const float4*>(b3 + hc * 32 + 8 * q + 4 * hh);
+        a3[0][4 * q] = bb.x; a3[0][4 * q + 1] = bb.y; a3[0][4 * q + 2] = bb.z; a3[0][4 * q + 3] = bb.w;
+      }
+      acc_zero<1>(a3lo);
+      wave_mma_h<1, true, 4>(E2h, 64, W3, 128, 64, hc * 32, 0, 4, a3, a3lo);
+      split_finish<1>(a3, a3lo);
 #pragma unroll
-        for (int j = 0; j < 4; j += 2) {   // packed-fp32 SiLU, two features at a time
+      for (int s_ = 0; s_ < 2; ++s_) {
+        h8 y1, y2;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {   // packed-fp32 SiLU, two features at a time, then the fp16 split
           f32x2 v;
-          v.x = a3[hc][0][4 * q + j] + bs[j]; v.y = a3[hc][0][4 * q + j + 1] + bs[j + 1];
+          v.x = a3[0][8 * s_ + j]; v.y = a3[0][8 * s_ + j + 1];
           v = ds_silu2(v);
-          ys[j] = v.x; ys[j + 1] = v.y;
+          y1[j] = (_Float16)v.x; y1[j + 1] = (_Float16)v.y;
+          y2[j] = (_Float16)((v.x - (float)y1[j]) * 2048.0f); y2[j + 1] = (_Float16)((v.y - (float)y1[j + 1]) * 2048.0f);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          a4[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp_at(W4, 64, f0 + j, r31), ys[j], a4[0][0], 0, 0, 0);
-          a4[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp_at(W4, 64, f0 + j, 32 + r31), ys[j], a4[1][0], 0, 0, 0);
+        for (int ft = 0; ft < 2; ++ft) {
+          const h8 w1 = __builtin_bit_cast(h8, W4[(((0 * 4 + hc) * 2 + s_) * 2 + ft) * 64]);
+          const h8 w2 = __builtin_bit_cast(h8, W4[(((1 * 4 + hc) * 2 + s_) * 2 + ft) * 64]);
+          a4[ft][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, y1, a4[ft][0], 0, 0, 0);
+          a4lo[ft][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, y2, a4lo[ft][0], 0, 0, 0);
+          a4lo[ft][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, y1, a4lo[ft][0], 0, 0, 0);
         }
       }
+    }
+    split_finish<1>(a4[0], a4lo[0]);
+    split_finish<1>(a4[1], a4lo[1]);
   }
-  // ---- gated residual in the transposed layout (lane = row, 4 consecutive features per register quad), in place
+  // ---- gated residual in the transposed layout (lane = row, 4 consecutive features per register quad): the FF input is read back
+  //      from its split planes (x1 + x2/2048), e_out goes into the same tile bytes as fp32 once every lane has read
   {
     const float* b4 = BW(c, blk, DS_BW_FF4_B);
     const float* grow = ada + (size_t)rmol[r31] * ADAC + 320;          // edge_gate_mlp of this row's molecule (dmt.py:168)
+    float4 xo[2][4];
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -839,11 +851,21 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
         const int n0 = ft * 32 + 8 * q + 4 * hh;
         const float4 g = *reinterpret_cast<const float4*>(grow + n0);
         const float4 bb = *reinterpret_cast<const float4*>(b4 + n0);
-        float4 x = *reinterpret_cast<const float4*>(&E2[r31][n0]);
+        const h4 p0 = *reinterpret_cast<const h4*>(E2h + r31 * LDW2 + n0);
+        const h4 p1 = *reinterpret_cast<const h4*>(E2h + r31 * LDW2 + 64 + n0);
+        float4 x;
+        x.x = fmaf((float)p1[0], 1.0f / 2048.0f, (float)p0[0]); x.y = fmaf((float)p1[1], 1.0f / 2048.0f, (float)p0[1]);
+        x.z = fmaf((float)p1[2], 1.0f / 2048.0f, (float)p0[2]); x.w = fmaf((float)p1[3], 1.0f / 2048.0f, (float)p0[3]);
         x.x += g.x * (a4[ft][0][4 * q + 0] + bb.x); x.y += g.y * (a4[ft][0][4 * q + 1] + bb.y);
         x.z += g.z * (a4[ft][0][4 * q + 2] + bb.z); x.w += g.w * (a4[ft][0][4 * q + 3] + bb.w);
-        *reinterpret_cast<float4*>(&E2[r31][n0]) = x;
+        xo[ft][q] = x;
       }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(&E2[r31][ft * 32 + 8 * q + 4 * hh]) = xo[ft][q];
   }
   // ---- e_out to global, coalesced (4 rows x 256 B per wave-instruction)
 #pragma unroll
@@ -863,7 +885,6 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
       acc_store<1, 192>(acc, c.ws.edge_hids + (size_t)row0 * 192 + 64 + 16 * blk, valid, [b](int, float v) { return v + b; });
     }
   }
-  _Float16* E2h = reinterpret_cast<_Float16*>(&E2[0][0]);
   {
     float4 v[8];
 #pragma unroll

@@ -162,6 +162,22 @@ def pack_linear_f16_split(weight: torch.Tensor) -> torch.Tensor:
     return t.reshape(-1).view(torch.float32).clone()
 
 
+def pack_ff4_chain(weight: torch.Tensor) -> torch.Tensor:
+    """ff_linear4 [64, 128] for the accumulator-as-operand chain of k_edge_update: the SiLU'd 32 x 32 accumulator tile hc of
+    ff_linear3 (lane = row, register i = hidden feature hc*32 + (i&3) + 8(i>>2) + 4h) is used, registers 8s .. 8s+7 at a time,
+    as the B fragment of a 32x32x16 f16 MFMA; the A fragment of lane (r, h) must hold, in element j, the weight of output
+    ft*32 + r for exactly that hidden feature.  Two fp16 planes (w = w1 + w2/2048); returned as the fp32 view of the bits."""
+    w = weight.detach().to(torch.float32).cpu()
+    assert tuple(w.shape) == (64, 128)
+    w1 = w.half()
+    planes = torch.stack([w1, ((w - w1.float()) * SPLIT_SCALE).half()])          # [2, 64, 128]
+    hc, s_, ft, h, r, j = torch.meshgrid(torch.arange(4), torch.arange(2), torch.arange(2), torch.arange(2), torch.arange(32),
+                                          torch.arange(8), indexing="ij")
+    k = hc * 32 + 16 * s_ + 8 * (j >> 2) + 4 * h + (j & 3)
+    out = planes[:, ft * 32 + r, k]                                              # [2, 4, 2, 2, 2, 32, 8]
+    return out.contiguous().reshape(-1).view(torch.float32).clone()
+
+
 def split_rows_f16(a: torch.Tensor) -> torch.Tensor:
     """fp32 [M, K] → the A-operand layout of ``ds_gemm_split``: halves [M][2][K] (a = a1 + a2/2048), returned as float16."""
     a = a.detach().to(torch.float32)
@@ -253,6 +269,8 @@ def pack_dmt_weights(sd: Dict[str, torch.Tensor]):
         put(bslot(b, "DS_BW_CM0_B"), pad_vec(sd[p + "equi_update.coord_mlp.0.bias"]))
         put(bslot(b, "DS_BW_CM2_W"), pack_linear(sd[p + "equi_update.coord_mlp.2.weight"]))
         put(bslot(b, "DS_BW_CM0_H"), pack_linear_f16_split(sd[p + "equi_update.coord_mlp.0.weight"]))
+        put(bslot(b, "DS_BW_FF3_H"), pack_linear_f16_split(sd[p + "ff_linear3.weight"]))
+        put(bslot(b, "DS_BW_FF4_C"), pack_ff4_chain(sd[p + "ff_linear4.weight"]))
         put(bslot(b, "DS_BW_N2E_H"), pack_linear_f16_split(sd[p + "node2edge_lin.weight"]))
         put(bslot(b, "DS_BW_FF1_H"), pack_linear_f16_split(sd[p + "ff_linear1.weight"]))
         put(bslot(b, "DS_BW_FF2_H"), pack_linear_f16_split(sd[p + "ff_linear2.weight"]))

@@ -76,6 +76,9 @@ enum ds_block_slot {
   DS_BW_E0_H, DS_BW_E1_H,                   /* lin_edge0 / lin_edge1 (64 -> 256) in the same split-fp16 layout (k_edge_geom) */
   DS_BW_ED_H,                               /* input_lin edge|dist part (128 -> 256) split-fp16 (k_edge_update) */
   DS_BW_QKV_H,                              /* q|k|v projection (256 -> 768) split-fp16 (k_node_qkv) */
+  DS_BW_FF3_H,                              /* ff_linear3 (64 -> 128) split-fp16 (k_edge_update, transposed) */
+  DS_BW_FF4_C,                              /* ff_linear4 (128 -> 64) split-fp16 in accumulator-chain order: halves [plane 2][hc 4][s 2][ft 2][lane 64][8],
+                                               element j of lane (r, h) = W[ft*32 + r][hc*32 + 16 s + 8 (j>>2) + 4 h + (j&3)] */
   DS_BW_N2E_H, DS_BW_FF1_H, DS_BW_FF2_H, DS_BW_NODE_RO_H, DS_BW_AC_H,   /* the five GEMMs of k_node_update, split-fp16 */
   DS_W_BLOCK_SLOTS
 };

@@ -1224,11 +1224,12 @@ __global__ __launch_bounds__(64) void k_pos_update(Ctx c, int last) {
 // Readout: node_pred_mlp (768->256->128->6) -> out_xh[..., 3:9] (dmt.py:391-393).
 __global__ __launch_bounds__(256) void k_node_readout(Ctx c, float* __restrict__ out_xh) {
   constexpr int T = 32;
-  __shared__ __attribute__((aligned(16))) float X[T][768 + DS_LDP];
-  __shared__ __attribute__((aligned(16))) float Y1[T][256 + DS_LDP];
+  // the 768- and 256-wide tiles in the split-fp16 layout (ds_device.h): their GEMMs run on the f16 pipe; the last, 128 -> 6, stays fp32
+  __shared__ __attribute__((aligned(16))) _Float16 X[T][2 * 768 + 8];
+  __shared__ __attribute__((aligned(16))) _Float16 Y1[T][2 * 256 + 8];
   __shared__ __attribute__((aligned(16))) float Y2[T][128 + DS_LDP];
   __shared__ int dn[T];   // dense output row of each tile row (-1 past the end)
-  const int tid = threadIdx.x, row0 = blockIdx.x * T;
+  const int tid = threadIdx.x, wave = tid >> 6, row0 = blockIdx.x * T;
   const int Nn = c.L.Nn;
   if (tid < T) dn[tid] = row0 + tid < Nn ? c.L.node_dense[row0 + tid] : -1;
   for (int i0 = tid; i0 < T * 192; i0 += 256 * 8) {   // eight loads in flight per thread (a plain loop pays one trip per load)
@@ -1241,20 +1242,39 @@ __global__ __launch_bounds__(256) void k_node_readout(Ctx c, float* __restrict__
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int idx = i0 + u * 256, row = idx / 192, k4 = idx - row * 192;
-      reinterpret_cast<float4*>(&X[row][0])[k4] = row0 + row < Nn ? v[u] : make_float4(0, 0, 0, 0);
+      split_store4(&X[row][0], 768, 4 * k4, row0 + row < Nn ? v[u] : make_float4(0, 0, 0, 0));
     }
   }
   __syncthreads();
   {
     const float* b = GW(c, DS_GW_NP0_B);
-    tile_gemm<1, 1>(&X[0][0], 768 + DS_LDP, 768, GW(c, DS_GW_NP0_W), 256, 8,
-                    [&](int row, int col, float v) { Y1[row][col] = ds_silu(v + b[col]); });
+    for (int ch = wave; ch < 8; ch += 4) {
+      asm volatile("" ::: "memory");
+      const int col = ch * 32 + (tid & 31), hhf = (tid & 63) >> 5;
+      const float bc = b[col];
+      f32x16 acc[1], lo[1];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] = bc;
+      acc_zero<1>(lo);
+      wave_mma_h<1, false, 8>(&X[0][0], 768, GW(c, DS_GW_NP0_H), 256, 768, ch * 32, 0, 48, acc, lo);
+      split_finish<1>(acc, lo);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) split_store1(&Y1[acc_row(i, hhf)][0], 256, col, ds_silu(acc[0][i]));
+    }
   }
   __syncthreads();
   {
     const float* b = GW(c, DS_GW_NP2_B);
-    tile_gemm<1, 1>(&Y1[0][0], 256 + DS_LDP, 256, GW(c, DS_GW_NP2_W), 128, 4,
-                    [&](int row, int col, float v) { Y2[row][col] = ds_silu(v + b[col]); });
+    const int col = wave * 32 + (tid & 31), hhf = (tid & 63) >> 5;
+    const float bc = b[col];
+    f32x16 acc[1], lo[1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][i] = bc;
+    acc_zero<1>(lo);
+    wave_mma_h<1, false, 8>(&Y1[0][0], 256, GW(c, DS_GW_NP2_H), 128, 256, wave * 32, 0, 16, acc, lo);
+    split_finish<1>(acc, lo);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Y2[acc_row(i, hhf)][col] = ds_silu(acc[0][i]);
   }
   __syncthreads();
   {
@@ -1269,7 +1289,7 @@ __global__ __launch_bounds__(256) void k_node_readout(Ctx c, float* __restrict__
 // Readout: edge_exist_mlp / edge_type_mlp (192->64->32->1 each) -> dense symmetric out_edge (dmt.py:394-399).
 __global__ __launch_bounds__(256) void k_edge_readout(Ctx c, float* __restrict__ out_edge) {
   constexpr int T = 64;
-  __shared__ __attribute__((aligned(16))) float X[T][192 + DS_LDP];
+  __shared__ __attribute__((aligned(16))) _Float16 X[T][2 * 192 + 8];   // split-fp16 layout: the 192 -> 64 GEMMs run on the f16 pipe
   __shared__ __attribute__((aligned(16))) float Y1[T][64 + DS_LDP];
   __shared__ __attribute__((aligned(16))) float Y2[T][32 + DS_LDP];
   __shared__ int oab[T], oba[T];   // dense output offsets of (a, b) and (b, a), resolved once per row (index chain of 2 trips)
@@ -1296,16 +1316,23 @@ __global__ __launch_bounds__(256) void k_edge_readout(Ctx c, float* __restrict__
 #pragma unroll
     for (int u = 0; u < 12; ++u) {
       const int idx = tid + u * 256, row = idx / 48, k4 = idx - row * 48;
-      reinterpret_cast<float4*>(&X[row][0])[k4] = row0 + row < Pp ? v[u] : make_float4(0, 0, 0, 0);
+      split_store4(&X[row][0], 192, 4 * k4, row0 + row < Pp ? v[u] : make_float4(0, 0, 0, 0));
     }
   }
   __syncthreads();
   for (int ch = 0; ch < 2; ++ch) {   // channel 0: edge_exist_mlp, channel 1: edge_type_mlp (dmt.py:394)
     const int g0 = ch == 0 ? DS_GW_EX0_W : DS_GW_ET0_W;
-    {
-      const float* b = GW(c, g0 + 1);
-      tile_gemm<2, 1>(&X[0][0], 192 + DS_LDP, 192, GW(c, g0), 64, 2,
-                      [&](int row, int col, float v) { Y1[row][col] = ds_silu(v + b[col]); });
+    {   // 64 rows x 64 columns over four waves: (row tile, column chunk) per wave
+      const int wave = tid >> 6, mt = wave >> 1, cc = wave & 1, col = cc * 32 + (tid & 31), hhf = (tid & 63) >> 5;
+      const float bc = GW(c, g0 + 1)[col];
+      f32x16 acc[1], lo[1];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] = bc;
+      acc_zero<1>(lo);
+      wave_mma_h<1, false, 4>(&X[mt * 32][0], 192, GW(c, ch == 0 ? DS_GW_EX0_H : DS_GW_ET0_H), 64, 192, cc * 32, 0, 12, acc, lo);
+      split_finish<1>(acc, lo);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Y1[mt * 32 + acc_row(i, hhf)][col] = ds_silu(acc[0][i]);
     }
     __syncthreads();
     {

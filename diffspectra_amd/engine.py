@@ -313,6 +313,10 @@ def pack_dmt_weights(sd: Dict[str, torch.Tensor]):
         for i in (0, 2, 4):
             put(gslot(f"DS_GW_{tag}{i}_W"), pack_linear(sd[f"{mlp}.{i}.weight"]))
             put(gslot(f"DS_GW_{tag}{i}_B"), pad_vec(sd[f"{mlp}.{i}.bias"]))
+    put(gslot("DS_GW_NP0_H"), pack_linear_f16_split(sd["node_pred_mlp.0.weight"]))
+    put(gslot("DS_GW_NP2_H"), pack_linear_f16_split(sd["node_pred_mlp.2.weight"]))
+    put(gslot("DS_GW_EX0_H"), pack_linear_f16_split(sd["edge_exist_mlp.0.weight"]))
+    put(gslot("DS_GW_ET0_H"), pack_linear_f16_split(sd["edge_type_mlp.0.weight"]))
     return torch.cat(chunks), offsets
 
 

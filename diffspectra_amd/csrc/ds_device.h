@@ -340,6 +340,68 @@ __device__ __forceinline__ void wave_mma_h(const _Float16* X, int K_tile, const 
     }
   }
 }
+// The same product with the weight stream requested PF k-blocks ahead through a register ring (8 registers per block), for a
+// wave that is alone on its SIMD's matrix pipe: one block ahead covers 6 MT x 32 cycles of a ~1-2 us L2 round trip, and with
+// no second MFMA wave to fill the gap every k-block then waits for its weights (k_equi_pairs: ISA showed s_waitcnt vmcnt
+// in front of every block).  NKB (k-blocks) is a compile-time constant so that the ring indices are.  `ring` carries the
+// first PF blocks in (requested by the caller with wring_h, e.g. under the previous epilogue) - no request is exposed at all.
+template <int PF>
+struct WRingH {
+  h8 w1[PF], w2[PF];
+};
+template <int PF>
+__device__ __forceinline__ void wring_h(WRingH<PF>& ring, const WStreamH& ws, int kb0) {
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    ring.w1[i] = wload_h(ws, 0, kb0 + i); ring.w2[i] = wload_h(ws, 1, kb0 + i);
+    __builtin_amdgcn_sched_barrier(0);   // in consumption order: loads return in issue order and the compiler would sort them by plane
+  }
+}
+template <int MT, bool TRANS, int NKB, int PF>
+__device__ __forceinline__ void wave_mma_h_deep(const _Float16* X, int K_tile, const WStreamH& ws, WRingH<PF>& ring, int kb0,
+                                                f32x16 (&hi)[MT], f32x16 (&lo)[MT], int xkb0 = 0) {
+  static_assert(PF <= NKB, "ring deeper than the product");
+  const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+  const int ldh = 2 * K_tile + 8;
+  const _Float16* xr = X + r * ldh + 8 * hh + (kb0 - xkb0) * 16;
+  h8 xa[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    xa[m][0] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh);
+    xa[m][1] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + K_tile);
+  }
+#pragma unroll
+  for (int i = 0; i < NKB; ++i) {
+    const int in = i + 1 < NKB ? i + 1 : i;
+    h8 xn[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      xn[m][0] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + in * 16);
+      xn[m][1] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + K_tile + in * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const h8 w1 = ring.w1[i % PF], w2 = ring.w2[i % PF];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (TRANS) {
+        hi[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xa[m][0], hi[m], 0, 0, 0);
+        lo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xa[m][1], lo[m], 0, 0, 0);
+        lo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, xa[m][0], lo[m], 0, 0, 0);
+      } else {
+        hi[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[m][0], w1, hi[m], 0, 0, 0);
+        lo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[m][1], w1, lo[m], 0, 0, 0);
+        lo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[m][0], w2, lo[m], 0, 0, 0);
+      }
+    }
+    if (i + PF < NKB) {   // the slot just consumed takes block i + PF
+      ring.w1[i % PF] = wload_h(ws, 0, kb0 + i + PF);
+      ring.w2[i % PF] = wload_h(ws, 1, kb0 + i + PF);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { xa[m][0] = xn[m][0]; xa[m][1] = xn[m][1]; }
+  }
+}
 template <int MT>
 __device__ __forceinline__ void split_finish(f32x16 (&hi)[MT], const f32x16 (&lo)[MT]) {   // hi += lo / 2048
 #pragma unroll

@@ -14,8 +14,8 @@
 
 #define ADAC DS_ADA_COLS
 #ifndef DS_EQUI_NCW
-#define DS_EQUI_NCW 8   // MFMA waves of k_equi_pairs (each owns 8 / NCW feature chunks); measured: 8 + 4 beats 4 + 8 by 11 %
-#define DS_EQUI_NLW 4   // loader waves (each owns 32 / NLW pairs of a tile)
+#define DS_EQUI_NCW 4   // MFMA waves of k_equi_pairs (each owns 8 / NCW feature chunks)
+#define DS_EQUI_NLW 4   // loader waves (each owns 32 / NLW pairs of a tile); 4 + 4 leaves both roles 256 registers
 #endif
 
 // Diagnostic build only (-DDS_STAMPS): per-phase shader-clock sums of wave 0 of every workgroup, accumulated into
@@ -967,122 +967,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
   }
   if (consumer) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
 
-  // Loader wave lw owns pairs lw, lw + NLW, ... of a tile (PPW pairs = 2 PPW rows).  The pair-table entries of a tile are
-  // fetched one produce() early.
-  const int lw = __builtin_amdgcn_readfirstlane(wave - NCW);
-  int pv_n = 0, av_n = 0, bv_n = 0, mv_n = 0, adj_n = 0;   // prefetched table entries, lane = (pair slot, direction)
-  auto fetch_idx = [&](int tile) {
-    const int p0 = tile * TP;
-    const int qv = lw + ((lane >> 1) & (PPW - 1)) * NLW;
-    pv_n = qv < min(TP, Pp - p0) ? p0 + qv : 0;                        // pairs past the end gather pair 0, zeroed below
-    av_n = c.L.pair_a[pv_n]; bv_n = c.L.pair_b[pv_n]; mv_n = c.L.pair_mol[pv_n]; adj_n = c.ws.adj[pv_n];
-  };
-  auto produce = [&](int tile, int buf, int gen, int tile_after) {
-    const int p0 = tile * TP;
-    const int npairs = min(TP, Pp - p0);
-    int na[PPW], nb[PPW], pm[PPW], pp[PPW];
-#pragma unroll
-    for (int u = 0; u < PPW; ++u) {
-      pp[u] = __builtin_amdgcn_readlane(pv_n, 2 * u); na[u] = __builtin_amdgcn_readlane(av_n, 2 * u);
-      nb[u] = __builtin_amdgcn_readlane(bv_n, 2 * u); pm[u] = __builtin_amdgcn_readlane(mv_n, 2 * u);
-    }
-    const int dir = lane & 1, qd = lw + ((lane >> 1) & (PPW - 1)) * NLW, bits = adj_n;
-    float4 pr = make_float4(0, 0, 0, 0), pc = pr;
-    if (lane < 2 * PPW) {
-      pr = reinterpret_cast<const float4*>(c.ws.pos)[dir ? bv_n : av_n];   // row atom (edge_index[0])
-      pc = reinterpret_cast<const float4*>(c.ws.pos)[dir ? av_n : bv_n];
-    }
-    // Four tile rows per pass (both directions of two pairs), one row per 16-lane DPP row, lane j of it holding the float4s at
-    // columns 4j + 64u: the LayerNorm sums are four DPP steps with every lane busy - ~15 VALU issues per row against ~55
-    // for the row-per-wave form.
-    const int g = lane >> 4, j = lane & 15, up = g >> 1, gdir = g & 1;
-    const float4* ac4 = reinterpret_cast<const float4*>(c.ws.ac);
-    const float4* ed4 = reinterpret_cast<const float4*>(c.ws.ed);
-    // The pair rows `ed` are the one HBM-latency stream of the kernel (written by k_edge_update just before, 0.66 GB per
-    // launch).  They travel by LDS-DMA straight into the X row slot they are consumed from (row 2q; both directions read it
-    // before either overwrites it), all rows of the wave's pairs requested up front: no registers, one exposed latency per tile.
-#pragma unroll
-    for (int i = 0; i < PPW; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ed4 + (size_t)pp[i] * 64 + lane),
-                                       (__attribute__((address_space(3))) void*)&Xh[buf][2 * (lw + NLW * i)][0], 16, 0, 0);
-    // ac rows: a lane of direction a -> b needs the h_row part of a and the h_col part of b, a lane of direction b -> a the h_row
-    // part of b and the h_col part of a.  Each lane KEEPS its part of the a-row (a changes about once per tile in the
-    // (a, b)-row-major pair order) and fetches its part of the b-row per pass: 4 gathers per pass instead of 8.
-    float4 Ka[4], Bv[4], sh[4], sc[4];
-    int cur_m = -1, cur_a = -1;
-    auto issue = [&](int bt) {   // gathers of pass bt: rows of pairs 2bt (DPP rows 0, 1) and 2bt + 1 (DPP rows 2, 3)
-      __builtin_amdgcn_sched_barrier(0);
-      const int i0 = 2 * bt, i1 = 2 * bt + 1;
-      const int ra = up ? na[i1] : na[i0], rb = up ? nb[i1] : nb[i0];
-      const float4* pb = ac4 + (size_t)rb * 128 + (gdir ? 0 : 64) + j;    // b: h_row part for b -> a lanes, h_col part for a -> b lanes
-#pragma unroll
-      for (int u = 0; u < 4; ++u) Bv[u] = pb[16 * u];
-      if (ra != cur_a) {
-        const float4* pa = ac4 + (size_t)ra * 128 + (gdir ? 64 : 0) + j;  // a: h_row part for a -> b lanes, h_col part for b -> a lanes
-#pragma unroll
-        for (int u = 0; u < 4; ++u) Ka[u] = pa[16 * u];
-        cur_a = ra;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    auto modulation = [&](int bt) {   // adaLN rows of pass bt's molecule; they change once per ~160 pairs
-      const int m = up ? pm[2 * bt + 1] : pm[2 * bt];
-      if (m != cur_m) {
-        const float4* ps = reinterpret_cast<const float4*>(adq + (size_t)m * ADAC) + j;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { sh[u] = ps[16 * u]; sc[u] = ps[64 + 16 * u]; }   // shift, scale (dmt.py:44)
-        cur_m = m;
-      }
-    };
-    issue(0);
-    modulation(0);
-    if (tile_after < ntiles) fetch_idx(tile_after);
-    __builtin_amdgcn_sched_barrier(0);
-    if (lane < 2 * PPW) {   // unit vector of pos[row] - pos[col], scaled (layers.py:345-346), + adjacency bits, for the tail
-      const float dx = pr.x - pc.x, dy = pr.y - pc.y, dz = pr.z - pc.z;
-      const float nrm = fmaxf(__builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);
-      const float sn = cscale * __builtin_amdgcn_rcpf(nrm);   // hardware sqrt / rcp (1 ulp): loader VALU issues are the scarce resource
-      float4 d;
-      d.x = dx * sn; d.y = dy * sn; d.z = dz * sn; d.w = __int_as_float(bits);
-      reinterpret_cast<float4*>(&dirs[gen][2 * qd + dir][0])[0] = d;
-    }
-#pragma unroll
-    for (int bt = 0; bt < NPASS; ++bt) {
-      if (bt == 0) {   // the DMA'd rows must have landed before they are read back (and nothing may be hoisted above this)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      DS_STAMP_W(8);
-      const int q = lw + (2 * bt + up) * NLW;
-      float4 x[4];   // a -> b: input_lin([h_a, h_b, e, d]);  b -> a: input_lin([h_b, h_a, e, d])  (dmt.py:39,45)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float4 e = reinterpret_cast<const float4*>(&Xh[buf][2 * q][0])[16 * u + j];
-        x[u].x = (Ka[u].x + Bv[u].x) + e.x; x[u].y = (Ka[u].y + Bv[u].y) + e.y;
-        x[u].z = (Ka[u].z + Bv[u].z) + e.z; x[u].w = (Ka[u].w + Bv[u].w) + e.w;
-      }
-      DS_STAMP(12);
-      if (bt + 1 < NPASS) issue(bt + 1);   // next pass's gathers fly behind this pass's LayerNorm
-      DS_STAMP(13);
-      ln_mod_quad256(x, sh, sc);
-      _Float16* xr = &Xh[buf][2 * q + gdir][0];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) split_store4(xr, 256, 64 * u + 4 * j, x[u]);
-      if (bt + 1 < NPASS) modulation(bt + 1);
-      DS_STAMP(14);
-    }
-    if (npairs < TP) {   // last tile only: rows of the pairs past the end (they were computed from pair 0) become zero rows
-      for (int i = 0; i < PPW; ++i) {
-        const int qz = lw + NLW * i;
-        if (qz >= npairs) {   // two 1040-byte row slots = 130 float4
-          float4* z = reinterpret_cast<float4*>(&Xh[buf][2 * qz][0]);
-          z[lane] = make_float4(0, 0, 0, 0);
-          z[64 + lane] = make_float4(0, 0, 0, 0);
-          if (lane < 2) z[128 + lane] = make_float4(0, 0, 0, 0);
-        }
-      }
-    }
-  };
+  const int lw = __builtin_amdgcn_readfirstlane(wave - NCW);   // loader wave lw owns pairs lw*PPW .. lw*PPW + PPW-1 of a tile
 
   // first loader wave: tail of a finished tile, one lane per directed edge (row 2q+dir of the tile)
   auto tail = [&](int tile, int pb, int gen) {
@@ -1110,6 +995,14 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
   const int first = blockIdx.x, stride = gridDim.x;
   if (first >= ntiles) return;
   if (consumer) {
+    // The weights do not depend on anything the workgroup computes: their stream runs PF k-blocks ahead through a register
+    // ring that is refilled for the next chunk as soon as a chunk's MFMAs are issued (ds_device.h, wave_mma_h_deep).
+    constexpr int PF = 8;
+    WStreamH wsh[CPW];
+#pragma unroll
+    for (int cc = 0; cc < CPW; ++cc) wsh[cc] = wstream_h(BW(c, blk, DS_BW_CM0_H), 256, 256, (wave + NCW * cc) * 32);
+    WRingH<PF> ring;
+    wring_h<PF>(ring, wsh[0], 0);
     __syncthreads();
     DS_STAMP(0);
     int it = 0;
@@ -1120,7 +1013,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
         const int ch = wave + NCW * cc;
         // coord_mlp.0 (256 -> 256) on the f16 matrix pipe with split operands (ds_device.h, wave_mma_h), transposed as before:
         // lane = edge row, registers = the chunk's 32 output features.
-        f32x16 acc1[2], acclo[2], acc2[2];
+        f32x16 acc1[2], acclo[2];
         {
           const float4* bp = reinterpret_cast<const float4*>(&cb0[ch][hh][0]);
 #pragma unroll
@@ -1132,35 +1025,46 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
             }
         }
         acc_zero<2>(acclo);
-        acc_zero<2>(acc2);
-        wave_mma_h<2, true, 16>(&Xh[buf][0][0], 256, BW(c, blk, DS_BW_CM0_H), 256, 256, ch * 32, 0, 16, acc1, acclo);
+        wave_mma_h_deep<2, true, 16, PF>(&Xh[buf][0][0], 256, wsh[cc], ring, 0, acc1, acclo);
+        wring_h<PF>(ring, wsh[(cc + 1) % CPW], 0);   // the next chunk's (next tile's) first blocks fly under the epilogue and the barrier
         split_finish<2>(acc1, acclo);
-        float w2f[16];
-        {
-          const float4* wp = reinterpret_cast<const float4*>(&cw2[ch][hh][min(lane & 31, 3)][0]);   // outputs >= 3: the zero row
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const float4 wv = wp[q4];
-            w2f[4 * q4] = wv.x; w2f[4 * q4 + 1] = wv.y; w2f[4 * q4 + 2] = wv.z; w2f[4 * q4 + 3] = wv.w;
-          }
-        }
+        // coord_mlp.2 (256 -> 3, dmt.py:34) on the VALU, fp32: a lane holds 16 of its row's 32 hidden features of this chunk, so
+        // the three outputs are 3 x 16 fused multiply-adds per row block (packed two at a time) - 48 v_pk_fma against the 32
+        // 64-cycle 32x32x2 fp32 MFMAs (29 of 32 output rows padding) that used to take 40 % of this wave's matrix-pipe time.
+        f32x2 so[2][3];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int i = 0; i < 16; i += 2) {
-            f32x2 y;   // SiLU of coord_mlp.0 (dmt.py:32-33), packed-fp32, two hidden features at a time
-            y.x = acc1[m][i]; y.y = acc1[m][i + 1];
-            y = ds_silu2(y);
-            acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[i], y.x, acc2[m], 0, 0, 0);       // coord_mlp.2 partial (dmt.py:34)
-            acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[i + 1], y.y, acc2[m], 0, 0, 0);
-          }
-        if (hh == 0) {   // out[j][row]: j = register 0..2 of the lower half, row = m*32 + lane
+          for (int o = 0; o < 3; ++o) so[m][o] = f32x2{0.0f, 0.0f};
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          float4 wv[3];
+#pragma unroll
+          for (int o = 0; o < 3; ++o) wv[o] = reinterpret_cast<const float4*>(&cw2[ch][hh][o][0])[q4];
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
-            float4 o;
-            o.x = acc2[m][0]; o.y = acc2[m][1]; o.z = acc2[m][2]; o.w = 0.0f;
-            reinterpret_cast<float4*>(&part[buf][ch][m * 32 + lane][0])[0] = o;
+            f32x2 y0, y1;   // SiLU of coord_mlp.0 (dmt.py:32-33), packed-fp32, two hidden features at a time
+            y0.x = acc1[m][4 * q4]; y0.y = acc1[m][4 * q4 + 1]; y1.x = acc1[m][4 * q4 + 2]; y1.y = acc1[m][4 * q4 + 3];
+            y0 = ds_silu2(y0); y1 = ds_silu2(y1);
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+              so[m][o] = __builtin_elementwise_fma(f32x2{wv[o].x, wv[o].y}, y0, so[m][o]);
+              so[m][o] = __builtin_elementwise_fma(f32x2{wv[o].z, wv[o].w}, y1, so[m][o]);
+            }
           }
+        }
+        {   // the other 16 features of the row sit in lane ^ 32: one v_permlane32_swap per output hands row block 0's upper
+            // halves to lanes 0-31 and row block 1's lower halves to lanes 32-63, so lane l ends up owning tile row l
+          float4 o4;
+          float* op = &o4.x;
+#pragma unroll
+          for (int o = 0; o < 3; ++o) {
+            const float s0 = so[0][o].x + so[0][o].y, s1 = so[1][o].x + so[1][o].y;
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s0), __float_as_uint(s1), false, false);
+            op[o] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+          }
+          o4.w = 0.0f;
+          reinterpret_cast<float4*>(&part[buf][ch][lane][0])[0] = o4;
         }
       }
       DS_STAMP(1);
@@ -1169,22 +1073,151 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
     }
     DS_STAMP_FLUSH(0);
   } else {
-    fetch_idx(first);
-    produce(first, 0, 0, first + stride);
-    __syncthreads();
+    // Loader wave: gather + LayerNorm + modulate PPW pairs (2 PPW rows) per tile, four rows per pass - both directions of two
+    // pairs, one row per 16-lane DPP row, lane j of it holding the float4s at columns 4j + 64u, so the LayerNorm sums are four
+    // DPP steps with every lane busy.  Memory latency is what a loader wave spends its time on (phase stamps,
+    // profiles/r02_equi_roles.md: 65 % of it sat in the wait at the head of each pass when every pass fetched its own rows),
+    // so the fetches run AHEAD of the arithmetic:
+    //  * the h_col / h_row parts of the b atoms (`ac`, 4 gathers per pass) of tile k+1 are requested into pass bt's registers
+    //    as soon as pass bt of tile k has consumed them - a whole tile interval before they are needed;
+    //  * the pair-table entries are fetched two tiles ahead (lane = (pair slot, direction));
+    //  * the pair rows `ed` (the one HBM stream, 0.66 GB per launch) go by LDS-DMA straight into the X row slots they are
+    //    consumed from, all PPW rows at the head of the interval - the buffer is only free then - and that one latency per
+    //    tile is what remains exposed; the previous tile's tail and the unit vectors are computed under it;
+    //  * the a atom's part is kept while a does not change (pairs are (a, b)-row-major and a wave owns consecutive pairs).
+    const int g = lane >> 4, j = lane & 15, up = g >> 1, gdir = g & 1, slot = (lane >> 1) & (PPW - 1), dir = lane & 1;
+    const float4* ac4 = reinterpret_cast<const float4*>(c.ws.ac);
+    const float4* ed4 = reinterpret_cast<const float4*>(c.ws.ed);
+    int pv_c = 0, av_c = 0, bv_c = 0, mv_c = 0, adj_c = 0;   // table entries of the tile being produced
+    int pv_x = 0, av_x = 0, bv_x = 0, mv_x = 0, adj_x = 0;   // ... and of the one after it
+#define DS_EQUI_FETCH_IDX(TILE, PV, AV, BV, MV, ADJ)                                                   \
+    do {                                                                                               \
+      const int p0_ = (TILE) * TP, qv_ = lw * PPW + slot;                                              \
+      PV = qv_ < min(TP, Pp - p0_) ? p0_ + qv_ : 0; /* pairs past the end gather pair 0, zeroed below */ \
+      AV = c.L.pair_a[PV]; BV = c.L.pair_b[PV]; MV = c.L.pair_mol[PV]; ADJ = c.ws.adj[PV];             \
+    } while (0)
+    // b: h_row part for b -> a lanes, h_col part for a -> b lanes (dmt.py:39,45)
+#define DS_EQUI_ISSUE_B(BT, BVREG)                                                                     \
+    do {                                                                                               \
+      const int r0_ = __builtin_amdgcn_readlane(BVREG, 4 * (BT)), r1_ = __builtin_amdgcn_readlane(BVREG, 4 * (BT) + 2); \
+      const float4* pb_ = ac4 + (size_t)(up ? r1_ : r0_) * 128 + (gdir ? 0 : 64) + j;                  \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) Bv[BT][u] = pb_[16 * u];                           \
+    } while (0)
+    float4 Bv[NPASS][4], Ka[4], sh[4], sc[4];
+    int cur_m = -1, cur_a = -1;
+    DS_EQUI_FETCH_IDX(first, pv_c, av_c, bv_c, mv_c, adj_c);
+    if (first + stride < ntiles) DS_EQUI_FETCH_IDX(first + stride, pv_x, av_x, bv_x, mv_x, adj_x);
+#pragma unroll
+    for (int bt = 0; bt < NPASS; ++bt) DS_EQUI_ISSUE_B(bt, bv_c);
     DS_STAMP(4);
-    int it = 0, prev_tile = -1;
-    for (int tile = first; tile < ntiles; tile += stride, ++it) {
-      const int next = tile + stride, buf = it & 1;
-      if (next < ntiles) produce(next, buf ^ 1, (it + 1) % 3, next + stride);
-      DS_STAMP(5);
-      if (wave == NCW && prev_tile >= 0) tail(prev_tile, buf ^ 1, (it + 2) % 3);   // part[buf^1]: written one interval ago
-      DS_STAMP(6);
-      __syncthreads();
+    int k = 0, tile_m1 = -1, tile_m2 = -1;
+    for (int tile = first;; tile += stride, ++k) {
+      const bool have = tile < ntiles;
+      if (have) {
+        const int buf = k & 1, gen = k % 3;
+        const int p0 = tile * TP, npairs = min(TP, Pp - p0);
+        const bool have_next = tile + stride < ntiles;
+        int na[PPW], pm[PPW], pp[PPW];
+#pragma unroll
+        for (int u = 0; u < PPW; ++u) {
+          pp[u] = __builtin_amdgcn_readlane(pv_c, 2 * u); na[u] = __builtin_amdgcn_readlane(av_c, 2 * u);
+          pm[u] = __builtin_amdgcn_readlane(mv_c, 2 * u);
+        }
+        float4 pr = make_float4(0, 0, 0, 0), pc = pr;
+        if (lane < 2 * PPW) {
+          pr = reinterpret_cast<const float4*>(c.ws.pos)[dir ? bv_c : av_c];   // row atom (edge_index[0])
+          pc = reinterpret_cast<const float4*>(c.ws.pos)[dir ? av_c : bv_c];
+        }
+        // a: h_row part for a -> b lanes, h_col part for b -> a lanes; M: adaLN rows of the molecule (they change once per ~160 pairs)
+#define DS_EQUI_ISSUE_A(BT)                                                                            \
+        do {                                                                                           \
+          const int ra_ = up ? na[2 * (BT) + 1] : na[2 * (BT)];                                        \
+          if (ra_ != cur_a) {                                                                          \
+            const float4* pa_ = ac4 + (size_t)ra_ * 128 + (gdir ? 64 : 0) + j;                         \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) Ka[u] = pa_[16 * u];                         \
+            cur_a = ra_;                                                                               \
+          }                                                                                            \
+        } while (0)
+#define DS_EQUI_ISSUE_M(BT)                                                                            \
+        do {                                                                                           \
+          const int m_ = up ? pm[2 * (BT) + 1] : pm[2 * (BT)];                                         \
+          if (m_ != cur_m) {                                                                           \
+            const float4* ps_ = reinterpret_cast<const float4*>(adq + (size_t)m_ * ADAC) + j;          \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) { sh[u] = ps_[16 * u]; sc[u] = ps_[64 + 16 * u]; } /* shift, scale (dmt.py:44) */ \
+            cur_m = m_;                                                                                \
+          }                                                                                            \
+        } while (0)
+        DS_EQUI_ISSUE_A(0);
+        DS_EQUI_ISSUE_M(0);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ed4 + (size_t)pp[i] * 64 + lane),
+                                           (__attribute__((address_space(3))) void*)&Xh[buf][2 * (lw * PPW + i)][0], 16, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        DS_STAMP(5);
+        if (wave == NCW && k >= 2) tail(tile_m2, k & 1, (k + 1) % 3);   // tile k-2: its partial sums were complete one barrier ago
+        if (lane < 2 * PPW) {   // unit vector of pos[row] - pos[col], scaled (layers.py:345-346), + adjacency bits, for the tail
+          const float dx = pr.x - pc.x, dy = pr.y - pc.y, dz = pr.z - pc.z;
+          const float nrm = fmaxf(__builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);
+          const float sn = cscale * __builtin_amdgcn_rcpf(nrm);   // hardware sqrt / rcp (1 ulp): loader VALU issues are the scarce resource
+          float4 d;
+          d.x = dx * sn; d.y = dy * sn; d.z = dz * sn; d.w = __int_as_float(adj_c);
+          reinterpret_cast<float4*>(&dirs[gen][2 * (lw * PPW + slot) + dir][0])[0] = d;
+        }
+        DS_STAMP(6);
+        // the DMA'd rows must have landed before they are read back (and nothing may be hoisted above this)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        DS_STAMP(8);
+#pragma unroll
+        for (int bt = 0; bt < NPASS; ++bt) {
+          const int q = lw * PPW + 2 * bt + up;
+          float4 x[4];   // a -> b: input_lin([h_a, h_b, e, d]);  b -> a: input_lin([h_b, h_a, e, d])  (dmt.py:39,45)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float4 e = reinterpret_cast<const float4*>(&Xh[buf][2 * q][0])[16 * u + j];
+            x[u].x = (Ka[u].x + Bv[bt][u].x) + e.x; x[u].y = (Ka[u].y + Bv[bt][u].y) + e.y;
+            x[u].z = (Ka[u].z + Bv[bt][u].z) + e.z; x[u].w = (Ka[u].w + Bv[bt][u].w) + e.w;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (have_next) DS_EQUI_ISSUE_B(bt, bv_x);     // the next tile's pass bt, a tile interval ahead
+          if (bt + 1 < NPASS) DS_EQUI_ISSUE_A(bt + 1);  // next pass's a part, if a changes
+          __builtin_amdgcn_sched_barrier(0);
+          DS_STAMP(12);
+          ln_mod_quad256(x, sh, sc);
+          _Float16* xr = &Xh[buf][2 * q + gdir][0];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) split_store4(xr, 256, 64 * u + 4 * j, x[u]);
+          if (bt + 1 < NPASS) DS_EQUI_ISSUE_M(bt + 1);  // sh / sc are free now: next pass's adaLN rows, if the molecule changes
+          DS_STAMP(14);
+        }
+        if (npairs < TP) {   // last tile only: rows of the pairs past the end (they were computed from pair 0) become zero rows
+          for (int i = 0; i < PPW; ++i) {
+            const int qz = lw * PPW + i;
+            if (qz >= npairs) {   // two 1040-byte row slots = 130 float4
+              float4* z = reinterpret_cast<float4*>(&Xh[buf][2 * qz][0]);
+              z[lane] = make_float4(0, 0, 0, 0);
+              z[64 + lane] = make_float4(0, 0, 0, 0);
+              if (lane < 2) z[128 + lane] = make_float4(0, 0, 0, 0);
+            }
+          }
+        }
+      } else if (wave == NCW && k >= 2) {
+        tail(tile_m2, k & 1, (k + 1) % 3);
+      }
       DS_STAMP(7);
-      prev_tile = tile;
+      __syncthreads();
+      DS_STAMP(9);
+      if (!have) break;
+      pv_c = pv_x; av_c = av_x; bv_c = bv_x; mv_c = mv_x; adj_c = adj_x;
+      if (tile + 2 * stride < ntiles) DS_EQUI_FETCH_IDX(tile + 2 * stride, pv_x, av_x, bv_x, mv_x, adj_x);
+      tile_m2 = tile_m1; tile_m1 = tile;
     }
-    if (wave == NCW) tail(prev_tile, (it + 1) & 1, (it + 2) % 3);
+    if (wave == NCW) tail(tile_m1, (k + 1) & 1, (k + 2) % 3);   // the last tile (k - 1)
+#undef DS_EQUI_FETCH_IDX
+#undef DS_EQUI_ISSUE_B
+#undef DS_EQUI_ISSUE_A
+#undef DS_EQUI_ISSUE_M
     DS_STAMP_FLUSH(NCW * 64);
   }
 }

@@ -402,6 +402,15 @@ __device__ __forceinline__ void wave_mma_h_deep(const _Float16* X, int K_tile, c
     for (int m = 0; m < MT; ++m) { xa[m][0] = xn[m][0]; xa[m][1] = xn[m][1]; }
   }
 }
+// Convenience form: stream + ring set up inside the call (one exposed weight round trip per call instead of one per k-block).
+template <int MT, bool TRANS, int NKB, int PF>
+__device__ __forceinline__ void wave_mma_h_ring(const _Float16* X, int K_tile, const float* __restrict__ Wh, int N, int K, int col0,
+                                                int kb0, f32x16 (&hi)[MT], f32x16 (&lo)[MT], int xkb0 = 0) {
+  const WStreamH ws = wstream_h(Wh, N, K, col0);
+  WRingH<PF> ring;
+  wring_h<PF>(ring, ws, kb0);
+  wave_mma_h_deep<MT, TRANS, NKB, PF>(X, K_tile, ws, ring, kb0, hi, lo, xkb0);
+}
 template <int MT>
 __device__ __forceinline__ void split_finish(f32x16 (&hi)[MT], const f32x16 (&lo)[MT]) {   // hi += lo / 2048
 #pragma unroll

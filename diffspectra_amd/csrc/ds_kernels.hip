@@ -13,6 +13,13 @@
 #include "ds_device.h"
 
 #define ADAC DS_ADA_COLS
+// k-blocks of weights in flight per wave in the 16-block GEMMs (ds_device.h, wave_mma_h_deep); measured 4 / 8 / 12: 8
+#ifndef DS_NODE_PF
+#define DS_NODE_PF 8
+#endif
+#ifndef DS_QKV_PF
+#define DS_QKV_PF 4
+#endif
 #ifndef DS_EQUI_NCW
 #define DS_EQUI_NCW 4   // MFMA waves of k_equi_pairs (each owns 8 / NCW feature chunks)
 #define DS_EQUI_NLW 4   // loader waves (each owns 32 / NLW pairs of a tile); 4 + 4 leaves both roles 256 registers
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(NW * 64) void k_node_qkv(Ctx c, int blk) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][i] = b;
     acc_zero<2>(lo);
-    wave_mma_h<2, false, 8>(&Xh[0][0], 256, BW(c, blk, DS_BW_QKV_H), 768, 256, col0 + ch * 32, 0, 16, acc, lo);
+    wave_mma_h_ring<2, false, 16, DS_QKV_PF>(&Xh[0][0], 256, BW(c, blk, DS_BW_QKV_H), 768, 256, col0 + ch * 32, 0, acc, lo);
     split_finish<2>(acc, lo);
     acc_store<2, 768>(acc, qkv + ch * 32, valid, [](int, float v) { return v; });
   }
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
     f32x16 acc[1], lo[1];
     acc_zero<1>(acc);
     acc_zero<1>(lo);
-    wave_mma_h<1, false, 8>(&B1[0][0], 256, BW(c, blk, DS_BW_N2E_H), 64, 256, wave * 32, 0, 16, acc, lo);
+    wave_mma_h_ring<1, false, 16, DS_NODE_PF>(&B1[0][0], 256, BW(c, blk, DS_BW_N2E_H), 64, 256, wave * 32, 0, acc, lo);
     split_finish<1>(acc, lo);
     acc_store<1, 64>(acc, c.ws.u + (size_t)row0 * 64 + wave * 32, Nn - row0, [](int, float v) { return v; });
   }
@@ -661,7 +668,7 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[0][i] = bf;
         acc_zero<1>(lo);
-        wave_mma_h<1, false, 8>(&H2[0][0], 256, W1, 512, 256, (half * 8 + ch) * 32, 0, 16, acc, lo);
+        wave_mma_h_ring<1, false, 16, DS_NODE_PF>(&H2[0][0], 256, W1, 512, 256, (half * 8 + ch) * 32, 0, acc, lo);
         split_finish<1>(acc, lo);
         // SiLU(FF1 + bias) -> hidden tile, two rows at a time (packed-fp32 epilogue)
 #pragma unroll
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
         asm volatile("" ::: "memory");
-        wave_mma_h<1, false, 8>(&B1[0][0], 256, W2, 256, 512, (wave + 4 * cc) * 32, half * 16, half * 16 + 16, acc2[cc], lo2[cc], half * 16);
+        wave_mma_h_ring<1, false, 16, DS_NODE_PF>(&B1[0][0], 256, W2, 256, 512, (wave + 4 * cc) * 32, half * 16, acc2[cc], lo2[cc], half * 16);
       }
       __syncthreads();
     }
@@ -719,13 +726,13 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
         const float b = br[it * 32 + (tid & 31)];
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[0][i] = b;
-        wave_mma_h<1, false, 8>(&H2[0][0], 256, BW(c, blk, DS_BW_NODE_RO_H), 64, 256, it * 32, 0, 16, acc, lo);
+        wave_mma_h_ring<1, false, 16, DS_NODE_PF>(&H2[0][0], 256, BW(c, blk, DS_BW_NODE_RO_H), 64, 256, it * 32, 0, acc, lo);
         split_finish<1>(acc, lo);
         acc_store<1, 768>(acc, c.ws.atom_hids + (size_t)row0 * 768 + 256 + 64 * blk + it * 32, Nn - row0, [](int, float v) { return v; });
       } else {
         const int ch = it - 2;
         acc_zero<1>(acc);
-        wave_mma_h<1, false, 8>(&H2[0][0], 256, BW(c, blk, DS_BW_AC_H), 512, 256, ch * 32, 0, 16, acc, lo);
+        wave_mma_h_ring<1, false, 16, DS_NODE_PF>(&H2[0][0], 256, BW(c, blk, DS_BW_AC_H), 512, 256, ch * 32, 0, acc, lo);
         split_finish<1>(acc, lo);
         acc_store<1, 512>(acc, c.ws.ac + (size_t)row0 * 512 + ch * 32, Nn - row0, [](int, float v) { return v; });
       }
@@ -1304,7 +1311,7 @@ __global__ __launch_bounds__(256) void k_node_readout(Ctx c, float* __restrict__
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[0][i] = bc;
     acc_zero<1>(lo);
-    wave_mma_h<1, false, 8>(&Y1[0][0], 256, GW(c, DS_GW_NP2_H), 128, 256, wave * 32, 0, 16, acc, lo);
+    wave_mma_h_ring<1, false, 16, 8>(&Y1[0][0], 256, GW(c, DS_GW_NP2_H), 128, 256, wave * 32, 0, acc, lo);
     split_finish<1>(acc, lo);
 #pragma unroll
     for (int i = 0; i < 16; ++i) Y2[acc_row(i, hhf)][col] = ds_silu(acc[0][i]);

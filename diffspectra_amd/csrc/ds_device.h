@@ -345,6 +345,9 @@ __device__ __forceinline__ void wave_mma_h(const _Float16* X, int K_tile, const 
 // no second MFMA wave to fill the gap every k-block then waits for its weights (k_equi_pairs: ISA showed s_waitcnt vmcnt
 // in front of every block).  NKB (k-blocks) is a compile-time constant so that the ring indices are.  `ring` carries the
 // first PF blocks in (requested by the caller with wring_h, e.g. under the previous epilogue) - no request is exposed at all.
+#ifndef DS_MMA_XD
+#define DS_MMA_XD 1   // X fragments ahead of the MFMAs (k-blocks); measured 1 / 2 / 3: no difference, 1 costs the fewest registers
+#endif
 template <int PF>
 struct WRingH {
   h8 w1[PF], w2[PF];
@@ -357,49 +360,49 @@ __device__ __forceinline__ void wring_h(WRingH<PF>& ring, const WStreamH& ws, in
     __builtin_amdgcn_sched_barrier(0);   // in consumption order: loads return in issue order and the compiler would sort them by plane
   }
 }
-template <int MT, bool TRANS, int NKB, int PF>
+template <int MT, bool TRANS, int NKB, int PF, int XD = DS_MMA_XD>
 __device__ __forceinline__ void wave_mma_h_deep(const _Float16* X, int K_tile, const WStreamH& ws, WRingH<PF>& ring, int kb0,
                                                 f32x16 (&hi)[MT], f32x16 (&lo)[MT], int xkb0 = 0) {
-  static_assert(PF <= NKB, "ring deeper than the product");
+  static_assert(PF <= NKB && XD <= NKB, "ring deeper than the product");
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const int ldh = 2 * K_tile + 8;
   const _Float16* xr = X + r * ldh + 8 * hh + (kb0 - xkb0) * 16;
-  h8 xa[MT][2];
+  h8 xq[XD][MT][2];   // the X fragments run XD k-blocks ahead as well (LDS is shared with every other wave of the workgroup)
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    xa[m][0] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh);
-    xa[m][1] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + K_tile);
-  }
+  for (int d = 0; d < XD; ++d)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      xq[d][m][0] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + d * 16);
+      xq[d][m][1] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + K_tile + d * 16);
+    }
 #pragma unroll
   for (int i = 0; i < NKB; ++i) {
-    const int in = i + 1 < NKB ? i + 1 : i;
-    h8 xn[MT][2];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      xn[m][0] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + in * 16);
-      xn[m][1] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + K_tile + in * 16);
-    }
     __builtin_amdgcn_sched_barrier(0);
     const h8 w1 = ring.w1[i % PF], w2 = ring.w2[i % PF];
+    h8 xa[MT][2];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      if (TRANS) {
-        hi[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xa[m][0], hi[m], 0, 0, 0);
-        lo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xa[m][1], lo[m], 0, 0, 0);
-        lo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, xa[m][0], lo[m], 0, 0, 0);
-      } else {
-        hi[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[m][0], w1, hi[m], 0, 0, 0);
-        lo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[m][1], w1, lo[m], 0, 0, 0);
-        lo[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[m][0], w2, lo[m], 0, 0, 0);
-      }
-    }
-    if (i + PF < NKB) {   // the slot just consumed takes block i + PF
+    for (int m = 0; m < MT; ++m) { xa[m][0] = xq[i % XD][m][0]; xa[m][1] = xq[i % XD][m][1]; }
+    // issue order: no two consecutive MFMAs accumulate into the same registers when there are two row tiles
+#define DS_MMA_(ACC, WV, XV) ACC = TRANS ? __builtin_amdgcn_mfma_f32_32x32x16_f16(WV, XV, ACC, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(XV, WV, ACC, 0, 0, 0)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) DS_MMA_(lo[m], w1, xa[m][1]);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) DS_MMA_(hi[m], w1, xa[m][0]);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) DS_MMA_(lo[m], w2, xa[m][0]);
+#undef DS_MMA_
+    if (i + PF < NKB) {   // the slots just consumed take blocks i + PF / i + XD
       ring.w1[i % PF] = wload_h(ws, 0, kb0 + i + PF);
       ring.w2[i % PF] = wload_h(ws, 1, kb0 + i + PF);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if (i + XD < NKB) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) { xa[m][0] = xn[m][0]; xa[m][1] = xn[m][1]; }
+      for (int m = 0; m < MT; ++m) {
+        xq[i % XD][m][0] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + (i + XD) * 16);
+        xq[i % XD][m][1] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + K_tile + (i + XD) * 16);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 // Convenience form: stream + ring set up inside the call (one exposed weight round trip per call instead of one per k-block).

@@ -28,6 +28,7 @@ def qm9s_config(spectra_version: str = "allspectra", device="cpu", steps: int = 
         name="QM9S", info_name="qm9_second_half", compress_edge=True, centered=True,
         include_aromatic=False, atom_types=5, bond_types=4, fc_scale=[-1.0, 1.0],
         max_node=29, spectra_version=spectra_version,
+        root="/path/to/dataset/QM9S", use_normalize=True,   # configs/diffspectra_qm9s.py:17,35
     )
     model = Config(
         name="DMT", pred_data=True, include_fc_charge=True, normalize_factors="1, 4, 4, 1",

@@ -83,11 +83,19 @@ def checkpoint_ids(config):
     return list(range(config.eval.begin_ckpt, config.eval.end_ckpt + 1))
 
 
-def diffspectra_evaluate(config, workdir: str, test_ds, eval_folder: str = "eval",
+def diffspectra_evaluate(config, workdir: str, test_ds=None, eval_folder: str = "eval",
                          metric_fns: Optional[Dict[str, Callable]] = None):
     """Sampling evaluation over the configured checkpoints; returns ``{ckpt: {'processed_mols', 'gt_pos', 'gt_rdmols',
-    'metrics'}}``.  ``metric_fns[name](processed_mols, gt_pos, gt_rdmols)`` are optional host-side callbacks."""
+    'metrics'}}``.  ``metric_fns[name](processed_mols, gt_pos, gt_rdmols)`` are optional host-side callbacks.
+
+    ``test_ds=None`` reads the reference's processed files under ``config.data.root`` (``run_lib.py:313`` ->
+    ``build_dataset.py:31-42``: the 'test' entry of ``split_dict_diffspectra_qm9.pt``) into the device-resident table of
+    ``qm9s_reader.ProcessedQM9S.packed_table`` - no PyG, no per-molecule Python."""
     os.makedirs(os.path.join(workdir, eval_folder), exist_ok=True)
+    if test_ds is None:
+        from .qm9s_reader import ProcessedQM9S
+        test_ds = ProcessedQM9S(config.data.root).packed_table(
+            config.data.spectra_version, split="test", device=config.device, normalize=getattr(config.data, "use_normalize", True))
     model = create_model(config)
     ema = ExponentialMovingAverage(model.parameters(), decay=config.model.ema_decay)
     state = dict(optimizer=None, model=model, ema=ema, step=0)

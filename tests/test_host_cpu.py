@@ -164,6 +164,103 @@ def test_packed_spectra_table():
         PackedSpectraTable([raw[0][:, :, :10], None, None], torch.tensor(n_atoms))
 
 
+def _write_processed_qm9s(proc_dir, mols, layout):
+    """Write data_qm9_allspectra.pt + split file the way InMemoryDataset.collate + torch.save do, WITHOUT PyG / RDKit: classes
+    named like theirs live in throw-away modules while pickling (PyG 2.4.0: Data.__dict__ = {_edge_attr_cls, _tensor_attr_cls,
+    _store}, GlobalStorage.__getstate__ = its __dict__ with _parent resolved; PyG 1.x: the tensors directly in Data.__dict__)."""
+    import sys
+    import types
+    names = ["torch_geometric", "torch_geometric.data", "torch_geometric.data.data", "torch_geometric.data.storage",
+             "rdkit", "rdkit.Chem", "rdkit.Chem.rdchem"]
+    mods = {n: types.ModuleType(n) for n in names}
+
+    def cls(module, name):
+        c = type(name, (), {"__module__": module})
+        setattr(mods[module], name, c)
+        return c
+    Data, Storage, Mol = cls("torch_geometric.data.data", "Data"), cls("torch_geometric.data.storage", "GlobalStorage"), cls("rdkit.Chem.rdchem", "Mol")
+    EdgeAttr, TensorAttr = cls("torch_geometric.data.data", "DataEdgeAttr"), cls("torch_geometric.data.data", "DataTensorAttr")
+    cat = lambda k, dim=0: torch.cat([m[k] for m in mols], dim)
+    cum = lambda sizes: torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int64)
+    M = len(mols)
+    rdmols = []
+    for i in range(M):
+        r = Mol()
+        r.tag = f"mol{i}"
+        rdmols.append(r)
+    mapping = {"atom_type": cat("atom_type"), "pos": cat("pos"), "edge_index": cat("edge_index", 1), "edge_type": cat("edge_type"),
+               "uv": cat("uv"), "ir": cat("ir"), "raman": cat("raman"),
+               "num_atom": torch.tensor([m["pos"].shape[0] for m in mols]), "idx": torch.arange(M), "rdmol": rdmols}
+    n = [m["pos"].shape[0] for m in mols]
+    ne = [m["edge_type"].shape[0] for m in mols]
+    one = torch.arange(M + 1)
+    slices = {"atom_type": cum(n), "pos": cum(n), "edge_index": cum(ne), "edge_type": cum(ne), "uv": one, "ir": one, "raman": one,
+              "num_atom": one, "idx": one, "rdmol": one}
+    data = Data()
+    if layout == "pyg2":
+        st = Storage()
+        st.__dict__.update({"_key": None, "_mapping": mapping, "_parent": data})
+        data.__dict__.update({"_edge_attr_cls": EdgeAttr, "_tensor_attr_cls": TensorAttr, "_store": st})
+    else:
+        data.__dict__.update(mapping)
+    os.makedirs(proc_dir, exist_ok=True)
+    saved = {k: sys.modules.get(k) for k in names}
+    sys.modules.update(mods)
+    try:
+        torch.save((data, slices), os.path.join(proc_dir, "data_qm9_allspectra.pt"))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    perm = np.random.RandomState(0).permutation(M)
+    torch.save({"first_train": perm[:2], "second_train": perm[2:4], "valid": perm[4:6], "test": perm[6:]},
+               os.path.join(proc_dir, "split_dict_diffspectra_qm9.pt"))
+    return perm
+
+
+@pytest.mark.parametrize("layout", ["pyg2", "pyg1"])
+def test_processed_qm9s_reader(tmp_path, layout):
+    """N3 (on-disk side): data_qm9_allspectra.pt + split_dict_diffspectra_qm9.pt -> the sampler's table, item for item what
+    ``dataset.index_select(split['test'])[i]`` + EdgeComSpectraTransform give (qm9s_dataset.py:153,306-312,357-361;
+    build_dataset.py:36-42,141-148), read without PyG or RDKit."""
+    from diffspectra_amd.qm9s_reader import ProcessedQM9S
+    M = 11
+    n_atoms = filler.sample_n_atoms(M, seed=9).tolist()
+    mols = []
+    for i, n in enumerate(n_atoms):
+        ne = 2 * max(n - 1, 0)
+        mols.append({"atom_type": torch.randint(0, 5, (n,)), "pos": filler.uniform(f"rd.pos{i}", (n, 3)),
+                     "edge_index": torch.randint(0, max(n, 1), (2, ne)), "edge_type": torch.randint(1, 4, (ne,)),
+                     "uv": filler.uniform(f"rd.uv{i}", (1, 701)).abs() * 30, "ir": filler.uniform(f"rd.ir{i}", (1, 3501)).abs() * 30,
+                     "raman": filler.uniform(f"rd.ra{i}", (1, 3501)).abs() * 30})
+    perm = _write_processed_qm9s(str(tmp_path / "processed"), mols, layout)
+    ds = ProcessedQM9S(str(tmp_path))                       # the dataset root, as config.data.root
+    assert len(ds) == M and sorted(ds.splits) == ["first_train", "second_train", "test", "valid"]
+    test_ids = perm[6:].tolist()
+    tab = ds.packed_table("allspectra", split="test")
+    assert len(tab) == len(test_ids)
+    for i, j in enumerate(test_ids):
+        it = tab[i]
+        assert int(it.num_atom) == n_atoms[j] and torch.equal(it.pos, mols[j]["pos"])
+        for name in ("uv", "ir", "raman"):
+            assert torch.equal(getattr(it, name), torch.log10(mols[j][name] + 1))
+        assert type(it.rdmol).__name__ == "Mol" and it.rdmol._state["tag"] == f"mol{j}"      # opaque, but the right molecule
+        assert torch.equal(ds.item_field("edge_index", j), mols[j]["edge_index"])           # concatenated along dim 1
+        assert torch.equal(ds.item_field("atom_type", j), mols[j]["atom_type"])
+    ctx, n_nodes, pos, _ = tab.batch([2, 0], "allspectra")
+    assert n_nodes == [n_atoms[test_ids[2]], n_atoms[test_ids[0]]] and ctx[1].shape == (2, 1, 3501)
+    assert torch.equal(ctx[0][1, 0], torch.log10(mols[test_ids[0]]["uv"][0] + 1))
+    raw = ds.packed_table("ir", split="valid", normalize=False)
+    assert torch.equal(raw[1].ir, mols[perm[5]]["ir"]) and raw.spectra[0] is None
+    assert len(ds.packed_table("ir", split=None)) == M
+    with pytest.raises(KeyError):
+        ds.split("train")
+    with pytest.raises(FileNotFoundError):
+        ProcessedQM9S(str(tmp_path / "nowhere"))
+
+
 def test_batched_stability_matches_scalar_restatement():
     """N4: the batched device-side bond-order / valence check equals the reference's pair-by-pair decision."""
     from diffspectra_amd.stability import check_stability_batch

@@ -908,6 +908,19 @@ def test_evaluate_driver(gpu_device, tmp_path):
     for a, b in zip(res[40]["processed_mols"], want):
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
         assert float((a[0] - b[0]).abs().max()) < 1e-5
+    # test_ds=None: the driver reads the reference's processed files under config.data.root (qm9s_reader) - same molecules as
+    # handing it the 'test' split of the same data item by item
+    from tests.test_host_cpu import _write_processed_qm9s
+    big, _ = _tiny_dataset(9)
+    mols = [{"atom_type": torch.zeros(int(it.num_atom), dtype=torch.long), "pos": it.pos, "edge_index": torch.zeros(2, 0, dtype=torch.long),
+             "edge_type": torch.zeros(0, dtype=torch.long), "uv": it.uv, "ir": it.ir, "raman": it.raman} for it in big]
+    perm = _write_processed_qm9s(str(tmp_path / "QM9S" / "processed"), mols, "pyg2")
+    cfg.data.root, cfg.data.use_normalize = str(tmp_path / "QM9S"), False
+    from_disk = EV.diffspectra_evaluate(cfg, str(tmp_path))
+    by_hand = EV.diffspectra_evaluate(cfg, str(tmp_path), [big[j] for j in perm[6:].tolist()])
+    assert len(from_disk[40]["processed_mols"]) == 3     # the split holds 3 molecules: one round of 3 (sampling.py:389-390)
+    for a, b in zip(from_disk[40]["processed_mols"], by_hand[40]["processed_mols"]):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
     with pytest.raises(FileNotFoundError):
         cfg.eval.begin_ckpt = cfg.eval.end_ckpt = 41
         EV.diffspectra_evaluate(cfg, str(tmp_path), ds)

@@ -199,8 +199,10 @@ __global__ __launch_bounds__(256) void k_pair_init(Ctx c, const float* __restric
 // Block stage A (pairs): d^2 -> CondGaussian RBF -> edge_emb(128->64) -> LN -> modulate -> tanh(lin_edge0/1).
 // dmt.py:136-139,145-149; layers.py:165-166,183.
 __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
-  constexpr int T = 64;
-  __shared__ __attribute__((aligned(16))) float X[T][128 + DS_LDP];
+  constexpr int T = 64, LDH = 2 * 128 + 8;
+  // [x', rbf63 | e64] in the split-fp16 layout (ds_device.h): edge_emb runs on the f16 matrix pipe (the fp32 form was 256
+  // 64-cycle MFMAs per workgroup, ~40 % of this kernel's time; now 96 32-cycle ones)
+  __shared__ __attribute__((aligned(16))) _Float16 Xh[T][LDH];
   __shared__ __attribute__((aligned(16))) float Y[T][64 + DS_LDP];
   __shared__ __attribute__((aligned(16))) float xs[T];
   __shared__ int rmol[T];
@@ -255,17 +257,27 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
       const float z = (x - mk) * rsk;
       float v = k ? __expf(-0.5f * (z * z)) * rak : x;             // layers.py:291-295,334 (k = 0 is the raw x')
       if (p >= Pp) { v = 0.0f; ev[j] = 0.0f; }
-      X[row][k] = v;
-      X[row][64 + k] = ev[j];
+      split_store1(&Xh[row][0], 128, k, v);
+      split_store1(&Xh[row][0], 128, 64 + k, ev[j]);
       if (p < Pp) c.ws.dist[(size_t)p * 64 + k] = v;
     }
   }
-  const BFrag pfe = tile_first<2, 1>(BW(c, blk, DS_BW_EDGE_EMB_W), 64, 128, 2);   // next GEMM's weights, ahead of the barrier
-  __syncthreads();
-  {
-    const float* bias = BW(c, blk, DS_BW_EDGE_EMB_B);
-    tile_gemm<2, 1>(&X[0][0], 128 + DS_LDP, 128, BW(c, blk, DS_BW_EDGE_EMB_W), 64, 2,
-                    [&](int row, int col, float v) { Y[row][col] = v + bias[col]; }, &pfe);
+  {   // edge_emb (128 -> 64): wave w owns row tile w >> 1, column chunk w & 1; the whole weight chunk (8 k-blocks) is requested
+      // ahead of the barrier
+    const int wv = tid >> 6, mt = wv >> 1, cc = wv & 1, lane = tid & 63;
+    const WStreamH wse = wstream_h(BW(c, blk, DS_BW_EDGE_EMB_H), 64, 128, cc * 32);
+    WRingH<8> ring;
+    wring_h<8>(ring, wse, 0);
+    const float bcol = BW(c, blk, DS_BW_EDGE_EMB_B)[cc * 32 + (lane & 31)];
+    __syncthreads();
+    f32x16 acc[1], lo[1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][i] = bcol;
+    acc_zero<1>(lo);
+    wave_mma_h_deep<1, false, 8, 8>(&Xh[mt * 32][0], 128, wse, ring, 0, acc, lo);
+    split_finish<1>(acc, lo);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Y[mt * 32 + acc_row(i, lane >> 5)][cc * 32 + (lane & 31)] = acc[0][i];
   }
   __syncthreads();
   // norm1_edge + modulate (dmt.py:149) -> ws.ye in the split-fp16 layout (two 64-half planes per pair row).  The two 64 -> 256

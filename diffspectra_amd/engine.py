@@ -279,6 +279,7 @@ def pack_dmt_weights(sd: Dict[str, torch.Tensor]):
         put(bslot(b, "DS_BW_E0_H"), pack_linear_f16_split(sd[p + "attn_mpnn.lin_edge0.weight"]))
         put(bslot(b, "DS_BW_E1_H"), pack_linear_f16_split(sd[p + "attn_mpnn.lin_edge1.weight"]))
         put(bslot(b, "DS_BW_ED_H"), pack_linear_f16_split(win[:, 512:640]))
+        put(bslot(b, "DS_BW_EDGE_EMB_H"), pack_linear_f16_split(sd[p + "edge_emb.weight"]))
         mean, std, astd = _rbf_tables(sd, p + "dist_layer")
         put(bslot(b, "DS_BW_RBF_MEAN"), mean)
         put(bslot(b, "DS_BW_RBF_STD"), std)

@@ -80,6 +80,7 @@ enum ds_block_slot {
   DS_BW_FF4_C,                              /* ff_linear4 (128 -> 64) split-fp16 in accumulator-chain order: halves [plane 2][hc 4][s 2][ft 2][lane 64][8],
                                                element j of lane (r, h) = W[ft*32 + r][hc*32 + 16 s + 8 (j>>2) + 4 h + (j&3)] */
   DS_BW_N2E_H, DS_BW_FF1_H, DS_BW_FF2_H, DS_BW_NODE_RO_H, DS_BW_AC_H,   /* the five GEMMs of k_node_update, split-fp16 */
+  DS_BW_EDGE_EMB_H,                         /* edge_emb (128 -> 64, rows [x', rbf63, e64]) split-fp16 (k_edge_geom) */
   DS_W_BLOCK_SLOTS
 };
 enum ds_global_slot {

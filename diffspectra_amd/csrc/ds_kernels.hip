@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(256) void k_node_readout(Ctx c, float* __restrict__
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[0][i] = bc;
       acc_zero<1>(lo);
-      wave_mma_h<1, false, 8>(&X[0][0], 768, GW(c, DS_GW_NP0_H), 256, 768, ch * 32, 0, 48, acc, lo);
+      wave_mma_h_ring<1, false, 48, 8>(&X[0][0], 768, GW(c, DS_GW_NP0_H), 256, 768, ch * 32, 0, acc, lo);
       split_finish<1>(acc, lo);
 #pragma unroll
       for (int i = 0; i < 16; ++i) split_store1(&Y1[acc_row(i, hhf)][0], 256, col, ds_silu(acc[0][i]));
@@ -1386,7 +1386,7 @@ __global__ __launch_bounds__(256) void k_edge_readout(Ctx c, float* __restrict__
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[0][i] = bc;
       acc_zero<1>(lo);
-      wave_mma_h<1, false, 4>(&X[mt * 32][0], 192, GW(c, ch == 0 ? DS_GW_EX0_H : DS_GW_ET0_H), 64, 192, cc * 32, 0, 12, acc, lo);
+      wave_mma_h_ring<1, false, 12, 6>(&X[mt * 32][0], 192, GW(c, ch == 0 ? DS_GW_EX0_H : DS_GW_ET0_H), 64, 192, cc * 32, 0, acc, lo);
       split_finish<1>(acc, lo);
 #pragma unroll
       for (int i = 0; i < 16; ++i) Y1[mt * 32 + acc_row(i, hhf)][col] = ds_silu(acc[0][i]);
@@ -1476,14 +1476,19 @@ __global__ __launch_bounds__(256) void k_gemm_ada(const _Float16* __restrict__ A
   f32x16 acc[MT], lo[MT];
   acc_zero<MT>(acc);
   acc_zero<MT>(lo);
+  // weights: a chunk's four k-blocks sit in a register ring that is re-requested for the NEXT chunk as soon as this chunk's
+  // MFMAs are issued - their L2 round trip flies under the A staging and the barrier (ds_device.h, wave_mma_h_deep)
+  const WStreamH wsw = wstream_h(Wh, N, K, active ? col0 : 0);
+  WRingH<4> ring;
+  wring_h<4>(ring, wsw, 0);
   fetch(0);
   stash(0);
   __syncthreads();
   for (int kc = 0; kc < nchunks; ++kc) {
     const int cur = kc & 1;
     if (kc + 1 < nchunks) fetch(kc + 1);
-    if (active) wave_mma_h<MT, false, 4>(&X[cur][0][0], KC, Wh, N, K, col0, kc * 4, kc * 4 + 4, acc, lo, kc * 4);
-    if (kc + 1 < nchunks) stash(cur ^ 1);
+    if (active) wave_mma_h_deep<MT, false, 4, 4>(&X[cur][0][0], KC, wsw, ring, kc * 4, acc, lo, kc * 4);
+    if (kc + 1 < nchunks) { wring_h<4>(ring, wsw, kc * 4 + 4); stash(cur ^ 1); }
     __syncthreads();
   }
   if (!active) return;

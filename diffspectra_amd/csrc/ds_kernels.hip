@@ -993,7 +993,8 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
 
   const int lw = __builtin_amdgcn_readfirstlane(wave - NCW);   // loader wave lw owns pairs lw*PPW .. lw*PPW + PPW-1 of a tile
 
-  // first loader wave: tail of a finished tile, one lane per directed edge (row 2q+dir of the tile)
+  // consumer wave 0: tail of a finished tile, one lane per directed edge (row 2q+dir of the tile); the loaders are the critical
+  // path of a tile interval (phase stamps: 97 % busy against the consumers' 88 %), so the tail rides with a consumer
   auto tail = [&](int tile, int pb, int gen) {
     const int p0 = tile * TP;
     const int npairs = min(TP, Pp - p0);
@@ -1091,10 +1092,12 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
           reinterpret_cast<float4*>(&part[buf][ch][lane][0])[0] = o4;
         }
       }
+      if (wave == 0 && it > 0) tail(tile - stride, buf ^ 1, (it + 2) % 3);   // previous tile: its partial sums were complete one barrier ago
       DS_STAMP(1);
       __syncthreads();
       DS_STAMP(2);
     }
+    if (wave == 0) tail(ntiles - 1, (it + 1) & 1, (it + 2) % 3);   // the last tile (it - 1)
     DS_STAMP_FLUSH(0);
   } else {
     // Loader wave: gather + LayerNorm + modulate PPW pairs (2 PPW rows) per tile, four rows per pass - both directions of two
@@ -1130,11 +1133,16 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
     float4 Bv[NPASS][4], Ka[4], sh[4], sc[4];
     int cur_m = -1, cur_a = -1;
     DS_EQUI_FETCH_IDX(first, pv_c, av_c, bv_c, mv_c, adj_c);
+    float4 pr = make_float4(0, 0, 0, 0), pc = pr;
+    if (lane < 2 * PPW) {
+      pr = reinterpret_cast<const float4*>(c.ws.pos)[dir ? bv_c : av_c];   // row atom (edge_index[0])
+      pc = reinterpret_cast<const float4*>(c.ws.pos)[dir ? av_c : bv_c];
+    }
     if (first + stride < ntiles) DS_EQUI_FETCH_IDX(first + stride, pv_x, av_x, bv_x, mv_x, adj_x);
 #pragma unroll
     for (int bt = 0; bt < NPASS; ++bt) DS_EQUI_ISSUE_B(bt, bv_c);
     DS_STAMP(4);
-    int k = 0, tile_m1 = -1, tile_m2 = -1;
+    int k = 0;
     for (int tile = first;; tile += stride, ++k) {
       const bool have = tile < ntiles;
       if (have) {
@@ -1146,11 +1154,6 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
         for (int u = 0; u < PPW; ++u) {
           pp[u] = __builtin_amdgcn_readlane(pv_c, 2 * u); na[u] = __builtin_amdgcn_readlane(av_c, 2 * u);
           pm[u] = __builtin_amdgcn_readlane(mv_c, 2 * u);
-        }
-        float4 pr = make_float4(0, 0, 0, 0), pc = pr;
-        if (lane < 2 * PPW) {
-          pr = reinterpret_cast<const float4*>(c.ws.pos)[dir ? bv_c : av_c];   // row atom (edge_index[0])
-          pc = reinterpret_cast<const float4*>(c.ws.pos)[dir ? av_c : bv_c];
         }
         // a: h_row part for a -> b lanes, h_col part for b -> a lanes; M: adaLN rows of the molecule (they change once per ~160 pairs)
 #define DS_EQUI_ISSUE_A(BT)                                                                            \
@@ -1179,7 +1182,6 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
                                            (__attribute__((address_space(3))) void*)&Xh[buf][2 * (lw * PPW + i)][0], 16, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         DS_STAMP(5);
-        if (wave == NCW && k >= 2) tail(tile_m2, k & 1, (k + 1) % 3);   // tile k-2: its partial sums were complete one barrier ago
         if (lane < 2 * PPW) {   // unit vector of pos[row] - pos[col], scaled (layers.py:345-346), + adjacency bits, for the tail
           const float dx = pr.x - pc.x, dy = pr.y - pc.y, dz = pr.z - pc.z;
           const float nrm = fmaxf(__builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);
@@ -1187,6 +1189,10 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
           float4 d;
           d.x = dx * sn; d.y = dy * sn; d.z = dz * sn; d.w = __int_as_float(adj_c);
           reinterpret_cast<float4*>(&dirs[gen][2 * (lw * PPW + slot) + dir][0])[0] = d;
+          if (have_next) {   // the next tile's positions, a tile interval ahead like its other rows
+            pr = reinterpret_cast<const float4*>(c.ws.pos)[dir ? bv_x : av_x];
+            pc = reinterpret_cast<const float4*>(c.ws.pos)[dir ? av_x : bv_x];
+          }
         }
         DS_STAMP(6);
         // the DMA'd rows must have landed before they are read back (and nothing may be hoisted above this)
@@ -1226,8 +1232,6 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
             }
           }
         }
-      } else if (wave == NCW && k >= 2) {
-        tail(tile_m2, k & 1, (k + 1) % 3);
       }
       DS_STAMP(7);
       __syncthreads();
@@ -1235,9 +1239,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
       if (!have) break;
       pv_c = pv_x; av_c = av_x; bv_c = bv_x; mv_c = mv_x; adj_c = adj_x;
       if (tile + 2 * stride < ntiles) DS_EQUI_FETCH_IDX(tile + 2 * stride, pv_x, av_x, bv_x, mv_x, adj_x);
-      tile_m2 = tile_m1; tile_m1 = tile;
     }
-    if (wave == NCW) tail(tile_m1, (k + 1) & 1, (k + 2) % 3);   // the last tile (k - 1)
 #undef DS_EQUI_FETCH_IDX
 #undef DS_EQUI_ISSUE_B
 #undef DS_EQUI_ISSUE_A

@@ -253,8 +253,8 @@ int ds_layernorm_affine(const float* x, const float* gamma, const float* beta, f
                         float eps, void* stream);
 
 /* Measurement hook (bench.py roofline leg): time every `every`-th launch of one block-stage kernel with HIP events
- * recorded on the launch stream.  kernel: 0 edge_geom, 1 node_qkv, 2 attn_logits, 3 node_update, 4 edge_update,
- * 5 equi_pairs, 6 attn_agg; kernel < 0 disables.  ds_profile_read synchronises the recorded events, returns the summed
+ * recorded on the launch stream.  kernel: 0 edge_geom, 1 node_qkv, 2 attn_fused, 3 node_update, 4 edge_update,
+ * 5 equi_pairs (6 is unused since the attention kernels were fused); kernel < 0 disables.  ds_profile_read synchronises the recorded events, returns the summed
  * duration and the sample count, and resets the counters.  Process-global instrumentation state; off by default. */
 int ds_profile_config(int kernel, int every, int max_samples);
 int ds_profile_read(double* total_ms, int64_t* samples);

@@ -113,8 +113,11 @@ __global__ void k_pair_flags(Ctx c, const float* __restrict__ cond_x, const floa
     const int lb = db - m * c.L.N;
     const float ce = cond_edge_x[((size_t)da * c.L.N + lb) * 2 + 0];
     bits = (ce >= c.edge_th ? 1 : 0) | (d2 <= c.cutoff ? 2 : 0);
-    // one atomic per wave, not per pair: every pair of a batch hitting one address serialised the kernel at the L2
-    if (__ballot(d2 != 0.0f) != 0 && (threadIdx.x & 63) == __builtin_ctzll(__ballot(d2 != 0.0f))) atomicOr(&c.ws.flags[0], 1);
+    // one atomic per wave, not per pair, and none once the flag is up: ten thousand atomics on one address were this
+    // kernel's whole 0.12 ms (a stale 0 only costs one more atomic)
+    const unsigned long long nz = __ballot(d2 != 0.0f);
+    if (nz != 0 && (threadIdx.x & 63) == __builtin_ctzll(nz) && __atomic_load_n(&c.ws.flags[0], __ATOMIC_RELAXED) == 0)
+      atomicOr(&c.ws.flags[0], 1);
   }
   c.ws.adj[p] = bits;
 }

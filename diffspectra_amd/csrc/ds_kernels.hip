@@ -1349,71 +1349,118 @@ __global__ __launch_bounds__(256) void k_node_readout(Ctx c, float* __restrict__
 }
 
 // Readout: edge_exist_mlp / edge_type_mlp (192->64->32->1 each) -> dense symmetric out_edge (dmt.py:394-399).
+// ROW-PARALLEL and register-resident: every wave owns 32 pair rows and there is no LDS tile and no barrier (the tile form had
+// seven barrier-separated phases per 64 rows and ran at 0.42 ms per step against ~0.1 ms of HBM time).  A lane (row r, k-half h)
+// loads its row's 8 consecutive inputs of every 16-deep k-block straight from `edge_hids` and keeps them as split-fp16 B
+// fragments (96 registers for the 32 x 192 tile); 192 -> 64 runs transposed (lane = row, registers = 32 output features per
+// chunk), its SiLU'd accumulators - split in registers - are the B operand of the 64 -> 32 MFMAs (weights in accumulator-chain
+// order, DS_GW_EX2_C / ET2_C), and 32 -> 1 is 16 fused multiply-adds per lane plus one v_permlane32_swap.
 __global__ __launch_bounds__(256) void k_edge_readout(Ctx c, float* __restrict__ out_edge) {
-  constexpr int T = 64;
-  __shared__ __attribute__((aligned(16))) _Float16 X[T][2 * 192 + 8];   // split-fp16 layout: the 192 -> 64 GEMMs run on the f16 pipe
-  __shared__ __attribute__((aligned(16))) float Y1[T][64 + DS_LDP];
-  __shared__ __attribute__((aligned(16))) float Y2[T][32 + DS_LDP];
-  __shared__ int oab[T], oba[T];   // dense output offsets of (a, b) and (b, a), resolved once per row (index chain of 2 trips)
-  const int tid = threadIdx.x, row0 = blockIdx.x * T;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int Pp = c.L.Pp;
-  if (tid < T) {
-    const int p = row0 + tid;
-    int ab = -1, ba = -1;
-    if (p < Pp) {
-      const int da = c.L.node_dense[c.L.pair_a[p]], db = c.L.node_dense[c.L.pair_b[p]];
-      const int mN = c.L.pair_mol[p] * c.L.N;
-      ab = (da * c.L.N + (db - mN)) * 2;
-      ba = (db * c.L.N + (da - mN)) * 2;
-    }
-    oab[tid] = ab; oba[tid] = ba;
-  }
-  {   // 64 rows x 48 float4: all twelve loads of a thread in flight together
-    float4 v[12];
+  const int row0 = (blockIdx.x * 4 + wave) * 32;
+  if (row0 >= Pp) return;                    // whole wave leaves; nothing below synchronises across waves
+  const int p = min(row0 + r, Pp - 1);
+  const bool valid = row0 + r < Pp;
+  // dense output offsets of (a, b) and (b, a): an index chain of two trips, started first
+  const int pa = c.L.pair_a[p], pb = c.L.pair_b[p], pm = c.L.pair_mol[p];
+  h8 x1[12], x2[12];
+  {
+    const float4* src = reinterpret_cast<const float4*>(c.ws.edge_hids + (size_t)p * 192 + 8 * hh);
 #pragma unroll
-    for (int u = 0; u < 12; ++u) {
-      const int idx = tid + u * 256, row = idx / 48, k4 = idx - row * 48;
-      v[u] = reinterpret_cast<const float4*>(c.ws.edge_hids + (size_t)min(row0 + row, Pp - 1) * 192)[k4];
-    }
+    for (int g4 = 0; g4 < 3; ++g4) {         // four k-blocks (eight 16-byte loads) in flight at a time
+      float4 v[4][2];
 #pragma unroll
-    for (int u = 0; u < 12; ++u) {
-      const int idx = tid + u * 256, row = idx / 48, k4 = idx - row * 48;
-      split_store4(&X[row][0], 192, 4 * k4, row0 + row < Pp ? v[u] : make_float4(0, 0, 0, 0));
+      for (int u = 0; u < 4; ++u) { v[u][0] = src[(g4 * 4 + u) * 4]; v[u][1] = src[(g4 * 4 + u) * 4 + 1]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float xs[8] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w, v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const _Float16 a1 = (_Float16)xs[t];
+          x1[g4 * 4 + u][t] = a1;
+          x2[g4 * 4 + u][t] = (_Float16)((xs[t] - (float)a1) * 2048.0f);
+        }
+      }
     }
   }
-  __syncthreads();
+  const int da = c.L.node_dense[pa], db = c.L.node_dense[pb];
+  const int mN = pm * c.L.N;
+  const size_t oab = ((size_t)da * c.L.N + (db - mN)) * 2, oba = ((size_t)db * c.L.N + (da - mN)) * 2;
   for (int ch = 0; ch < 2; ++ch) {   // channel 0: edge_exist_mlp, channel 1: edge_type_mlp (dmt.py:394)
     const int g0 = ch == 0 ? DS_GW_EX0_W : DS_GW_ET0_W;
-    {   // 64 rows x 64 columns over four waves: (row tile, column chunk) per wave
-      const int wave = tid >> 6, mt = wave >> 1, cc = wave & 1, col = cc * 32 + (tid & 31), hhf = (tid & 63) >> 5;
-      const float bc = GW(c, g0 + 1)[col];
-      f32x16 acc[1], lo[1];
+    const float* b0 = GW(c, g0 + 1);
+    const float* b2 = GW(c, g0 + 3);
+    const uint4* W2 = reinterpret_cast<const uint4*>(GW(c, ch == 0 ? DS_GW_EX2_C : DS_GW_ET2_C)) + lane;   // [plane][hc][s][lane]
+    f32x16 a2, a2lo;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[0][i] = bc;
-      acc_zero<1>(lo);
-      wave_mma_h_ring<1, false, 12, 6>(&X[mt * 32][0], 192, GW(c, ch == 0 ? DS_GW_EX0_H : DS_GW_ET0_H), 64, 192, cc * 32, 0, acc, lo);
-      split_finish<1>(acc, lo);
+    for (int q = 0; q < 4; ++q) {      // accumulate onto the layer's bias: registers 4q .. 4q+3 are features 8q + 4h ..
+      const float4 bb = *reinterpret_cast<const float4*>(b2 + 8 * q + 4 * hh);
+      a2[4 * q] = bb.x; a2[4 * q + 1] = bb.y; a2[4 * q + 2] = bb.z; a2[4 * q + 3] = bb.w;
+    }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) Y1[mt * 32 + acc_row(i, hhf)][col] = ds_silu(acc[0][i]);
-    }
-    __syncthreads();
-    {
-      const float* b = GW(c, g0 + 3);
-      tile_gemm<2, 1>(&Y1[0][0], 64 + DS_LDP, 64, GW(c, g0 + 2), 32, 1,
-                      [&](int row, int col, float v) { Y2[row][col] = ds_silu(v + b[col]); });
-    }
-    __syncthreads();
-    {
-      const float b0 = GW(c, g0 + 5)[0];
-      tile_gemm<2, 1>(&Y2[0][0], 32 + DS_LDP, 32, GW(c, g0 + 4), 32, 1, [&](int row, int col, float v) {
-        if (col == 0 && oab[row] >= 0) {
-          const float val = v + b0;   // 0.5*(x + x) == x: the symmetrisation of dmt.py:399 is exact here
-          out_edge[(size_t)oab[row] + ch] = val;
-          out_edge[(size_t)oba[row] + ch] = val;
+    for (int i = 0; i < 16; ++i) a2lo[i] = 0.0f;
+#pragma unroll
+    for (int hc = 0; hc < 2; ++hc) {
+      asm volatile("" ::: "memory");
+      const WStreamH ws0 = wstream_h(GW(c, ch == 0 ? DS_GW_EX0_H : DS_GW_ET0_H), 64, 192, hc * 32);
+      WRingH<6> ring;
+      wring_h<6>(ring, ws0, 0);
+      f32x16 a1, a1lo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bb = *reinterpret_cast<const float4*>(b0 + hc * 32 + 8 * q + 4 * hh);
+        a1[4 * q] = bb.x; a1[4 * q + 1] = bb.y; a1[4 * q + 2] = bb.z; a1[4 * q + 3] = bb.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a1lo[i] = 0.0f;
+#pragma unroll
+      for (int kb = 0; kb < 12; ++kb) {
+        const h8 w1 = ring.w1[kb % 6], w2 = ring.w2[kb % 6];
+        a1lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x2[kb], a1lo, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x1[kb], a1, 0, 0, 0);
+        a1lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, x1[kb], a1lo, 0, 0, 0);
+        if (kb + 6 < 12) { ring.w1[kb % 6] = wload_h(ws0, 0, kb + 6); ring.w2[kb % 6] = wload_h(ws0, 1, kb + 6); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a1[i] = fmaf(a1lo[i], 1.0f / 2048.0f, a1[i]);
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        h8 y1, y2;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {   // packed-fp32 SiLU, two features at a time, then the fp16 split
+          f32x2 v;
+          v.x = a1[8 * s_ + j]; v.y = a1[8 * s_ + j + 1];
+          v = ds_silu2(v);
+          y1[j] = (_Float16)v.x; y1[j + 1] = (_Float16)v.y;
+          y2[j] = (_Float16)((v.x - (float)y1[j]) * 2048.0f); y2[j + 1] = (_Float16)((v.y - (float)y1[j + 1]) * 2048.0f);
         }
-      });
+        const h8 w1 = __builtin_bit_cast(h8, W2[((0 * 2 + hc) * 2 + s_) * 64]);
+        const h8 w2 = __builtin_bit_cast(h8, W2[((1 * 2 + hc) * 2 + s_) * 64]);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, y1, a2, 0, 0, 0);
+        a2lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, y2, a2lo, 0, 0, 0);
+        a2lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, y1, a2lo, 0, 0, 0);
+      }
     }
-    __syncthreads();
+    // 32 -> 1 on the VALU: this lane holds features (i & 3) + 8 (i >> 2) + 4 h of its row; the other half sits in lane ^ 32
+    const float* W4 = GW(c, g0 + 4);
+    f32x2 s2 = {0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      f32x2 v;
+      v.x = fmaf(a2lo[i], 1.0f / 2048.0f, a2[i]); v.y = fmaf(a2lo[i + 1], 1.0f / 2048.0f, a2[i + 1]);
+      v = ds_silu2(v);
+      const f32x2 w = {wp_at(W4, 32, acc_row(i, hh), 0), wp_at(W4, 32, acc_row(i + 1, hh), 0)};
+      s2 = __builtin_elementwise_fma(w, v, s2);
+    }
+    const float part = s2.x + s2.y;
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+    const float val = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) + GW(c, g0 + 5)[0];   // 0.5*(x + x) == x: the symmetrisation of dmt.py:399 is exact here
+    if (valid && hh == 0) {
+      out_edge[oab + ch] = val;
+      out_edge[oba + ch] = val;
+    }
   }
 }
 
@@ -2128,7 +2175,7 @@ int ds_stage_readout(const ds_weights* w, const ds_layout* L, ds_workspace* ws, 
   if (hipMemsetAsync(out_xh, 0, nx * sizeof(float), s) != hipSuccess) return DS_ERR_LAUNCH;
   if (hipMemsetAsync(out_edge, 0, ne * sizeof(float), s) != hipSuccess) return DS_ERR_LAUNCH;
   hipLaunchKernelGGL(k_node_readout, dim3((L->Nn + 31) / 32), dim3(256), 0, s, c, out_xh);
-  if (L->Pp > 0) hipLaunchKernelGGL(k_edge_readout, dim3((L->Pp + 63) / 64), dim3(256), 0, s, c, out_edge);
+  if (L->Pp > 0) hipLaunchKernelGGL(k_edge_readout, dim3((L->Pp + 127) / 128), dim3(256), 0, s, c, out_edge);
   hipLaunchKernelGGL(k_final_pos, dim3((L->B + 63) / 64), dim3(64), 0, s, c, out_xh);
   return launch_status();
 }

@@ -168,13 +168,14 @@ def pack_ff4_chain(weight: torch.Tensor) -> torch.Tensor:
     as the B fragment of a 32x32x16 f16 MFMA; the A fragment of lane (r, h) must hold, in element j, the weight of output
     ft*32 + r for exactly that hidden feature.  Two fp16 planes (w = w1 + w2/2048); returned as the fp32 view of the bits."""
     w = weight.detach().to(torch.float32).cpu()
-    assert tuple(w.shape) == (64, 128)
+    n_out, k_in = w.shape                                                        # ff_linear4: (64, 128); edge readout .2: (32, 64)
+    assert n_out % 32 == 0 and k_in % 32 == 0
     w1 = w.half()
-    planes = torch.stack([w1, ((w - w1.float()) * SPLIT_SCALE).half()])          # [2, 64, 128]
-    hc, s_, ft, h, r, j = torch.meshgrid(torch.arange(4), torch.arange(2), torch.arange(2), torch.arange(2), torch.arange(32),
-                                          torch.arange(8), indexing="ij")
+    planes = torch.stack([w1, ((w - w1.float()) * SPLIT_SCALE).half()])          # [2, N, K]
+    hc, s_, ft, h, r, j = torch.meshgrid(torch.arange(k_in // 32), torch.arange(2), torch.arange(n_out // 32), torch.arange(2),
+                                          torch.arange(32), torch.arange(8), indexing="ij")
     k = hc * 32 + 16 * s_ + 8 * (j >> 2) + 4 * h + (j & 3)
-    out = planes[:, ft * 32 + r, k]                                              # [2, 4, 2, 2, 2, 32, 8]
+    out = planes[:, ft * 32 + r, k]                                              # [2, K/32, 2, N/32, 2, 32, 8]
     return out.contiguous().reshape(-1).view(torch.float32).clone()
 
 
@@ -318,6 +319,8 @@ def pack_dmt_weights(sd: Dict[str, torch.Tensor]):
     put(gslot("DS_GW_NP2_H"), pack_linear_f16_split(sd["node_pred_mlp.2.weight"]))
     put(gslot("DS_GW_EX0_H"), pack_linear_f16_split(sd["edge_exist_mlp.0.weight"]))
     put(gslot("DS_GW_ET0_H"), pack_linear_f16_split(sd["edge_type_mlp.0.weight"]))
+    put(gslot("DS_GW_EX2_C"), pack_ff4_chain(sd["edge_exist_mlp.2.weight"]))
+    put(gslot("DS_GW_ET2_C"), pack_ff4_chain(sd["edge_type_mlp.2.weight"]))
     return torch.cat(chunks), offsets
 
 

@@ -97,6 +97,8 @@ enum ds_global_slot {
   DS_GW_ET0_W, DS_GW_ET0_B, DS_GW_ET2_W, DS_GW_ET2_B, DS_GW_ET4_W, DS_GW_ET4_B, /* edge_type_mlp  192->64->32->1(32) */
   DS_GW_NP0_H, DS_GW_NP2_H,                 /* node_pred_mlp.0 (768 -> 256) and .2 (256 -> 128) in the split-fp16 layout (k_node_readout) */
   DS_GW_EX0_H, DS_GW_ET0_H,                 /* edge_exist_mlp.0 / edge_type_mlp.0 (192 -> 64) split-fp16 (k_edge_readout) */
+  DS_GW_EX2_C, DS_GW_ET2_C,                 /* edge_exist_mlp.2 / edge_type_mlp.2 (64 -> 32) split-fp16 in the accumulator-chain order of DS_BW_FF4_C:
+                                               halves [plane 2][hc 2][s 2][ft 1][lane 64][8] (k_edge_readout) */
   DS_W_GLOBAL_SLOTS
 };
 #define DS_W_NUM_SLOTS (DS_NBLOCKS * DS_W_BLOCK_SLOTS + DS_W_GLOBAL_SLOTS)

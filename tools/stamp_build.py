@@ -31,7 +31,7 @@ def main():
     s = open(SRC).read()
     import re
     s = re.sub(r"\n\s*DS_STAMP(_W)?\(\d+\);", "", s)
-    s = re.sub(r"\n\s*DS_STAMP_FLUSH\(\d+\);", "", s)           # drop the in-tree stamps, re-insert uniformly
+    s = re.sub(r"\n\s*DS_STAMP_FLUSH\([^)]*\);", "", s)           # drop the in-tree stamps, re-insert uniformly
     s = s.replace("  DS_STAMP_INIT();\n", "")
     for spec in sys.argv[1:]:
         name, base = spec.split(":")

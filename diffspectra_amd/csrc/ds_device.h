@@ -405,6 +405,59 @@ __device__ __forceinline__ void wave_mma_h_deep(const _Float16* X, int K_tile, c
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+// Two 32-column chunks of the weight matrix against the SAME X fragments (transposed form): every X fragment read from LDS
+// feeds 6 MT MFMAs instead of 3 MT - half the LDS operand traffic of two wave_mma_h_deep calls.  Costs a second accumulator
+// pair and a second ring.
+template <int MT, int NKB, int PF>
+__device__ __forceinline__ void wave_mma_h_deep_t2(const _Float16* X, int K_tile, const WStreamH& wsA, const WStreamH& wsB,
+                                                   WRingH<PF>& ringA, WRingH<PF>& ringB, f32x16 (&hiA)[MT], f32x16 (&loA)[MT],
+                                                   f32x16 (&hiB)[MT], f32x16 (&loB)[MT]) {
+  static_assert(PF <= NKB, "ring deeper than the product");
+  const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+  const int ldh = 2 * K_tile + 8;
+  const _Float16* xr = X + r * ldh + 8 * hh;
+  h8 xa[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    xa[m][0] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh);
+    xa[m][1] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + K_tile);
+  }
+#pragma unroll
+  for (int i = 0; i < NKB; ++i) {
+    const int in = i + 1 < NKB ? i + 1 : i;
+    h8 xn[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      xn[m][0] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + in * 16);
+      xn[m][1] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + K_tile + in * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const h8 a1 = ringA.w1[i % PF], a2 = ringA.w2[i % PF], b1 = ringB.w1[i % PF], b2 = ringB.w2[i % PF];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      loA[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xa[m][1], loA[m], 0, 0, 0);
+      loB[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, xa[m][1], loB[m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      hiA[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xa[m][0], hiA[m], 0, 0, 0);
+      hiB[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, xa[m][0], hiB[m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      loA[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, xa[m][0], loA[m], 0, 0, 0);
+      loB[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b2, xa[m][0], loB[m], 0, 0, 0);
+    }
+    if (i + PF < NKB) {
+      ringA.w1[i % PF] = wload_h(wsA, 0, i + PF); ringA.w2[i % PF] = wload_h(wsA, 1, i + PF);
+      ringB.w1[i % PF] = wload_h(wsB, 0, i + PF); ringB.w2[i % PF] = wload_h(wsB, 1, i + PF);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { xa[m][0] = xn[m][0]; xa[m][1] = xn[m][1]; }
+  }
+}
+
 // Convenience form: stream + ring set up inside the call (one exposed weight round trip per call instead of one per k-block).
 template <int MT, bool TRANS, int NKB, int PF>
 __device__ __forceinline__ void wave_mma_h_ring(const _Float16* X, int K_tile, const float* __restrict__ Wh, int N, int K, int col0,

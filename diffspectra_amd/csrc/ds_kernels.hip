@@ -20,6 +20,9 @@
 #ifndef DS_QKV_PF
 #define DS_QKV_PF 4
 #endif
+#ifndef DS_EQUI_T2
+#define DS_EQUI_T2 1   // k_equi_pairs: a MFMA wave runs its two feature chunks against shared X fragments
+#endif
 #ifndef DS_EQUI_NCW
 #define DS_EQUI_NCW 4   // MFMA waves of k_equi_pairs (each owns 8 / NCW feature chunks)
 #define DS_EQUI_NLW 4   // loader waves (each owns 32 / NLW pairs of a tile); 4 + 4 leaves both roles 256 registers
@@ -1025,40 +1028,38 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
   if (consumer) {
     // The weights do not depend on anything the workgroup computes: their stream runs PF k-blocks ahead through a register
     // ring that is refilled for the next chunk as soon as a chunk's MFMAs are issued (ds_device.h, wave_mma_h_deep).
-    constexpr int PF = 8;
+    constexpr int PF = DS_EQUI_T2 ? 4 : 8;
     WStreamH wsh[CPW];
 #pragma unroll
     for (int cc = 0; cc < CPW; ++cc) wsh[cc] = wstream_h(BW(c, blk, DS_BW_CM0_H), 256, 256, (wave + NCW * cc) * 32);
     WRingH<PF> ring;
     wring_h<PF>(ring, wsh[0], 0);
+#if DS_EQUI_T2
+    WRingH<PF> ringB;
+    wring_h<PF>(ringB, wsh[CPW - 1], 0);
+#endif
     __syncthreads();
     DS_STAMP(0);
     int it = 0;
     for (int tile = first; tile < ntiles; tile += stride, ++it) {
       const int buf = it & 1;
+      // coord_mlp.0 (256 -> 256) on the f16 matrix pipe with split operands (ds_device.h), transposed: lane = edge row,
+      // registers = a chunk's 32 output features; the MFMA chain accumulates onto the coord_mlp.0 bias.
+      auto bias_init = [&](int ch, f32x16 (&acc1)[2]) {
+        const float4* bp = reinterpret_cast<const float4*>(&cb0[ch][hh][0]);
 #pragma unroll
-      for (int cc = 0; cc < CPW; ++cc) {
-        const int ch = wave + NCW * cc;
-        // coord_mlp.0 (256 -> 256) on the f16 matrix pipe with split operands (ds_device.h, wave_mma_h), transposed as before:
-        // lane = edge row, registers = the chunk's 32 output features.
-        f32x16 acc1[2], acclo[2];
-        {
-          const float4* bp = reinterpret_cast<const float4*>(&cb0[ch][hh][0]);
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {   // the MFMA chain accumulates onto the coord_mlp.0 bias
-              const float4 bv = bp[q4];
-              acc1[m][4 * q4] = bv.x; acc1[m][4 * q4 + 1] = bv.y; acc1[m][4 * q4 + 2] = bv.z; acc1[m][4 * q4 + 3] = bv.w;
-            }
-        }
-        acc_zero<2>(acclo);
-        wave_mma_h_deep<2, true, 16, PF>(&Xh[buf][0][0], 256, wsh[cc], ring, 0, acc1, acclo);
-        wring_h<PF>(ring, wsh[(cc + 1) % CPW], 0);   // the next chunk's (next tile's) first blocks fly under the epilogue and the barrier
-        split_finish<2>(acc1, acclo);
-        // coord_mlp.2 (256 -> 3, dmt.py:34) on the VALU, fp32: a lane holds 16 of its row's 32 hidden features of this chunk, so
-        // the three outputs are 3 x 16 fused multiply-adds per row block (packed two at a time) - 48 v_pk_fma against the 32
-        // 64-cycle 32x32x2 fp32 MFMAs (29 of 32 output rows padding) that used to take 40 % of this wave's matrix-pipe time.
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 bv = bp[q4];
+            acc1[m][4 * q4] = bv.x; acc1[m][4 * q4 + 1] = bv.y; acc1[m][4 * q4 + 2] = bv.z; acc1[m][4 * q4 + 3] = bv.w;
+          }
+      };
+      // SiLU (dmt.py:32-33), then coord_mlp.2 (256 -> 3, dmt.py:34) on the VALU, fp32: a lane holds 16 of its row's 32 hidden
+      // features of this chunk, so the three outputs are 3 x 16 fused multiply-adds per row block (packed two at a time) - 48
+      // v_pk_fma against the 32 64-cycle 32x32x2 fp32 MFMAs (29 of 32 output rows padding) that used to take 40 % of this wave's
+      // matrix-pipe time.
+      auto epilogue = [&](int ch, const f32x16 (&acc1)[2]) {
         f32x2 so[2][3];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -1071,7 +1072,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
           for (int o = 0; o < 3; ++o) wv[o] = reinterpret_cast<const float4*>(&cw2[ch][hh][o][0])[q4];
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
-            f32x2 y0, y1;   // SiLU of coord_mlp.0 (dmt.py:32-33), packed-fp32, two hidden features at a time
+            f32x2 y0, y1;   // packed-fp32, two hidden features at a time
             y0.x = acc1[m][4 * q4]; y0.y = acc1[m][4 * q4 + 1]; y1.x = acc1[m][4 * q4 + 2]; y1.y = acc1[m][4 * q4 + 3];
             y0 = ds_silu2(y0); y1 = ds_silu2(y1);
 #pragma unroll
@@ -1081,18 +1082,46 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
             }
           }
         }
-        {   // the other 16 features of the row sit in lane ^ 32: one v_permlane32_swap per output hands row block 0's upper
-            // halves to lanes 0-31 and row block 1's lower halves to lanes 32-63, so lane l ends up owning tile row l
-          float4 o4;
-          float* op = &o4.x;
+        // the other 16 features of the row sit in lane ^ 32: one v_permlane32_swap per output hands row block 0's upper
+        // halves to lanes 0-31 and row block 1's lower halves to lanes 32-63, so lane l ends up owning tile row l
+        float4 o4;
+        float* op = &o4.x;
 #pragma unroll
-          for (int o = 0; o < 3; ++o) {
-            const float s0 = so[0][o].x + so[0][o].y, s1 = so[1][o].x + so[1][o].y;
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s0), __float_as_uint(s1), false, false);
-            op[o] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-          }
-          o4.w = 0.0f;
-          reinterpret_cast<float4*>(&part[buf][ch][lane][0])[0] = o4;
+        for (int o = 0; o < 3; ++o) {
+          const float s0 = so[0][o].x + so[0][o].y, s1 = so[1][o].x + so[1][o].y;
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s0), __float_as_uint(s1), false, false);
+          op[o] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        o4.w = 0.0f;
+        reinterpret_cast<float4*>(&part[buf][ch][lane][0])[0] = o4;
+      };
+#if DS_EQUI_T2
+      if constexpr (CPW == 2) {   // both chunks of the wave against the same X fragments: half the LDS operand reads
+        f32x16 accA[2], loA[2], accB[2], loB[2];
+        bias_init(wave, accA);
+        bias_init(wave + NCW, accB);
+        acc_zero<2>(loA);
+        acc_zero<2>(loB);
+        wave_mma_h_deep_t2<2, 16, PF>(&Xh[buf][0][0], 256, wsh[0], wsh[1], ring, ringB, accA, loA, accB, loB);
+        wring_h<PF>(ring, wsh[0], 0);    // the next tile's first blocks fly under the epilogues and the barrier
+        wring_h<PF>(ringB, wsh[1], 0);
+        split_finish<2>(accA, loA);
+        epilogue(wave, accA);
+        split_finish<2>(accB, loB);
+        epilogue(wave + NCW, accB);
+      } else
+#endif
+      {
+#pragma unroll
+        for (int cc = 0; cc < CPW; ++cc) {
+          const int ch = wave + NCW * cc;
+          f32x16 acc1[2], acclo[2];
+          bias_init(ch, acc1);
+          acc_zero<2>(acclo);
+          wave_mma_h_deep<2, true, 16, PF>(&Xh[buf][0][0], 256, wsh[cc], ring, 0, acc1, acclo);
+          wring_h<PF>(ring, wsh[(cc + 1) % CPW], 0);   // the next chunk's (next tile's) first blocks fly under the epilogue and the barrier
+          split_finish<2>(acc1, acclo);
+          epilogue(ch, acc1);
         }
       }
       if (wave == 0 && it > 0) tail(tile - stride, buf ^ 1, (it + 2) % 3);   // previous tile: its partial sums were complete one barrier ago

@@ -31,7 +31,8 @@ def main():
         j = json.loads(line[-1])
         row = {"molecules_per_gpu": m, "molecules_per_sec": j["value"], "ms_per_denoise_iteration": j["ms_per_step"] / j["config"]["denoise_iterations_per_step"],
                "us_per_molecule_iteration": j["ms_per_step"] / j["config"]["denoise_iterations_per_step"] * 1e3 / m,
-               "equi_frac": (j["roofline"] or {}).get("frac"), "whole_path_frac": j["whole_path"]["frac_of_fp32_mfma_peak"], "flags": args.extra}
+               "equi_frac": (j["roofline"] or {}).get("frac"), "equi_vs_fp32_mfma_peak": (j["roofline"] or {}).get("vs_fp32_mfma_peak"),
+               "whole_path_vs_fp32_mfma_peak": j["whole_path"].get("vs_fp32_mfma_peak"), "flags": args.extra}
         rows.append(row)
         print(json.dumps(row), flush=True)
     with open(args.out, "a") as f:

@@ -555,13 +555,17 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
 #pragma unroll
   for (int k = 0; k < 2; ++k) acc[k] = make_float4(0, 0, 0, 0);
   const int hd = lane >> 2;
+  // Two barriers per chunk: the next chunk's ye rows are committed while this chunk's rows are visited (Yc's readers - the
+  // projection - are past the first barrier), its alpha / pair tables right after the second one (read again only behind the
+  // next projection's barrier).
   fetch(0, true);
+  commit(true);
+  __syncthreads();
   for (int ck = 0; ck < nchunks; ++ck) {
-    commit(true);
-    __syncthreads();
     if (ck + 1 < nchunks) fetch(ck + 1, true);
     project();
     __syncthreads();
+    if (ck + 1 < nchunks) *reinterpret_cast<uint4*>(&Yc[tid >> 4][(tid & 15) * 8]) = yv;
     const int rows = min(64, P - ck * 64);
     const int my_ab = pab[lane];           // the chunk's 64 (a, b) pairs, one per lane
     // rows in which this wave owns a target, as a lane mask: the loop visits only those (~16 of 64), in ascending row order
@@ -587,6 +591,10 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
       }
     }
     __syncthreads();                       // Tt / AL / pab are rewritten by the next chunk
+    if (ck + 1 < nchunks) {
+      if (tid < 512) reinterpret_cast<float4*>(&AL[tid >> 3][0])[tid & 7] = av;
+      if (tid < 64) pab[tid] = abv;
+    }
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {

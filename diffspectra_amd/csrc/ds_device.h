@@ -405,23 +405,24 @@ __device__ __forceinline__ void wave_mma_h_deep(const _Float16* X, int K_tile, c
     __builtin_amdgcn_sched_barrier(0);
   }
 }
-// Two 32-column chunks of the weight matrix against the SAME X fragments (transposed form): every X fragment read from LDS
-// feeds 6 MT MFMAs instead of 3 MT - half the LDS operand traffic of two wave_mma_h_deep calls.  Costs a second accumulator
-// pair and a second ring.
-template <int MT, int NKB, int PF>
+// Two 32-column chunks (of one weight matrix or of two) against the SAME X fragments: every X fragment read from LDS feeds
+// 6 MT MFMAs instead of 3 MT - half the LDS operand traffic of two wave_mma_h_deep calls and twice the matrix work per
+// k-block to cover the operand latencies.  Costs a second accumulator pair and a second ring.
+template <int MT, bool TRANS, int NKB, int PF>
 __device__ __forceinline__ void wave_mma_h_deep_t2(const _Float16* X, int K_tile, const WStreamH& wsA, const WStreamH& wsB,
-                                                   WRingH<PF>& ringA, WRingH<PF>& ringB, f32x16 (&hiA)[MT], f32x16 (&loA)[MT],
-                                                   f32x16 (&hiB)[MT], f32x16 (&loB)[MT]) {
+                                                   WRingH<PF>& ringA, WRingH<PF>& ringB, int kb0, f32x16 (&hiA)[MT], f32x16 (&loA)[MT],
+                                                   f32x16 (&hiB)[MT], f32x16 (&loB)[MT], int xkb0 = 0) {
   static_assert(PF <= NKB, "ring deeper than the product");
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const int ldh = 2 * K_tile + 8;
-  const _Float16* xr = X + r * ldh + 8 * hh;
+  const _Float16* xr = X + r * ldh + 8 * hh + (kb0 - xkb0) * 16;
   h8 xa[MT][2];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     xa[m][0] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh);
     xa[m][1] = *reinterpret_cast<const h8*>(xr + m * 32 * ldh + K_tile);
   }
+#define DS_MMA_(ACC, WV, XV) ACC = TRANS ? __builtin_amdgcn_mfma_f32_32x32x16_f16(WV, XV, ACC, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(XV, WV, ACC, 0, 0, 0)
 #pragma unroll
   for (int i = 0; i < NKB; ++i) {
     const int in = i + 1 < NKB ? i + 1 : i;
@@ -434,28 +435,33 @@ __device__ __forceinline__ void wave_mma_h_deep_t2(const _Float16* X, int K_tile
     __builtin_amdgcn_sched_barrier(0);
     const h8 a1 = ringA.w1[i % PF], a2 = ringA.w2[i % PF], b1 = ringB.w1[i % PF], b2 = ringB.w2[i % PF];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      loA[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xa[m][1], loA[m], 0, 0, 0);
-      loB[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, xa[m][1], loB[m], 0, 0, 0);
-    }
+    for (int m = 0; m < MT; ++m) { DS_MMA_(loA[m], a1, xa[m][1]); DS_MMA_(loB[m], b1, xa[m][1]); }
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      hiA[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xa[m][0], hiA[m], 0, 0, 0);
-      hiB[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, xa[m][0], hiB[m], 0, 0, 0);
-    }
+    for (int m = 0; m < MT; ++m) { DS_MMA_(hiA[m], a1, xa[m][0]); DS_MMA_(hiB[m], b1, xa[m][0]); }
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      loA[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, xa[m][0], loA[m], 0, 0, 0);
-      loB[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b2, xa[m][0], loB[m], 0, 0, 0);
-    }
+    for (int m = 0; m < MT; ++m) { DS_MMA_(loA[m], a2, xa[m][0]); DS_MMA_(loB[m], b2, xa[m][0]); }
     if (i + PF < NKB) {
-      ringA.w1[i % PF] = wload_h(wsA, 0, i + PF); ringA.w2[i % PF] = wload_h(wsA, 1, i + PF);
-      ringB.w1[i % PF] = wload_h(wsB, 0, i + PF); ringB.w2[i % PF] = wload_h(wsB, 1, i + PF);
+      ringA.w1[i % PF] = wload_h(wsA, 0, kb0 + i + PF); ringA.w2[i % PF] = wload_h(wsA, 1, kb0 + i + PF);
+      ringB.w1[i % PF] = wload_h(wsB, 0, kb0 + i + PF); ringB.w2[i % PF] = wload_h(wsB, 1, kb0 + i + PF);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int m = 0; m < MT; ++m) { xa[m][0] = xn[m][0]; xa[m][1] = xn[m][1]; }
   }
+#undef DS_MMA_
+}
+// One-call form: both streams' rings set up inside.
+template <int MT, bool TRANS, int NKB, int PF>
+__device__ __forceinline__ void wave_mma_h_ring_t2(const _Float16* X, int K_tile, const WStreamH& wsA, const WStreamH& wsB, int kb0,
+                                                   f32x16 (&hiA)[MT], f32x16 (&loA)[MT], f32x16 (&hiB)[MT], f32x16 (&loB)[MT], int xkb0 = 0) {
+  WRingH<PF> ringA, ringB;
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {   // interleaved in consumption order
+    ringA.w1[i] = wload_h(wsA, 0, kb0 + i); ringA.w2[i] = wload_h(wsA, 1, kb0 + i);
+    ringB.w1[i] = wload_h(wsB, 0, kb0 + i); ringB.w2[i] = wload_h(wsB, 1, kb0 + i);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  wave_mma_h_deep_t2<MT, TRANS, NKB, PF>(X, K_tile, wsA, wsB, ringA, ringB, kb0, hiA, loA, hiB, loB, xkb0);
 }
 
 // Convenience form: stream + ring set up inside the call (one exposed weight round trip per call instead of one per k-block).

@@ -17,6 +17,9 @@
 #ifndef DS_NODE_PF
 #define DS_NODE_PF 8
 #endif
+#ifndef DS_NODE_PF2
+#define DS_NODE_PF2 4   // per ring when two chunks share the X fragments
+#endif
 #ifndef DS_QKV_PF
 #define DS_QKV_PF 4
 #endif
@@ -683,36 +686,42 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
       const int col = (wave + 4 * cc) * 32 + (tid & 31);
       gAv[cc] = gsec[(size_t)mA * ADAC + col]; gBv[cc] = gsec[(size_t)mB * ADAC + col]; bbv[cc] = BW(c, blk, DS_BW_FF2_B)[col];
     }
+    // Both 32-column chunks of the wave (ch = wave, wave + 4) run against the same X fragments (wave_mma_h_ring_t2): half the
+    // LDS operand reads and 6 MFMAs per k-block to cover the operand latencies instead of 3.
     for (int half = 0; half < 2; ++half) {
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc) {   // this wave's two 32-column chunks of the 256-wide hidden half
+      {
         asm volatile("" ::: "memory");
-        const int ch = wave + 4 * cc;
-        const int colf = ch * 32 + (tid & 31), hhf = (tid & 63) >> 5;
-        const float bf = b1[half * 256 + colf];
-        f32x16 acc[1], lo[1];
+        const int hhf = (tid & 63) >> 5;
+        f32x16 acc[2][1], lo[2][1];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[0][i] = bf;
-        acc_zero<1>(lo);
-        wave_mma_h_ring<1, false, 16, DS_NODE_PF>(&H2[0][0], 256, W1, 512, 256, (half * 8 + ch) * 32, 0, acc, lo);
-        split_finish<1>(acc, lo);
-        // SiLU(FF1 + bias) -> hidden tile, two rows at a time (packed-fp32 epilogue)
+        for (int cc = 0; cc < 2; ++cc) {
+          const float bf = b1[half * 256 + (wave + 4 * cc) * 32 + (tid & 31)];
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          f32x2 v;
-          v.x = acc[0][i]; v.y = acc[0][i + 1];
-          v = ds_silu2(v);
-          const int r0 = acc_row(i, hhf);
-          split_store1(&B1[r0][0], 256, colf, v.x);
-          split_store1(&B1[r0 + 1][0], 256, colf, v.y);
+          for (int i = 0; i < 16; ++i) acc[cc][0][i] = bf;
+          acc_zero<1>(lo[cc]);
+        }
+        wave_mma_h_ring_t2<1, false, 16, DS_NODE_PF2>(&H2[0][0], 256, wstream_h(W1, 512, 256, (half * 8 + wave) * 32),
+                                                     wstream_h(W1, 512, 256, (half * 8 + wave + 4) * 32), 0, acc[0], lo[0], acc[1], lo[1]);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          split_finish<1>(acc[cc], lo[cc]);
+          const int colf = (wave + 4 * cc) * 32 + (tid & 31);
+          // SiLU(FF1 + bias) -> hidden tile, two rows at a time (packed-fp32 epilogue)
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {
+            f32x2 v;
+            v.x = acc[cc][0][i]; v.y = acc[cc][0][i + 1];
+            v = ds_silu2(v);
+            const int r0 = acc_row(i, hhf);
+            split_store1(&B1[r0][0], 256, colf, v.x);
+            split_store1(&B1[r0 + 1][0], 256, colf, v.y);
+          }
         }
       }
       __syncthreads();
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc) {
-        asm volatile("" ::: "memory");
-        wave_mma_h_ring<1, false, 16, DS_NODE_PF>(&B1[0][0], 256, W2, 256, 512, (wave + 4 * cc) * 32, half * 16, acc2[cc], lo2[cc], half * 16);
-      }
+      asm volatile("" ::: "memory");
+      wave_mma_h_ring_t2<1, false, 16, DS_NODE_PF2>(&B1[0][0], 256, wstream_h(W2, 256, 512, wave * 32), wstream_h(W2, 256, 512, (wave + 4) * 32),
+                                                   half * 16, acc2[0], lo2[0], acc2[1], lo2[1], half * 16);
       __syncthreads();
     }
     split_finish<1>(acc2[0], lo2[0]);
@@ -742,26 +751,41 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
     }
   }
   __syncthreads();
-  {   // per-block readout slice (256 -> 64) and the node parts of equi_update.input_lin (256 -> 512): 18 chunks over 4 waves
+  {   // per-block readout slice (256 -> 64, chunks 0-1) and the node parts of equi_update.input_lin (256 -> 512, chunks 2-17):
+      // 18 chunks over 4 waves, two at a time against shared X fragments (chunks it, it + 4), the last two singly
     const float* br = BW(c, blk, DS_BW_NODE_RO_B);
-    for (int it = wave; it < 18; it += 4) {
-      asm volatile("" ::: "memory");
-      f32x16 acc[1], lo[1];
-      acc_zero<1>(lo);
-      if (it < 2) {
-        const float b = br[it * 32 + (tid & 31)];
+    auto ws_of = [&](int it) {
+      return it < 2 ? wstream_h(BW(c, blk, DS_BW_NODE_RO_H), 64, 256, it * 32) : wstream_h(BW(c, blk, DS_BW_AC_H), 512, 256, (it - 2) * 32);
+    };
+    auto bias_of = [&](int it) { return it < 2 ? br[it * 32 + (tid & 31)] : 0.0f; };
+    auto store_of = [&](int it, const f32x16 (&acc)[1]) {
+      if (it < 2) acc_store<1, 768>(acc, c.ws.atom_hids + (size_t)row0 * 768 + 256 + 64 * blk + it * 32, Nn - row0, [](int, float v) { return v; });
+      else acc_store<1, 512>(acc, c.ws.ac + (size_t)row0 * 512 + (it - 2) * 32, Nn - row0, [](int, float v) { return v; });
+    };
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[0][i] = b;
-        wave_mma_h_ring<1, false, 16, DS_NODE_PF>(&H2[0][0], 256, BW(c, blk, DS_BW_NODE_RO_H), 64, 256, it * 32, 0, acc, lo);
-        split_finish<1>(acc, lo);
-        acc_store<1, 768>(acc, c.ws.atom_hids + (size_t)row0 * 768 + 256 + 64 * blk + it * 32, Nn - row0, [](int, float v) { return v; });
-      } else {
-        const int ch = it - 2;
-        acc_zero<1>(acc);
-        wave_mma_h_ring<1, false, 16, DS_NODE_PF>(&H2[0][0], 256, BW(c, blk, DS_BW_AC_H), 512, 256, ch * 32, 0, acc, lo);
-        split_finish<1>(acc, lo);
-        acc_store<1, 512>(acc, c.ws.ac + (size_t)row0 * 512 + ch * 32, Nn - row0, [](int, float v) { return v; });
-      }
+    for (int pr = 0; pr < 2; ++pr) {
+      asm volatile("" ::: "memory");
+      const int itA = wave + 8 * pr, itB = itA + 4;
+      f32x16 acc[2][1], lo[2][1];
+      const float bA = bias_of(itA), bB = bias_of(itB);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc[0][0][i] = bA; acc[1][0][i] = bB; }
+      acc_zero<1>(lo[0]); acc_zero<1>(lo[1]);
+      wave_mma_h_ring_t2<1, false, 16, DS_NODE_PF2>(&H2[0][0], 256, ws_of(itA), ws_of(itB), 0, acc[0], lo[0], acc[1], lo[1]);
+      split_finish<1>(acc[0], lo[0]);
+      store_of(itA, acc[0]);
+      split_finish<1>(acc[1], lo[1]);
+      store_of(itB, acc[1]);
+    }
+    if (wave < 2) {   // chunks 16, 17
+      asm volatile("" ::: "memory");
+      const int it = 16 + wave;
+      f32x16 acc[1], lo[1];
+      acc_zero<1>(acc);
+      acc_zero<1>(lo);
+      wave_mma_h_ring<1, false, 16, DS_NODE_PF>(&H2[0][0], 256, BW(c, blk, DS_BW_AC_H), 512, 256, (it - 2) * 32, 0, acc, lo);
+      split_finish<1>(acc, lo);
+      store_of(it, acc);
     }
   }
 }
@@ -1110,7 +1134,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
         bias_init(wave + NCW, accB);
         acc_zero<2>(loA);
         acc_zero<2>(loB);
-        wave_mma_h_deep_t2<2, 16, PF>(&Xh[buf][0][0], 256, wsh[0], wsh[1], ring, ringB, accA, loA, accB, loB);
+        wave_mma_h_deep_t2<2, true, 16, PF>(&Xh[buf][0][0], 256, wsh[0], wsh[1], ring, ringB, 0, accA, loA, accB, loB);
         wring_h<PF>(ring, wsh[0], 0);    // the next tile's first blocks fly under the epilogues and the barrier
         wring_h<PF>(ringB, wsh[1], 0);
         split_finish<2>(accA, loA);

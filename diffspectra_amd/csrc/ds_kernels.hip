@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
     }
     xs[tid] = x;
     rmol[tid] = m;
+    if (p < c.L.Pp) c.ws.dist[p] = x;   // k_edge_update recomputes the 64 CondGaussian features from it: 4 bytes per pair instead of 256 each way
   }
   __syncthreads();
   // adaLN shift/scale of the LayerNorm further down, requested now (they only need rmol): wave w normalises rows
@@ -268,7 +269,6 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
       if (p >= Pp) { v = 0.0f; ev[j] = 0.0f; }
       split_store1(&Xh[row][0], 128, k, v);
       split_store1(&Xh[row][0], 128, 64 + k, ev[j]);
-      if (p < Pp) c.ws.dist[(size_t)p * 64 + k] = v;
     }
   }
   {   // edge_emb (128 -> 64): wave w owns row tile w >> 1, column chunk w & 1; the whole weight chunk (8 k-blocks) is requested
@@ -820,9 +820,21 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
   }
   {
     const float4* bn = reinterpret_cast<const float4*>(BW(c, blk, DS_BW_N2E_B));
+    // CondGaussian features of this block (layers.py:291-295,334), recomputed from the modulated squared distance k_edge_geom
+    // left in ws.dist - the same expression, constants and hardware ops as there, so the same bits - instead of 256 bytes per
+    // pair through HBM each way: a lane owns features 4 k4 .. 4 k4 + 3 (feature 0 is the raw x')
+    float rm[4], rs[4], ra[4];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {   // 32 rows x 16 float4 (one 16-lane DPP row per tile row); 28 gathers in flight
+    for (int t = 0; t < 4; ++t) {
+      const int k = 4 * (lane & 15) + t;
+      rm[t] = k ? BW(c, blk, DS_BW_RBF_MEAN)[k - 1] : 0.0f;
+      rs[t] = __builtin_amdgcn_rcpf(k ? BW(c, blk, DS_BW_RBF_STD)[k - 1] : 1.0f);
+      ra[t] = __builtin_amdgcn_rcpf(k ? BW(c, blk, DS_BW_RBF_ASTD)[k - 1] : 1.0f);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {   // 32 rows x 16 float4 (one 16-lane DPP row per tile row); 24 gathers in flight
       float4 ua[4], ub[4], ve[4], vd[4], vg[4], sh[4], sc[4];
+      float xd[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int idx = lane + (it * 4 + u) * 64, row = idx >> 4, k4 = idx & 15;
@@ -831,7 +843,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
         ua[u] = reinterpret_cast<const float4*>(c.ws.u + (size_t)rpa[row] * 64)[k4];
         ub[u] = reinterpret_cast<const float4*>(c.ws.u + (size_t)rpb[row] * 64)[k4];
         ve[u] = reinterpret_cast<const float4*>(c.ws.e + pc * 64)[k4];
-        vd[u] = reinterpret_cast<const float4*>(c.ws.dist + pc * 64)[k4];
+        xd[u] = c.ws.dist[pc];
         vg[u] = reinterpret_cast<const float4*>(ad + 128)[k4];   // edge_gate_msa
         sh[u] = reinterpret_cast<const float4*>(ad + 192)[k4];   // edge_shift_mlp
         sc[u] = reinterpret_cast<const float4*>(ad + 256)[k4];   // edge_scale_mlp
@@ -844,6 +856,16 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
         r.x = ve[u].x + vg[u].x * ((ua[u].x + ub[u].x) + b.x); r.y = ve[u].y + vg[u].y * ((ua[u].y + ub[u].y) + b.y);
         r.z = ve[u].z + vg[u].z * ((ua[u].z + ub[u].z) + b.z); r.w = ve[u].w + vg[u].w * ((ua[u].w + ub[u].w) + b.w);
         r = ln_mod_reg64(r, sh[u], sc[u]);   // norm2_edge + modulate (dmt.py:166)
+        {
+          float f[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float z = (xd[u] - rm[t]) * rs[t];
+            f[t] = __expf(-0.5f * (z * z)) * ra[t];
+          }
+          if (k4 == 0) f[0] = xd[u];
+          vd[u] = make_float4(f[0], f[1], f[2], f[3]);
+        }
         if (row >= valid) { r = make_float4(0, 0, 0, 0); vd[u] = r; }
         split_store4(E2h + row * LDW2, 64, 4 * k4, r);      // the FF input: an MFMA operand and (reconstructed) the residual
         split_store4(Dh + row * LDW2, 64, 4 * k4, vd[u]);   // CondGaussian features: only ever an MFMA operand -> split-fp16 layout

@@ -391,7 +391,7 @@ class Workspace:
         Nn, Pp, B = max(L.Nn, 1), max(L.Pp, 1), L.B
         self.t = dict(pos=f(Nn, 4), h=f(Nn, 256), e=f(Pp, 64), atom_hids=f(Nn, 768), edge_hids=f(Pp, 192),
                       tfeat=f(B, 24), tmid=f(B, 1024), temb_silu=f(B, 1024), ada=f(B, ADA_COLS), qkv=f(Nn, 768),
-                      ye=f(Pp, 64), dist=f(Pp, 64), attn=f(Nn, 256), u=f(Nn, 64), ac=f(Nn, 512),
+                      ye=f(Pp, 64), dist=f(Pp), attn=f(Nn, 256), u=f(Nn, 64), ac=f(Nn, 512),
                       ed=f(Pp, 256), lg=f(Pp, 32), tr=f(Pp, 8),
                       adj=torch.zeros(Pp, dtype=torch.int32, device=device),
                       flags=torch.zeros(64, dtype=torch.int32, device=device))

@@ -140,7 +140,8 @@ typedef struct ds_workspace {        /* all device fp32 unless noted; sizes in f
   float* ye;         /* [Pp,64 floats]: LayerNorm'd + modulated edge features of the current block (dmt.py:149) as two fp16 planes per
                         row, halves [Pp][2][64] (a = a1 + a2/2048): the MFMA operand from which k_attn_fused recomputes
                         tanh(lin_edge0 e) / tanh(lin_edge1 e) per molecule instead of streaming them through HBM */
-  float* dist;       /* [Pp,64]  CondGaussian features of the current block */
+  float* dist;       /* [Pp]     modulated squared distance x' of the current block (layers.py:330-331); its 64 CondGaussian
+                        features are recomputed where they are consumed (k_edge_geom, k_edge_update) */
   float* attn;       /* [Nn,256] */
   float* u;          /* [Nn,64]  node2edge_lin weight applied per node (no bias) */
   float* ac;         /* [Nn,512] input_lin row part | col part */

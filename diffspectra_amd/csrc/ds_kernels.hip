@@ -107,9 +107,10 @@ __global__ void k_time_feat(Ctx c, const float* __restrict__ noise_level) {
 // Init (dmt.py:323-345,363-377): per-pair adjacency bits + "any non-zero conditioning distance" flag.
 __global__ void k_pair_flags(Ctx c, const float* __restrict__ cond_x, const float* __restrict__ cond_edge_x) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= c.L.Pp) return;
+  const bool valid = p < c.L.Pp;
   int bits = 3;
-  if (cond_x != nullptr) {
+  bool nonzero = false;
+  if (valid && cond_x != nullptr) {
     const int da = c.L.node_dense[c.L.pair_a[p]], db = c.L.node_dense[c.L.pair_b[p]];
     const float* pa = cond_x + (size_t)da * 9;
     const float* pb = cond_x + (size_t)db * 9;
@@ -119,13 +120,17 @@ __global__ void k_pair_flags(Ctx c, const float* __restrict__ cond_x, const floa
     const int lb = db - m * c.L.N;
     const float ce = cond_edge_x[((size_t)da * c.L.N + lb) * 2 + 0];
     bits = (ce >= c.edge_th ? 1 : 0) | (d2 <= c.cutoff ? 2 : 0);
-    // one atomic per wave, not per pair, and none once the flag is up: ten thousand atomics on one address were this
-    // kernel's whole 0.12 ms (a stale 0 only costs one more atomic)
-    const unsigned long long nz = __ballot(d2 != 0.0f);
-    if (nz != 0 && (threadIdx.x & 63) == __builtin_ctzll(nz) && __atomic_load_n(&c.ws.flags[0], __ATOMIC_RELAXED) == 0)
-      atomicOr(&c.ws.flags[0], 1);
+    nonzero = d2 != 0.0f;
   }
-  c.ws.adj[p] = bits;
+  if (valid) c.ws.adj[p] = bits;
+  // "distances.sum() == 0" (dmt.py:364): the flag is raised by a plain store of 1 per workgroup that saw a non-zero distance.
+  // Read-modify-write atomics on the one address - per pair, then per wave - serialised at the L2 and WERE this kernel's time
+  // (0.13 ms with one atomicOr per wave, 8.6 us without); every writer stores the same value, so no atomic is needed, and
+  // 1024-thread workgroups keep the writers few (same-address stores still cost ~35 ns each at the L2).
+  if (cond_x != nullptr) {
+    const int any = __syncthreads_or(nonzero ? 1 : 0);
+    if (any && threadIdx.x == 0) __hip_atomic_store(&c.ws.flags[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // Node init: packed positions, h0 = node_emb([h, cond_h]) (12 -> 256), atom_hids[:, 0:256] = h0.
@@ -2229,7 +2234,7 @@ int ds_stage_init(const ds_weights* w, const ds_layout* L, ds_workspace* ws, con
   Ctx c;
   if (!make_ctx(c, w, L, ws, s) || !xh || !edge_x || ((cond_x == nullptr) != (cond_edge_x == nullptr))) return DS_ERR_ARG;
   if (hipMemsetAsync(ws->flags, 0, 8 * sizeof(int32_t), s) != hipSuccess) return DS_ERR_LAUNCH;
-  if (L->Pp > 0) hipLaunchKernelGGL(k_pair_flags, dim3((L->Pp + 255) / 256), dim3(256), 0, s, c, cond_x, cond_edge_x);
+  if (L->Pp > 0) hipLaunchKernelGGL(k_pair_flags, dim3((L->Pp + 1023) / 1024), dim3(1024), 0, s, c, cond_x, cond_edge_x);
   hipLaunchKernelGGL(k_node_init, dim3(L->Nn), dim3(256), 0, s, c, xh, cond_x);
   if (L->Pp > 0) hipLaunchKernelGGL(k_pair_init, dim3((L->Pp + 63) / 64), dim3(256), 0, s, c, edge_x, cond_x, cond_edge_x);
   return launch_status();

@@ -1002,21 +1002,22 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
 // serve both directions (ed is read from HBM once per step instead of twice).
 // x = A_r + C_c + ed_{rc} -> LN -> modulate -> [256->256, SiLU] -> [256->3] -> tanh -> head mix -> CoorsNorm; the per-edge
 // translation vectors go to tr[2p + dir] and k_pos_update sums them per atom in the reference's edge order.
-// The 256->256 GEMM is computed TRANSPOSED (lane = edge row, registers = output features) so that its SiLU'd
-// accumulators are directly the B operand of the 256->3 MFMA: the hidden activations never touch LDS.
+// The 256->256 GEMM runs on the f16 matrix pipe with split operands (ds_device.h), TRANSPOSED (lane = edge row, registers =
+// output features), so that the 256->3 layer is 48 packed-fp32 FMAs per row block on the lane's own registers: the hidden
+// activations never touch LDS.
 //
-// Warp-specialised and persistent: one 768-thread workgroup per CU loops over tiles.  Waves 8-11 (loaders, raised
-// priority, one per SIMD) gather + LayerNorm + modulate tile i+1 into the other half of a double-buffered LDS tile,
-// precompute its unit coordinate differences, and finish tile i-1's tail (tanh, head mix, CoorsNorm -> tr) while waves
-// 0-7 (two per SIMD, priority 0) run the MFMA chain on tile i, each owning 32 of the 256 hidden features.  One barrier
-// per tile.  Measured (tools/micro/): a wave that alternates gather and MFMA phases loses its memory issue
-// slots to a co-resident MFMA stream, and VALU work next to that stream issues about six times slower than alone, so the
-// roles are split and one MFMA wave's SiLU epilogue overlaps the other's MFMAs on the same SIMD.  Round-2 measurements
-// (profiles/r02_equi_roles.md): with the loaders idle the kernel takes 1.36 ms per launch (4096 molecules; the MFMA
-// pipes are then 92 % busy), with the consumers idle 0.45 ms, together 1.57 ms - the loaders' ~950 instructions per tile
-// issue ~4x slower beside two MFMA waves per SIMD whatever the priorities, and the consumers wait ~11 % at the barrier.
-// Hence the loaders' diet: the HBM-latency stream (`ed` rows) goes by LDS-DMA into the X rows, the LayerNorm runs four rows
-// per pass (one per DPP row), the ac / adaLN gathers of the next pass fly behind the current pass's arithmetic.
+// Warp-specialised and persistent: one (NCW + NLW) x 64-thread workgroup per CU owns a contiguous range of tiles.  The NLW
+// loader waves (raised priority, one per SIMD) gather + LayerNorm + modulate tile i+1 into the other half of a
+// double-buffered split-fp16 LDS tile and precompute its unit coordinate differences while the NCW consumer waves (one per
+// SIMD with 4 + 4, priority 0) run the MFMA chain on tile i, each owning 8 / NCW 32-feature chunks of the 256 hidden
+// features (both of a wave's chunks against the same X fragments); consumer wave 0 finishes tile i-1's tail (tanh, head mix,
+// CoorsNorm -> tr).  One barrier per tile.  Why the roles are split (tools/micro/): a wave that alternates
+// gather and MFMA phases loses its memory issue slots to a co-resident MFMA stream, and dependent VALU work next to that
+// stream stretches ~2.4x.  What each role needed (profiles/r02_equi_roles.md, in-kernel stamps): the loaders spent 65 % of
+// their time waiting for rows they had just requested - their fetches now run a tile ahead (see the loader branch); the
+// consumers waited for weights requested one k-block ahead - their weight stream now runs 4 k-blocks ahead per chunk through
+// register rings that are refilled for the next tile under the epilogue and the barrier.  4 + 4 waves: both roles need more
+// than the 168 registers a 12-wave workgroup leaves.
 template <int NCW, int NLW>
 __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk) {
   constexpr int T = 64, TP = 32, LDH = 2 * 256 + 8, NCH = 8;

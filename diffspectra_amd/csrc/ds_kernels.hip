@@ -210,8 +210,9 @@ __global__ __launch_bounds__(256) void k_pair_init(Ctx c, const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// Block stage A (pairs): d^2 -> CondGaussian RBF -> edge_emb(128->64) -> LN -> modulate -> tanh(lin_edge0/1).
-// dmt.py:136-139,145-149; layers.py:165-166,183.
+// Block stage A (pairs): d^2 -> CondGaussian RBF -> edge_emb(128->64) -> LN -> modulate -> the 256-byte split-fp16 row `ye`
+// (k_attn_fused evaluates tanh(lin_edge0/1 ye) on chip) and the modulated distance x' (k_edge_update recomputes the RBF from it).
+// dmt.py:136-139,145-149; layers.py:328-334.
 __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
   constexpr int T = 64, LDH = 2 * 128 + 8;
   // [x', rbf63 | e64] in the split-fp16 layout (ds_device.h): edge_emb runs on the f16 matrix pipe (the fp32 form was 256

@@ -135,22 +135,39 @@ __global__ void k_pair_flags(Ctx c, const float* __restrict__ cond_x, const floa
 
 // Node init: packed positions, h0 = node_emb([h, cond_h]) (12 -> 256), atom_hids[:, 0:256] = h0.
 __global__ __launch_bounds__(256) void k_node_init(Ctx c, const float* __restrict__ xh, const float* __restrict__ cond_x) {
-  const int row = blockIdx.x;
+  constexpr int R = 8;                       // rows per workgroup: one workgroup per row ran at the dispatcher's rate (73 k workgroups)
+  const int row0 = blockIdx.x * R;
   const int col = threadIdx.x;
-  __shared__ __attribute__((aligned(16))) float in[16];
-  const int d = c.L.node_dense[row];
-  if (col < 6) in[col] = xh[(size_t)d * 9 + 3 + col];
-  else if (col < 12) in[col] = cond_x ? cond_x[(size_t)d * 9 + 3 + (col - 6)] : 0.0f;
-  if (col < 3) c.ws.pos[(size_t)row * 4 + col] = xh[(size_t)d * 9 + col];
-  if (col == 3) c.ws.pos[(size_t)row * 4 + 3] = 0.0f;
+  __shared__ __attribute__((aligned(16))) float in[R][16];
+  if (col < R * 16) {
+    const int rr = col >> 4, k = col & 15, row = row0 + rr;
+    float v = 0.0f;
+    if (row < c.L.Nn) {
+      const int d = c.L.node_dense[row];
+      if (k < 6) v = xh[(size_t)d * 9 + 3 + k];
+      else if (k < 12) v = cond_x ? cond_x[(size_t)d * 9 + 3 + (k - 6)] : 0.0f;
+      else if (k < 15) v = xh[(size_t)d * 9 + (k - 12)];      // positions ride along in slots 12..14
+    }
+    in[rr][k] = v;
+  }
   __syncthreads();
   const float* W = GW(c, DS_GW_NODE_EMB_W);
-  float acc = 0.0f;
+  float w[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) acc += in[k] * wp_at(W, 256, k, col);
-  acc += GW(c, DS_GW_NODE_EMB_B)[col];
-  c.ws.h[(size_t)row * 256 + col] = acc;
-  c.ws.atom_hids[(size_t)row * 768 + col] = acc;
+  for (int k = 0; k < 12; ++k) w[k] = wp_at(W, 256, k, col);
+  const float bias = GW(c, DS_GW_NODE_EMB_B)[col];
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+    const int row = row0 + rr;
+    if (row >= c.L.Nn) break;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc += in[rr][k] * w[k];
+    acc += bias;
+    c.ws.h[(size_t)row * 256 + col] = acc;
+    c.ws.atom_hids[(size_t)row * 768 + col] = acc;
+    if (col < 4) c.ws.pos[(size_t)row * 4 + col] = col < 3 ? in[rr][12 + col] : 0.0f;
+  }
 }
 
 // Pair init: edge_attr0 = edge_emb([edge_x(2), cond_edge_x(2), dist(64)]) (68 -> 64); edge_hids[:, 0:64].
@@ -2237,7 +2254,7 @@ int ds_stage_init(const ds_weights* w, const ds_layout* L, ds_workspace* ws, con
   if (!make_ctx(c, w, L, ws, s) || !xh || !edge_x || ((cond_x == nullptr) != (cond_edge_x == nullptr))) return DS_ERR_ARG;
   if (hipMemsetAsync(ws->flags, 0, 8 * sizeof(int32_t), s) != hipSuccess) return DS_ERR_LAUNCH;
   if (L->Pp > 0) hipLaunchKernelGGL(k_pair_flags, dim3((L->Pp + 1023) / 1024), dim3(1024), 0, s, c, cond_x, cond_edge_x);
-  hipLaunchKernelGGL(k_node_init, dim3(L->Nn), dim3(256), 0, s, c, xh, cond_x);
+  hipLaunchKernelGGL(k_node_init, dim3((L->Nn + 7) / 8), dim3(256), 0, s, c, xh, cond_x);
   if (L->Pp > 0) hipLaunchKernelGGL(k_pair_init, dim3((L->Pp + 63) / 64), dim3(256), 0, s, c, edge_x, cond_x, cond_edge_x);
   return launch_status();
 }

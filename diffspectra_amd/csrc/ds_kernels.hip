@@ -1369,12 +1369,21 @@ __global__ __launch_bounds__(64) void k_pos_update(Ctx c, int last) {
   if (r < n) {
     const float4* tr = reinterpret_cast<const float4*>(c.ws.tr);
     float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    for (int cc = 0; cc < n; ++cc) {
-      if (cc == r) continue;
-      const int lo = r < cc ? r : cc, hi = r < cc ? cc : r;
-      const int pl = lo * (2 * n - lo - 1) / 2 + (hi - lo - 1);
-      const float4 t = tr[(size_t)(p0 + pl) * 2 + (r < cc ? 0 : 1)];
-      sx += t.x; sy += t.y; sz += t.z;
+    for (int c0 = 0; c0 < n; c0 += 8) {   // eight partners' vectors in flight, added in ascending partner order
+      float4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int cc = c0 + u;
+        t[u] = make_float4(0, 0, 0, 0);
+        if (cc < n && cc != r) {
+          const int lo = r < cc ? r : cc, hi = r < cc ? cc : r;
+          const int pl = lo * (2 * n - lo - 1) / 2 + (hi - lo - 1);
+          t[u] = tr[(size_t)(p0 + pl) * 2 + (r < cc ? 0 : 1)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c0 + u < n && c0 + u != r) { sx += t[u].x; sy += t[u].y; sz += t[u].z; }
     }
     const float* pp = c.ws.pos + (size_t)(n0 + r) * 4;
     x = pp[0] + sx; y = pp[1] + sy; z = pp[2] + sz;

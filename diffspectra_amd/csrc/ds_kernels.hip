@@ -2007,23 +2007,38 @@ __global__ __launch_bounds__(64) void k_spec_attention(const float* __restrict__
   // residual scores are kept TRANSPOSED, [b][h][key j][query i]: the lanes of a wave are consecutive queries, so every
   // access below is one contiguous 256-byte segment (query-major rows made each lane touch its own cache line)
   float* scol = scores + ((size_t)b * heads + h) * L * L + i;
-  float mx = -INFINITY;
-  for (int j = 0; j < L; ++j) {
-    float s = 0.0f;
-#pragma unroll
-    for (int d = 0; d < DK; ++d) s += q[d] * Ks[j * DK + d];
-    s *= scale;
-    if (has_prev) s += scol[(size_t)j * L];
-    scol[(size_t)j * L] = s;
-    mx = fmaxf(mx, s);
-  }
-  float den = 0.0f, o[DK];
+  // One pass with a running maximum (the scores are written for the next layer and never read back here: the [B, heads, L, L]
+  // tensor is this kernel's whole HBM bill - 4.1 GB per launch with the two-pass form).  Blocks of 8 keys: one rescale per block.
+  float mx = -INFINITY, den = 0.0f, o[DK];
   for (int d = 0; d < DK; ++d) o[d] = 0.0f;
-  for (int j = 0; j < L; ++j) {
-    const float p = expf(scol[(size_t)j * L] - mx);
-    den += p;
+  for (int j0 = 0; j0 < L; j0 += 8) {
+    float sv[8];
+    float bm = -INFINITY;
 #pragma unroll
-    for (int d = 0; d < DK; ++d) o[d] += p * Vs[j * DK + d];
+    for (int u = 0; u < 8; ++u) {
+      const int j = min(j0 + u, L - 1);
+      float s = 0.0f;
+#pragma unroll
+      for (int d = 0; d < DK; ++d) s += q[d] * Ks[j * DK + d];
+      s *= scale;
+      if (has_prev) s += scol[(size_t)j * L];
+      sv[u] = s;
+      if (j0 + u < L) { scol[(size_t)j * L] = s; bm = fmaxf(bm, s); }
+    }
+    const float nm = fmaxf(mx, bm), r = expf(mx - nm);   // mx = -inf on the first block: r = 0
+    den *= r;
+#pragma unroll
+    for (int d = 0; d < DK; ++d) o[d] *= r;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (j0 + u < L) {
+        const float p = expf(sv[u] - nm);
+        den += p;
+#pragma unroll
+        for (int d = 0; d < DK; ++d) o[d] += p * Vs[(j0 + u) * DK + d];
+      }
+    }
+    mx = nm;
   }
   for (int d = 0; d < DK; ++d) out[((size_t)b * L + i) * D + h * DK + d] = o[d] / den;
 }

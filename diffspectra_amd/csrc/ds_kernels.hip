@@ -1981,19 +1981,20 @@ __global__ __launch_bounds__(64) void k_check_stability(ds_layout L, const float
   if (a == 0) { nr_stable[m] = cnt; mol_stable[m] = cnt == n ? 1 : 0; }
 }
 
-// SpecFormer residual-score attention (specformer.py:401-424): one workgroup per (molecule, head, 64-query tile).
+// SpecFormer residual-score attention (specformer.py:401-424): one workgroup per (molecule, head) and up to 1024 queries - one
+// query per thread, K / V of the head staged in LDS once for all of them.
 // qkv [B, L, 3*heads*dk] (q | k | v); scores [B, heads, L, L] holds prev on entry (if has_prev) and the new
 // pre-softmax scores on exit; out [B, L, heads*dk].
-__global__ __launch_bounds__(64) void k_spec_attention(const float* __restrict__ qkv, float* __restrict__ scores,
+__global__ __launch_bounds__(1024) void k_spec_attention(const float* __restrict__ qkv, float* __restrict__ scores,
                                                        float* __restrict__ out, int B, int L, int heads, float scale,
                                                        int has_prev) {
   constexpr int DK = 8;
   extern __shared__ __attribute__((aligned(16))) float kv[];   // K [L][8] then V [L][8]
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * blockDim.x, tid = threadIdx.x;
   const int D = heads * DK;
   float* Ks = kv;
   float* Vs = kv + (size_t)L * DK;
-  for (int idx = tid; idx < L * DK; idx += 64) {
+  for (int idx = tid; idx < L * DK; idx += blockDim.x) {
     const int j = idx / DK, d = idx - j * DK;
     const float* base = qkv + ((size_t)b * L + j) * 3 * D + h * DK + d;
     Ks[idx] = base[D];
@@ -2402,8 +2403,9 @@ int ds_check_stability(const ds_layout* L, const float* pos, const int32_t* atom
 int ds_spec_attention(const float* qkv, float* scores, float* out, int B, int L, int heads, int dk, float scale, int has_prev,
                       void* stream) {
   if (!qkv || !scores || !out || dk != 8 || B <= 0 || L <= 0) return DS_ERR_ARG;
-  dim3 grid((L + 63) / 64, heads, B);
-  hipLaunchKernelGGL(k_spec_attention, grid, dim3(64), (size_t)L * 8 * 2 * sizeof(float), (hipStream_t)stream, qkv, scores, out, B,
+  const int threads = min(1024, (L + 63) / 64 * 64);
+  dim3 grid((L + threads - 1) / threads, heads, B);
+  hipLaunchKernelGGL(k_spec_attention, grid, dim3(threads), (size_t)L * 8 * 2 * sizeof(float), (hipStream_t)stream, qkv, scores, out, B,
                      L, heads, scale, has_prev);
   return launch_status();
 }

@@ -249,6 +249,36 @@ def test_gemm_row_groups(gpu_device):
     assert float(z[:, :5].abs().max()) == 0.0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,has_prev", [(347, 0), (139, 1), (1100, 1)])
+def test_spec_attention_vs_torch(gpu_device, L, has_prev):
+    """ds_spec_attention (specformer.py:401-424: scores = q k^T * scale + prev, softmax over keys, @ v; the new pre-softmax
+    scores are handed to the next layer) against a plain torch fp32 evaluation - including a sequence longer than one
+    1024-thread workgroup.  The score tensor is kept key-major ([b][h][key][query])."""
+    import ctypes as C
+    from diffspectra_amd import engine as E
+    lib = E.load_library()
+    d = gpu_device
+    B, H, DK = 2, 3, 8
+    D = H * DK
+    g = torch.Generator().manual_seed(5 + L)
+    qkv = torch.randn(B, L, 3 * D, generator=g)
+    prev = torch.randn(B, H, L, L, generator=g) * 0.5          # [b][h][key][query]
+    scale = 0.37
+    q, k, v = (qkv[..., i * D:(i + 1) * D].reshape(B, L, H, DK).permute(0, 2, 1, 3) for i in range(3))
+    s_ref = torch.einsum("bhid,bhjd->bhij", q, k) * scale     # [b][h][query][key]
+    if has_prev:
+        s_ref = s_ref + prev.transpose(-1, -2)
+    o_ref = torch.einsum("bhij,bhjd->bhid", torch.softmax(s_ref, -1), v).permute(0, 2, 1, 3).reshape(B, L, D)
+    scores = prev.clone().to(d) if has_prev else torch.zeros(B, H, L, L, device=d)
+    out = torch.empty(B, L, D, device=d)
+    qd = qkv.to(d)
+    E._check(lib.ds_spec_attention(E._ptr(qd), E._ptr(scores), E._ptr(out), C.c_int(B), C.c_int(L), C.c_int(H), C.c_int(DK),
+                                   C.c_float(scale), C.c_int(has_prev), E._stream()), "ds_spec_attention")
+    assert_close(out, o_ref, 2e-5, "attention output")
+    assert_close(scores.transpose(-1, -2), s_ref, 2e-5, "pre-softmax scores for the next layer")
+
+
 # ------------------------------------------------------------------------------------------------ stages
 
 def _oracle_edge_maps(L, N):

@@ -231,12 +231,18 @@ def main():
             done = sampler.advance(self.st, slice_len)
             self.iters += self.st.i - before
             if done:
-                pos, one_hot, fc, edge_types = S.post_process(self.st.x_mean, 5, True, node_mask, inv, self.st.edge_mean,
-                                                              edge_mask, True, engine=eng)
-                rec = shard.pack_records_u8(pos, one_hot.argmax(-1), fc, edge_types)   # 1 248-byte record per molecule
-                self.rec = shard.gather_records(rec)                                  # final gather over xGMI
-                self.st = None
+                self.close()
                 self.passes += 1
+
+        def close(self):
+            """Post-processing, 1 248-byte records and the final gather over xGMI on the current state of the pass."""
+            if self.st is None:
+                return
+            pos, one_hot, fc, edge_types = S.post_process(self.st.x_mean, 5, True, node_mask, inv, self.st.edge_mean,
+                                                          edge_mask, True, engine=eng)
+            rec = shard.pack_records_u8(pos, one_hot.argmax(-1), fc, edge_types)
+            self.rec = shard.gather_records(rec)
+            self.st = None
 
     def sync():
         if world > 1:
@@ -262,6 +268,9 @@ def main():
         t_step = max_over_ranks(time.perf_counter() - t0)
         if rank == 0:
             log(f"warmup step {w + 1}/{args.warmup} done ({t_step * 1e3:.0f} ms, {slice_len} denoise iterations x {M} molecules)")
+    if args.warmup > 0:
+        warm.close()      # the pass-closing code path once, untimed: its torch kernels and the collective load lazily on first use
+        sync()
     del warm
     steps = args.steps
     if t_step > 0 and steps * t_step > args.budget_s:

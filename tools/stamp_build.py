@@ -40,7 +40,7 @@ def main():
     tmp = os.path.join(ROOT, "diffspectra_amd", "csrc", "_stamped.hip")
     open(tmp, "w").write(s)
     try:
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed",
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
                         "-DDS_STAMPS", tmp, "-o", os.path.join(ROOT, "diffspectra_amd", "libdiffspectra_hip_stamps.so")], check=True)
     finally:
         os.remove(tmp)

@@ -462,19 +462,20 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     for (int kb = 0; kb < 4; ++kb) {
       const h8 x1 = *reinterpret_cast<const h8*>(xr + kb * 16);
       const h8 x2 = *reinterpret_cast<const h8*>(xr + 64 + kb * 16);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1, wf[0][kb], acc[0], 0, 0, 0);
-      lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x2, wf[0][kb], lo[0], 0, 0, 0);
-      lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1, wf[1][kb], lo[0], 0, 0, 0);
+      // transposed product (weights as the A operand): lane = tile row, registers = 4 consecutive features per quad, so the
+      // tanh'ed tile goes to LDS as four 16-byte stores per lane instead of sixteen 4-byte ones
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][kb], x1, acc[0], 0, 0, 0);
+      lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][kb], x2, lo[0], 0, 0, 0);
+      lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][kb], x1, lo[0], 0, 0, 0);
     }
     split_finish<1>(acc, lo);
-    const int col = (wave & 7) * 32 + (lane & 31);
+    float* trow = &Tt[mt * 32 + (lane & 31)][(wave & 7) * 32 + 4 * hh];
 #pragma unroll
-    for (int i = 0; i < 16; i += 2) {
-      f32x2 v;
-      v.x = acc[0][i]; v.y = acc[0][i + 1];
-      v = ds_tanh2(v);                                   // layers.py:165-166,183
-      const int r0 = mt * 32 + acc_row(i, hh);
-      Tt[r0][col] = v.x; Tt[r0 + 1][col] = v.y;
+    for (int q = 0; q < 4; ++q) {
+      f32x2 v0, v1;
+      v0.x = acc[0][4 * q]; v0.y = acc[0][4 * q + 1]; v1.x = acc[0][4 * q + 2]; v1.y = acc[0][4 * q + 3];
+      v0 = ds_tanh2(v0); v1 = ds_tanh2(v1);              // layers.py:165-166,183
+      *reinterpret_cast<float4*>(trow + 8 * q) = make_float4(v0.x, v0.y, v1.x, v1.y);
     }
   };
 

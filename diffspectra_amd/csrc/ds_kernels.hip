@@ -407,7 +407,11 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   __shared__ __attribute__((aligned(16))) float Tt[64][LDT];                 // 66,560 B  tanh(te0 / te1) of the chunk
   __shared__ __attribute__((aligned(16))) _Float16 Yc[64][LDY];              // 17,408 B  ye rows of the chunk (split-fp16 layout)
   __shared__ __attribute__((aligned(16))) float AL[64][32];                  //  8,192 B  alpha of the chunk's pairs, both directions
-  __shared__ int pab[64];                                                    // (a << 8) | b, local atom indices of the chunk's pairs
+  // (a << 8) | b local atom indices and adjacency bits of the chunk's pairs, double-buffered by chunk parity: a wave that is
+  // through with chunk k's logits commits chunk k+1's tables while slower waves still read chunk k's (the barrier at the top of
+  // an iteration bounds the skew to one chunk)
+  __shared__ int pab[2][64];
+  __shared__ int padj[2][64];
   const int m = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5;
   const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
   const int p0 = c.L.pair_off[m], P = c.L.pair_off[m + 1] - p0;
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   // with one workgroup per CU nothing else hides their latency.
   uint4 yv;
   float4 av = make_float4(0, 0, 0, 0);
-  int abv = 0;
+  int abv = 0, adjv = 0;
   auto fetch = [&](int ck, bool with_alpha) {
     {   // 64 rows x 16 pieces of 16 bytes: one per thread
       const int pl = ck * 64 + (tid >> 4);
@@ -435,12 +439,13 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     if (tid < 64) {
       const int pl = ck * 64 + tid;
       abv = pl < P ? ((c.L.pair_a[p0 + pl] - n0) << 8) | (c.L.pair_b[p0 + pl] - n0) : 0;
+      if (!with_alpha) adjv = pl < P ? c.ws.adj[p0 + pl] : 0;   // the two adjacency heads' logits (phase 1): fetched with the chunk, not inside its logit loop
     }
   };
-  auto commit = [&](bool with_alpha) {
+  auto commit = [&](bool with_alpha, int pb) {
     *reinterpret_cast<uint4*>(&Yc[tid >> 4][(tid & 15) * 8]) = yv;
     if (with_alpha && tid < 512) reinterpret_cast<float4*>(&AL[tid >> 3][0])[tid & 7] = av;
-    if (tid < 64) pab[tid] = abv;
+    if (tid < 64) { pab[pb][tid] = abv; padj[pb][tid] = adjv; }
   };
   // wave w owns output columns 32 (w & 7) .. +31 of row tile w >> 3; its lin_edge0 / lin_edge1 fragments (64 -> 256, split-fp16
   // planes) live in registers for a whole phase: 8 x 16 bytes
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   }
   // ---- phase 1: logits
   for (int ck = 0; ck < nchunks; ++ck) {
-    commit(false);
+    commit(false, ck & 1);
     __syncthreads();                       // Yc / pab of this chunk (and, first time, QK) visible; every reader of the previous Tt is past it
     if (ck + 1 < nchunks) fetch(ck + 1, false);
     project();
@@ -508,13 +513,13 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
       float* out = c.ws.lg + (size_t)(p0 + pl) * 32;
       if (hs >= 14) {
         if (hs == 14) {
-          const int bits = c.ws.adj[p0 + pl];
+          const int bits = padj[ck & 1][row];
           const float h0 = (bits & 1) ? 1.0f : -1e10f, h1 = (bits & 2) ? 1.0f : -1e10f;   // layers.py:171-174
           out[0] = h0; out[1] = h1; out[16] = h0; out[17] = h1;
         }
         continue;
       }
-      const int a = pab[row] >> 8, b = pab[row] & 255;
+      const int a = pab[ck & 1][row] >> 8, b = pab[ck & 1][row] & 255;
       const float2* t0 = reinterpret_cast<const float2*>(&Tt[row][hs * 18]);
       const float2* qa = reinterpret_cast<const float2*>(QK + a * QS + hs * 18);
       const float2* qb = reinterpret_cast<const float2*>(QK + b * QS + hs * 18);
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   // projection - are past the first barrier), its alpha / pair tables right after the second one (read again only behind the
   // next projection's barrier).
   fetch(0, true);
-  commit(true);
+  commit(true, 0);
   __syncthreads();
   for (int ck = 0; ck < nchunks; ++ck) {
     if (ck + 1 < nchunks) fetch(ck + 1, true);
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     __syncthreads();
     if (ck + 1 < nchunks) *reinterpret_cast<uint4*>(&Yc[tid >> 4][(tid & 15) * 8]) = yv;
     const int rows = min(64, P - ck * 64);
-    const int my_ab = pab[lane];           // the chunk's 64 (a, b) pairs, one per lane
+    const int my_ab = pab[ck & 1][lane];   // the chunk's 64 (a, b) pairs, one per lane
     // rows in which this wave owns a target, as a lane mask: the loop visits only those (~16 of 64), in ascending row order
     unsigned long long todo = __ballot(lane < rows && ((((my_ab >> 8) & 15) == wave) || ((my_ab & 15) == wave)));
     while (todo) {
@@ -620,7 +625,7 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     __syncthreads();                       // Tt / AL / pab are rewritten by the next chunk
     if (ck + 1 < nchunks) {
       if (tid < 512) reinterpret_cast<float4*>(&AL[tid >> 3][0])[tid & 7] = av;
-      if (tid < 64) pab[tid] = abv;
+      if (tid < 64) pab[(ck + 1) & 1][tid] = abv;
     }
   }
 #pragma unroll

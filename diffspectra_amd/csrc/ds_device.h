@@ -244,6 +244,14 @@ __device__ __forceinline__ void wave_mma(const float* X, int ldx, const float* _
 //   X tile in LDS : [row][plane 0: K halves | plane 1: K halves | 8 halves pad]  (row stride 2K + 8 halves = K + 4 dwords: the
 //                   16-byte fragment reads of 16 consecutive rows hit 16 distinct 4-bank groups, like the fp32 tiles)
 //   weights       : two planes in MFMA operand order, halves [plane][K/16][k-half][N][8] (engine.pack_linear_f16_split)
+// Range: a split value covers fp16's exponent range, not fp32's.  Every kernel that converts fp32 to split planes first calls
+// ds_fp16_saturate(): MODE.FP16_OVFL (hwreg MODE bit 23) makes v_cvt_f16_f32 clamp an overflowing result to +-65504 instead
+// of producing inf (true inf / NaN inputs are preserved), at no instruction cost - measured on gfx950 with
+// tools/micro/fp16_ovfl.hip: 7e4 -> (65504, 65504) = 65536, 1e6 -> 65536, inf -> inf, NaN -> NaN.  An activation with
+// |x| >= 65536 therefore SATURATES at +-65536 (both planes clamp) where it used to turn into inf - inf = NaN; values below
+// 65520 are converted exactly as before.  Weights are range-checked at pack time (engine.pack_linear_f16_split).
+__device__ __forceinline__ void ds_fp16_saturate() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
+
 __device__ __forceinline__ void split_store4(_Float16* row, int K, int col, float4 v) {   // columns col .. col+3 of a tile row
   const float xs[4] = {v.x, v.y, v.z, v.w};
   h4 h1, h2;

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256) void k_node_init(Ctx c, const float* __restric
 // Pair init: edge_attr0 = edge_emb([edge_x(2), cond_edge_x(2), dist(64)]) (68 -> 64); edge_hids[:, 0:64].
 __global__ __launch_bounds__(256) void k_pair_init(Ctx c, const float* __restrict__ edge_x, const float* __restrict__ cond_x,
                                                    const float* __restrict__ cond_edge_x) {
+  ds_fp16_saturate();
   constexpr int T = 64;
   __shared__ __attribute__((aligned(16))) float X[T][72 + DS_LDP];
   __shared__ __attribute__((aligned(16))) float xs[T];
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256) void k_pair_init(Ctx c, const float* __restric
 // (k_attn_fused evaluates tanh(lin_edge0/1 ye) on chip) and the modulated distance x' (k_edge_update recomputes the RBF from it).
 // dmt.py:136-139,145-149; layers.py:328-334.
 __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
+  ds_fp16_saturate();
   constexpr int T = 64, LDH = 2 * 128 + 8;
   // [x', rbf63 | e64] in the split-fp16 layout (ds_device.h): edge_emb runs on the f16 matrix pipe (the fp32 form was 256
   // 64-cycle MFMAs per workgroup, ~40 % of this kernel's time; now 96 32-cycle ones)
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(256) void k_edge_geom(Ctx c, int blk) {
 // that the launch keeps >= 4 workgroups per CU at bench sizes - the LayerNorm of the tile is simply done by both halves.
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_node_qkv(Ctx c, int blk) {
+  ds_fp16_saturate();
   constexpr int NT = NW * 64;
   constexpr int T = 64;
   constexpr int LDH = 2 * 256 + 8;
@@ -402,6 +405,7 @@ __global__ __launch_bounds__(NW * 64) void k_node_qkv(Ctx c, int blk) {
 //            reference's scatter-add (layers.py:178-186)
 // q|k of the molecule's atoms are staged in LDS for phase 1, V takes their place for phase 2.
 __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
+  ds_fp16_saturate();
   constexpr int NW = 16, NT = NW * 64, QS = 512 + 32, LDT = 256 + 4, LDY = 2 * 64 + 8;
   __shared__ __attribute__((aligned(16))) float QK[DS_MAX_ATOMS * QS];       // 63,104 B; phase 2: V [n][256]
   __shared__ __attribute__((aligned(16))) float Tt[64][LDT];                 // 66,560 B  tanh(te0 / te1) of the chunk
@@ -640,6 +644,7 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
 // in place, per-block readout slice (256->64) and the node parts of equi_update.input_lin (256->512).
 // dmt.py:156-163,387,39-45.  66.5 kB LDS -> two workgroups per CU.
 __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
+  ds_fp16_saturate();
   constexpr int T = 32, LDH = 2 * 256 + 8;
   // both tiles in the split-fp16 layout of ds_device.h (every use is an MFMA operand; the one fp32 re-read - the residual of
   // the FF - reconstructs x1 + x2/2048, 2^-23 relative from the original); same bytes as the fp32 tiles they replace
@@ -826,6 +831,7 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
 // chained in registers: FF3 is computed transposed (lane = row, registers = hidden features) and its SiLU'd accumulators
 // are the B operand of the FF4 MFMAs; the gated residual is applied in that transposed layout with 16-byte LDS accesses.
 __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
+  ds_fp16_saturate();
   constexpr int R = 32, LDW = 64 + DS_LDP;
   __shared__ __attribute__((aligned(16))) float E2s[4][R][LDW];   // residual stream, then e_out in place
   __shared__ __attribute__((aligned(16))) float Ds[4][R][LDW];    // CondGaussian features of this block
@@ -1044,6 +1050,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
 // than the 168 registers a 12-wave workgroup leaves.
 template <int NCW, int NLW>
 __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk) {
+  ds_fp16_saturate();
   constexpr int T = 64, TP = 32, LDH = 2 * 256 + 8, NCH = 8;
   constexpr int CPW = NCH / NCW;     // 32-feature chunks of the hidden layer per consumer wave
   constexpr int PPW = TP / NLW;      // pairs per loader wave and tile
@@ -1407,6 +1414,7 @@ __global__ __launch_bounds__(64) void k_pos_update(Ctx c, int last) {
 // ------------------------------------------------------------------------------------------------
 // Readout: node_pred_mlp (768->256->128->6) -> out_xh[..., 3:9] (dmt.py:391-393).
 __global__ __launch_bounds__(256) void k_node_readout(Ctx c, float* __restrict__ out_xh) {
+  ds_fp16_saturate();
   constexpr int T = 32;
   // the 768- and 256-wide tiles in the split-fp16 layout (ds_device.h): their GEMMs run on the f16 pipe; the last, 128 -> 6, stays fp32
   __shared__ __attribute__((aligned(16))) _Float16 X[T][2 * 768 + 8];
@@ -1478,6 +1486,7 @@ __global__ __launch_bounds__(256) void k_node_readout(Ctx c, float* __restrict__
 // chunk), its SiLU'd accumulators - split in registers - are the B operand of the 64 -> 32 MFMAs (weights in accumulator-chain
 // order, DS_GW_EX2_C / ET2_C), and 32 -> 1 is 16 fused multiply-adds per lane plus one v_permlane32_swap.
 __global__ __launch_bounds__(256) void k_edge_readout(Ctx c, float* __restrict__ out_edge) {
+  ds_fp16_saturate();
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int Pp = c.L.Pp;
   const int row0 = (blockIdx.x * 4 + wave) * 32;
@@ -1608,6 +1617,7 @@ __global__ void k_final_pos(Ctx c, float* __restrict__ out_xh) {
 
 // temb = tm3_out (+ ctx); store SiLU(temb) — the input of every *time_mlp Linear (dmt.py:354; nn.SiLU first in each).
 __global__ void k_temb_finish(Ctx c, const float* __restrict__ tm3, int tm3_rows, const float* __restrict__ ctx) {
+  ds_fp16_saturate();
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)c.L.B * 1024) return;
   const size_t b = i >> 10, col = i & 1023;
@@ -1623,6 +1633,7 @@ __global__ void k_temb_finish(Ctx c, const float* __restrict__ tm3, int tm3_rows
 // double-buffered in LDS with the next chunk fetched into registers while the current one is multiplied.
 __global__ __launch_bounds__(256) void k_gemm_ada(const _Float16* __restrict__ A, const float* __restrict__ Wh, const float* __restrict__ bias,
                                                   float* __restrict__ C, int ldc, int M, int K, int N) {
+  ds_fp16_saturate();
   constexpr int T = 64, KC = 64, LDH = 2 * KC + 8, MT = T / 32;
   __shared__ __attribute__((aligned(16))) _Float16 X[2][T][LDH];
   const int tid = threadIdx.x, wave = tid >> 6;

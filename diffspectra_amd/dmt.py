@@ -67,18 +67,32 @@ class DMT(nn.Module):
         return matched
 
     def _weights_key(self):
-        """Fingerprint of the current weights: device + the 1- and 2-norm of every floating-point parameter and buffer.
+        """Fingerprint of the current weights: device + a position-sensitive 64-bit checksum of every floating-point parameter
+        and buffer (``ds_fingerprint``: one kernel over all tensors + one 8-byte device->host copy).
 
         ``Tensor._version`` is not enough: both EMA implementations write with ``p.data.copy_(...)`` (reference
-        models/ema.py:55,77), which leaves the version counter untouched.  Two fused multi-tensor reductions and one
-        small device->host copy per ``engine()`` call (once per sampling pass / per drop-in ``forward``)."""
+        models/ema.py:55,77), which leaves the version counter untouched.  The checksum weights every element by a hash of
+        its position, so sign flips, row / head permutations and copies from an equal-norm tensor all change it."""
+        import ctypes as C
+        from .engine import load_library, _check, _stream
         ts = [t.detach() for t in list(self.parameters()) + list(self.buffers()) if t.is_floating_point()]
         dev = ts[0].device
         if dev.type != "cuda":
             return (str(dev),)
-        with torch.no_grad():
-            fp = torch.stack(torch._foreach_norm(ts, 1) + torch._foreach_norm(ts, 2)).double().cpu()
-        return (str(dev), tuple(t.data_ptr() for t in ts[:4]), fp.numpy().tobytes())
+        ptrs = tuple(t.data_ptr() for t in ts)
+        tab = getattr(self, "_fp_table", None)
+        if tab is None or tab[0] != ptrs:
+            if any(t.dtype != torch.float32 or not t.is_contiguous() for t in ts):
+                raise RuntimeError("DMT parameters must be contiguous fp32 tensors")
+            prefix = [0]
+            for t in ts:
+                prefix.append(prefix[-1] + t.numel())
+            tab = (ptrs, torch.tensor(ptrs, dtype=torch.int64, device=dev), torch.tensor(prefix, dtype=torch.int64, device=dev),
+                   torch.zeros(1, dtype=torch.int64, device=dev))
+            self._fp_table = tab
+        _check(load_library().ds_fingerprint(C.c_void_p(tab[1].data_ptr()), C.c_void_p(tab[2].data_ptr()), C.c_int32(len(ts)),
+                                             C.c_void_p(tab[3].data_ptr()), _stream()), "ds_fingerprint")
+        return (str(dev), ptrs[:4], int(tab[3].item()))
 
     def invalidate_engine(self):
         """Drop the packed weights; the next call re-packs from the current parameters."""

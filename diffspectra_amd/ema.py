@@ -1,0 +1,75 @@
+"""Exponential moving average of the trainable parameters - the surface of reference ``models/ema.py``.
+
+Same constructor (``parameters, decay, use_num_updates=True``), same state layout (``decay``, ``num_updates``,
+``shadow_params`` = list of the trainable tensors in ``parameters()`` order, ``ema.py:79-85``) and the same five operations
+(``update :24-42``, ``copy_to :44-55``, ``store :57-64``, ``restore :66-77``, ``state_dict / load_state_dict``), so that
+``run_lib``-style callers (``store -> copy_to -> sample -> restore``; ``losses.py:115-122``) and checkpoints written by the
+reference work unchanged.  The arithmetic runs as multi-tensor ops over the whole parameter list (one launch per operation
+instead of one per tensor); ``copy_to`` / ``restore`` notify a HIP ``DMT`` that its packed weights are stale.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+
+
+def _trainable(parameters) -> List[torch.Tensor]:
+    return [p for p in parameters if p.requires_grad]
+
+
+class ExponentialMovingAverage:
+    def __init__(self, parameters: Iterable[torch.nn.Parameter], decay: float, use_num_updates: bool = True):
+        if decay < 0.0 or decay > 1.0:
+            raise ValueError("Decay must be between 0 and 1")
+        self.decay = decay
+        self.num_updates = 0 if use_num_updates else None
+        self.shadow_params = [p.detach().clone() for p in parameters if p.requires_grad]
+        self.collected_params: List[torch.Tensor] = []
+
+    def effective_decay(self) -> float:
+        """The decay ``update`` will apply next: min(decay, (1 + n) / (10 + n)) with n counted after the increment (ema.py:34-37)."""
+        if self.num_updates is None:
+            return self.decay
+        n = self.num_updates + 1
+        return min(self.decay, (1 + n) / (10 + n))
+
+    @torch.no_grad()
+    def update(self, parameters) -> None:
+        """shadow -= (1 - decay) * (shadow - param) for every trainable parameter (ema.py:24-42)."""
+        decay = self.effective_decay()
+        if self.num_updates is not None:
+            self.num_updates += 1
+        params = [p.detach() for p in _trainable(parameters)]
+        if len(params) != len(self.shadow_params):
+            raise ValueError(f"EMA holds {len(self.shadow_params)} tensors, got {len(params)} trainable parameters")
+        if not params:
+            return
+        one_minus_decay = 1.0 - decay
+        diff = torch._foreach_sub(self.shadow_params, params)          # (shadow - param)
+        torch._foreach_mul_(diff, one_minus_decay)
+        torch._foreach_sub_(self.shadow_params, diff)
+
+    @torch.no_grad()
+    def copy_to(self, parameters) -> None:
+        params = _trainable(parameters)
+        if len(params) != len(self.shadow_params):
+            raise ValueError(f"EMA holds {len(self.shadow_params)} tensors, the model has {len(params)} trainable ones")
+        for shadow, p in zip(self.shadow_params, params):
+            p.data.copy_(shadow.data.to(p.device))
+
+    def store(self, parameters) -> None:
+        self.collected_params = [p.detach().clone() for p in parameters]
+
+    @torch.no_grad()
+    def restore(self, parameters) -> None:
+        for c, p in zip(self.collected_params, parameters):
+            p.data.copy_(c.data)
+
+    def state_dict(self):
+        return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)
+
+    def load_state_dict(self, state_dict) -> None:
+        self.decay = state_dict["decay"]
+        self.num_updates = state_dict["num_updates"]
+        self.shadow_params = state_dict["shadow_params"]

@@ -144,6 +144,17 @@ def pack_linear(weight: torch.Tensor, n_pad_to: int = 32) -> torch.Tensor:
 
 
 SPLIT_SCALE = 2048.0   # 2^11: the low fp16 plane of a split operand is stored scaled so that it keeps 11 significant bits
+F16_MAX = 65504.0      # a split value has fp16's exponent range: |w| must stay below this (activations saturate in the kernels)
+
+
+def _check_split_range(w: torch.Tensor, what: str) -> None:
+    """A weight at or beyond fp16's largest finite value cannot be carried as two fp16 planes (its high plane would be inf and
+    every product NaN).  No trained DMT comes near it (random-init |w| < 1); refuse loudly instead of computing garbage."""
+    m = float(w.abs().max()) if w.numel() else 0.0
+    if not (m < F16_MAX):
+        raise ValueError(f"{what}: max |w| = {m:.4g} is outside the split-fp16 range (|w| < {F16_MAX:g}); "
+                         "this weight cannot run on the f16 matrix pipe")
+
 
 
 def pack_linear_f16_split(weight: torch.Tensor) -> torch.Tensor:
@@ -151,6 +162,7 @@ def pack_linear_f16_split(weight: torch.Tensor) -> torch.Tensor:
     2^-23 |w|), in the A-operand order of v_mfma_f32_32x32x16_f16: halves [plane][K/16][k-half][N][8], k = 16 kb + 8 h + j;
     returned as the fp32 view of those bits (the packed weight buffer is fp32)."""
     w = weight.detach().to(torch.float32).cpu()
+    _check_split_range(w, "pack_linear_f16_split")
     if w.shape[0] % 32:                                               # zero rows up to the MFMA tile width
         w = torch.cat([w, torch.zeros(32 - w.shape[0] % 32, w.shape[1])], 0)
     N, K = w.shape
@@ -168,6 +180,7 @@ def pack_ff4_chain(weight: torch.Tensor) -> torch.Tensor:
     as the B fragment of a 32x32x16 f16 MFMA; the A fragment of lane (r, h) must hold, in element j, the weight of output
     ft*32 + r for exactly that hidden feature.  Two fp16 planes (w = w1 + w2/2048); returned as the fp32 view of the bits."""
     w = weight.detach().to(torch.float32).cpu()
+    _check_split_range(w, "pack_ff4_chain")
     n_out, k_in = w.shape                                                        # ff_linear4: (64, 128); edge readout .2: (32, 64)
     assert n_out % 32 == 0 and k_in % 32 == 0
     w1 = w.half()
@@ -182,8 +195,9 @@ def pack_ff4_chain(weight: torch.Tensor) -> torch.Tensor:
 def split_rows_f16(a: torch.Tensor) -> torch.Tensor:
     """fp32 [M, K] → the A-operand layout of ``ds_gemm_split``: halves [M][2][K] (a = a1 + a2/2048), returned as float16."""
     a = a.detach().to(torch.float32)
-    a1 = a.half()
-    a2 = ((a - a1.float()) * SPLIT_SCALE).half()
+    sat = lambda t: torch.where(torch.isfinite(t), t.clamp(-F16_MAX, F16_MAX), t)      # the kernels' saturating conversion
+    a1 = sat(a).half()
+    a2 = sat((a - a1.float()) * SPLIT_SCALE).half()
     return torch.stack([a1, a2], dim=1).contiguous()
 
 
@@ -377,12 +391,16 @@ class Layout:
 
     def check_edge_symmetry(self, edge: torch.Tensor, name: str = "edge_x"):
         """The pair layout stores one value per unordered pair: ``edge[b,i,j,:] == edge[b,j,i,:]`` must hold on valid pairs."""
+        key = (name, edge.data_ptr(), edge._version, tuple(edge.shape))
+        if getattr(self, "_sym_ok", None) == key:          # same storage, unmodified since the last check (a blocking .any() saved)
+            return
         e = edge.detach().reshape(self.B, self.N, self.N, -1)
         v = torch.from_numpy(self.valid).to(e.device)
         m = (v.unsqueeze(1) & v.unsqueeze(2)).unsqueeze(-1)
         if bool(((e != e.transpose(1, 2)) & m).any()):
             raise ValueError(f"{name} is not symmetric in its two atom indices; the MI355X path stores edge features per "
                              "unordered pair and does not support directed edge inputs")
+        self._sym_ok = key
 
 
 class Workspace:

@@ -12,44 +12,15 @@ from __future__ import annotations
 
 import logging
 import os
-from typing import Callable, Dict, Iterable, Optional
+from typing import Callable, Dict, Optional
 
 import torch
 
+from .ema import ExponentialMovingAverage  # noqa: F401  (re-exported: the checkpoint contract's EMA holder)
 from .noise_schedule import NoiseScheduleVP
 from .registry import create_model
 from .sampling import get_cond_sampling_eval_fn
 from .scalers import get_data_inverse_scaler
-
-
-class ExponentialMovingAverage:
-    """Inference-side holder of a checkpoint's EMA weights.
-
-    Only what evaluation needs of reference ``models/ema.py``: the checkpoint state layout (``decay``, ``num_updates``,
-    ``shadow_params`` = list in ``parameters()`` order of the trainable tensors, ``ema.py:79-85``) and ``copy_to``
-    (``ema.py:44-55``).  The training-side half (``update`` / ``store`` / ``restore``) belongs to the training step
-     and is not part of this path."""
-
-    def __init__(self, parameters: Iterable[torch.nn.Parameter], decay: float):
-        if not 0.0 <= decay <= 1.0:
-            raise ValueError("Decay must be between 0 and 1")
-        self.decay, self.num_updates = decay, 0
-        self.shadow_params = [p.detach().clone() for p in parameters if p.requires_grad]
-
-    def load_state_dict(self, state_dict):
-        self.decay, self.num_updates = state_dict["decay"], state_dict["num_updates"]
-        self.shadow_params = state_dict["shadow_params"]
-
-    def state_dict(self):
-        return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": self.shadow_params}
-
-    @torch.no_grad()
-    def copy_to(self, parameters):
-        trainable = [p for p in parameters if p.requires_grad]
-        if len(trainable) != len(self.shadow_params):
-            raise ValueError(f"EMA holds {len(self.shadow_params)} tensors, the model has {len(trainable)} trainable ones")
-        for shadow, p in zip(self.shadow_params, trainable):
-            p.copy_(shadow.to(p.device))
 
 
 def restore_checkpoint(ckpt_path: str, state: Dict, device) -> Dict:
@@ -69,9 +40,10 @@ def restore_checkpoint(ckpt_path: str, state: Dict, device) -> Dict:
 
 def save_checkpoint(ckpt_path: str, state: Dict) -> None:
     """utils.py:23-30."""
-    saved = {"model": state["model"].state_dict(), "ema": state["ema"].state_dict(), "step": state["step"]}
-    if state.get("optimizer") is not None:
+    saved = {}
+    if state.get("optimizer") is not None:            # same key order as the reference's file
         saved["optimizer"] = state["optimizer"].state_dict()
+    saved.update(model=state["model"].state_dict(), ema=state["ema"].state_dict(), step=state["step"])
     torch.save(saved, ckpt_path)
 
 

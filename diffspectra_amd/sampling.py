@@ -353,57 +353,121 @@ def _sampling_fn_factory(config, sampler, batch_size, n_samples, inverse_scaler,
             print("Generate {}, Total {}.".format(len(processed), n_samples))
         return processed[:n_samples * top_k], gt_pos[:n_samples * top_k], gt_mols[:n_samples * top_k]
 
-    def sharded(model, eng, perm):
-        device = eng.device
-        rank, world = shard.world_info()
-        slot_ds = perm[:n_samples].repeat_interleave(top_k)         # dataset item of every sample slot
-        n_slots = slot_ds.numel()
-        n_atoms = _num_atoms(ds, slot_ds.tolist())
-        mine = shard.assign_slots(n_atoms, rank, world)
-        seed = int(getattr(config.sampling, "seed", 42))
-        recs = []
-        for lo in range(0, mine.numel(), batch_size):
-            slots = mine[lo:lo + batch_size]
-            context, n_nodes, _, _ = _assemble(ds, slot_ds[slots], version)
-            bs = len(n_nodes)
-            node_mask, edge_mask = build_masks(n_nodes, bs, device)
-            x_node, x_edge = sampler.sampling(model, None, node_mask, edge_mask, None, context, mol_ids=slots, seed=seed)
-            pos, one_hot, fc, edge_types = post_process(x_node, atom_types, include_fc, node_mask, inverse_scaler,
-                                                        x_edge, edge_mask, config.data.compress_edge, engine=eng)
-            recs.append(shard.pack_records_u8(pos, one_hot.argmax(-1), fc, edge_types))
-        rec = torch.cat(recs) if recs else torch.zeros(0, shard.RECORD_BYTES, dtype=torch.uint8, device=device)
-        counts = [shard.assign_slots(n_atoms, r, world).numel() for r in range(world)]
-        allrec = shard.gather_records(rec, counts)                   # the only collective of the path
-        owner_order = torch.cat([shard.assign_slots(n_atoms, r, world) for r in range(world)])
-        by_slot = torch.empty_like(allrec)
-        by_slot[owner_order.to(allrec.device)] = allrec
-        pos, atom, fc, et = (t.cpu() for t in shard.unpack_records_u8(by_slot))     # ONE device->host copy per tensor
-        processed = []
-        for k in range(n_slots):
-            n = n_atoms[k]
-            processed.append((pos[k, :n].clone(), atom[k, :n].clone(), et[k, :n, :n].clone(), fc[k, :n].clone()))
-        gt_pos, gt_mols = _ground_truth(ds, slot_ds.tolist())
-        if rank == 0:
-            print("Generate {}, Total {}.".format(len(processed), n_samples * top_k))
-        return processed, gt_pos, gt_mols
+    class ShardedRun:
+        """One sharded evaluation in resumable form: ``advance(n)`` runs the next n denoise iterations of this rank's
+        micro-batches (opening a micro-batch with SpecFormer + initial noise and closing it with post-processing + record
+        packing as it goes), ``finish()`` does the only collective of the path and returns the three lists.
+        ``sampling_fn(model)`` is ``start(model)`` advanced to the end; ``bench.py`` times the same object in slices."""
+
+        def __init__(self, model, eng, perm):
+            self.model, self.eng, self.device = model, eng, eng.device
+            self.rank, self.world = shard.world_info()
+            self.slot_ds = perm[:n_samples].repeat_interleave(top_k)         # dataset item of every sample slot
+            self.n_atoms = _num_atoms(ds, self.slot_ds.tolist())
+            self.mine = shard.assign_slots(self.n_atoms, self.rank, self.world)
+            self.seed = int(getattr(config.sampling, "seed", 42))
+            self.batches = [self.mine[lo:lo + batch_size] for lo in range(0, self.mine.numel(), batch_size)]
+            self.steps_per_batch = len(sampler.t_array)
+            self.total_iters = len(self.batches) * self.steps_per_batch
+            self.iters_done, self.next_batch, self.cur, self.recs = 0, 0, None, []
+
+        def _open(self):
+            slots = self.batches[self.next_batch]
+            context, n_nodes, _, _ = _assemble(ds, self.slot_ds[slots], version)
+            node_mask, edge_mask = build_masks(n_nodes, len(n_nodes), self.device)
+            st = sampler.begin(self.model, None, node_mask, edge_mask, None, context, mol_ids=slots, seed=self.seed)
+            self.cur = (st, node_mask, edge_mask)
+            self.next_batch += 1
+
+        def _close(self):
+            st, node_mask, edge_mask = self.cur
+            pos, one_hot, fc, edge_types = post_process(st.x_mean, atom_types, include_fc, node_mask, inverse_scaler,
+                                                        st.edge_mean, edge_mask, config.data.compress_edge, engine=self.eng)
+            self.recs.append(shard.pack_records_u8(pos, one_hot.argmax(-1), fc, edge_types))
+            self.cur = None
+
+        @property
+        def done(self):
+            return self.cur is None and self.next_batch >= len(self.batches)
+
+        def advance(self, n_iters=None):
+            """Run up to ``n_iters`` more denoise iterations (all remaining ones by default); True when every micro-batch of
+            this rank is sampled and packed."""
+            left = self.total_iters - self.iters_done if n_iters is None else int(n_iters)
+            while left > 0 and not self.done:
+                if self.cur is None:
+                    self._open()
+                st = self.cur[0]
+                before = st.i
+                finished = sampler.advance(st, left)
+                left -= st.i - before
+                self.iters_done += st.i - before
+                if finished:
+                    self._close()
+            return self.done
+
+        def finish(self, partial=False):
+            """Gather the records of all ranks (the only collective) and unpack them, in slot order, on every rank.
+            ``partial=True`` closes an in-flight micro-batch from its current state (bench warm-up of the closing code path)."""
+            if partial:
+                if self.cur is not None:
+                    self._close()
+                done_slots = [torch.cat(self.batches[:len(self.recs)])] if self.recs else []
+                rec = torch.cat(self.recs) if self.recs else torch.zeros(0, shard.RECORD_BYTES, dtype=torch.uint8, device=self.device)
+                cnt = torch.tensor([rec.shape[0]], dtype=torch.int64)
+                counts = [int(c) for c in shard.all_gather_counts(cnt, self.device)]
+                return shard.gather_records(rec, counts), done_slots
+            if not self.done:
+                raise RuntimeError("finish() before every micro-batch was sampled; call advance() to the end first")
+            n_slots = self.slot_ds.numel()
+            rec = torch.cat(self.recs) if self.recs else torch.zeros(0, shard.RECORD_BYTES, dtype=torch.uint8, device=self.device)
+            owners = [shard.assign_slots(self.n_atoms, r, self.world) for r in range(self.world)]
+            allrec = shard.gather_records(rec, [o.numel() for o in owners])           # the only collective of the path
+            by_slot = torch.empty_like(allrec)
+            by_slot[torch.cat(owners).to(allrec.device)] = allrec
+            self.records_by_slot = by_slot
+            pos, atom, fc, et = (t.cpu() for t in shard.unpack_records_u8(by_slot))     # ONE device->host copy per tensor
+            processed = []
+            for k in range(n_slots):
+                n = self.n_atoms[k]
+                processed.append((pos[k, :n].clone(), atom[k, :n].clone(), et[k, :n, :n].clone(), fc[k, :n].clone()))
+            gt_pos, gt_mols = _ground_truth(ds, self.slot_ds.tolist())
+            if self.rank == 0:
+                print("Generate {}, Total {}.".format(len(processed), n_samples * top_k))
+            return processed, gt_pos, gt_mols
+
+    def _permutation(eng):
+        if fixed_seed:
+            torch.manual_seed(42)                              # sampling.py:387
+        perm = torch.randperm(len(ds))
+        if not fixed_seed:
+            perm = shard.broadcast_from_rank0(perm, eng.device)      # an unseeded permutation must still be ONE permutation
+        return perm
+
+    def start(model):
+        """The resumable form of ``sampling_fn(model)`` (philox noise source only): a ``ShardedRun``."""
+        if noise_source != "philox":
+            raise RuntimeError("start() drives the sharded (philox) path; noise_source='torch' is the monolithic reference order")
+        model.eval()
+        eng = _hip_model(model).engine()
+        with torch.no_grad():
+            return ShardedRun(model, eng, _permutation(eng))
 
     def sampling_fn(model):
         model.eval()
         eng = _hip_model(model).engine()
         with torch.no_grad():
-            if fixed_seed:
-                torch.manual_seed(42)                              # sampling.py:387
-            perm = torch.randperm(len(ds))
-            from .shard import world_info, broadcast_from_rank0
-            if not fixed_seed:
-                perm = broadcast_from_rank0(perm, eng.device)      # an unseeded permutation must still be ONE permutation
+            perm = _permutation(eng)
             if noise_source == "torch":
-                if world_info()[1] != 1:
+                if shard.world_info()[1] != 1:
                     raise RuntimeError("noise_source='torch' reproduces the reference's single-process draw order; "
                                        "multi-rank sampling needs noise_source='philox'")
                 return reference_order(model, eng, perm)
-            return sharded(model, eng, perm)
+            run = ShardedRun(model, eng, perm)
+            run.advance()
+            return run.finish()
 
+    sampling_fn.start = start
     return sampling_fn
 
 

@@ -101,6 +101,17 @@ def broadcast_from_rank0(t: torch.Tensor, device) -> torch.Tensor:
     return buf.cpu()
 
 
+def all_gather_counts(count: torch.Tensor, device):
+    """Every rank's value of the one-element int64 host tensor ``count`` (list of ints, rank order)."""
+    if world_info()[1] == 1:
+        return [int(count.item())]
+    world = dist.get_world_size()
+    buf = count.clone() if dist.get_backend() == "gloo" else count.to(device)
+    out = torch.empty(world, dtype=buf.dtype, device=buf.device)
+    dist.all_gather_into_tensor(out, buf)
+    return out.cpu().tolist()
+
+
 def gather_records(rec: torch.Tensor, counts=None) -> torch.Tensor:
     """all_gather of per-rank record blocks → [sum(counts), record] on every rank, in rank order.
 

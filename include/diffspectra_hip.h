@@ -262,6 +262,12 @@ int ds_layernorm_affine(const float* x, const float* gamma, const float* beta, f
 int ds_profile_config(int kernel, int every, int max_samples);
 int ds_profile_read(double* total_ms, int64_t* samples);
 
+/* Position-sensitive 64-bit checksum of a list of fp32 device tensors (wrap-around sum of bits(x) * odd(hash(index)) + index over
+ * the concatenation): what the drop-in DMT.forward uses to notice that its packed weights are stale after an in-place edit that
+ * leaves Tensor._version untouched (models/ema.py:55,77 write through .data).  ptrs [n] device array of device pointers,
+ * prefix [n+1] device int64 element offsets of each tensor in the concatenation, out device uint64 (zeroed here). */
+int ds_fingerprint(const float* const* ptrs, const int64_t* prefix, int32_t n, uint64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,12 +96,15 @@ EDGE_GAIN = (16.0, 64.0)                        # edge_exist_mlp.4.weight, edge_
 NODE_BIAS0 = (0.06, -0.09, 0.02, 0.10, 0.28, -0.37)   # starting point of the per-case calibration
 EDGE_BIAS0 = (-0.19, -0.71)
 ALLSPECTRA_FULL_ATOMS = [5, 9, 12]              # molecules of the all-spectra 1000-step golden trajectory (G9)
+MAX_SIZE_FULL_ATOMS = [29, 6]                   # G15: a 1000-step trajectory that contains a maximum-size (n = 29) molecule
 DIVERSE_CASES = {                               # tag -> (spectra version, denoise steps, n_atoms)
     "allspectra_S5": ("allspectra", 5, RAGGED),
     "ir_S50": ("ir", 50, RAGGED),
     "ir_S1000": ("ir", 1000, FULL_LENGTH_ATOMS),
     "allspectra_S1000": ("allspectra", 1000, ALLSPECTRA_FULL_ATOMS),
 }
+# G15 re-uses the calibrated readout of ir_S1000 (diverse_readout.json holds a copy under its tag): with 812 directed edges and
+# 29 atoms the outputs spread over their range without a calibration of their own (30+ minutes of CPU oracle per iteration).
 
 
 def apply_readout(state_dict, node_bias, edge_bias):

@@ -181,7 +181,7 @@ class _ReplayRandn:
         return t.clone()
 
 
-def g5_trajectory(mods, plan=(("allspectra", 5, None), ("ir", 50, None)), fname="g5_trajectory.npz", self_cond_type="ori"):
+def g5_trajectory(mods, plan=(("allspectra", 5, None), ("ir", 50, None)), fname="g5_trajectory.npz", self_cond_type="ori", tag_suffix=""):
     out = {}
     for version, steps, n_atoms in plan:
         cfg, model = ref_model(mods, version)
@@ -190,7 +190,7 @@ def g5_trajectory(mods, plan=(("allspectra", 5, None), ("ir", 50, None)), fname=
         if self_cond_type == "clamp":
             model.load_state_dict(cases.readout_gain(model.state_dict()), strict=True)
         else:   # de-trivialised integer outputs: calibrated readout perturbation of this case (calibrate_diverse.py)
-            model.load_state_dict(cases.readout_diverse(model.state_dict(), f"{version}_S{steps}"), strict=True)
+            model.load_state_dict(cases.readout_diverse(model.state_dict(), f"{version}_S{steps}{tag_suffix}"), strict=True)
         tr = cases.trajectory_inputs(version, steps) if n_atoms is None else cases.trajectory_inputs(version, steps, n_atoms)
         ns = mods.noise_schedule.NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0)
         time_steps = torch.linspace(ns.T, 1e-3, steps)
@@ -215,7 +215,7 @@ def g5_trajectory(mods, plan=(("allspectra", 5, None), ("ir", 50, None)), fname=
         pos, one_hot, fc, et = mods.sampling.post_process(x_mean.clone(), 5, True, tr["node_mask"], inv, e_mean.clone(),
                                                           tr["edge_mask"], True)
         mols = mods.sampling.mol_process(one_hot, pos, fc, tr["n_atoms"], et)
-        tag = f"{version}_S{steps}"
+        tag = f"{version}_S{steps}{tag_suffix}"
         out[tag + "_x_mean"], out[tag + "_edge_mean"] = x_mean.numpy(), e_mean.numpy()
         out[tag + "_pos"], out[tag + "_atom_type"] = pos.numpy(), one_hot.argmax(-1).numpy()
         out[tag + "_fc"], out[tag + "_edge_type"] = fc.numpy(), et.numpy()
@@ -238,6 +238,11 @@ def g7_full_length(mods):
 def g9_full_length_allspectra(mods):
     """1000 steps on the headline configuration (all-spectra, SpecFormer conditioning) with injected noise."""
     g5_trajectory(mods, plan=(("allspectra", 1000, cases.ALLSPECTRA_FULL_ATOMS),), fname="g9_trajectory_1000_allspectra.npz")
+
+
+def g15_full_length_max_size(mods):
+    """1000 steps with a maximum-size molecule (n = 29, 812 directed edges) in the batch: the largest tiles every kernel sees."""
+    g5_trajectory(mods, plan=(("ir", 1000, cases.MAX_SIZE_FULL_ATOMS),), fname="g15_trajectory_1000_n29.npz", tag_suffix="_n29")
 
 
 def g8_clamp_self_cond(mods):
@@ -351,6 +356,114 @@ def g12_bond_orders():
     print("G12 bond-order histogram", np.bincount(orders.reshape(-1), minlength=4), "valence", valence)
 
 
+def _pickle_globals(path):
+    """Class / function names the ``torch.save`` archive's pickle refers to (GLOBAL / STACK_GLOBAL opcodes of data.pkl)."""
+    import pickletools
+    import zipfile
+    with zipfile.ZipFile(path) as z:
+        name = next(n for n in z.namelist() if n.endswith("data.pkl"))
+        data = z.read(name)
+    names, strings = set(), []
+    for op, arg, _ in pickletools.genops(data):
+        if op.name in ("SHORT_BINUNICODE", "BINUNICODE", "UNICODE"):
+            strings.append(arg)
+        elif op.name == "GLOBAL":
+            names.add(arg.replace(" ", "."))
+        elif op.name == "STACK_GLOBAL":
+            names.add(strings[-2] + "." + strings[-1])
+    return sorted(names)
+
+
+def g14_checkpoint(mods):
+    """Row N2: the reference's own checkpoint artefacts (``utils.save_checkpoint`` utils.py:23-30, ``models/ema.py``,
+    ``losses.get_optimizer`` losses.py:14-25).  Commits a MANIFEST of the file the reference writes (top-level keys, EMA state
+    keys, shadow-parameter count, dtype / shape lists, pickled class names, a few value checksums), the outcome of the
+    reference's ``restore_checkpoint(strict=True)`` on a file written by ``diffspectra_amd.evaluate.save_checkpoint``, and a short
+    ``ExponentialMovingAverage.update`` trace (decay warm-up, ema.py:24-42)."""
+    import tempfile
+    ref_ema = importlib.import_module("models.ema")
+    ref_losses = importlib.import_module("losses")
+    from diffspectra_amd import evaluate as my_eval
+    from diffspectra_amd.ema import ExponentialMovingAverage as MyEMA
+    from diffspectra_amd.registry import create_model
+    import diffspectra_amd.dmt  # noqa: F401
+    man = {}
+    cfg, model = ref_model(mods, "allspectra")
+    cfg.optim = types.SimpleNamespace(optimizer="AdamW", lr=2e-4, beta1=0.9, eps=1e-8, weight_decay=0.0)
+    ema = ref_ema.ExponentialMovingAverage(model.parameters(), decay=0.999)
+    opt = ref_losses.get_optimizer(cfg, model.parameters())
+    # one real optimizer step so that the optimizer state holds exp_avg / exp_avg_sq / max_exp_avg_sq (amsgrad) entries
+    for i, p in enumerate(model.parameters()):
+        if p.requires_grad:
+            p.grad = torch.full_like(p, 1e-3 * ((i % 7) - 3))
+    opt.step()
+    ema.update(model.parameters())
+    state = dict(optimizer=opt, model=model, ema=ema, step=1234)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "checkpoint_7.pth")
+        mods.top_utils.save_checkpoint(path, state)
+        man["file_bytes"] = os.path.getsize(path)
+        man["pickle_globals"] = _pickle_globals(path)
+        loaded = torch.load(path, map_location="cpu")
+        man["top_level_keys"] = list(loaded.keys())
+        man["step"] = loaded["step"]
+        man["model_entries"] = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in loaded["model"].items()]
+        man["ema_keys"] = list(loaded["ema"].keys())
+        man["ema_decay"], man["ema_num_updates"] = loaded["ema"]["decay"], loaded["ema"]["num_updates"]
+        man["ema_shadow_type"] = type(loaded["ema"]["shadow_params"]).__name__
+        man["ema_shadow"] = [[list(t.shape), str(t.dtype).replace("torch.", "")] for t in loaded["ema"]["shadow_params"]]
+        man["optimizer_keys"] = list(loaded["optimizer"].keys())
+        pg = loaded["optimizer"]["param_groups"][0]
+        man["optimizer_param_group"] = {k: (v if not isinstance(v, (list, tuple)) or k == "betas" else len(v)) for k, v in pg.items()}
+        man["optimizer_state_keys"] = sorted(next(iter(loaded["optimizer"]["state"].values())).keys())
+        man["optimizer_state_count"] = len(loaded["optimizer"]["state"])
+        # the reference-written file through OUR loader: strict load + EMA + step, then EMA copy_to -> the model holds the shadow values
+        my_cfg = cases.config_for("allspectra")
+        my_cfg.device = torch.device("cpu")
+        mine = create_model(my_cfg)
+        my_state = dict(optimizer=None, model=mine, ema=MyEMA(mine.parameters(), decay=0.5), step=0)
+        my_state = my_eval.restore_checkpoint(path, my_state, device="cpu")
+        my_state["ema"].copy_to(mine.parameters())
+        ok = my_state["step"] == 1234 and my_state["ema"].decay == 0.999 and my_state["ema"].num_updates == 1
+        for (n, p), s_ in zip([(n, p) for n, p in mine.named_parameters() if p.requires_grad], ema.shadow_params):
+            ok = ok and torch.equal(p.detach(), s_)
+        man["reference_file_loads_here"] = bool(ok)
+        # the reverse: a file OUR save_checkpoint writes, through the reference's restore_checkpoint(strict=True)
+        my_opt = torch.optim.AdamW(mine.parameters(), lr=2e-4, amsgrad=True, weight_decay=1e-12)
+        for i, p in enumerate(mine.parameters()):
+            if p.requires_grad:
+                p.grad = torch.full_like(p, 1e-3 * ((i % 5) - 2))
+        my_opt.step()
+        my_state["ema"].update(mine.parameters())
+        path2 = os.path.join(td, "checkpoint_8.pth")
+        my_eval.save_checkpoint(path2, dict(optimizer=my_opt, model=mine, ema=my_state["ema"], step=77))
+        man["our_pickle_globals"] = _pickle_globals(path2)
+        cfg2, model2 = ref_model(mods, "allspectra")
+        ema2 = ref_ema.ExponentialMovingAverage(model2.parameters(), decay=0.1)
+        opt2 = ref_losses.get_optimizer(cfg, model2.parameters())
+        st2 = mods.top_utils.restore_checkpoint(path2, dict(optimizer=opt2, model=model2, ema=ema2, step=0), "cpu")
+        same = st2["step"] == 77 and all(torch.equal(a, b) for a, b in zip(model2.state_dict().values(), mine.state_dict().values()))
+        same = same and all(torch.equal(a, b) for a, b in zip(ema2.shadow_params, my_state["ema"].shadow_params))
+        man["reference_restores_our_file"] = bool(same)
+    # EMA.update trace: 12 updates of three small tensors with a deterministic parameter drift
+    ps = [torch.nn.Parameter(filler.normal(f"g14.p{i}", (5, 3))) for i in range(3)]
+    ps[1].requires_grad_(False)                                   # skipped by the EMA (ema.py:20-21)
+    e = ref_ema.ExponentialMovingAverage(ps, decay=0.999)
+    trace = []
+    for k in range(12):
+        with torch.no_grad():
+            for i, p in enumerate(ps):
+                p.add_(filler.normal(f"g14.d{i}.{k}", (5, 3)) * 0.1)
+        e.update(ps)
+        trace.append([t.clone() for t in e.shadow_params])
+    man["ema_trace_num_updates"] = e.num_updates
+    with open(cases.fixture_path("g14_checkpoint_manifest.json"), "w") as f:
+        json.dump(man, f)
+    cases.save_npz("g14_ema_trace.npz", **{f"k{k}_s{j}": t.numpy() for k, row in enumerate(trace) for j, t in enumerate(row)})
+    print("G14", man["top_level_keys"], man["ema_keys"], len(man["ema_shadow"]), "shadow tensors;", "ours->ref", man["reference_restores_our_file"],
+          "ref->ours", man["reference_file_loads_here"], man["pickle_globals"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -364,7 +477,8 @@ def main():
     mods = import_reference()
     todo = {"G0": g0_manifest, "G1": g1_schedule, "G2": g2_specformer, "G3": g3_components, "G4": g4_forward,
             "G5": g5_trajectory, "G6": g6_post_process, "G7": g7_full_length, "G8": g8_clamp_self_cond,
-            "G9": g9_full_length_allspectra, "G10": g10_pretrained_specformer, "G11": g11_sampling_fn}
+            "G9": g9_full_length_allspectra, "G10": g10_pretrained_specformer, "G11": g11_sampling_fn,
+            "G14": g14_checkpoint, "G15": g15_full_length_max_size}
     for k, fn in todo.items():
         if not only or k in only:
             fn(mods)

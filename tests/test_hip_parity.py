@@ -80,9 +80,9 @@ def integer_parity_report(tag, x_mean, e_mean, g, node_mask, edge_mask, got_atom
     """Margin statistics and mismatch counts of the integer outputs (SURVEY §7 'hard parts').
 
     A decision's margin is its distance (in model-output units) from the threshold that would flip it, measured on the
-    REFERENCE trajectory; ``drift`` is the largest |HIP - reference| on the same tensors.  Decisions whose margin exceeds
-    4x drift must agree bit for bit; closer ones are counted and printed - a flip there is fp32 summation order, not a bug,
-    and it is reported rather than hidden."""
+    REFERENCE trajectory; ``drift`` is the largest |HIP - reference| on the same tensors.  The committed fixtures must be
+    reproduced EXACTLY (north_star: bit-exact argmax): zero mismatches, whatever the margin.  The margin histogram is printed
+    as a diagnostic of how much head-room that exactness has."""
     rx, re_ = g[tag + "_x_mean"], g[tag + "_edge_mean"]
     nm = node_mask.squeeze(-1).bool().cpu()
     em = edge_mask.reshape(re_.shape[:3]).bool().cpu()
@@ -104,9 +104,7 @@ def integer_parity_report(tag, x_mean, e_mean, g, node_mask, edge_mask, got_atom
         hist = [int(((marg >= lo) & (marg < hi)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
         print(f"[{tag}] {name:10s} decisions {marg.numel():5d}  margin min {float(marg.min()):.2e} median {float(marg.median()):.2e}  "
               f"histogram [<1e-4,<1e-3,<1e-2,<1e-1,>=1e-1] {hist}  mismatches {int(mis.sum())}")
-        safe = marg > 4.0 * drift
-        assert int((mis & safe).sum()) == 0, f"{tag}: {name} differs where the margin is > 4 x drift"
-        assert int(mis.sum()) <= int((~safe).sum())
+        assert int(mis.sum()) == 0, f"{tag}: {int(mis.sum())} {name} decisions differ from the reference (closest margin {float(marg.min()):.2e}, drift {drift:.2e})"
     cls = g[tag + "_atom_type"][nm].unique().tolist()
     orders = g[tag + "_edge_type"][em].unique().tolist()
     print(f"[{tag}] reference atom types {cls}, bond orders {orders}, non-zero charges {int((g[tag + '_fc'].squeeze(-1)[nm] != 0).sum())}")
@@ -126,7 +124,7 @@ def run_injected_trajectory(model, cfg, version, steps, n_atoms, d):
     return tr, x_mean, e_mean
 
 
-def check_trajectory_golden(gpu_device, fixture, version, steps, n_atoms=None):
+def check_trajectory_golden(gpu_device, fixture, version, steps, n_atoms=None, tag_suffix=""):
     """Injected-noise ancestral trajectory on the HIP path vs the reference's own run, with the de-trivialised readout
     weights of the case (tests/golden/calibrate_diverse.py): tolerance on coordinates/logits, integer outputs exact
     wherever the decision margin allows, margins and mismatch counts printed."""
@@ -136,7 +134,7 @@ def check_trajectory_golden(gpu_device, fixture, version, steps, n_atoms=None):
     cfg = cfg.clone()
     cfg.sampling.steps = steps
     g = cases.load_npz(fixture)
-    tag = f"{version}_S{steps}"
+    tag = f"{version}_S{steps}{tag_suffix}"
     d = gpu_device
     with swapped_weights(model, lambda sd: cases.readout_diverse(sd, tag)):
         tr, x_mean, e_mean = run_injected_trajectory(model, cfg, version, steps, n_atoms, d)
@@ -214,6 +212,118 @@ def test_split_fp16_gemm_accuracy(gpu_device):
     out = torch.zeros(64, 32, device=d)
     E.gemm_split(lib, E.split_rows_f16(A).to(d), E.pack_linear_f16_split(W).to(d), None, out, 64, 64, 32)
     assert torch.equal(out.cpu(), A @ W.t())
+
+
+def test_split_fp16_range_saturates(gpu_device):
+    """The split-fp16 arithmetic has fp16's exponent range.  Activations at or beyond it SATURATE at +-65536 (MODE.FP16_OVFL in
+    every converting kernel) instead of turning into inf - inf = NaN; weights beyond it are refused at pack time."""
+    from diffspectra_amd import engine as E
+    lib = E.load_library()
+    d = gpu_device
+    with pytest.raises(ValueError):
+        E.pack_linear_f16_split(torch.full((32, 64), 7e4))
+    with pytest.raises(ValueError):
+        E.pack_ff4_chain(torch.full((64, 128), -1e5))
+    E.pack_linear_f16_split(torch.full((32, 64), 65503.0))                       # the largest finite fp16 magnitudes are fine
+    # host converter (what ds_gemm_split's callers use) = the kernels' saturating conversion
+    A = torch.zeros(64, 64)
+    A[0, 0], A[1, 1], A[2, 2], A[3, 3], A[4, 4] = 65519.0, 65520.0, 7e4, -1e6, 3e38
+    sp = E.split_rows_f16(A)
+    rec = sp[:, 0].float() + sp[:, 1].float() / 2048.0
+    assert torch.isfinite(rec).all()
+    assert rec[0, 0] == 65519.0 and rec[1, 1] == 65520.0 and rec[2, 2] == 65536.0 and rec[3, 3] == -65536.0 and rec[4, 4] == 65536.0
+    W = torch.eye(64)
+    out = torch.full((64, 64), float("nan"), device=d)
+    E.gemm_split(lib, sp.to(d), E.pack_linear_f16_split(W).to(d), None, out, 64, 64, 64)
+    o = out.cpu()
+    assert torch.isfinite(o).all() and o[0, 0] == 65519.0 and o[2, 2] == 65536.0 and o[3, 3] == -65536.0
+
+
+def _oracle_forward_f64(sd, cfg, a):
+    """The oracle in fp64 (same code, default dtype switched): the truth both fp32 evaluations are measured against."""
+    torch.set_default_dtype(torch.float64)
+    try:
+        dd = lambda t: None if t is None else ([x.double() for x in t] if isinstance(t, (list, tuple)) else t.double())
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        return oracle.dmt_forward(sd64, cfg, dd(a["xh"]), dd(a["node_mask"]), dd(a["edge_mask"]), dd(a["edge_x"]), dd(a["noise_level"]),
+                                  dd(a["cond_x"]), dd(a["cond_edge_x"]), context=dd(a["context"]))
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def _checkpoint_like(sd):
+    """Weight statistics a trained checkpoint can have and the U(+-1/sqrt(fan_in)) filler never does: adaLN scale / shift / gate
+    outputs 30x larger, a few residual-stream channels at 1e4 magnitude, weights with 1e-6 entries, large CondGaussian inputs."""
+    out = dict(sd)
+    for k, v in sd.items():
+        if ".time_mlp.1." in k or "node_time_mlp.1." in k or "edge_time_mlp.1." in k:
+            out[k] = v * 30.0
+        elif k.endswith("node_emb.weight"):
+            w = v.clone()
+            w[[3, 77, 200]] *= 1e4                                      # three residual-stream channels ~1e4
+            out[k] = w
+        elif k.endswith("ff_linear1.weight") or k.endswith("ff_linear3.weight") or k.endswith("coord_mlp.0.weight"):
+            w = v.clone()
+            w[::3] *= 1e-5                                              # rows of ~1e-6 entries next to ordinary ones
+            out[k] = w
+    return out
+
+
+def test_forward_with_checkpoint_like_statistics(gpu_device):
+    """Range-proofing of the split-fp16 path: a forward with checkpoint-like weight statistics stays finite and
+    within 2e-5 (relative to the output scale) of the fp64 truth - and no worse than a few times the fp32 CPU oracle's own error."""
+    cfg, model = gpu_model("ir", gpu_device)
+    d = gpu_device
+    a = cases.forward_inputs("ir", False)
+    with swapped_weights(model, _checkpoint_like):
+        xh, ef = model(torch.zeros(4, device=d), a["xh"].to(d), a["node_mask"].to(d), a["edge_mask"].to(d),
+                       context=to_dev(a["context"], d), edge_x=a["edge_x"].to(d), noise_level=a["noise_level"].to(d),
+                       cond_x=to_dev(a["cond_x"], d), cond_edge_x=to_dev(a["cond_edge_x"], d))
+        sd = {k[7:]: v.detach().cpu() for k, v in model.state_dict().items()}
+    cpu_cfg = cases.config_for("ir")
+    ref32 = oracle.dmt_forward(sd, cpu_cfg, a["xh"], a["node_mask"], a["edge_mask"], a["edge_x"], a["noise_level"], a["cond_x"],
+                               a["cond_edge_x"], context=a["context"])
+    ref64 = _oracle_forward_f64(sd, cpu_cfg, a)
+    assert torch.isfinite(xh).all() and torch.isfinite(ef).all()
+    for name, got, r32, r64 in (("xh", xh, ref32[0], ref64[0]), ("edge", ef, ref32[1], ref64[1])):
+        scale = max(1.0, float(r64.abs().max()))
+        e_hip = float((got.cpu().double() - r64).abs().max()) / scale
+        e_cpu = float((r32.double() - r64).abs().max()) / scale
+        print(f"[checkpoint-like {name}] output scale {scale:.3g}: HIP vs fp64 {e_hip:.2e}, fp32 CPU oracle vs fp64 {e_cpu:.2e}")
+        assert e_hip <= 2e-5, (name, e_hip)
+        assert e_hip <= 8 * max(e_cpu, 1e-7), (name, e_hip, e_cpu)
+
+
+def test_forward_saturates_instead_of_nan(gpu_device):
+    """Activations driven far beyond 65504 (edge embedding x 1e7, node embedding x 1e6): the fp32 reference stays finite, and so
+    must the split-fp16 path - saturated operands, no inf - inf = NaN, NaN guard not triggered."""
+    cfg, model = gpu_model("ir", gpu_device)
+    d = gpu_device
+    a = cases.forward_inputs("ir", False)
+
+    def huge(sd):
+        out = dict(sd)
+        for k, v in sd.items():
+            if k.endswith("module.edge_emb.weight") or k == "edge_emb.weight":
+                out[k] = v * 1e7
+            elif k.endswith("module.node_emb.weight") or k == "node_emb.weight":
+                out[k] = v * 1e6
+        return out
+
+    with swapped_weights(model, huge):
+        xh, ef = model(torch.zeros(4, device=d), a["xh"].to(d), a["node_mask"].to(d), a["edge_mask"].to(d),
+                       context=to_dev(a["context"], d), edge_x=a["edge_x"].to(d), noise_level=a["noise_level"].to(d),
+                       cond_x=to_dev(a["cond_x"], d), cond_edge_x=to_dev(a["cond_edge_x"], d))
+        eng = model.module.engine()
+        L, ws = eng.layout_for(a["node_mask"].to(d), a["edge_mask"].to(d))
+        flags = ws.t["flags"].cpu()
+        sd = {k[7:]: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = oracle.dmt_forward(sd, cases.config_for("ir"), a["xh"], a["node_mask"], a["edge_mask"], a["edge_x"], a["noise_level"],
+                             a["cond_x"], a["cond_edge_x"], context=a["context"])
+    assert torch.isfinite(ref[0]).all() and torch.isfinite(ref[1]).all()          # the fp32 reference is finite here
+    assert torch.isfinite(xh).all() and torch.isfinite(ef).all(), "split-fp16 path produced inf/NaN where fp32 is finite"
+    assert int(flags[1]) == 0, "NaN guard (dmt.py:407-409) fired"
+    assert float(xh[..., :3].abs().max()) > 0
 
 
 def test_gemm_identity_asymmetric(gpu_device):
@@ -966,6 +1076,11 @@ def test_g9_full_length_trajectory_allspectra_golden(gpu_device):
     check_trajectory_golden(gpu_device, "g9_trajectory_1000_allspectra.npz", "allspectra", 1000, cases.ALLSPECTRA_FULL_ATOMS)
 
 
+def test_g15_full_length_trajectory_max_size_golden(gpu_device):
+    """1000 injected-noise steps with a maximum-size (n = 29) molecule in the batch, vs the reference's run."""
+    check_trajectory_golden(gpu_device, "g15_trajectory_1000_n29.npz", "ir", 1000, cases.MAX_SIZE_FULL_ATOMS, tag_suffix="_n29")
+
+
 def test_unconditional_config4_vs_oracle(gpu_device):
     """BASELINE config 4: ``ctx_emb = NULL`` (zero context embedding, SpecFormer skipped) on a 256-molecule QM9-histogram
     batch against ``oracle.dmt_forward(context_emb = 0)``, first-step and general branch."""
@@ -990,6 +1105,61 @@ def test_unconditional_config4_vs_oracle(gpu_device):
         # and a NULL context really is the zero embedding, not a stale one from an earlier call
         out0, oute0 = eng.forward(L, ws, x.to(d), ex.to(d), nl.to(d), to_dev(c1, d), to_dev(c2, d), zero_ctx.to(d))
         assert torch.equal(out0, out) and torch.equal(oute0, oute)
+
+
+def test_benchmark_batch_sizes(gpu_device):
+    """The batch sizes the benchmark runs at.
+    (a) BASELINE config 4's batch of 4096 molecules, zero context: slices of the batched forward against the single-call oracle
+        on the same molecules (as test_full_size_properties does at 256).
+    (b) 14 000 molecules resident at once - every [Pp, 256]-wide pair tensor beyond 2^31 bytes - against 512-molecule batches
+        of the same molecules: catches 32-bit offset overflow in kernels and buffer descriptors."""
+    from diffspectra_amd import filler
+    cfg, model = gpu_model("allspectra", gpu_device)
+    eng = model.module.engine()
+    d = gpu_device
+    cpu_cfg, sd = procedural_state_dict("allspectra")
+    # (a)
+    M = 4096
+    n_atoms = filler.sample_n_atoms(M, seed=4).tolist()
+    x, ex, node_mask, edge_mask = filler.synthetic_state(n_atoms, "b4096.x")
+    cx, cex, _, _ = filler.synthetic_state(n_atoms, "b4096.c")
+    nl = filler.uniform("b4096.nl", (M,), -6, 6)
+    L, ws = eng.layout_for(node_mask, edge_mask)
+    out, oute = eng.forward(L, ws, x.to(d), ex.to(d), nl.to(d), cx.to(d), cex.to(d), None)
+    out, oute = out.cpu(), oute.cpu()
+    assert torch.isfinite(out).all() and torch.isfinite(oute).all()
+    for lo in (0, 2040, M - 8):
+        sl = slice(lo, lo + 8)
+        nm, em = filler.masks_from_n_atoms(n_atoms[sl])
+        N = nm.shape[1]
+        ref, refe = oracle.dmt_forward(sd, cpu_cfg, x[sl, :N], nm, em, ex[sl, :N, :N], nl[sl], cx[sl, :N], cex[sl, :N, :N],
+                                       context_emb=torch.zeros(8, 1024))
+        assert_close(out[sl, :N], ref, TOL_FORWARD, f"4096-molecule batch, molecules {lo}..{lo + 8} xh")
+        assert_close(oute[sl, :N, :N], refe, TOL_FORWARD, f"4096-molecule batch, molecules {lo}..{lo + 8} edges")
+        assert float(out[sl, N:].abs().max() if N < out.shape[1] else 0.0) == 0.0
+    del out, oute, L, ws
+    # (b)
+    M = 14000
+    n_atoms = filler.sample_n_atoms(M, seed=0).tolist()
+    x, ex, node_mask, edge_mask = filler.synthetic_state(n_atoms, "bb.x")
+    cx, cex, _, _ = filler.synthetic_state(n_atoms, "bb.c")
+    nl = torch.full((M,), 0.5)
+    ctx = filler.normal("bb.ctx", (M, 1024)) * 0.5
+    L, ws = eng.layout_for(node_mask, edge_mask)
+    assert L.Pp * 256 * 4 > 2 ** 31, "the batch must push the widest pair tensor beyond 2^31 bytes"
+    out, oute = eng.forward(L, ws, x.to(d), ex.to(d), nl.to(d), cx.to(d), cex.to(d), ctx.to(d))
+    out, oute = out.cpu(), oute.cpu()
+    assert torch.isfinite(out).all() and torch.isfinite(oute).all()
+    for lo in (0, M // 2 - 256, M - 512):
+        sl = slice(lo, lo + 512)
+        nm, em = filler.masks_from_n_atoms(n_atoms[sl])
+        N = nm.shape[1]
+        L2, ws2 = eng.layout_for(nm, em)
+        o2, e2 = eng.forward(L2, ws2, x[sl, :N].contiguous().to(d), ex[sl, :N, :N].contiguous().to(d), nl[sl].to(d),
+                             cx[sl, :N].contiguous().to(d), cex[sl, :N, :N].contiguous().to(d), ctx[sl].to(d))
+        assert_close(o2.cpu(), out[sl, :N], TOL_FORWARD, f"14000-molecule batch vs 512-molecule batch at {lo}: xh")
+        assert_close(e2.cpu(), oute[sl, :N, :N], TOL_FORWARD, f"14000-molecule batch vs 512-molecule batch at {lo}: edges")
+    eng._layouts.clear()                                   # release the 14 000-molecule workspace
 
 
 @pytest.mark.parametrize("variant", ["spec_model", "plain_model"])
@@ -1123,16 +1293,34 @@ def test_stability_kernel_vs_reference_decisions(gpu_device):
 
 
 def test_batched_stability_on_device(gpu_device):
-    """N4 plumbing: the batched stability check (torch tensor ops) gives the same answer on GPU tensors as on CPU tensors;
-    its decisions are pinned to the reference's ``get_bond_order`` by tests/test_oracle_golden.py::test_g12_*."""
-    from diffspectra_amd import filler
+    """N4: ``check_stability_batch`` (the HIP kernel behind the package API) equals the reference's pair-by-pair decision
+    (``oracle/stability.py``, pinned to ``get_bond_order`` by golden G12) on a fixture that exercises every outcome."""
     from diffspectra_amd.stability import check_stability_batch
-    n_atoms = filler.sample_n_atoms(64, seed=5).tolist()
-    x, _, node_mask, _ = filler.synthetic_state(n_atoms, "stab.x")
-    pos = x[:, :, :3] * 1.3
-    types = (filler.uniform("stab.t", (64, x.shape[1])) * 5).long().clamp(0, 4)
-    cpu = check_stability_batch(pos, types, node_mask)
-    dev = check_stability_batch(pos.to(gpu_device), types.to(gpu_device), node_mask.to(gpu_device))
-    for a, b in zip(cpu, dev):
-        assert torch.equal(a, b.cpu())
-    assert int(cpu[3].sum()) > 0                      # the fixture does contain bonds
+    from oracle import stability as ost
+    cfg, model = gpu_model("ir", gpu_device)
+    eng = model.module.engine()
+    gen = torch.Generator().manual_seed(11)
+    n_atoms = [1, 2, 5, 9, 18, 29]
+    B, N = len(n_atoms), max(n_atoms)
+    # positions on a jittered grid with ~1.1-1.6 A spacing so that all four outcomes (none/single/double/triple) occur
+    pos = torch.zeros(B, N, 3)
+    types = torch.randint(0, 5, (B, N), generator=gen)
+    mask = torch.zeros(B, N)
+    for b, n in enumerate(n_atoms):
+        grid = torch.stack(torch.meshgrid(torch.arange(4.0), torch.arange(4.0), torch.arange(2.0), indexing="ij"), -1).reshape(-1, 3)
+        pos[b, :n] = grid[:n] * (1.05 + 0.1 * b) + 0.08 * torch.randn(n, 3, generator=gen)
+        mask[b, :n] = 1
+    types[3, 0], types[3, 1] = 1, 2                   # a C#N pair at triple-bond distance
+    pos[3, 1] = pos[3, 0] + torch.tensor([1.15, 0.0, 0.0])
+    d = gpu_device
+    stable, nr_stable, cnt, order = (t.cpu() for t in check_stability_batch(pos.to(d), types.to(d), mask.to(d), engine=eng))
+    seen = set()
+    for b, n in enumerate(n_atoms):
+        want = ost.check_stability(pos[b, :n].tolist(), types[b, :n].tolist())
+        assert (bool(stable[b]), int(nr_stable[b]), int(cnt[b])) == want[:3]
+        assert order[b, :n, :n].tolist() == want[3]
+        assert int(order[b, n:].abs().sum()) == 0 and int(order[b, :, n:].abs().sum()) == 0
+        seen |= {o for row in want[3] for o in row}
+    assert seen == {0, 1, 2, 3}                       # the fixture exercises every branch of get_bond_order
+    with pytest.raises(RuntimeError):
+        check_stability_batch(pos.to(d), types.to(d), mask.to(d))

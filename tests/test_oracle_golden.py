@@ -304,26 +304,14 @@ def test_g10_pretrained_specformer_loader(variant):
 
 
 def test_g12_bond_orders_pin_the_stability_oracle():
-    """oracle/stability.py and the product's batched check against the reference's own ``get_bond_order`` /
-    ``allowed_bonds`` (evaluation/bond_analyze.py:5-45,85,90,108-133)."""
+    """oracle/stability.py against the reference's own ``get_bond_order`` / ``allowed_bonds`` (evaluation/bond_analyze.py:5-45,85,
+    90,108-133); the product's HIP kernel is held to the same sweep on the GPU (test_stability_kernel_vs_reference_decisions)."""
     from oracle import stability as ost
-    from diffspectra_amd.stability import bond_orders, _VALENCE
     g = cases.load_npz("g12_bond_orders.npz")
     dist = cases.bond_distance_sweep()
-    assert g["valence"].tolist() == [ost.ALLOWED[a] for a in ost.DECODER] == list(_VALENCE)
+    assert g["valence"].tolist() == [ost.ALLOWED[a] for a in ost.DECODER]
     want = g["orders"]
     for i, a in enumerate(ost.DECODER):
         for j, b in enumerate(ost.DECODER):
             got = [ost.get_bond_order(a, b, d) for d in dist.tolist()]
             assert got == want[i, j].tolist(), (a, b)
-    # product (fp32 tensors): every point that is not exactly ON a threshold (those are fp64-vs-fp32 rounding cases)
-    off = np.abs(dist * 100 - np.round(dist * 100)) > 1e-6
-    d32 = torch.from_numpy(dist[off]).float()
-    for i in range(5):
-        for j in range(5):
-            pos = torch.zeros(len(d32), 2, 3)
-            pos[:, 1, 0] = d32
-            types = torch.tensor([[i, j]]).expand(len(d32), 2)
-            o = bond_orders(pos, types, torch.ones(len(d32), 2))
-            assert o[:, 0, 1].tolist() == want[i, j][torch.from_numpy(off)].tolist(), (i, j)
-            assert torch.equal(o[:, 0, 1], o[:, 1, 0])

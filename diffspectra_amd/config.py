@@ -37,14 +37,20 @@ def qm9s_config(spectra_version: str = "allspectra", device="cpu", steps: int = 
         self_cond_type="ori", edge_quan_th=0.0, n_extra_heads=2, CoM=True, mlp_ratio=2,
         spatial_cut_off=2.0, softmax_inf=True, trans_name="TransMixLayer", cond_ch=1,
         pretrained_specformer_path="", patch_len=[20, 50, 50], stride=[10, 25, 25],
+        loss_weights="1., 0.25, 0.1", noise_align=True,                        # configs/diffspectra_qm9s.py:79-80
     )
     sde = Config(schedule="cosine", continuous_beta_0=0.1, continuous_beta_1=20.0)
     sampling = Config(method="ancestral", steps=steps, noise_source="philox", seed=42)
     evaluate = Config(batch_size=batch_size, num_samples=num_samples, sampling_temperature=1.0, enable_sampling=True,
                       begin_ckpt=40, end_ckpt=40, ckpts="")
+    # training side (configs/diffspectra_qm9s.py:85-127): batch 128 per GPU, AdamW-amsgrad lr 2e-4, warm-up 100 000 steps,
+    # adaptive gradient clipping capped at 10
+    training = Config(batch_size=128, reduce_mean=False, n_iters=2000000, snapshot_freq=50000, num_gpus=1)
+    optim = Config(weight_decay=0, optimizer="AdamW", lr=2e-4, beta1=0.9, eps=1e-8, warmup=100000, grad_clip=10.0,
+                   disable_grad_log=True)
     return Config(
         exp_type="diffspectra", pred_edge=True, only_2D=False, data=data, model=model, sde=sde,
-        sampling=sampling, eval=evaluate, seed=42, device=device,
+        sampling=sampling, eval=evaluate, training=training, optim=optim, seed=42, device=device,
     )
 
 

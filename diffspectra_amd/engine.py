@@ -195,9 +195,10 @@ def pack_ff4_chain(weight: torch.Tensor) -> torch.Tensor:
 def split_rows_f16(a: torch.Tensor) -> torch.Tensor:
     """fp32 [M, K] → the A-operand layout of ``ds_gemm_split``: halves [M][2][K] (a = a1 + a2/2048), returned as float16."""
     a = a.detach().to(torch.float32)
-    sat = lambda t: torch.where(torch.isfinite(t), t.clamp(-F16_MAX, F16_MAX), t)      # the kernels' saturating conversion
+    fin = torch.isfinite(a)
+    sat = lambda t: torch.where(fin, t.clamp(-F16_MAX, F16_MAX), t)                    # the kernels' saturating conversion
     a1 = sat(a).half()
-    a2 = sat((a - a1.float()) * SPLIT_SCALE).half()
+    a2 = sat(((a.double() - a1.double()) * SPLIT_SCALE).float()).half()               # fused on the device: no fp32 overflow in between
     return torch.stack([a1, a2], dim=1).contiguous()
 
 

@@ -189,6 +189,50 @@ def sampling_fn_noise_queue(case, perm):
     return queue
 
 
+TRAIN_ATOMS = [3, 7, 1, 12, 29, 9]             # G13 training batch: ragged, with a single-atom and a maximum-size molecule
+
+
+def training_batch(version: str, n_atoms=TRAIN_ATOMS, salt: int = 0):
+    """A collated training batch in the format of ``CollateSpectra.__call__`` (datasets/build_dataset.py:357-395): un-centred
+    positions, one-hot atom types, formal charges, dense edge features [exist, bond order / 3] (``EdgeComSpectraTransform``
+    :106-138, compress_edge), masks and spectra.  Procedural, reproducible on both sides."""
+    B, N = len(n_atoms), max(n_atoms)
+    node_mask, edge_mask = filler.masks_from_n_atoms(n_atoms)
+    nm = node_mask.squeeze(-1)
+    pos = (filler.normal("g13.pos", (B, N, 3), salt) * 1.3 + 0.4) * node_mask          # not zero-CoM (translation augmentation)
+    types = (filler.uniform("g13.type", (B, N), salt=salt) * 5).long().clamp(0, 4)
+    atom_one_hot = torch.nn.functional.one_hot(types, 5).float() * node_mask
+    fc = ((filler.uniform("g13.fc", (B, N, 1), salt=salt) * 3).floor() - 1.0) * node_mask
+    u = filler.uniform("g13.bond", (B, N, N), salt=salt)
+    u = torch.triu(u, 1)
+    u = u + u.transpose(1, 2)
+    order = torch.zeros(B, N, N)
+    order[u > 0.6], order[u > 0.8], order[u > 0.93] = 1.0, 2.0, 3.0
+    em = edge_mask.reshape(B, N, N)
+    order = order * em
+    edge_one_hot = torch.stack([(order > 0).float(), order / 3.0], dim=-1)
+    return dict(atom_one_hot=atom_one_hot, edge_one_hot=edge_one_hot, positions=pos, formal_charges=fc, atom_mask=nm,
+                edge_mask=edge_mask, context=spectra_for(version, B, salt + 3), n_atoms=list(n_atoms))
+
+
+def training_draws(n_atoms=TRAIN_ATOMS, salt: int = 0):
+    """The random draws of one ``loss_fn`` call (losses.py:314-317), injected on both sides: ``torch.rand(B)`` for t, then the
+    three ``randn`` tensors of the noise samplers (pos [B,N,3], feat [B,N,6], edge [B,2,N,N])."""
+    B, N = len(n_atoms), max(n_atoms)
+    return dict(t_raw=filler.uniform("g13.t", (B,), 0.02, 0.98, salt=salt),
+                randn=[filler.normal("g13.n.pos", (B, N, 3), salt), filler.normal("g13.n.feat", (B, N, 6), salt),
+                       filler.normal("g13.n.edge", (B, 2, N, N), salt)])
+
+
+# parameters whose FULL gradient the training golden stores (one per kernel family); every other parameter is pinned by its
+# gradient norm and by a 64-entry strided sample
+TRAIN_FULL_GRADS = ("e_block_0.attn_mpnn.lin_edge0.weight", "e_block_7.equi_update.coord_mlp.0.weight", "node_emb.weight",
+                    "e_block_3.node_time_mlp.1.bias", "e_block_0.dist_layer.means.weight", "e_block_5.dist_layer.stds.weight",
+                    "e_block_2.equi_update.coord_norm.scale", "time_mlp.0.weights", "e_block_4.attn_mpnn.lin_query.weight",
+                    "e_block_6.ff_linear4.weight", "edge_type_mlp.4.weight", "cond_lin.weight",
+                    "cond_encoder.backbone.encoder.layers.1.norm_attn.1.weight", "cond_encoder.out_norm.bias")
+
+
 def bond_distance_sweep():
     """Distances (Angstrom) for the bond-order golden (G12): a 1 pm grid over 0.5-2.0 A plus points 1e-4 A either side of
     every integer-picometre threshold in that range, so each ``<`` comparison is exercised on both sides."""

@@ -464,6 +464,101 @@ def g14_checkpoint(mods):
           "ref->ours", man["reference_file_loads_here"], man["pickle_globals"])
 
 
+class _ReplayRand:
+    def __init__(self, t):
+        self.t, self.calls = t, 0
+
+    def __call__(self, *size, **kw):
+        self.calls += 1
+        assert tuple(size) == tuple(self.t.shape) or (len(size) == 1 and int(size[0]) == self.t.numel()), size
+        return self.t.clone()
+
+
+def grad_sample_index(numel: int, count: int = 64):
+    return torch.linspace(0, numel - 1, min(count, numel)).round().long()
+
+
+def g13_training(mods):
+    """Row N1: the reference's own training loss and gradients - ``get_sde_graph_loss_fn`` (losses.py:286-396, train=True) on
+    ``DataParallel(DMT)`` with every random draw injected (``torch.rand`` for t, the three noise ``randn``s, the self-conditioning
+    coin ``random()``), dropout 0.0 (stage A), BatchNorm in training mode.  Stored: loss, the tensors the loss is built from
+    (alpha_t, sigma_t, Kabsch rotations and aligned target, z_t, predictions), per-parameter gradient norms and strided samples
+    for ALL parameters, full gradients for one tensor per kernel family, and the BatchNorm running statistics after the step."""
+    ref_losses = importlib.import_module("losses")
+    out = {}
+    for version in ("ir", "allspectra"):
+        for coin_name, coin in (("selfcond", 0.0), ("plain", 1.0)):
+            if version == "allspectra" and coin_name == "plain":
+                continue
+            cfg = cases.config_for(version)
+            cfg.device = torch.device("cpu")
+            cfg.model.dropout = 0.0
+            model = torch.nn.DataParallel(mods.model_utils._MODELS["DMT"](cfg))
+            model.load_state_dict(filler.fill_state_dict(model.state_dict()), strict=True)
+            ns = mods.noise_schedule.NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0)
+            scaler = mods.top_utils.get_data_scaler(cfg)
+            loss_fn = ref_losses.get_sde_graph_loss_fn(ns, True, scaler, cfg)
+            batch = cases.training_batch(version)
+            draws = cases.training_draws()
+            replay_n = _ReplayRandn(draws["randn"])
+            replay_u = _ReplayRand(draws["t_raw"])
+            real_randn, real_rand, real_coin = torch.randn, torch.rand, ref_losses.random
+            seen = {}
+            real_forward = model.module.forward
+
+            def spy(t, xh, node_mask, edge_mask, context=None, *a, **kw):
+                r = real_forward(t, xh, node_mask, edge_mask, context, *a, **kw)
+                key = "cond" if not torch.is_grad_enabled() else "pred"
+                seen[key] = (r[0].detach().clone(), r[1].detach().clone())
+                seen.setdefault("z_t", xh.detach().clone())
+                seen.setdefault("edge_z_t", kw["edge_x"].detach().clone())
+                seen.setdefault("noise_level", kw["noise_level"].detach().clone())
+                seen.setdefault("alpha_t", kw["alpha_t"].detach().clone())
+                seen.setdefault("sigma_t", kw["sigma_t"].detach().clone())
+                return r
+
+            model.module.forward = spy
+            torch.randn, torch.rand, ref_losses.random = replay_n, replay_u, (lambda: coin)
+            try:
+                loss = loss_fn(model, {k: v for k, v in batch.items() if k != "n_atoms"})
+                loss.backward()
+            finally:
+                torch.randn, torch.rand, ref_losses.random = real_randn, real_rand, real_coin
+                model.module.forward = real_forward
+            assert not replay_n.queue and replay_u.calls == 1
+            tag = f"{version}_{coin_name}"
+            out[tag + "_loss"] = loss.detach().numpy()
+            for k in ("z_t", "edge_z_t", "noise_level", "alpha_t", "sigma_t"):
+                out[f"{tag}_{k}"] = seen[k].numpy()
+            out[tag + "_pred"], out[tag + "_edge_pred"] = seen["pred"][0].numpy(), seen["pred"][1].numpy()
+            if "cond" in seen:
+                out[tag + "_cond_x"], out[tag + "_cond_edge_x"] = seen["cond"][0].numpy(), seen["cond"][1].numpy()
+            # Kabsch alignment of the clean positions onto z_t (losses.py:414-452), recomputed from the same tensors
+            xh, edge_x, node_mask, edge_mask, _ = ref_losses.process_edge_batch({k: v for k, v in batch.items() if k != "n_atoms"},
+                                                                             cfg.device, True, scaler, None, "DMT")
+            out[tag + "_xh"], out[tag + "_edge_x"] = xh.numpy(), edge_x.numpy()
+            out[tag + "_rotations"] = ref_losses.kabsch_batch(seen["z_t"][:, :, :3], xh[:, :, :3]).numpy()
+            out[tag + "_align_pos"] = ref_losses.get_align_position(seen["z_t"], xh).numpy()
+            names, norms, samples = [], [], []
+            for n, p in model.module.named_parameters():
+                g = p.grad if p.grad is not None else torch.zeros_like(p)
+                names.append(n)
+                norms.append(float(g.double().norm()))
+                samples.append(g.reshape(-1)[grad_sample_index(g.numel())].numpy())
+                if n in cases.TRAIN_FULL_GRADS:
+                    out[f"{tag}_grad::{n}"] = g.numpy()
+            out[tag + "_grad_names"] = np.array(json.dumps(names))
+            out[tag + "_grad_norms"] = np.array(norms)
+            out[tag + "_grad_samples"] = np.concatenate([np.pad(s_, (0, 64 - len(s_))) for s_ in samples]).reshape(len(names), 64)
+            bn = "cond_encoder.backbone.encoder.layers.0.norm_attn.1."
+            sd = {k[7:]: v for k, v in model.state_dict().items()}
+            out[tag + "_bn_running_mean"], out[tag + "_bn_running_var"] = sd[bn + "running_mean"].numpy(), sd[bn + "running_var"].numpy()
+            out[tag + "_bn_batches"] = sd[bn + "num_batches_tracked"].numpy()
+            print("G13", tag, "loss", float(loss), "total grad norm", float(np.sqrt(np.sum(np.square(norms)))),
+                  "zero-grad tensors", [n for n, v in zip(names, norms) if v == 0.0])
+    cases.save_npz("g13_training.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -478,7 +573,7 @@ def main():
     todo = {"G0": g0_manifest, "G1": g1_schedule, "G2": g2_specformer, "G3": g3_components, "G4": g4_forward,
             "G5": g5_trajectory, "G6": g6_post_process, "G7": g7_full_length, "G8": g8_clamp_self_cond,
             "G9": g9_full_length_allspectra, "G10": g10_pretrained_specformer, "G11": g11_sampling_fn,
-            "G14": g14_checkpoint, "G15": g15_full_length_max_size}
+            "G13": g13_training, "G14": g14_checkpoint, "G15": g15_full_length_max_size}
     for k, fn in todo.items():
         if not only or k in only:
             fn(mods)

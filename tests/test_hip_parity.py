@@ -253,19 +253,23 @@ def _oracle_forward_f64(sd, cfg, a):
 
 def _checkpoint_like(sd):
     """Weight statistics a trained checkpoint can have and the U(+-1/sqrt(fan_in)) filler never does: adaLN scale / shift / gate
-    outputs 30x larger, a few residual-stream channels at 1e4 magnitude, weights with 1e-6 entries, large CondGaussian inputs."""
+    outputs 30x larger (every block's node / edge / equi / dist time_mlp), a few residual-stream channels at 1e4 magnitude,
+    weights with 1e-6 entries.  (The top-level 17 -> 1024 time MLP is left alone: scaling it as well makes the forward
+    ill-conditioned - the fp32 CPU oracle itself is then 10 % away from fp64.)"""
+    import re
     out = dict(sd)
-    for k, v in sd.items():
-        if ".time_mlp.1." in k or "node_time_mlp.1." in k or "edge_time_mlp.1." in k:
-            out[k] = v * 30.0
-        elif k.endswith("node_emb.weight"):
+    for key, v in sd.items():
+        k = key[7:] if key.startswith("module.") else key
+        if re.match(r"e_block_\d+\.(node_time_mlp|edge_time_mlp|equi_update\.time_mlp|dist_layer\.time_mlp)\.1\.", k):
+            out[key] = v * 30.0
+        elif k == "node_emb.weight":
             w = v.clone()
             w[[3, 77, 200]] *= 1e4                                      # three residual-stream channels ~1e4
-            out[k] = w
-        elif k.endswith("ff_linear1.weight") or k.endswith("ff_linear3.weight") or k.endswith("coord_mlp.0.weight"):
+            out[key] = w
+        elif re.match(r"e_block_\d+\.(ff_linear1|ff_linear3|equi_update\.coord_mlp\.0)\.weight", k):
             w = v.clone()
             w[::3] *= 1e-5                                              # rows of ~1e-6 entries next to ordinary ones
-            out[k] = w
+            out[key] = w
     return out
 
 

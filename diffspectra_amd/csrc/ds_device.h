@@ -248,7 +248,7 @@ __device__ __forceinline__ void wave_mma(const float* X, int ldx, const float* _
 // ds_fp16_saturate(): MODE.FP16_OVFL (hwreg MODE bit 23) makes v_cvt_f16_f32 clamp an overflowing result to +-65504 instead
 // of producing inf (true inf / NaN inputs are preserved), at no instruction cost - measured on gfx950 with
 // tools/micro/fp16_ovfl.hip: 7e4 -> (65504, 65504) = 65536, 1e6 -> 65536, inf -> inf, NaN -> NaN.  An activation with
-// |x| >= 65536 therefore SATURATES at +-65536 (both planes clamp) where it used to turn into inf - inf = NaN; values below
+// |x| >= 65536 therefore SATURATES at +-65535.98 (both planes clamp at 65504) where it used to turn into inf - inf = NaN; values below
 // 65520 are converted exactly as before.  Weights are range-checked at pack time (engine.pack_linear_f16_split).
 __device__ __forceinline__ void ds_fp16_saturate() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
 

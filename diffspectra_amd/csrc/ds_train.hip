@@ -1,0 +1,1422 @@
+// diffspectra_amd — gfx950 kernels of the TRAINING path (include/diffspectra_train.h): forward and hand-written backward of every
+// operation of the DMT graph over the packed-ragged layout.  fp32 storage and arithmetic, GEMMs on v_mfma_f32_32x32x2_f32.
+// Stage A of row N1: correctness against the reference's autograd first; one workgroup per molecule for everything that
+// reduces over a molecule's rows (adaLN gradients, attention, coordinate update), fixed summation orders everywhere (no float
+// atomics), so a step is reproducible bit for bit.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/diffspectra_hip.h"
+#include "../../include/diffspectra_train.h"
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+namespace {
+
+#define DST_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? DS_OK : DS_ERR_LAUNCH)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int pair_index(int n, int lo, int hi) { return lo * (2 * n - lo - 1) / 2 + (hi - lo - 1); }
+
+// ------------------------------------------------------------------------------------------------------------------ GEMM
+__global__ __launch_bounds__(256) void k_tr_gemm(dst_gemm_args g, int splits, int kchunk) {
+  __shared__ float As[16][68];
+  __shared__ float Bs[16][68];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int z = blockIdx.z;
+  const int kbeg = z * kchunk;
+  const int kend = min(g.K, kbeg + kchunk);
+  f32x16_t acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  const bool a_kfast = (g.a_cs == 1), b_nfast = (g.b_cs == 1);
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      int mm, kk;
+      if (a_kfast) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
+      const int gm = m0 + mm, gk = k0 + kk;
+      As[kk][mm] = (gm < g.M && gk < kend) ? g.A[(int64_t)gm * g.a_rs + (int64_t)gk * g.a_cs] : 0.0f;
+      int nn, kb;
+      if (b_nfast) { nn = e & 63; kb = e >> 6; } else { kb = e & 15; nn = e >> 4; }
+      const int gn = n0 + nn, gkb = k0 + kb;
+      Bs[kb][nn] = (gn < g.N && gkb < kend) ? g.B[(int64_t)gkb * g.b_rs + (int64_t)gn * g.b_cs] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 2) {
+      const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
+      const float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int col = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = m0 + wm * 32 + (i >> 2) * 8 + (lane >> 5) * 4 + (i & 3);
+    if (row < g.M && col < g.N) {
+      if (splits > 1) {
+        g.partial[((int64_t)z * g.M + row) * g.N + col] = acc[i];
+      } else {
+        float v = acc[i] + (g.bias ? g.bias[col] : 0.0f);
+        float* c = g.C + (int64_t)row * g.ldc + col;
+        if (g.accumulate) v += *c;
+        *c = v;
+      }
+    }
+  }
+}
+
+__global__ void k_tr_gemm_reduce(dst_gemm_args g, int splits) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)g.M * g.N) return;
+  const int row = (int)(idx / g.N), col = (int)(idx % g.N);
+  float v = g.bias ? g.bias[col] : 0.0f;
+  for (int z = 0; z < splits; ++z) v += g.partial[(int64_t)z * g.M * g.N + idx];
+  float* c = g.C + (int64_t)row * g.ldc + col;
+  if (g.accumulate) v += *c;
+  *c = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ colsum / sumsq
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ X, int64_t ld, int R, int C, float* __restrict__ partial,
+                                                         int rows_per_chunk) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+  float s = 0.0f;
+  if (col < C)
+    for (int r = r0 + rl; r < r1; r += 4) s += X[(int64_t)r * ld + col];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < C) partial[(int64_t)blockIdx.y * C + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void k_colsum_final(const float* __restrict__ partial, int chunks, int C, float* __restrict__ out, int accumulate) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= C) return;
+  float s = 0.0f;
+  for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * C + col];
+  out[col] = accumulate ? out[col] + s : s;
+}
+__global__ __launch_bounds__(256) void k_sumsq_partial(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float s = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ elementwise
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__global__ void k_act_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t n, int kind) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  float r;
+  if (kind == 1) r = v * sigmoidf_(v);
+  else if (kind == 2) r = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  else r = tanhf(v);
+  y[i] = r;
+}
+__global__ void k_act_bwd(const float* __restrict__ dy, const float* __restrict__ ref, float* __restrict__ dx, int64_t n, int kind) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = ref[i];
+  float d;
+  if (kind == 1) { const float s = sigmoidf_(v); d = s * (1.0f + v * (1.0f - s)); }
+  else if (kind == 2) d = 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * expf(-0.5f * v * v) * 0.39894228040143267794f;
+  else d = 1.0f - v * v;
+  dx[i] = dy[i] * d;
+}
+__global__ void k_axpy(float a, const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += a * x[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------------ LN + modulate
+template <int C>
+__global__ __launch_bounds__(256) void k_lnmod_fwd(const float* __restrict__ x, const int32_t* __restrict__ seg_off, int seg_mul,
+                                                    const float* __restrict__ ada, int64_t ada_ld, int shift_off, int scale_off,
+                                                    float* __restrict__ y, float* __restrict__ stats) {
+  constexpr int V = C / 64;
+  const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r0 = seg_off[m] * seg_mul, r1 = seg_off[m + 1] * seg_mul;
+  float sh[V], sc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    sh[j] = ada[(int64_t)m * ada_ld + shift_off + lane + 64 * j];
+    sc[j] = ada[(int64_t)m * ada_ld + scale_off + lane + 64 * j];
+  }
+  for (int r = r0 + wave; r < r1; r += 4) {
+    float v[V], s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { v[j] = x[(int64_t)r * C + lane + 64 * j]; s += v[j]; }
+    const float mean = wave_sum(s) * (1.0f / C);
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { const float d = v[j] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + 1e-6f);
+#pragma unroll
+    for (int j = 0; j < V; ++j) y[(int64_t)r * C + lane + 64 * j] = ((v[j] - mean) * rstd) * (1.0f + sc[j]) + sh[j];
+    if (lane == 0) { stats[(int64_t)r * 2] = mean; stats[(int64_t)r * 2 + 1] = rstd; }
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_lnmod_bwd(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
+                                                    const int32_t* __restrict__ seg_off, int seg_mul, const float* __restrict__ ada,
+                                                    float* __restrict__ d_ada, int64_t ada_ld, int shift_off, int scale_off,
+                                                    float* __restrict__ dx, int accumulate) {
+  constexpr int V = C / 64;
+  __shared__ float red[2][4][C];
+  const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r0 = seg_off[m] * seg_mul, r1 = seg_off[m + 1] * seg_mul;
+  float sc[V], dsh[V], dsc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { sc[j] = ada[(int64_t)m * ada_ld + scale_off + lane + 64 * j]; dsh[j] = 0.0f; dsc[j] = 0.0f; }
+  for (int r = r0 + wave; r < r1; r += 4) {
+    const float mean = stats[(int64_t)r * 2], rstd = stats[(int64_t)r * 2 + 1];
+    float xh[V], gg[V], s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float g = dy[(int64_t)r * C + lane + 64 * j];
+      xh[j] = (x[(int64_t)r * C + lane + 64 * j] - mean) * rstd;
+      dsh[j] += g;
+      dsc[j] += g * xh[j];
+      gg[j] = g * (1.0f + sc[j]);
+      s1 += gg[j];
+      s2 += gg[j] * xh[j];
+    }
+    const float m1 = wave_sum(s1) * (1.0f / C), m2 = wave_sum(s2) * (1.0f / C);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float d = rstd * (gg[j] - m1 - xh[j] * m2);
+      float* o = dx + (int64_t)r * C + lane + 64 * j;
+      *o = accumulate ? *o + d : d;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) { red[0][wave][lane + 64 * j] = dsh[j]; red[1][wave][lane + 64 * j] = dsc[j]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    d_ada[(int64_t)m * ada_ld + shift_off + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    d_ada[(int64_t)m * ada_ld + scale_off + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ gated residual
+template <int C>
+__global__ __launch_bounds__(256) void k_gate_add_fwd(const float* __restrict__ r_, const float* __restrict__ z, const int32_t* __restrict__ seg_off,
+                                                       int seg_mul, const float* __restrict__ ada, int64_t ada_ld, int gate_off,
+                                                       float* __restrict__ out) {
+  constexpr int V = C / 64;
+  const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r0 = seg_off[m] * seg_mul, r1 = seg_off[m + 1] * seg_mul;
+  float g[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) g[j] = ada[(int64_t)m * ada_ld + gate_off + lane + 64 * j];
+  for (int r = r0 + wave; r < r1; r += 4)
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int64_t i = (int64_t)r * C + lane + 64 * j;
+      out[i] = r_[i] + g[j] * z[i];
+    }
+}
+template <int C>
+__global__ __launch_bounds__(256) void k_gate_add_bwd(const float* __restrict__ dout, const float* __restrict__ z, const int32_t* __restrict__ seg_off,
+                                                       int seg_mul, const float* __restrict__ ada, float* __restrict__ d_ada, int64_t ada_ld,
+                                                       int gate_off, float* __restrict__ dr, int accumulate_r, float* __restrict__ dz) {
+  constexpr int V = C / 64;
+  __shared__ float red[4][C];
+  const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r0 = seg_off[m] * seg_mul, r1 = seg_off[m + 1] * seg_mul;
+  float g[V], dg[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { g[j] = ada[(int64_t)m * ada_ld + gate_off + lane + 64 * j]; dg[j] = 0.0f; }
+  for (int r = r0 + wave; r < r1; r += 4)
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int64_t i = (int64_t)r * C + lane + 64 * j;
+      const float d = dout[i];
+      dg[j] += d * z[i];
+      dz[i] = g[j] * d;
+      if (dr) dr[i] = accumulate_r ? dr[i] + d : d;
+    }
+#pragma unroll
+  for (int j = 0; j < V; ++j) red[wave][lane + 64 * j] = dg[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) d_ada[(int64_t)m * ada_ld + gate_off + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ geometry
+// local pair tables of one molecule in LDS
+__device__ __forceinline__ void fill_pair_tables(int n, unsigned char* pa, unsigned char* pb) {
+  for (int a = threadIdx.x; a < n; a += blockDim.x)
+    for (int b = a + 1; b < n; ++b) {
+      const int idx = pair_index(n, a, b);
+      pa[idx] = (unsigned char)a;
+      pb[idx] = (unsigned char)b;
+    }
+}
+
+#define DST_GAUSS_A 2.50662732f /* fp32((2 * 3.14159) ** 0.5): the Python-float constant of layers.py:293-294 as torch applies it */
+
+__global__ __launch_bounds__(256) void k_geom_fwd(dst_layout L, const float* __restrict__ pos, const float* __restrict__ ada, int64_t ada_ld,
+                                                   int dist_off, const float* __restrict__ means, const float* __restrict__ stds,
+                                                   float* __restrict__ X, int64_t ldx, float* __restrict__ xs, float* __restrict__ d2s) {
+  __shared__ unsigned char pa[406], pb[406];
+  __shared__ float sp[29][3];
+  const int m = blockIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
+  fill_pair_tables(n, pa, pb);
+  for (int i = threadIdx.x; i < n * 3; i += 256) sp[i / 3][i % 3] = pos[(int64_t)(n0 + i / 3) * 3 + i % 3];
+  __syncthreads();
+  const float a = DST_GAUSS_A;
+  const float dsc = ada[(int64_t)m * ada_ld + dist_off], dsh = ada[(int64_t)m * ada_ld + dist_off + 1];
+  for (int it = threadIdx.x; it < np * 64; it += 256) {
+    const int p = it >> 6, k = it & 63;
+    const int ia = pa[p], ib = pb[p];
+    const float dx = sp[ia][0] - sp[ib][0], dy = sp[ia][1] - sp[ib][1], dz = sp[ia][2] - sp[ib][2];
+    const float d2 = dx * dx + dy * dy + dz * dz;
+    const float x = d2 * (dsc + 1.0f) + dsh;
+    float f;
+    if (k == 0) {
+      f = x;
+      xs[p0 + p] = x;
+      d2s[p0 + p] = d2;
+    } else {
+      const float sd = fabsf(stds[k - 1]) + 1e-5f;
+      const float u = (x - means[k - 1]) / sd;
+      f = expf(-0.5f * (u * u)) / (a * sd);
+    }
+    X[(int64_t)(p0 + p) * ldx + k] = f;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_geom_bwd(dst_layout L, const float* __restrict__ pos, const float* __restrict__ ada, float* __restrict__ d_ada,
+                                                   int64_t ada_ld, int dist_off, const float* __restrict__ means, const float* __restrict__ stds,
+                                                   const float* __restrict__ xs, const float* __restrict__ d2s, const float* __restrict__ g1, int64_t ld1,
+                                                   const float* __restrict__ g2, int64_t ld2, float* __restrict__ dms, float* __restrict__ dd2,
+                                                   float* __restrict__ dpos) {
+  __shared__ float red[4][130];
+  __shared__ float sp[29][3];
+  const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
+  for (int i = threadIdx.x; i < n * 3; i += 256) sp[i / 3][i % 3] = pos[(int64_t)(n0 + i / 3) * 3 + i % 3];
+  const float a = DST_GAUSS_A;
+  const float dsc = ada[(int64_t)m * ada_ld + dist_off];
+  float mu = 0.0f, sraw = 1.0f, sd = 1.0f;
+  if (lane > 0) { mu = means[lane - 1]; sraw = stds[lane - 1]; sd = fabsf(sraw) + 1e-5f; }
+  float dmu = 0.0f, dsd = 0.0f, a_dsc = 0.0f, a_dsh = 0.0f;
+  for (int p = wave; p < np; p += 4) {                       // one wave per pair, lane = feature
+    const float x = xs[p0 + p];
+    float g = g1[(int64_t)(p0 + p) * ld1 + lane];
+    if (g2) g += g2[(int64_t)(p0 + p) * ld2 + lane];
+    float dxl;
+    if (lane == 0) {
+      dxl = g;
+    } else {
+      const float u = (x - mu) / sd;
+      const float G = expf(-0.5f * (u * u)) / (a * sd);
+      const float t = g * G;
+      dxl = -t * u / sd;
+      dmu += t * u / sd;
+      dsd += t * (u * u - 1.0f) / sd;
+    }
+    const float dx = wave_sum(dxl);
+    if (lane == 0) {
+      const float d2 = d2s[p0 + p];
+      a_dsc += dx * d2;
+      a_dsh += dx;
+      dd2[p0 + p] = dx * (1.0f + dsc);
+    }
+  }
+  red[wave][lane] = dmu;
+  red[wave][64 + lane] = dsd * (sraw < 0.0f ? -1.0f : 1.0f);
+  if (lane == 0) { red[wave][128] = a_dsc; red[wave][129] = a_dsh; }
+  __syncthreads();
+  if (threadIdx.x < 128) dms[(int64_t)m * 128 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < 2)
+    d_ada[(int64_t)m * ada_ld + dist_off + threadIdx.x] = (red[0][128 + threadIdx.x] + red[1][128 + threadIdx.x]) + (red[2][128 + threadIdx.x] + red[3][128 + threadIdx.x]);
+  if (dpos) {                                              // d d2 / d pos, fixed partner order
+    for (int it = threadIdx.x; it < n * 3; it += 256) {
+      const int i = it / 3, c = it % 3;
+      float s = 0.0f;
+      for (int j = 0; j < n; ++j) {
+        if (j == i) continue;
+        const int p = p0 + (i < j ? pair_index(n, i, j) : pair_index(n, j, i));
+        s += 2.0f * dd2[p] * (sp[i][c] - sp[j][c]);
+      }
+      dpos[(int64_t)(n0 + i) * 3 + c] += s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ attention
+// logits / alpha scratch in LDS: [directed edge (2 * 406)][16 heads]
+__global__ __launch_bounds__(256) void k_attn_fwd(dst_layout L, const float* __restrict__ qkv, const float* __restrict__ te0, const float* __restrict__ te1,
+                                                   const int32_t* __restrict__ adj, float* __restrict__ out, float* __restrict__ alpha) {
+  __shared__ float lg[812 * 16];
+  __shared__ unsigned char pa[406], pb[406];
+  const int m = blockIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
+  fill_pair_tables(n, pa, pb);
+  __syncthreads();
+  // logits: directed edge d = 2p + dir; dir 0: source a -> target b, dir 1: source b -> target a
+  for (int it = threadIdx.x; it < np * 2 * 16; it += 256) {
+    const int d = it >> 4, hd = it & 15, p = d >> 1, dir = d & 1;
+    const int src = dir ? pb[p] : pa[p], tgt = dir ? pa[p] : pb[p];
+    float v;
+    if (hd < 2) {
+      v = ((adj[p0 + p] >> hd) & 1) ? 1.0f : -1e10f;
+    } else {
+      const int c0 = (hd - 2) * 18;
+      const float* q = qkv + (int64_t)(n0 + tgt) * 768 + c0;
+      const float* k = qkv + (int64_t)(n0 + src) * 768 + 256 + c0;
+      const float* e = te0 + (int64_t)(p0 + p) * 256 + c0;
+      float s = 0.0f;
+      for (int c = 0; c < 18; ++c) s += q[c] * k[c] * e[c];
+      v = s / 4.0f;
+    }
+    lg[it] = v;
+  }
+  __syncthreads();
+  // softmax over the sources of every (target, head)
+  for (int it = threadIdx.x; it < n * 16; it += 256) {
+    const int t = it >> 4, hd = it & 15;
+    float mx = -INFINITY;
+    for (int s = 0; s < n; ++s) {
+      if (s == t) continue;
+      const int d = s < t ? 2 * pair_index(n, s, t) : 2 * pair_index(n, t, s) + 1;   // s<t: a=s -> b=t (dir 0); s>t: b=s -> a=t (dir 1)
+      mx = fmaxf(mx, lg[d * 16 + hd]);
+    }
+    float den = 0.0f;
+    for (int s = 0; s < n; ++s) {
+      if (s == t) continue;
+      const int d = s < t ? 2 * pair_index(n, s, t) : 2 * pair_index(n, t, s) + 1;
+      const float ex = expf(lg[d * 16 + hd] - mx);
+      lg[d * 16 + hd] = ex;
+      den += ex;
+    }
+    den += 1e-16f;
+    for (int s = 0; s < n; ++s) {
+      if (s == t) continue;
+      const int d = s < t ? 2 * pair_index(n, s, t) : 2 * pair_index(n, t, s) + 1;
+      const float al = lg[d * 16 + hd] / den;
+      lg[d * 16 + hd] = al;
+      alpha[(int64_t)(2 * p0 + d) * 16 + hd] = al;
+    }
+  }
+  __syncthreads();
+  // aggregation onto the target, ascending source order
+  for (int it = threadIdx.x; it < n * 256; it += 256) {
+    const int t = it >> 8, col = it & 255, hd = col >> 4;
+    float s = 0.0f;
+    for (int sN = 0; sN < n; ++sN) {
+      if (sN == t) continue;
+      const int p = sN < t ? pair_index(n, sN, t) : pair_index(n, t, sN);
+      const int d = sN < t ? 2 * p : 2 * p + 1;
+      s += qkv[(int64_t)(n0 + sN) * 768 + 512 + col] * te1[(int64_t)(p0 + p) * 256 + col] * lg[d * 16 + hd];
+    }
+    out[(int64_t)(n0 + t) * 256 + col] = s;
+  }
+  if (n == 1)
+    for (int col = threadIdx.x; col < 256; col += 256) out[(int64_t)n0 * 256 + col] = 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_attn_bwd(dst_layout L, const float* __restrict__ qkv, const float* __restrict__ te0, const float* __restrict__ te1,
+                                                   const float* __restrict__ alpha, const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                   float* __restrict__ dte0, float* __restrict__ dte1) {
+  __shared__ float dl[812 * 16];      // d alpha, then d logit (the 64 kB static LDS limit leaves no room for a copy of alpha)
+  __shared__ unsigned char pa[406], pb[406];
+  const int m = blockIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
+  const float* __restrict__ al = alpha + (int64_t)2 * p0 * 16;
+  fill_pair_tables(n, pa, pb);
+  __syncthreads();
+  // d alpha[d, hd] = sum_c dout[tgt, hd, c] v[src, hd, c] te1[p, hd, c]
+  for (int it = threadIdx.x; it < np * 32; it += 256) {
+    const int d = it >> 4, hd = it & 15, p = d >> 1, dir = d & 1;
+    const int src = dir ? pb[p] : pa[p], tgt = dir ? pa[p] : pb[p];
+    const float* go = dout + (int64_t)(n0 + tgt) * 256 + hd * 16;
+    const float* v = qkv + (int64_t)(n0 + src) * 768 + 512 + hd * 16;
+    const float* e = te1 + (int64_t)(p0 + p) * 256 + hd * 16;
+    float s = 0.0f;
+    for (int c = 0; c < 16; ++c) s += go[c] * v[c] * e[c];
+    dl[it] = s;
+  }
+  __syncthreads();
+  // softmax backward per (target, head): dlogit = alpha (dalpha - sum alpha dalpha)
+  for (int it = threadIdx.x; it < n * 16; it += 256) {
+    const int t = it >> 4, hd = it & 15;
+    float dot = 0.0f;
+    for (int s = 0; s < n; ++s) {
+      if (s == t) continue;
+      const int d = s < t ? 2 * pair_index(n, s, t) : 2 * pair_index(n, t, s) + 1;
+      dot += al[d * 16 + hd] * dl[d * 16 + hd];
+    }
+    for (int s = 0; s < n; ++s) {
+      if (s == t) continue;
+      const int d = s < t ? 2 * pair_index(n, s, t) : 2 * pair_index(n, t, s) + 1;
+      dl[d * 16 + hd] = al[d * 16 + hd] * (dl[d * 16 + hd] - dot);
+    }
+  }
+  __syncthreads();
+  // node-side gradients: thread per (node, column of the 768-wide q|k|v row)
+  for (int it = threadIdx.x; it < n * 768; it += 256) {
+    const int i = it / 768, col = it % 768;
+    float s = 0.0f;
+    if (col < 252) {                                   // dq[i]: i is the target
+      const int hd = col / 18 + 2;
+      for (int j = 0; j < n; ++j) {
+        if (j == i) continue;
+        const int p = j < i ? pair_index(n, j, i) : pair_index(n, i, j);
+        const int d = j < i ? 2 * p : 2 * p + 1;       // source j -> target i
+        s += dl[d * 16 + hd] * qkv[(int64_t)(n0 + j) * 768 + 256 + col] * te0[(int64_t)(p0 + p) * 256 + col];
+      }
+      s *= 0.25f;
+    } else if (col >= 256 && col < 508) {              // dk[i]: i is the source
+      const int c = col - 256, hd = c / 18 + 2;
+      for (int t = 0; t < n; ++t) {
+        if (t == i) continue;
+        const int p = i < t ? pair_index(n, i, t) : pair_index(n, t, i);
+        const int d = i < t ? 2 * p : 2 * p + 1;       // source i -> target t
+        s += dl[d * 16 + hd] * qkv[(int64_t)(n0 + t) * 768 + c] * te0[(int64_t)(p0 + p) * 256 + c];
+      }
+      s *= 0.25f;
+    } else if (col >= 512) {                           // dv[i]: i is the source
+      const int c = col - 512, hd = c >> 4;
+      for (int t = 0; t < n; ++t) {
+        if (t == i) continue;
+        const int p = i < t ? pair_index(n, i, t) : pair_index(n, t, i);
+        const int d = i < t ? 2 * p : 2 * p + 1;
+        s += dout[(int64_t)(n0 + t) * 256 + c] * te1[(int64_t)(p0 + p) * 256 + c] * al[d * 16 + hd];
+      }
+    }
+    dqkv[(int64_t)(n0 + i) * 768 + col] = s;
+  }
+  // pair-side gradients (both directions of a pair)
+  for (int it = threadIdx.x; it < np * 256; it += 256) {
+    const int p = it >> 8, col = it & 255;
+    const int a = pa[p], b = pb[p];
+    {
+      const int hd = col >> 4;
+      const float va = qkv[(int64_t)(n0 + a) * 768 + 512 + col], vb = qkv[(int64_t)(n0 + b) * 768 + 512 + col];
+      dte1[(int64_t)(p0 + p) * 256 + col] = dout[(int64_t)(n0 + b) * 256 + col] * va * al[(2 * p) * 16 + hd] +
+                                            dout[(int64_t)(n0 + a) * 256 + col] * vb * al[(2 * p + 1) * 16 + hd];
+    }
+    float g0 = 0.0f;
+    if (col < 252) {
+      const int hd = col / 18 + 2;
+      const float qa = qkv[(int64_t)(n0 + a) * 768 + col], qb = qkv[(int64_t)(n0 + b) * 768 + col];
+      const float ka = qkv[(int64_t)(n0 + a) * 768 + 256 + col], kb = qkv[(int64_t)(n0 + b) * 768 + 256 + col];
+      g0 = 0.25f * (dl[(2 * p) * 16 + hd] * qb * ka + dl[(2 * p + 1) * 16 + hd] * qa * kb);
+    }
+    dte0[(int64_t)(p0 + p) * 256 + col] = g0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ gathers
+__global__ __launch_bounds__(256) void k_pair_sum_fwd(dst_layout L, const float* __restrict__ u, int C, const float* __restrict__ bias, float* __restrict__ s) {
+  __shared__ unsigned char pa[406], pb[406];
+  const int m = blockIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
+  fill_pair_tables(n, pa, pb);
+  __syncthreads();
+  for (int it = threadIdx.x; it < np * C; it += 256) {
+    const int p = it / C, c = it % C;
+    s[(int64_t)(p0 + p) * C + c] = u[(int64_t)(n0 + pa[p]) * C + c] + u[(int64_t)(n0 + pb[p]) * C + c] + (bias ? bias[c] : 0.0f);
+  }
+}
+__global__ __launch_bounds__(256) void k_pair_sum_bwd(dst_layout L, const float* __restrict__ ds, int C, float* __restrict__ du, int accumulate) {
+  const int m = blockIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m];
+  for (int it = threadIdx.x; it < n * C; it += 256) {
+    const int i = it / C, c = it % C;
+    float s = 0.0f;
+    for (int j = 0; j < n; ++j) {
+      if (j == i) continue;
+      const int p = i < j ? pair_index(n, i, j) : pair_index(n, j, i);
+      s += ds[(int64_t)(p0 + p) * C + c];
+    }
+    float* o = du + (int64_t)(n0 + i) * C + c;
+    *o = accumulate ? *o + s : s;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_zbuild_fwd(dst_layout L, const float* __restrict__ ac, const float* __restrict__ ed, float* __restrict__ z) {
+  __shared__ unsigned char pa[406], pb[406];
+  const int m = blockIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
+  fill_pair_tables(n, pa, pb);
+  __syncthreads();
+  for (int it = threadIdx.x; it < np * 2 * 256; it += 256) {
+    const int d = it >> 8, c = it & 255, p = d >> 1, dir = d & 1;
+    const int row = dir ? pb[p] : pa[p], col = dir ? pa[p] : pb[p];
+    z[(int64_t)(2 * p0 + d) * 256 + c] = ac[(int64_t)(n0 + row) * 512 + c] + ac[(int64_t)(n0 + col) * 512 + 256 + c] + ed[(int64_t)(p0 + p) * 256 + c];
+  }
+}
+__global__ __launch_bounds__(256) void k_zbuild_bwd(dst_layout L, const float* __restrict__ dz, float* __restrict__ dac, float* __restrict__ ded) {
+  const int m = blockIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
+  for (int it = threadIdx.x; it < np * 256; it += 256) {
+    const int p = it >> 8, c = it & 255;
+    ded[(int64_t)(p0 + p) * 256 + c] = dz[(int64_t)(2 * (p0 + p)) * 256 + c] + dz[(int64_t)(2 * (p0 + p) + 1) * 256 + c];
+  }
+  for (int it = threadIdx.x; it < n * 512; it += 256) {
+    const int i = it >> 9, c = it & 511, as_col = c >> 8, cc = c & 255;
+    float s = 0.0f;
+    for (int j = 0; j < n; ++j) {
+      if (j == i) continue;
+      const int p = i < j ? pair_index(n, i, j) : pair_index(n, j, i);
+      // directed edge with row = i (as_col 0) or col = i (as_col 1): dir 0 has row = lo, dir 1 has row = hi
+      const int dir = (as_col == 0) ? (i < j ? 0 : 1) : (i < j ? 1 : 0);
+      s += dz[(int64_t)(2 * (p0 + p) + dir) * 256 + cc];
+    }
+    dac[(int64_t)(n0 + i) * 512 + c] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ coordinates
+__global__ __launch_bounds__(256) void k_coord_fwd(dst_layout L, const float* __restrict__ pos, const float* __restrict__ c2, const int32_t* __restrict__ adj,
+                                                    const float* __restrict__ coord_scale, float* __restrict__ pos_out) {
+  __shared__ float sp[29][3], sn[29][3];
+  const int m = blockIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m];
+  for (int i = threadIdx.x; i < n * 3; i += 256) sp[i / 3][i % 3] = pos[(int64_t)(n0 + i / 3) * 3 + i % 3];
+  __syncthreads();
+  const float scale = coord_scale[0];
+  for (int it = threadIdx.x; it < n * 3; it += 256) {
+    const int r = it / 3, comp = it % 3;
+    float agg = 0.0f;
+    for (int c = 0; c < n; ++c) {                         // ascending col = the order of the reference's scatter
+      if (c == r) continue;
+      const int p = r < c ? pair_index(n, r, c) : pair_index(n, c, r);
+      const int d = 2 * (p0 + p) + (r < c ? 0 : 1);       // directed edge (row r, col c)
+      const float dx = sp[r][0] - sp[c][0], dy = sp[r][1] - sp[c][1], dz = sp[r][2] - sp[c][2];
+      const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);
+      const int bits = adj[p0 + p];
+      const float inv = (tanhf(c2[(int64_t)d * 3]) + ((bits & 1) ? tanhf(c2[(int64_t)d * 3 + 1]) : 0.0f) +
+                         ((bits & 2) ? tanhf(c2[(int64_t)d * 3 + 2]) : 0.0f)) / 3.0f;
+      const float df = comp == 0 ? dx : (comp == 1 ? dy : dz);
+      agg += (df / nrm * scale) * inv;
+    }
+    sn[r][comp] = sp[r][comp] + agg;
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < n * 3; it += 256) {
+    const int comp = it % 3;
+    float mean = 0.0f;
+    for (int i = 0; i < n; ++i) mean += sn[i][comp];
+    mean /= (float)n;
+    pos_out[(int64_t)(n0 + it / 3) * 3 + comp] = sn[it / 3][comp] - mean;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_coord_bwd(dst_layout L, const float* __restrict__ pos, const float* __restrict__ c2, const int32_t* __restrict__ adj,
+                                                    const float* __restrict__ coord_scale, const float* __restrict__ dpos_out, float* __restrict__ dpos_in,
+                                                    float* __restrict__ dc2, float* __restrict__ dscale_part) {
+  __shared__ float sp[29][3], g[29][3];
+  __shared__ float dcd[812][3];                          // d coord_diff per directed edge
+  __shared__ float red[4];
+  __shared__ unsigned char pa[406], pb[406];
+  const int m = blockIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
+  fill_pair_tables(n, pa, pb);
+  for (int i = threadIdx.x; i < n * 3; i += 256) sp[i / 3][i % 3] = pos[(int64_t)(n0 + i / 3) * 3 + i % 3];
+  __syncthreads();
+  // centre-of-mass projection of the incoming gradient
+  for (int it = threadIdx.x; it < n * 3; it += 256) {
+    const int comp = it % 3;
+    float mean = 0.0f;
+    for (int i = 0; i < n; ++i) mean += dpos_out[(int64_t)(n0 + i) * 3 + comp];
+    mean /= (float)n;
+    g[it / 3][comp] = dpos_out[(int64_t)(n0 + it / 3) * 3 + comp] - mean;
+  }
+  __syncthreads();
+  const float scale = coord_scale[0];
+  float dscale = 0.0f;
+  for (int d = threadIdx.x; d < np * 2; d += 256) {       // thread per directed edge (row r, col c)
+    const int p = d >> 1, dir = d & 1;
+    const int r = dir ? pb[p] : pa[p], c = dir ? pa[p] : pb[p];
+    const float dx = sp[r][0] - sp[c][0], dy = sp[r][1] - sp[c][1], dz = sp[r][2] - sp[c][2];
+    const float raw = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float nrm = fmaxf(raw, 1e-8f);
+    const float ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
+    const int bits = adj[p0 + p];
+    const int64_t e = (int64_t)(2 * p0 + d) * 3;
+    const float t0 = tanhf(c2[e]), t1 = tanhf(c2[e + 1]), t2 = tanhf(c2[e + 2]);
+    const float inv = (t0 + ((bits & 1) ? t1 : 0.0f) + ((bits & 2) ? t2 : 0.0f)) / 3.0f;
+    const float gx = g[r][0], gy = g[r][1], gz = g[r][2];   // d trans = d pos_new[row]
+    const float gu = gx * ux + gy * uy + gz * uz;
+    dscale += gu * inv;
+    const float dinv = gu * scale;
+    dc2[e] = dinv / 3.0f * (1.0f - t0 * t0);
+    dc2[e + 1] = (bits & 1) ? dinv / 3.0f * (1.0f - t1 * t1) : 0.0f;
+    dc2[e + 2] = (bits & 2) ? dinv / 3.0f * (1.0f - t2 * t2) : 0.0f;
+    // d unit = g * scale * inv ; d diff = (d unit - u (u . d unit)) / nrm   (zero when the norm is clamped)
+    const float k = scale * inv;
+    float ex = 0.0f, ey = 0.0f, ez = 0.0f;
+    if (raw > 1e-8f) {
+      ex = k * (gx - ux * gu) / nrm;
+      ey = k * (gy - uy * gu) / nrm;
+      ez = k * (gz - uz * gu) / nrm;
+    } else {
+      ex = k * gx / nrm; ey = k * gy / nrm; ez = k * gz / nrm;   // clamp(min) passes the gradient of diff / const
+    }
+    dcd[d][0] = ex; dcd[d][1] = ey; dcd[d][2] = ez;
+  }
+  dscale = wave_sum(dscale);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dscale;
+  __syncthreads();
+  if (threadIdx.x == 0) dscale_part[m] = (red[0] + red[1]) + (red[2] + red[3]);
+  for (int it = threadIdx.x; it < n * 3; it += 256) {
+    const int i = it / 3, comp = it % 3;
+    float s = g[i][comp];                                  // identity path pos -> pos_new
+    for (int j = 0; j < n; ++j) {
+      if (j == i) continue;
+      const int p = i < j ? pair_index(n, i, j) : pair_index(n, j, i);
+      const int d_row = 2 * p + (i < j ? 0 : 1);           // edge (row i, col j): + d diff
+      const int d_col = 2 * p + (i < j ? 1 : 0);           // edge (row j, col i): - d diff
+      s += dcd[d_row][comp] - dcd[d_col][comp];
+    }
+    dpos_in[(int64_t)(n0 + i) * 3 + comp] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ time features
+__global__ void k_time_feat_fwd(const float* __restrict__ nl, const float* __restrict__ w, int B, float* __restrict__ f) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float x = nl[b];
+  f[(int64_t)b * 17] = x;
+  for (int i = 0; i < 8; ++i) {
+    const float fr = ((x * w[i]) * 2.0f) * 3.14159265358979323846f;
+    f[(int64_t)b * 17 + 1 + i] = sinf(fr);
+    f[(int64_t)b * 17 + 9 + i] = cosf(fr);
+  }
+}
+__global__ __launch_bounds__(64) void k_time_feat_bwd(const float* __restrict__ nl, const float* __restrict__ w, const float* __restrict__ df, int B,
+                                                       float* __restrict__ dw) {
+  const int i = blockIdx.x;                                // one wave per frequency
+  float s = 0.0f;
+  for (int b = threadIdx.x; b < B; b += 64) {
+    const float x = nl[b];
+    const float fr = ((x * w[i]) * 2.0f) * 3.14159265358979323846f;
+    s += (df[(int64_t)b * 17 + 1 + i] * cosf(fr) - df[(int64_t)b * 17 + 9 + i] * sinf(fr)) * (x * 2.0f * 3.14159265358979323846f);
+  }
+  s = wave_sum(s);
+  if (threadIdx.x == 0) dw[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ loss
+__global__ __launch_bounds__(256) void k_loss(dst_layout L, const float* __restrict__ pos, const float* __restrict__ feat, const float* __restrict__ edge,
+                                               const float* __restrict__ tpos, const float* __restrict__ tfeat, const float* __restrict__ tedge,
+                                               const float* __restrict__ wm, float w_pos, float w_type, float w_edge, float* __restrict__ loss_m,
+                                               float* __restrict__ dpos, float* __restrict__ dfeat, float* __restrict__ dedge) {
+  __shared__ float red[3][4];
+  const int m = blockIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
+  const float w = wm[m];
+  float lp = 0.0f, lt = 0.0f, le = 0.0f;
+  for (int it = threadIdx.x; it < n * 3; it += 256) {
+    const float d = pos[(int64_t)n0 * 3 + it] - tpos[(int64_t)n0 * 3 + it];
+    lp += d * d;
+    dpos[(int64_t)n0 * 3 + it] = w * w_pos * (2.0f / 3.0f) * d;
+  }
+  for (int it = threadIdx.x; it < n * 6; it += 256) {
+    const float d = feat[(int64_t)n0 * 6 + it] - tfeat[(int64_t)n0 * 6 + it];
+    lt += d * d;
+    dfeat[(int64_t)n0 * 6 + it] = w * w_type * (2.0f / 6.0f) * d;
+  }
+  for (int it = threadIdx.x; it < np * 2; it += 256) {
+    const float d = edge[(int64_t)p0 * 2 + it] - tedge[(int64_t)p0 * 2 + it];
+    le += d * d;                                            // every pair sits in two cells of the dense edge tensor
+    dedge[(int64_t)p0 * 2 + it] = w * w_edge * 2.0f * d;    // 2 cells * (1/2 channel mean) * 2 d
+  }
+  lp = wave_sum(lp); lt = wave_sum(lt); le = wave_sum(le);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lp; red[1][threadIdx.x >> 6] = lt; red[2][threadIdx.x >> 6] = le; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const float b = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const float c = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    loss_m[m] = w * (w_pos * a / 3.0f + w_type * b / 6.0f + w_edge * c);     // c: 2 cells * mean over 2 channels = 1
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ noising / Kabsch
+__global__ __launch_bounds__(256) void k_noising(dst_layout L, const float* __restrict__ alpha, const float* __restrict__ sigma, const float* __restrict__ x,
+                                                  const float* __restrict__ raw, float* __restrict__ z, const float* __restrict__ ex,
+                                                  const float* __restrict__ eraw, float* __restrict__ ez) {
+  __shared__ float mean[3];
+  const int m = blockIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
+  const float a = alpha[m], s = sigma[m];
+  if (threadIdx.x < 3) {
+    float t = 0.0f;
+    for (int i = 0; i < n; ++i) t += raw[(int64_t)(n0 + i) * 9 + threadIdx.x];
+    mean[threadIdx.x] = t / (float)n;
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < n * 9; it += 256) {
+    const int c = it % 9;
+    float e = raw[(int64_t)n0 * 9 + it];
+    if (c < 3) e -= mean[c];
+    z[(int64_t)n0 * 9 + it] = a * x[(int64_t)n0 * 9 + it] + s * e;
+  }
+  for (int it = threadIdx.x; it < np * 2; it += 256) ez[(int64_t)p0 * 2 + it] = a * ex[(int64_t)p0 * 2 + it] + s * eraw[(int64_t)p0 * 2 + it];
+}
+
+// 3x3 SVD by one-sided Jacobi on columns (fp64): A V = U S.
+__device__ void svd3(const double A[3][3], double U[3][3], double S[3], double V[3][3]) {
+  double W[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { W[i][j] = A[i][j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double al = 0, be = 0, ga = 0;
+        for (int i = 0; i < 3; ++i) { al += W[i][p] * W[i][p]; be += W[i][q] * W[i][q]; ga += W[i][p] * W[i][q]; }
+        off = fmax(off, fabs(ga) / (sqrt(al * be) + 1e-300));
+        if (fabs(ga) < 1e-300) continue;
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < 3; ++i) {
+          const double wp = W[i][p], wq = W[i][q];
+          W[i][p] = c * wp - s * wq; W[i][q] = s * wp + c * wq;
+          const double vp = V[i][p], vq = V[i][q];
+          V[i][p] = c * vp - s * vq; V[i][q] = s * vp + c * vq;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  for (int j = 0; j < 3; ++j) {
+    S[j] = sqrt(W[0][j] * W[0][j] + W[1][j] * W[1][j] + W[2][j] * W[2][j]);
+    for (int i = 0; i < 3; ++i) U[i][j] = S[j] > 1e-300 ? W[i][j] / S[j] : 0.0;
+  }
+  // sort singular values descending (the sign correction of Kabsch acts on the smallest one)
+  for (int a = 0; a < 2; ++a)
+    for (int b = a + 1; b < 3; ++b)
+      if (S[b] > S[a]) {
+        const double ts = S[a]; S[a] = S[b]; S[b] = ts;
+        for (int i = 0; i < 3; ++i) {
+          const double tu = U[i][a]; U[i][a] = U[i][b]; U[i][b] = tu;
+          const double tv = V[i][a]; V[i][a] = V[i][b]; V[i][b] = tv;
+        }
+      }
+  // complete a rank-deficient U to an orthonormal basis (columns with zero singular value)
+  if (S[2] <= 1e-300 * 0 + 1e-14 * (S[0] + 1e-300)) {
+    if (S[1] > 1e-14 * (S[0] + 1e-300)) {
+      U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+      U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+      U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_kabsch(dst_layout L, const float* __restrict__ pred, int64_t ldp, const float* __restrict__ tar, int64_t ldt,
+                                                float* __restrict__ rot, float* __restrict__ aligned) {
+  __shared__ float R[9];
+  const int m = blockIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0;
+  if (threadIdx.x == 0) {
+    double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, U[3][3], S[3], V[3][3];
+    for (int k = 0; k < n; ++k)
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[i][j] += (double)pred[(int64_t)(n0 + k) * ldp + i] * (double)tar[(int64_t)(n0 + k) * ldt + j];
+    svd3(A, U, S, V);
+    const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                       A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+    const double sg = det > 0 ? 1.0 : (det < 0 ? -1.0 : 0.0);
+    for (int i = 0; i < 3; ++i)
+      for (int l = 0; l < 3; ++l) R[i * 3 + l] = (float)(U[i][0] * V[l][0] + U[i][1] * V[l][1] + sg * U[i][2] * V[l][2]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) rot[(int64_t)m * 9 + threadIdx.x] = R[threadIdx.x];
+  // aligned[j, k] = sum_i rot[k, i] tar[j, i]   (einsum "...ki, ...ji -> ...jk", losses.py:420)
+  for (int it = threadIdx.x; it < n * 3; it += 64) {
+    const int j = it / 3, k = it % 3;
+    const float* t = tar + (int64_t)(n0 + j) * ldt;
+    aligned[(int64_t)(n0 + j) * 3 + k] = R[k * 3] * t[0] + R[k * 3 + 1] * t[1] + R[k * 3 + 2] * t[2];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ BatchNorm (training)
+// stage 1: per-chunk column sums of x and x^2 in fp64-free two-pass form: first the mean, then the centred second moment.
+__global__ __launch_bounds__(256) void k_bn_sum(const float* __restrict__ x, int R, int C, const float* __restrict__ mean, float* __restrict__ partial,
+                                                 int rows_per_chunk) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+  float s = 0.0f;
+  if (col < C) {
+    const float mu = mean ? mean[col] : 0.0f;
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float v = x[(int64_t)r * C + col];
+      s += mean ? (v - mu) * (v - mu) : v;
+    }
+  }
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < C) partial[(int64_t)blockIdx.y * C + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void k_bn_finish_mean(const float* __restrict__ partial, int chunks, int C, int R, float* __restrict__ stats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.0f;
+  for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * C + c];
+  stats[c] = s / (float)R;
+}
+__global__ void k_bn_finish_var(const float* __restrict__ partial, int chunks, int C, int R, float eps, float* __restrict__ stats,
+                                float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.0f;
+  for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * C + c];
+  const float var = s / (float)R;
+  stats[C + c] = 1.0f / sqrtf(var + eps);
+  if (running_mean) {
+    running_mean[c] = 0.9f * running_mean[c] + 0.1f * stats[c];
+    running_var[c] = 0.9f * running_var[c] + 0.1f * (s / (float)(R - 1));
+  }
+}
+__global__ void k_bn_apply(const float* __restrict__ x, int64_t total, int C, const float* __restrict__ stats, const float* __restrict__ gamma,
+                           const float* __restrict__ beta, float* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  y[i] = (x[i] - stats[c]) * stats[C + c] * gamma[c] + beta[c];
+}
+// backward stage 1: per-chunk sums of dy and dy * xhat
+__global__ __launch_bounds__(256) void k_bn_bwd_sum(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats, int R, int C,
+                                                     float* __restrict__ partial, int rows_per_chunk, int chunks) {
+  __shared__ float red[2][4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+  float s1 = 0.0f, s2 = 0.0f;
+  if (col < C) {
+    const float mu = stats[col], rs = stats[C + col];
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float g = dy[(int64_t)r * C + col];
+      s1 += g;
+      s2 += g * ((x[(int64_t)r * C + col] - mu) * rs);
+    }
+  }
+  red[0][rl][threadIdx.x & 63] = s1;
+  red[1][rl][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (rl == 0 && col < C) {
+    const int t = threadIdx.x;
+    partial[(int64_t)blockIdx.y * C + col] = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
+    partial[(int64_t)(chunks + blockIdx.y) * C + col] = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+  }
+}
+__global__ void k_bn_bwd_finish(const float* __restrict__ partial, int chunks, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.0f, s2 = 0.0f;
+  for (int k = 0; k < chunks; ++k) { s1 += partial[(int64_t)k * C + c]; s2 += partial[(int64_t)(chunks + k) * C + c]; }
+  dbeta[c] = s1;
+  dgamma[c] = s2;
+}
+__global__ void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, int64_t total, int C, int R, const float* __restrict__ stats,
+                               const float* __restrict__ gamma, const float* __restrict__ dgamma, const float* __restrict__ dbeta, float* __restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const float xh = (x[i] - stats[c]) * stats[C + c];
+  dx[i] = gamma[c] * stats[C + c] * (dy[i] - dbeta[c] / (float)R - xh * dgamma[c] / (float)R);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ SpecFormer attention
+// one workgroup per (batch, head, block of 4 query rows): dk = 8
+__global__ __launch_bounds__(256) void k_spec_attn_fwd(const float* __restrict__ qkv, const float* __restrict__ prev, float* __restrict__ scores,
+                                                        float* __restrict__ attn, float* __restrict__ out, int B, int Lq, int H, int dk, float scale) {
+  extern __shared__ float sm[];                           // K [L][dk], V [L][dk]
+  float* Ks = sm;
+  float* Vs = sm + (size_t)Lq * dk;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int D = H * dk;
+  for (int i = threadIdx.x; i < Lq * dk; i += 256) {
+    const int l = i / dk, c = i % dk;
+    Ks[i] = qkv[((int64_t)b * Lq + l) * 3 * D + D + h * dk + c];
+    Vs[i] = qkv[((int64_t)b * Lq + l) * 3 * D + 2 * D + h * dk + c];
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int qi = blockIdx.y * 4 + wave; qi < Lq; qi += gridDim.y * 4) {
+    float q[16];
+    for (int c = 0; c < dk; ++c) q[c] = qkv[((int64_t)b * Lq + qi) * 3 * D + h * dk + c];
+    const int64_t rowbase = (((int64_t)b * H + h) * Lq + qi) * Lq;
+    float mx = -INFINITY;
+    for (int k = lane; k < Lq; k += 64) {
+      float s = 0.0f;
+      for (int c = 0; c < dk; ++c) s += q[c] * Ks[k * dk + c];
+      s *= scale;
+      if (prev) s += prev[rowbase + k];
+      scores[rowbase + k] = s;
+      mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float den = 0.0f;
+    for (int k = lane; k < Lq; k += 64) {
+      const float e = expf(scores[rowbase + k] - mx);
+      attn[rowbase + k] = e;
+      den += e;
+    }
+    den = wave_sum(den);
+    float acc[16];
+    for (int c = 0; c < dk; ++c) acc[c] = 0.0f;
+    for (int k = lane; k < Lq; k += 64) {
+      const float a = attn[rowbase + k] / den;
+      attn[rowbase + k] = a;
+      for (int c = 0; c < dk; ++c) acc[c] += a * Vs[k * dk + c];
+    }
+    for (int c = 0; c < dk; ++c) {
+      const float s = wave_sum(acc[c]);
+      if (lane == 0) out[((int64_t)b * Lq + qi) * D + h * dk + c] = s;
+    }
+  }
+}
+
+// backward, pass 1 (per query row): dV partial is handled in pass 2; here dS = attn * (dA - sum attn dA) (+ dscores_in), dq.
+__global__ __launch_bounds__(256) void k_spec_attn_bwd_q(const float* __restrict__ qkv, const float* __restrict__ attn, const float* __restrict__ dout,
+                                                          const float* __restrict__ dscores_in, float* __restrict__ dqkv, float* __restrict__ dscores,
+                                                          int B, int Lq, int H, int dk, float scale) {
+  extern __shared__ float sm[];
+  float* Ks = sm;
+  float* Vs = sm + (size_t)Lq * dk;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int D = H * dk;
+  for (int i = threadIdx.x; i < Lq * dk; i += 256) {
+    const int l = i / dk, c = i % dk;
+    Ks[i] = qkv[((int64_t)b * Lq + l) * 3 * D + D + h * dk + c];
+    Vs[i] = qkv[((int64_t)b * Lq + l) * 3 * D + 2 * D + h * dk + c];
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int qi = blockIdx.y * 4 + wave; qi < Lq; qi += gridDim.y * 4) {
+    float go[16];
+    for (int c = 0; c < dk; ++c) go[c] = dout[((int64_t)b * Lq + qi) * D + h * dk + c];
+    const int64_t rowbase = (((int64_t)b * H + h) * Lq + qi) * Lq;
+    float dot = 0.0f;
+    for (int k = lane; k < Lq; k += 64) {
+      float da = 0.0f;
+      for (int c = 0; c < dk; ++c) da += go[c] * Vs[k * dk + c];
+      dscores[rowbase + k] = da;                           // d attn, for now
+      dot += attn[rowbase + k] * da;
+    }
+    dot = wave_sum(dot);
+    float dq[16];
+    for (int c = 0; c < dk; ++c) dq[c] = 0.0f;
+    for (int k = lane; k < Lq; k += 64) {
+      float ds = attn[rowbase + k] * (dscores[rowbase + k] - dot);
+      if (dscores_in) ds += dscores_in[rowbase + k];
+      dscores[rowbase + k] = ds;
+      for (int c = 0; c < dk; ++c) dq[c] += ds * Ks[k * dk + c];
+    }
+    for (int c = 0; c < dk; ++c) {
+      const float s = wave_sum(dq[c]) * scale;
+      if (lane == 0) dqkv[((int64_t)b * Lq + qi) * 3 * D + h * dk + c] = s;
+    }
+  }
+}
+// backward, pass 2 (per key row): dk[k] = scale * sum_q dS[q,k] q[q], dv[k] = sum_q attn[q,k] dout[q]
+__global__ __launch_bounds__(256) void k_spec_attn_bwd_kv(const float* __restrict__ qkv, const float* __restrict__ attn, const float* __restrict__ dout,
+                                                           const float* __restrict__ dscores, float* __restrict__ dqkv, int B, int Lq, int H, int dk,
+                                                           float scale) {
+  extern __shared__ float sm[];
+  float* Qs = sm;
+  float* Gs = sm + (size_t)Lq * dk;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int D = H * dk;
+  for (int i = threadIdx.x; i < Lq * dk; i += 256) {
+    const int l = i / dk, c = i % dk;
+    Qs[i] = qkv[((int64_t)b * Lq + l) * 3 * D + h * dk + c];
+    Gs[i] = dout[((int64_t)b * Lq + l) * D + h * dk + c];
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t base = ((int64_t)b * H + h) * Lq * Lq;
+  for (int ki = blockIdx.y * 4 + wave; ki < Lq; ki += gridDim.y * 4) {
+    float dkk[16], dvv[16];
+    for (int c = 0; c < dk; ++c) { dkk[c] = 0.0f; dvv[c] = 0.0f; }
+    for (int q = lane; q < Lq; q += 64) {
+      const float ds = dscores[base + (int64_t)q * Lq + ki], a = attn[base + (int64_t)q * Lq + ki];
+      for (int c = 0; c < dk; ++c) { dkk[c] += ds * Qs[q * dk + c]; dvv[c] += a * Gs[q * dk + c]; }
+    }
+    for (int c = 0; c < dk; ++c) {
+      const float s1 = wave_sum(dkk[c]) * scale, s2 = wave_sum(dvv[c]);
+      if (lane == 0) {
+        dqkv[((int64_t)b * Lq + ki) * 3 * D + D + h * dk + c] = s1;
+        dqkv[((int64_t)b * Lq + ki) * 3 * D + 2 * D + h * dk + c] = s2;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ LayerNorm (affine)
+__global__ __launch_bounds__(64) void k_ln_affine_fwd(const float* __restrict__ x, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, float* __restrict__ y, float* __restrict__ stats) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  float s = 0.0f;
+  for (int c = lane; c < C; c += 64) s += x[(int64_t)r * C + c];
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.0f;
+  for (int c = lane; c < C; c += 64) { const float d = x[(int64_t)r * C + c] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  for (int c = lane; c < C; c += 64) y[(int64_t)r * C + c] = (x[(int64_t)r * C + c] - mean) * rstd * gamma[c] + beta[c];
+  if (lane == 0) { stats[(int64_t)r * 2] = mean; stats[(int64_t)r * 2 + 1] = rstd; }
+}
+__global__ __launch_bounds__(64) void k_ln_affine_bwd(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats, int C,
+                                                       const float* __restrict__ gamma, float* __restrict__ dx) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const float mean = stats[(int64_t)r * 2], rstd = stats[(int64_t)r * 2 + 1];
+  float s1 = 0.0f, s2 = 0.0f;
+  for (int c = lane; c < C; c += 64) {
+    const float g = dy[(int64_t)r * C + c] * gamma[c], xh = (x[(int64_t)r * C + c] - mean) * rstd;
+    s1 += g;
+    s2 += g * xh;
+  }
+  const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+  for (int c = lane; c < C; c += 64) {
+    const float g = dy[(int64_t)r * C + c] * gamma[c], xh = (x[(int64_t)r * C + c] - mean) * rstd;
+    dx[(int64_t)r * C + c] = rstd * (g - m1 - xh * m2);
+  }
+}
+__global__ void k_ln_affine_bwd_params(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats, int R, int C,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.0f, s2 = 0.0f;
+  for (int r = 0; r < R; ++r) {
+    const float g = dy[(int64_t)r * C + c];
+    s1 += g;
+    s2 += g * ((x[(int64_t)r * C + c] - stats[(int64_t)r * 2]) * stats[(int64_t)r * 2 + 1]);
+  }
+  dbeta[c] = s1;
+  dgamma[c] = s2;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ optimizer
+__global__ void k_adamw_ema(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, float* __restrict__ vmax,
+                            float* __restrict__ ema, int64_t n, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2,
+                            float clip, float ema_omd) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float grad = g[i] * clip;
+  float w = p[i];
+  w *= (1.0f - lr * wd);                                    // decoupled weight decay (torch.optim.AdamW)
+  const float mi = beta1 * m[i] + (1.0f - beta1) * grad;
+  const float vi = beta2 * v[i] + (1.0f - beta2) * grad * grad;
+  const float vm = fmaxf(vmax[i], vi);                      // amsgrad
+  m[i] = mi; v[i] = vi; vmax[i] = vm;
+  const float denom = sqrtf(vm) / sqrtf(bc2) + eps;
+  w -= (lr / bc1) * (mi / denom);
+  p[i] = w;
+  if (ema) { const float s = ema[i]; ema[i] = s - ema_omd * (s - w); }
+}
+
+inline dim3 grid1d(int64_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+}  // namespace
+
+// ====================================================================================================================== C-ABI
+extern "C" {
+
+int dst_gemm(const dst_gemm_args* a, void* stream) {
+  if (!a || !a->C || a->M < 0 || a->N < 0 || a->K < 0 || (a->K > 0 && (!a->A || !a->B))) return DS_ERR_ARG;
+  if (a->M == 0 || a->N == 0) return DS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dst_gemm_args g = *a;
+  const int tm = (g.M + 63) / 64, tn = (g.N + 63) / 64;
+  const int64_t tiles = (int64_t)tm * tn;
+  int splits = 1;
+  if (g.K >= 1024 && tiles < 512 && g.partial) {
+    splits = (int)(1024 / tiles);
+    const int max_by_k = (g.K + 255) / 256;
+    if (splits > max_by_k) splits = max_by_k;
+    const int64_t cap = g.partial_cap / ((int64_t)g.M * g.N);
+    if (splits > cap) splits = (int)cap;
+    if (splits < 1) splits = 1;
+  }
+  int kchunk = ((g.K + splits - 1) / splits + 15) / 16 * 16;
+  if (kchunk < 16) kchunk = 16;
+  splits = g.K > 0 ? (g.K + kchunk - 1) / kchunk : 1;
+  hipLaunchKernelGGL(k_tr_gemm, dim3(tn, tm, splits), dim3(256), 0, s, g, splits, kchunk);
+  if (splits > 1) hipLaunchKernelGGL(k_tr_gemm_reduce, grid1d((int64_t)g.M * g.N), dim3(256), 0, s, g, splits);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_colsum(const float* X, int64_t ld, int32_t R, int32_t C, float* out, int32_t accumulate, float* scratch, int64_t scratch_cap,
+               void* stream) {
+  if (!X || !out || !scratch || R < 0 || C <= 0) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int chunks = (R + 511) / 512;
+  if (chunks < 1) chunks = 1;
+  if (chunks > 1024) chunks = 1024;
+  if ((int64_t)chunks * C > scratch_cap) chunks = (int)(scratch_cap / C);
+  if (chunks < 1) return DS_ERR_ARG;
+  const int rpc = (R + chunks - 1) / chunks > 0 ? (R + chunks - 1) / chunks : 1;
+  hipLaunchKernelGGL(k_colsum_partial, dim3((C + 63) / 64, chunks), dim3(256), 0, s, X, ld, (int)R, (int)C, scratch, rpc);
+  hipLaunchKernelGGL(k_colsum_final, grid1d(C), dim3(256), 0, s, (const float*)scratch, chunks, (int)C, out, (int)accumulate);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_sumsq(const float* x, int64_t n, float* out, int32_t accumulate, float* scratch, int64_t scratch_cap, void* stream) {
+  if (!x || !out || !scratch || scratch_cap < 256) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_sumsq_partial, dim3(256), dim3(256), 0, s, x, n, scratch);
+  hipLaunchKernelGGL(k_colsum_partial, dim3(1, 1), dim3(256), 0, s, (const float*)scratch, (int64_t)1, 256, 1, scratch + 256, 256);
+  hipLaunchKernelGGL(k_colsum_final, dim3(1), dim3(64), 0, s, (const float*)(scratch + 256), 1, 1, out, (int)accumulate);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_act_fwd(const float* x, float* y, int64_t n, int32_t kind, void* stream) {
+  if (!x || !y || kind < 1 || kind > 3) return DS_ERR_ARG;
+  if (n == 0) return DS_OK;
+  hipLaunchKernelGGL(k_act_fwd, grid1d(n), dim3(256), 0, (hipStream_t)stream, x, y, n, (int)kind);
+  return DST_CHECK_LAUNCH();
+}
+int dst_act_bwd(const float* dy, const float* ref, float* dx, int64_t n, int32_t kind, void* stream) {
+  if (!dy || !ref || !dx || kind < 1 || kind > 3) return DS_ERR_ARG;
+  if (n == 0) return DS_OK;
+  hipLaunchKernelGGL(k_act_bwd, grid1d(n), dim3(256), 0, (hipStream_t)stream, dy, ref, dx, n, (int)kind);
+  return DST_CHECK_LAUNCH();
+}
+int dst_axpy(float a, const float* x, float* y, int64_t n, void* stream) {
+  if (!x || !y) return DS_ERR_ARG;
+  if (n == 0) return DS_OK;
+  hipLaunchKernelGGL(k_axpy, grid1d(n), dim3(256), 0, (hipStream_t)stream, a, x, y, n);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_lnmod_fwd(const float* x, int32_t C, const int32_t* seg_off, int32_t seg_mul, int32_t B, const float* ada, int64_t ada_ld,
+                  int32_t shift_off, int32_t scale_off, float* y, float* stats, void* stream) {
+  if (!x || !seg_off || !ada || !y || !stats || (C != 64 && C != 256) || B <= 0) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 64) hipLaunchKernelGGL(k_lnmod_fwd<64>, dim3(B), dim3(256), 0, s, x, seg_off, (int)seg_mul, ada, ada_ld, (int)shift_off, (int)scale_off, y, stats);
+  else hipLaunchKernelGGL(k_lnmod_fwd<256>, dim3(B), dim3(256), 0, s, x, seg_off, (int)seg_mul, ada, ada_ld, (int)shift_off, (int)scale_off, y, stats);
+  return DST_CHECK_LAUNCH();
+}
+int dst_lnmod_bwd(const float* dy, const float* x, const float* stats, int32_t C, const int32_t* seg_off, int32_t seg_mul, int32_t B,
+                  const float* ada, float* d_ada, int64_t ada_ld, int32_t shift_off, int32_t scale_off, float* dx, int32_t accumulate,
+                  void* stream) {
+  if (!dy || !x || !stats || !seg_off || !ada || !d_ada || !dx || (C != 64 && C != 256) || B <= 0) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 64)
+    hipLaunchKernelGGL(k_lnmod_bwd<64>, dim3(B), dim3(256), 0, s, dy, x, stats, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)shift_off, (int)scale_off, dx, (int)accumulate);
+  else
+    hipLaunchKernelGGL(k_lnmod_bwd<256>, dim3(B), dim3(256), 0, s, dy, x, stats, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)shift_off, (int)scale_off, dx, (int)accumulate);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_gate_add_fwd(const float* r, const float* z, int32_t C, const int32_t* seg_off, int32_t seg_mul, int32_t B, const float* ada,
+                     int64_t ada_ld, int32_t gate_off, float* out, void* stream) {
+  if (!r || !z || !seg_off || !ada || !out || (C != 64 && C != 256) || B <= 0) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 64) hipLaunchKernelGGL(k_gate_add_fwd<64>, dim3(B), dim3(256), 0, s, r, z, seg_off, (int)seg_mul, ada, ada_ld, (int)gate_off, out);
+  else hipLaunchKernelGGL(k_gate_add_fwd<256>, dim3(B), dim3(256), 0, s, r, z, seg_off, (int)seg_mul, ada, ada_ld, (int)gate_off, out);
+  return DST_CHECK_LAUNCH();
+}
+int dst_gate_add_bwd(const float* dout, const float* z, int32_t C, const int32_t* seg_off, int32_t seg_mul, int32_t B, const float* ada,
+                     float* d_ada, int64_t ada_ld, int32_t gate_off, float* dr, int32_t accumulate_r, float* dz, void* stream) {
+  if (!dout || !z || !seg_off || !ada || !d_ada || !dz || (C != 64 && C != 256) || B <= 0) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 64)
+    hipLaunchKernelGGL(k_gate_add_bwd<64>, dim3(B), dim3(256), 0, s, dout, z, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)gate_off, dr, (int)accumulate_r, dz);
+  else
+    hipLaunchKernelGGL(k_gate_add_bwd<256>, dim3(B), dim3(256), 0, s, dout, z, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)gate_off, dr, (int)accumulate_r, dz);
+  return DST_CHECK_LAUNCH();
+}
+
+#define DST_L_OK(L) ((L) && (L)->B > 0 && (L)->node_off && (L)->pair_off)
+
+int dst_geom_fwd(const dst_layout* L, const float* pos, const float* ada, int64_t ada_ld, int32_t dist_off, const float* means,
+                 const float* stds, float* X, int64_t ldx, float* xs, float* d2s, void* stream) {
+  if (!DST_L_OK(L) || !pos || !ada || !means || !stds || !X || !xs || !d2s) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_geom_fwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, pos, ada, ada_ld, (int)dist_off, means, stds, X, ldx, xs, d2s);
+  return DST_CHECK_LAUNCH();
+}
+int dst_geom_bwd(const dst_layout* L, const float* pos, const float* ada, float* d_ada, int64_t ada_ld, int32_t dist_off,
+                 const float* means, const float* stds, const float* xs, const float* d2s, const float* g1, int64_t ld1, const float* g2,
+                 int64_t ld2, float* dms, float* dd2_scratch, float* dpos, void* stream) {
+  if (!DST_L_OK(L) || !pos || !ada || !d_ada || !means || !stds || !xs || !d2s || !g1 || !dms || !dd2_scratch) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_geom_bwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, pos, ada, d_ada, ada_ld, (int)dist_off, means, stds, xs, d2s, g1,
+                     ld1, g2, ld2, dms, dd2_scratch, dpos);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_attn_fwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, const int32_t* adj, float* out, float* alpha,
+                 void* stream) {
+  if (!DST_L_OK(L) || !qkv || !te0 || !te1 || !adj || !out || !alpha) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_attn_fwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, qkv, te0, te1, adj, out, alpha);
+  return DST_CHECK_LAUNCH();
+}
+int dst_attn_bwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, const float* alpha, const float* dout, float* dqkv,
+                 float* dte0, float* dte1, float* scratch, void* stream) {
+  (void)scratch;
+  if (!DST_L_OK(L) || !qkv || !te0 || !te1 || !alpha || !dout || !dqkv || !dte0 || !dte1) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_attn_bwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, qkv, te0, te1, alpha, dout, dqkv, dte0, dte1);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_pair_sum_fwd(const dst_layout* L, const float* u, int32_t C, const float* bias, float* s, void* stream) {
+  if (!DST_L_OK(L) || !u || !s || C <= 0) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_pair_sum_fwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, u, (int)C, bias, s);
+  return DST_CHECK_LAUNCH();
+}
+int dst_pair_sum_bwd(const dst_layout* L, const float* ds, int32_t C, float* du, int32_t accumulate, void* stream) {
+  if (!DST_L_OK(L) || !ds || !du || C <= 0) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_pair_sum_bwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, ds, (int)C, du, (int)accumulate);
+  return DST_CHECK_LAUNCH();
+}
+int dst_zbuild_fwd(const dst_layout* L, const float* ac, const float* ed, float* z, void* stream) {
+  if (!DST_L_OK(L) || !ac || !ed || !z) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_zbuild_fwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, ac, ed, z);
+  return DST_CHECK_LAUNCH();
+}
+int dst_zbuild_bwd(const dst_layout* L, const float* dz, float* dac, float* ded, void* stream) {
+  if (!DST_L_OK(L) || !dz || !dac || !ded) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_zbuild_bwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, dz, dac, ded);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_coord_fwd(const dst_layout* L, const float* pos, const float* c2, const int32_t* adj, const float* coord_scale, float* pos_out,
+                  void* stream) {
+  if (!DST_L_OK(L) || !pos || !c2 || !adj || !coord_scale || !pos_out) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_coord_fwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, pos, c2, adj, coord_scale, pos_out);
+  return DST_CHECK_LAUNCH();
+}
+int dst_coord_bwd(const dst_layout* L, const float* pos, const float* c2, const int32_t* adj, const float* coord_scale, const float* dpos_out,
+                  float* dpos_in, float* dc2, float* dscale_part, void* stream) {
+  if (!DST_L_OK(L) || !pos || !c2 || !adj || !coord_scale || !dpos_out || !dpos_in || !dc2 || !dscale_part) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_coord_bwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, pos, c2, adj, coord_scale, dpos_out, dpos_in, dc2, dscale_part);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_time_feat_fwd(const float* noise_level, const float* w, int32_t B, float* f, void* stream) {
+  if (!noise_level || !w || !f || B <= 0) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_time_feat_fwd, grid1d(B, 64), dim3(64), 0, (hipStream_t)stream, noise_level, w, (int)B, f);
+  return DST_CHECK_LAUNCH();
+}
+int dst_time_feat_bwd(const float* noise_level, const float* w, const float* df, int32_t B, float* dw, void* stream) {
+  if (!noise_level || !w || !df || !dw || B <= 0) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_time_feat_bwd, dim3(8), dim3(64), 0, (hipStream_t)stream, noise_level, w, df, (int)B, dw);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_loss(const dst_layout* L, const float* pos, const float* feat, const float* edge, const float* tpos, const float* tfeat,
+             const float* tedge, const float* wm, float w_pos, float w_type, float w_edge, float* loss_m, float* dpos, float* dfeat,
+             float* dedge, void* stream) {
+  if (!DST_L_OK(L) || !pos || !feat || !edge || !tpos || !tfeat || !tedge || !wm || !loss_m || !dpos || !dfeat || !dedge) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_loss, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, pos, feat, edge, tpos, tfeat, tedge, wm, w_pos, w_type, w_edge, loss_m,
+                     dpos, dfeat, dedge);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_noising(const dst_layout* L, const float* alpha, const float* sigma, const float* x, const float* raw, float* z, const float* ex,
+                const float* eraw, float* ez, void* stream) {
+  if (!DST_L_OK(L) || !alpha || !sigma || !x || !raw || !z || !ex || !eraw || !ez) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_noising, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, alpha, sigma, x, raw, z, ex, eraw, ez);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_kabsch(const dst_layout* L, const float* pred, int64_t ld_pred, const float* tar, int64_t ld_tar, float* rot, float* aligned,
+               void* stream) {
+  if (!DST_L_OK(L) || !pred || !tar || !rot || !aligned) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_kabsch, dim3(L->B), dim3(64), 0, (hipStream_t)stream, *L, pred, ld_pred, tar, ld_tar, rot, aligned);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_bn_fwd(const float* x, int32_t R, int32_t C, const float* gamma, const float* beta, float eps, float* y, float* stats,
+               float* running_mean, float* running_var, float* scratch, int64_t scratch_cap, void* stream) {
+  if (!x || !gamma || !beta || !y || !stats || !scratch || R < 2 || C <= 0) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int chunks = (R + 511) / 512;
+  if (chunks > 1024) chunks = 1024;
+  if ((int64_t)chunks * C > scratch_cap) chunks = (int)(scratch_cap / C);
+  if (chunks < 1) return DS_ERR_ARG;
+  const int rpc = (R + chunks - 1) / chunks;
+  hipLaunchKernelGGL(k_bn_sum, dim3((C + 63) / 64, chunks), dim3(256), 0, s, x, (int)R, (int)C, (const float*)nullptr, scratch, rpc);
+  hipLaunchKernelGGL(k_bn_finish_mean, grid1d(C), dim3(256), 0, s, (const float*)scratch, chunks, (int)C, (int)R, stats);
+  hipLaunchKernelGGL(k_bn_sum, dim3((C + 63) / 64, chunks), dim3(256), 0, s, x, (int)R, (int)C, (const float*)stats, scratch, rpc);
+  hipLaunchKernelGGL(k_bn_finish_var, grid1d(C), dim3(256), 0, s, (const float*)scratch, chunks, (int)C, (int)R, eps, stats, running_mean, running_var);
+  hipLaunchKernelGGL(k_bn_apply, grid1d((int64_t)R * C), dim3(256), 0, s, x, (int64_t)R * C, (int)C, (const float*)stats, gamma, beta, y);
+  return DST_CHECK_LAUNCH();
+}
+int dst_bn_bwd(const float* dy, const float* x, const float* stats, int32_t R, int32_t C, const float* gamma, float* dx, float* dgamma,
+               float* dbeta, float* scratch, int64_t scratch_cap, void* stream) {
+  if (!dy || !x || !stats || !gamma || !dx || !dgamma || !dbeta || !scratch || R < 2 || C <= 0) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int chunks = (R + 511) / 512;
+  if (chunks > 1024) chunks = 1024;
+  if ((int64_t)2 * chunks * C > scratch_cap) chunks = (int)(scratch_cap / (2 * C));
+  if (chunks < 1) return DS_ERR_ARG;
+  const int rpc = (R + chunks - 1) / chunks;
+  hipLaunchKernelGGL(k_bn_bwd_sum, dim3((C + 63) / 64, chunks), dim3(256), 0, s, dy, x, stats, (int)R, (int)C, scratch, rpc, chunks);
+  hipLaunchKernelGGL(k_bn_bwd_finish, grid1d(C), dim3(256), 0, s, (const float*)scratch, chunks, (int)C, dgamma, dbeta);
+  hipLaunchKernelGGL(k_bn_bwd_apply, grid1d((int64_t)R * C), dim3(256), 0, s, dy, x, (int64_t)R * C, (int)C, (int)R, stats, gamma, (const float*)dgamma,
+                     (const float*)dbeta, dx);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_spec_attn_fwd(const float* qkv, const float* prev, float* scores, float* attn, float* out, int32_t B, int32_t L, int32_t H,
+                      int32_t dk, float scale, void* stream) {
+  if (!qkv || !scores || !attn || !out || B <= 0 || L <= 0 || H <= 0 || dk <= 0 || dk > 16) return DS_ERR_ARG;
+  const size_t lds = (size_t)2 * L * dk * sizeof(float);
+  if (lds > 64 * 1024) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_spec_attn_fwd, dim3(B * H, 8), dim3(256), lds, (hipStream_t)stream, qkv, prev, scores, attn, out, (int)B, (int)L, (int)H, (int)dk, scale);
+  return DST_CHECK_LAUNCH();
+}
+int dst_spec_attn_bwd(const float* qkv, const float* attn, const float* dout, const float* dscores_in, float* dqkv, float* dscores,
+                      int32_t B, int32_t L, int32_t H, int32_t dk, float scale, void* stream) {
+  if (!qkv || !attn || !dout || !dqkv || !dscores || B <= 0 || L <= 0 || H <= 0 || dk <= 0 || dk > 16) return DS_ERR_ARG;
+  const size_t lds = (size_t)2 * L * dk * sizeof(float);
+  if (lds > 64 * 1024) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_spec_attn_bwd_q, dim3(B * H, 8), dim3(256), lds, s, qkv, attn, dout, dscores_in, dqkv, dscores, (int)B, (int)L, (int)H, (int)dk, scale);
+  hipLaunchKernelGGL(k_spec_attn_bwd_kv, dim3(B * H, 8), dim3(256), lds, s, qkv, attn, dout, (const float*)dscores, dqkv, (int)B, (int)L, (int)H, (int)dk, scale);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_ln_affine_fwd(const float* x, int32_t R, int32_t C, const float* gamma, const float* beta, float eps, float* y, float* stats,
+                      void* stream) {
+  if (!x || !gamma || !beta || !y || !stats || R <= 0 || C <= 0) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_ln_affine_fwd, dim3(R), dim3(64), 0, (hipStream_t)stream, x, (int)C, gamma, beta, eps, y, stats);
+  return DST_CHECK_LAUNCH();
+}
+int dst_ln_affine_bwd(const float* dy, const float* x, const float* stats, int32_t R, int32_t C, const float* gamma, float* dx,
+                      float* dgamma, float* dbeta, void* stream) {
+  if (!dy || !x || !stats || !gamma || !dx || !dgamma || !dbeta || R <= 0 || C <= 0) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_ln_affine_bwd, dim3(R), dim3(64), 0, s, dy, x, stats, (int)C, gamma, dx);
+  hipLaunchKernelGGL(k_ln_affine_bwd_params, grid1d(C), dim3(256), 0, s, dy, x, stats, (int)R, (int)C, dgamma, dbeta);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_adamw_ema(float* p, const float* g, float* m, float* v, float* vmax, float* ema, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float bc1, float bc2, float clip_coef, float ema_one_minus_decay, void* stream) {
+  if (!p || !g || !m || !v || !vmax || n < 0) return DS_ERR_ARG;
+  if (n == 0) return DS_OK;
+  hipLaunchKernelGGL(k_adamw_ema, grid1d(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, ema, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+                     clip_coef, ema_one_minus_decay);
+  return DST_CHECK_LAUNCH();
+}
+
+}  // extern "C"

@@ -1,0 +1,579 @@
+"""Training graph of the DMT on the HIP training library: forward tape + hand-written backward.
+
+The reference trains through ``torch.autograd`` over ``models/dmt.py``; here every operation of that graph has an explicit forward
+and backward kernel in ``csrc/ds_train.hip`` (C-ABI ``include/diffspectra_train.h``) over the packed-ragged layout, and this module
+strings them together: ``DmtTrainGraph.forward`` records the activations a backward needs, ``backward`` walks the tape in
+reverse and writes the gradient of every parameter.  PyTorch allocates the buffers, slices / concatenates them and owns the
+parameters; no arithmetic of the model runs in PyTorch, and there is no CPU path (``engine.load_library`` raises without the .so).
+
+Same de-duplicated formulation as the sampling kernels (exactly result-preserving): adaLN / time MLPs once per
+molecule, ``input_lin`` split into row / column / edge parts, ``node2edge_lin`` per node, edge-side tensors once per unordered
+pair (a pair row's gradient is the sum over its two directed edges - every backward operation is linear in the incoming gradient).
+Dropout is the identity (stage A: the reference's p = 0 arithmetic, pinned by golden G13).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import engine as E
+
+TRAIN_HEADER = os.path.join(E._ROOT, "include", "diffspectra_train.h")
+ADA, ADA_STRIDE, ADA_TOP = E.ADA_COLS, E.ADA_STRIDE, E.CONSTS["DS_ADA_TOP"]
+NODE_OFF, EDGE_OFF, EQUI_OFF, DIST_OFF = (E.CONSTS[k] for k in ("DS_ADA_NODE", "DS_ADA_EDGE", "DS_ADA_EQUI", "DS_ADA_DIST"))
+NB = E.NB
+SILU, GELU, TANH = 1, 2, 3
+
+
+class DstGemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("a_rs", C.c_int64), ("a_cs", C.c_int64), ("B", C.c_void_p), ("b_rs", C.c_int64), ("b_cs", C.c_int64),
+                ("C", C.c_void_p), ("ldc", C.c_int64), ("bias", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("accumulate", C.c_int32), ("partial", C.c_void_p), ("partial_cap", C.c_int64)]
+
+
+class DstLayout(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Nn", C.c_int32), ("Pp", C.c_int32), ("_pad", C.c_int32), ("node_off", C.c_void_p), ("pair_off", C.c_void_p)]
+
+
+def train_exports() -> List[str]:
+    txt = re.sub(r"/\*.*?\*/", "", open(TRAIN_HEADER).read(), flags=re.S)
+    return re.findall(r"^\s*int\s+(dst_\w+)\s*\(", txt, flags=re.M)
+
+
+_lib = None
+
+
+def load_train_library() -> C.CDLL:
+    """The training entry points live in the same shared library as the sampling path; fail loudly if any is missing."""
+    global _lib
+    if _lib is None:
+        lib = E.load_library()
+        for name in train_exports():
+            getattr(lib, name).restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+class MV:
+    """A row-major matrix view into a device tensor: ``rows x cols`` at element offset ``off`` with row stride ``ld``."""
+    __slots__ = ("t", "rows", "cols", "ld", "off")
+
+    def __init__(self, t: torch.Tensor, rows: int, cols: int, ld: int, off: int = 0):
+        self.t, self.rows, self.cols, self.ld, self.off = t, rows, cols, ld, off
+
+    @property
+    def ptr(self) -> int:
+        return self.t.data_ptr() + 4 * self.off
+
+
+def mv(t: torch.Tensor, c0: Optional[int] = None, c1: Optional[int] = None, r0: int = 0, r1: Optional[int] = None) -> MV:
+    """View of a contiguous 2-D (or 1-D as one row) fp32 tensor, optionally restricted to columns c0:c1 / rows r0:r1."""
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    if t.dim() == 1:
+        t2r, t2c = 1, t.shape[0]
+    else:
+        t2r, t2c = t.shape[0], int(np.prod(t.shape[1:]))
+    c0 = 0 if c0 is None else c0
+    c1 = t2c if c1 is None else c1
+    r1 = t2r if r1 is None else r1
+    return MV(t, r1 - r0, c1 - c0, t2c, r0 * t2c + c0)
+
+
+class Ops:
+    """ctypes wrappers over the dst_* entry points, issued on torch's current stream."""
+
+    def __init__(self, device):
+        self.lib = load_train_library()
+        self.dev = torch.device(device)
+        self.scratch = torch.empty(48 * 1024 * 1024, dtype=torch.float32, device=self.dev)     # split-K partials / column sums
+
+    def _s(self):
+        return E._stream()
+
+    def gemm(self, A: MV, Bm: MV, Cm: MV, ta: bool, tb: bool, bias: Optional[torch.Tensor] = None, acc: bool = False):
+        M, K = (A.cols, A.rows) if ta else (A.rows, A.cols)
+        a_rs, a_cs = (1, A.ld) if ta else (A.ld, 1)
+        K2, N = (Bm.cols, Bm.rows) if tb else (Bm.rows, Bm.cols)
+        b_rs, b_cs = (1, Bm.ld) if tb else (Bm.ld, 1)
+        assert K == K2 and Cm.rows == M and Cm.cols == N, (M, K, K2, N, Cm.rows, Cm.cols)
+        if bias is not None:
+            assert bias.numel() == N
+        args = DstGemmArgs(A=A.ptr, a_rs=a_rs, a_cs=a_cs, B=Bm.ptr, b_rs=b_rs, b_cs=b_cs, C=Cm.ptr, ldc=Cm.ld,
+                           bias=None if bias is None else bias.data_ptr(), M=M, N=N, K=K, accumulate=int(acc),
+                           partial=self.scratch.data_ptr(), partial_cap=self.scratch.numel())
+        E._check(self.lib.dst_gemm(C.byref(args), self._s()), "dst_gemm")
+
+    def colsum(self, X: MV, out: torch.Tensor, acc: bool = False):
+        assert out.numel() == X.cols
+        E._check(self.lib.dst_colsum(C.c_void_p(X.ptr), C.c_int64(X.ld), C.c_int32(X.rows), C.c_int32(X.cols), E._ptr(out), C.c_int32(int(acc)),
+                                     E._ptr(self.scratch), C.c_int64(self.scratch.numel()), self._s()), "dst_colsum")
+
+    # y = x W^T + b ; dx (+)= dy W ; dW = dy^T x ; db = colsum(dy)
+    def lin_fwd(self, x: MV, W: MV, b, y: MV):
+        self.gemm(x, W, y, False, True, bias=b)
+
+    def lin_bwd_x(self, dy: MV, W: MV, dx: MV, acc: bool = False):
+        self.gemm(dy, W, dx, False, False, acc=acc)
+
+    def lin_bwd_w(self, dy: MV, x: MV, dW: MV, db: Optional[torch.Tensor] = None, acc: bool = False):
+        self.gemm(dy, x, dW, True, False, acc=acc)
+        if db is not None:
+            self.colsum(dy, db, acc=acc)
+
+    def act_fwd(self, x, y, kind):
+        E._check(self.lib.dst_act_fwd(E._ptr(x), E._ptr(y), C.c_int64(x.numel()), C.c_int32(kind), self._s()), "dst_act_fwd")
+
+    def act_bwd(self, dy, ref, dx, kind):
+        E._check(self.lib.dst_act_bwd(E._ptr(dy), E._ptr(ref), E._ptr(dx), C.c_int64(dy.numel()), C.c_int32(kind), self._s()), "dst_act_bwd")
+
+    def axpy(self, a, x, y):
+        E._check(self.lib.dst_axpy(C.c_float(a), E._ptr(x), E._ptr(y), C.c_int64(x.numel()), self._s()), "dst_axpy")
+
+    def lnmod_fwd(self, x, Cc, seg, mul, B, ada, sh, sc, y, stats):
+        E._check(self.lib.dst_lnmod_fwd(E._ptr(x), C.c_int32(Cc), E._ptr(seg), C.c_int32(mul), C.c_int32(B), E._ptr(ada), C.c_int64(ADA), C.c_int32(sh),
+                                        C.c_int32(sc), E._ptr(y), E._ptr(stats), self._s()), "dst_lnmod_fwd")
+
+    def lnmod_bwd(self, dy, x, stats, Cc, seg, mul, B, ada, d_ada, sh, sc, dx, acc):
+        E._check(self.lib.dst_lnmod_bwd(E._ptr(dy), E._ptr(x), E._ptr(stats), C.c_int32(Cc), E._ptr(seg), C.c_int32(mul), C.c_int32(B), E._ptr(ada),
+                                        E._ptr(d_ada), C.c_int64(ADA), C.c_int32(sh), C.c_int32(sc), E._ptr(dx), C.c_int32(int(acc)), self._s()),
+                 "dst_lnmod_bwd")
+
+    def gate_add_fwd(self, r, z, Cc, seg, mul, B, ada, g, out):
+        E._check(self.lib.dst_gate_add_fwd(E._ptr(r), E._ptr(z), C.c_int32(Cc), E._ptr(seg), C.c_int32(mul), C.c_int32(B), E._ptr(ada), C.c_int64(ADA),
+                                           C.c_int32(g), E._ptr(out), self._s()), "dst_gate_add_fwd")
+
+    def gate_add_bwd(self, dout, z, Cc, seg, mul, B, ada, d_ada, g, dr, acc_r, dz):
+        E._check(self.lib.dst_gate_add_bwd(E._ptr(dout), E._ptr(z), C.c_int32(Cc), E._ptr(seg), C.c_int32(mul), C.c_int32(B), E._ptr(ada), E._ptr(d_ada),
+                                           C.c_int64(ADA), C.c_int32(g), E._ptr(dr), C.c_int32(int(acc_r)), E._ptr(dz), self._s()), "dst_gate_add_bwd")
+
+
+class TrainLayout:
+    """The packed-ragged tables of ``engine.Layout`` plus what the training kernels need (dense <-> packed index tensors)."""
+
+    def __init__(self, node_mask: torch.Tensor, device):
+        self.L = E.Layout(node_mask, device)
+        L = self.L
+        self.B, self.N, self.Nn, self.Pp = L.B, L.N, L.Nn, L.Pp
+        self.c = DstLayout(B=L.B, Nn=L.Nn, Pp=L.Pp, _pad=0, node_off=L.t["node_off"].data_ptr(), pair_off=L.t["pair_off"].data_ptr())
+        nd = L.t["node_dense"].long()
+        a, b = L.t["pair_a"].long(), L.t["pair_b"].long()
+        self.node_dense = nd                                              # [Nn] -> row of the dense [B*N] node arrays
+        self.pair_dense = nd[a] * L.N + (nd[b] % L.N)                     # [Pp] -> row (b, i, j) of the dense [B*N*N] edge arrays, i < j
+        self.pair_dense_t = nd[b] * L.N + (nd[a] % L.N)                   # the transposed cell (b, j, i)
+        self.node_mol = L.t["node_mol"].long()
+        self.pair_mol = L.t["pair_mol"].long()
+        self.node_off, self.pair_off = L.t["node_off"], L.t["pair_off"]
+
+    def pack_nodes(self, dense: torch.Tensor) -> torch.Tensor:
+        return dense.reshape(self.B * self.N, -1).index_select(0, self.node_dense).contiguous()
+
+    def pack_pairs(self, dense: torch.Tensor) -> torch.Tensor:
+        return dense.reshape(self.B * self.N * self.N, -1).index_select(0, self.pair_dense).contiguous()
+
+    def unpack_nodes(self, packed: torch.Tensor) -> torch.Tensor:
+        out = torch.zeros(self.B * self.N, packed.shape[1], dtype=packed.dtype, device=packed.device)
+        out[self.node_dense] = packed
+        return out.reshape(self.B, self.N, -1)
+
+    def unpack_pairs(self, packed: torch.Tensor) -> torch.Tensor:
+        out = torch.zeros(self.B * self.N * self.N, packed.shape[1], dtype=packed.dtype, device=packed.device)
+        out[self.pair_dense] = packed
+        out[self.pair_dense_t] = packed
+        return out.reshape(self.B, self.N, self.N, -1)
+
+
+ADA_PARTS = (("node_time_mlp.1", NODE_OFF, 1536), ("edge_time_mlp.1", EDGE_OFF, 384), ("equi_update.time_mlp.1", EQUI_OFF, 512),
+             ("dist_layer.time_mlp.1", DIST_OFF, 2))
+
+
+class DmtTrainGraph:
+    """Forward tape and backward of one DMT evaluation (conditioning embedding given) on packed tensors.
+
+    ``params``: name -> fp32 device tensor (reference names, no ``module.`` prefix).  ``grads`` (same names) receives the gradients."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], config, device):
+        self.p = params
+        self.cfg = config
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("the training graph runs on an MI355X only; diffspectra_amd has no CPU path")
+        self.ops = Ops(self.dev)
+        self.lib = self.ops.lib
+        self.edge_th = float(config.model.edge_quan_th)
+        self.cutoff = float(config.model.spatial_cut_off)
+
+    # ------------------------------------------------------------------ helpers
+    def f(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.dev)
+
+    def z(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+
+    def assemble_ada(self):
+        """All ``*time_mlp`` Linears as one [ADA_COLS, 1024] weight / [ADA_COLS] bias (rows in the column order of the adaLN table)."""
+        W, b = self.z(ADA, 1024), self.z(ADA)
+        for blk in range(NB):
+            for name, off, rows in ADA_PARTS:
+                o = blk * ADA_STRIDE + off
+                W[o:o + rows] = self.p[f"e_block_{blk}.{name}.weight"]
+                b[o:o + rows] = self.p[f"e_block_{blk}.{name}.bias"]
+        W[ADA_TOP:ADA_TOP + 2] = self.p["dist_layer.time_mlp.1.weight"]
+        b[ADA_TOP:ADA_TOP + 2] = self.p["dist_layer.time_mlp.1.bias"]
+        return W, b
+
+    def scatter_ada_grads(self, dW, db, grads):
+        for blk in range(NB):
+            for name, off, rows in ADA_PARTS:
+                o = blk * ADA_STRIDE + off
+                grads[f"e_block_{blk}.{name}.weight"] = dW[o:o + rows].clone()
+                grads[f"e_block_{blk}.{name}.bias"] = db[o:o + rows].clone()
+        grads["dist_layer.time_mlp.1.weight"] = dW[ADA_TOP:ADA_TOP + 2].clone()
+        grads["dist_layer.time_mlp.1.bias"] = db[ADA_TOP:ADA_TOP + 2].clone()
+
+    def _geom_fwd(self, TL, pos, ada, dist_off, prefix, X, ldx, col0, xs, d2s):
+        E._check(self.lib.dst_geom_fwd(C.byref(TL.c), E._ptr(pos), E._ptr(ada), C.c_int64(ADA), C.c_int32(dist_off),
+                                       E._ptr(self.p[prefix + "means.weight"]), E._ptr(self.p[prefix + "stds.weight"]),
+                                       C.c_void_p(X.data_ptr() + 4 * col0), C.c_int64(ldx), E._ptr(xs), E._ptr(d2s), E._stream()), "dst_geom_fwd")
+
+    def _geom_bwd(self, TL, pos, ada, d_ada, dist_off, prefix, xs, d2s, g1, g2, dms, dd2, dpos):
+        E._check(self.lib.dst_geom_bwd(C.byref(TL.c), E._ptr(pos), E._ptr(ada), E._ptr(d_ada), C.c_int64(ADA), C.c_int32(dist_off),
+                                       E._ptr(self.p[prefix + "means.weight"]), E._ptr(self.p[prefix + "stds.weight"]), E._ptr(xs), E._ptr(d2s),
+                                       E._ptr(g1), C.c_int64(g1.shape[1]), E._ptr(g2), C.c_int64(0 if g2 is None else g2.shape[1]), E._ptr(dms),
+                                       E._ptr(dd2), E._ptr(dpos), E._stream()), "dst_geom_bwd")
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, TL: TrainLayout, xn, ex, noise_level, ctx_emb, cond_n=None, cond_e=None, save: bool = True):
+        """``xn [Nn,9]`` / ``ex [Pp,2]`` packed noisy state, ``noise_level [B]``, ``ctx_emb [B,1024]`` = cond_lin(SpecFormer(context)),
+        ``cond_n`` / ``cond_e`` packed self-conditioning prediction or None (dmt.py:332-345).  Returns (pos [Nn,3], atom_pred [Nn,6],
+        edge_pred [Pp,2]) and keeps the tape in ``self.t`` when ``save``."""
+        o, p, lib = self.ops, self.p, self.lib
+        B, Nn, Pp = TL.B, TL.Nn, TL.Pp
+        D = 2 * Pp
+        t: Dict[str, object] = dict(TL=TL, first=cond_n is None)
+        s = E._stream
+        # ---- time embedding + adaLN table (dmt.py:249-257,353-357; every *time_mlp)
+        tf = self.f(B, 17)
+        E._check(lib.dst_time_feat_fwd(E._ptr(noise_level), E._ptr(p["time_mlp.0.weights"]), C.c_int32(B), E._ptr(tf), s()), "dst_time_feat_fwd")
+        tm1, tg, temb, st = self.f(B, 1024), self.f(B, 1024), self.f(B, 1024), self.f(B, 1024)
+        o.lin_fwd(mv(tf), mv(p["time_mlp.1.weight"]), p["time_mlp.1.bias"], mv(tm1))
+        o.act_fwd(tm1, tg, GELU)
+        o.lin_fwd(mv(tg), mv(p["time_mlp.3.weight"]), p["time_mlp.3.bias"], mv(temb))
+        o.axpy(1.0, ctx_emb, temb)                                                       # time_emb = time_mlp(noise_level) + context
+        o.act_fwd(temb, st, SILU)
+        Wada, bada = self.assemble_ada()
+        ada = self.f(B, ADA)
+        o.lin_fwd(mv(st), mv(Wada), bada, mv(ada))
+        t.update(noise_level=noise_level, tf=tf, tm1=tm1, tg=tg, temb=temb, st=st, Wada=Wada, ada=ada)
+        # ---- inputs (dmt.py:323-377)
+        pos = xn[:, 0:3].contiguous()
+        X0n = torch.cat([xn[:, 3:9], cond_n[:, 3:9] if cond_n is not None else torch.zeros_like(xn[:, 3:9])], dim=1).contiguous()
+        h = self.f(Nn, 256)
+        o.lin_fwd(mv(X0n), mv(p["node_emb.weight"]), p["node_emb.bias"], mv(h))
+        X0p = self.z(Pp, 68)
+        X0p[:, 0:2] = ex
+        xs0 = d2c = None
+        if cond_n is not None:
+            X0p[:, 2:4] = cond_e
+            cpos = cond_n[:, 0:3].contiguous()
+            xs0, d2c = self.f(Pp), self.f(Pp)
+            self._geom_fwd(TL, cpos, ada, ADA_TOP, "dist_layer.", X0p, 68, 4, xs0, d2c)
+            adj = ((cond_e[:, 0] >= self.edge_th).to(torch.int32) | ((d2c <= self.cutoff).to(torch.int32) << 1)).contiguous()
+            t.update(cpos=cpos)
+        else:
+            adj = torch.full((Pp,), 3, dtype=torch.int32, device=self.dev)
+        e = self.f(Pp, 64)
+        o.lin_fwd(mv(X0p), mv(p["edge_emb.weight"]), p["edge_emb.bias"], mv(e))
+        t.update(X0n=X0n, X0p=X0p, xs0=xs0, d2c=d2c, adj=adj, h0=h, e0=e)
+        node_hids, edge_hids = [h], [e]
+        blocks = []
+        for i in range(NB):
+            bp = f"e_block_{i}."
+            a0 = i * ADA_STRIDE
+            bt: Dict[str, object] = dict(pos_in=pos, h_in=h, e_in=e)
+            # distances + CondGaussian features, edge embedding (dmt.py:136-139)
+            X1, xs, d2 = self.f(Pp, 128), self.f(Pp), self.f(Pp)
+            self._geom_fwd(TL, pos, ada, a0 + DIST_OFF, bp + "dist_layer.", X1, 128, 0, xs, d2)
+            X1[:, 64:128] = e
+            e1 = self.f(Pp, 64)
+            o.lin_fwd(mv(X1), mv(p[bp + "edge_emb.weight"]), p[bp + "edge_emb.bias"], mv(e1))
+            # adaLN modulate (dmt.py:148-149)
+            hn, st_n1 = self.f(Nn, 256), self.f(Nn, 2)
+            o.lnmod_fwd(h, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 0, a0 + NODE_OFF + 256, hn, st_n1)
+            en, st_e1 = self.f(Pp, 64), self.f(Pp, 2)
+            o.lnmod_fwd(e1, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 0, a0 + EDGE_OFF + 64, en, st_e1)
+            # attention (layers.py:131-186)
+            qkv = self.z(Nn, 768)
+            ap = bp + "attn_mpnn."
+            o.lin_fwd(mv(hn), mv(p[ap + "lin_query.weight"]), p[ap + "lin_query.bias"], mv(qkv, 0, 252))
+            o.lin_fwd(mv(hn), mv(p[ap + "lin_key.weight"]), p[ap + "lin_key.bias"], mv(qkv, 256, 508))
+            o.lin_fwd(mv(hn), mv(p[ap + "lin_value.weight"]), p[ap + "lin_value.bias"], mv(qkv, 512, 768))
+            te0, te1 = self.z(Pp, 256), self.f(Pp, 256)
+            o.lin_fwd(mv(en), mv(p[ap + "lin_edge0.weight"]), None, mv(te0, 0, 252))
+            o.lin_fwd(mv(en), mv(p[ap + "lin_edge1.weight"]), None, mv(te1))
+            o.act_fwd(te0, te0, TANH)
+            o.act_fwd(te1, te1, TANH)
+            attn, alpha = self.f(Nn, 256), self.f(max(D, 1), 16)
+            E._check(lib.dst_attn_fwd(C.byref(TL.c), E._ptr(qkv), E._ptr(te0), E._ptr(te1), E._ptr(adj), E._ptr(attn), E._ptr(alpha), s()), "dst_attn_fwd")
+            # node2edge (dmt.py:156-157) per node, then the pair sum
+            u, he = self.f(Nn, 64), self.f(Pp, 64)
+            o.lin_fwd(mv(attn), mv(p[bp + "node2edge_lin.weight"]), None, mv(u))
+            E._check(lib.dst_pair_sum_fwd(C.byref(TL.c), E._ptr(u), C.c_int32(64), E._ptr(p[bp + "node2edge_lin.bias"]), E._ptr(he), s()), "dst_pair_sum_fwd")
+            # node stream (dmt.py:159-163)
+            x1, y1, st_n2 = self.f(Nn, 256), self.f(Nn, 256), self.f(Nn, 2)
+            o.gate_add_fwd(h, attn, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 512, x1)
+            o.lnmod_fwd(x1, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 768, a0 + NODE_OFF + 1024, y1, st_n2)
+            f1, s1, f2, h_out = self.f(Nn, 512), self.f(Nn, 512), self.f(Nn, 256), self.f(Nn, 256)
+            o.lin_fwd(mv(y1), mv(p[bp + "ff_linear1.weight"]), p[bp + "ff_linear1.bias"], mv(f1))
+            o.act_fwd(f1, s1, SILU)
+            o.lin_fwd(mv(s1), mv(p[bp + "ff_linear2.weight"]), p[bp + "ff_linear2.bias"], mv(f2))
+            o.gate_add_fwd(y1, f2, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 1280, h_out)
+            # edge stream (dmt.py:165-169)
+            xe1, ye1, st_e2 = self.f(Pp, 64), self.f(Pp, 64), self.f(Pp, 2)
+            o.gate_add_fwd(e, he, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 128, xe1)
+            o.lnmod_fwd(xe1, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 192, a0 + EDGE_OFF + 256, ye1, st_e2)
+            f3, s3, f4, e_out = self.f(Pp, 128), self.f(Pp, 128), self.f(Pp, 64), self.f(Pp, 64)
+            o.lin_fwd(mv(ye1), mv(p[bp + "ff_linear3.weight"]), p[bp + "ff_linear3.bias"], mv(f3))
+            o.act_fwd(f3, s3, SILU)
+            o.lin_fwd(mv(s3), mv(p[bp + "ff_linear4.weight"]), p[bp + "ff_linear4.bias"], mv(f4))
+            o.gate_add_fwd(ye1, f4, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 320, e_out)
+            # equivariant update (dmt.py:37-60) + CoM removal (:385-386)
+            Win = p[bp + "equi_update.input_lin.weight"]                       # [256, 640] = [h_row | h_col | e | dist]
+            ac = self.f(Nn, 512)
+            o.lin_fwd(mv(h_out), mv(Win, 0, 256), None, mv(ac, 0, 256))
+            o.lin_fwd(mv(h_out), mv(Win, 256, 512), None, mv(ac, 256, 512))
+            X2 = self.f(Pp, 128)
+            X2[:, 0:64] = e_out
+            X2[:, 64:128] = X1[:, 0:64]
+            ed = self.f(Pp, 256)
+            o.lin_fwd(mv(X2), mv(Win, 512, 640), p[bp + "equi_update.input_lin.bias"], mv(ed))
+            zz, zn, st_z = self.f(max(D, 1), 256), self.f(max(D, 1), 256), self.f(max(D, 1), 2)
+            E._check(lib.dst_zbuild_fwd(C.byref(TL.c), E._ptr(ac), E._ptr(ed), E._ptr(zz), s()), "dst_zbuild_fwd")
+            o.lnmod_fwd(zz, 256, TL.pair_off, 2, B, ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256, zn, st_z)
+            c0, sc0, c2 = self.f(max(D, 1), 256), self.f(max(D, 1), 256), self.f(max(D, 1), 3)
+            o.lin_fwd(mv(zn, r1=D), mv(p[bp + "equi_update.coord_mlp.0.weight"]), p[bp + "equi_update.coord_mlp.0.bias"], mv(c0, r1=D))
+            o.act_fwd(c0, sc0, SILU)
+            o.lin_fwd(mv(sc0, r1=D), mv(p[bp + "equi_update.coord_mlp.2.weight"]), None, mv(c2, r1=D))
+            pos_out = self.f(Nn, 3)
+            E._check(lib.dst_coord_fwd(C.byref(TL.c), E._ptr(pos), E._ptr(c2), E._ptr(adj), E._ptr(p[bp + "equi_update.coord_norm.scale"]),
+                                       E._ptr(pos_out), s()), "dst_coord_fwd")
+            # per-block read-out features (dmt.py:387-388)
+            rn, re_ = self.f(Nn, 64), self.f(Pp, 16)
+            o.lin_fwd(mv(h_out), mv(p[f"node_{i}.weight"]), p[f"node_{i}.bias"], mv(rn))
+            o.lin_fwd(mv(e_out), mv(p[f"edge_{i}.weight"]), p[f"edge_{i}.bias"], mv(re_))
+            node_hids.append(rn)
+            edge_hids.append(re_)
+            if save:
+                bt.update(X1=X1, xs=xs, d2=d2, e1=e1, hn=hn, st_n1=st_n1, en=en, st_e1=st_e1, qkv=qkv, te0=te0, te1=te1, attn=attn, alpha=alpha,
+                          u=u, he=he, x1=x1, y1=y1, st_n2=st_n2, f1=f1, s1=s1, f2=f2, h_out=h_out, xe1=xe1, ye1=ye1, st_e2=st_e2, f3=f3, s3=s3,
+                          f4=f4, e_out=e_out, X2=X2, zz=zz, zn=zn, st_z=st_z, c0=c0, sc0=sc0, c2=c2)
+                blocks.append(bt)
+            pos, h, e = pos_out, h_out, e_out
+        # ---- read-out MLPs (dmt.py:391-394)
+        AH = torch.cat(node_hids, dim=1).contiguous()
+        EH = torch.cat(edge_hids, dim=1).contiguous()
+        n1, n1s, n2, n2s, atom_pred = self.f(Nn, 256), self.f(Nn, 256), self.f(Nn, 128), self.f(Nn, 128), self.f(Nn, 6)
+        o.lin_fwd(mv(AH), mv(p["node_pred_mlp.0.weight"]), p["node_pred_mlp.0.bias"], mv(n1))
+        o.act_fwd(n1, n1s, SILU)
+        o.lin_fwd(mv(n1s), mv(p["node_pred_mlp.2.weight"]), p["node_pred_mlp.2.bias"], mv(n2))
+        o.act_fwd(n2, n2s, SILU)
+        o.lin_fwd(mv(n2s), mv(p["node_pred_mlp.4.weight"]), p["node_pred_mlp.4.bias"], mv(atom_pred))
+        edge_pred = self.f(Pp, 2)
+        ro = {}
+        for col, name in ((0, "edge_exist_mlp"), (1, "edge_type_mlp")):
+            a1, a1s, a2, a2s = self.f(Pp, 64), self.f(Pp, 64), self.f(Pp, 32), self.f(Pp, 32)
+            o.lin_fwd(mv(EH), mv(p[name + ".0.weight"]), p[name + ".0.bias"], mv(a1))
+            o.act_fwd(a1, a1s, SILU)
+            o.lin_fwd(mv(a1s), mv(p[name + ".2.weight"]), p[name + ".2.bias"], mv(a2))
+            o.act_fwd(a2, a2s, SILU)
+            o.lin_fwd(mv(a2s), mv(p[name + ".4.weight"]), p[name + ".4.bias"], mv(edge_pred, col, col + 1))
+            ro[name] = (a1, a1s, a2, a2s)
+        if save:
+            t.update(blocks=blocks, AH=AH, EH=EH, n1=n1, n1s=n1s, n2=n2, n2s=n2s, ro=ro, pos_final=pos)
+            self.t = t
+        return pos, atom_pred, edge_pred
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dpos, datom, dedge) -> Dict[str, torch.Tensor]:
+        """Gradients of every DMT parameter (and ``ctx_emb`` under the key ``'@ctx_emb'``) given the gradients of the three outputs."""
+        o, p, lib, t = self.ops, self.p, self.lib, self.t
+        TL: TrainLayout = t["TL"]
+        B, Nn, Pp = TL.B, TL.Nn, TL.Pp
+        D = 2 * Pp
+        s = E._stream
+        ada = t["ada"]
+        g: Dict[str, torch.Tensor] = {}
+
+        def gw(name):                                       # gradient buffer of a parameter (fully written by its producer)
+            g[name] = torch.zeros_like(p[name])
+            return g[name]
+
+        d_ada = self.z(B, ADA)
+        # ---- read-out MLPs
+        dAH, dEH = self.f(Nn, 768), self.f(Pp, 192)
+
+        def mlp3_bwd(name, x, acts, dy: MV, dx, acc):
+            a1, a1s, a2, a2s = acts
+            o.lin_bwd_w(dy, mv(a2s), mv(gw(name + ".4.weight")), gw(name + ".4.bias"))
+            d2 = torch.empty_like(a2)
+            o.lin_bwd_x(dy, mv(p[name + ".4.weight"]), mv(d2))
+            o.act_bwd(d2, a2, d2, SILU)
+            o.lin_bwd_w(mv(d2), mv(a1s), mv(gw(name + ".2.weight")), gw(name + ".2.bias"))
+            d1 = torch.empty_like(a1)
+            o.lin_bwd_x(mv(d2), mv(p[name + ".2.weight"]), mv(d1))
+            o.act_bwd(d1, a1, d1, SILU)
+            o.lin_bwd_w(mv(d1), mv(x), mv(gw(name + ".0.weight")), gw(name + ".0.bias"))
+            o.lin_bwd_x(mv(d1), mv(p[name + ".0.weight"]), mv(dx), acc=acc)
+
+        mlp3_bwd("node_pred_mlp", t["AH"], (t["n1"], t["n1s"], t["n2"], t["n2s"]), mv(datom), dAH, False)
+        mlp3_bwd("edge_exist_mlp", t["EH"], t["ro"]["edge_exist_mlp"], mv(dedge, 0, 1), dEH, False)
+        mlp3_bwd("edge_type_mlp", t["EH"], t["ro"]["edge_type_mlp"], mv(dedge, 1, 2), dEH, True)
+        # ---- blocks, last to first
+        dh = self.z(Nn, 256)             # gradient of the block output h (later: block input of the next one)
+        de = self.z(Pp, 64)
+        dpos_out = dpos
+        dms_buf, dd2_buf, dsp = self.f(B, 128), self.f(max(Pp, 1)), self.f(B)
+        for i in reversed(range(NB)):
+            bt = t["blocks"][i]
+            bp = f"e_block_{i}."
+            a0 = i * ADA_STRIDE
+            ap = bp + "attn_mpnn."
+            # read-out features of this block
+            drn, dre = mv(dAH, 256 + 64 * i, 256 + 64 * (i + 1)), mv(dEH, 64 + 16 * i, 64 + 16 * (i + 1))
+            o.lin_bwd_w(drn, mv(bt["h_out"]), mv(gw(f"node_{i}.weight")), gw(f"node_{i}.bias"))
+            o.lin_bwd_x(drn, mv(p[f"node_{i}.weight"]), mv(dh), acc=True)
+            o.lin_bwd_w(dre, mv(bt["e_out"]), mv(gw(f"edge_{i}.weight")), gw(f"edge_{i}.bias"))
+            o.lin_bwd_x(dre, mv(p[f"edge_{i}.weight"]), mv(de), acc=True)
+            # equivariant update
+            dpos_in, dc2 = self.f(Nn, 3), self.f(max(D, 1), 3)
+            E._check(lib.dst_coord_bwd(C.byref(TL.c), E._ptr(bt["pos_in"]), E._ptr(bt["c2"]), E._ptr(t["adj"]), E._ptr(p[bp + "equi_update.coord_norm.scale"]),
+                                       E._ptr(dpos_out), E._ptr(dpos_in), E._ptr(dc2), E._ptr(dsp), s()), "dst_coord_bwd")
+            o.colsum(mv(dsp.view(B, 1)), gw(bp + "equi_update.coord_norm.scale"))
+            Win = p[bp + "equi_update.input_lin.weight"]
+            dWin = gw(bp + "equi_update.input_lin.weight")
+            o.lin_bwd_w(mv(dc2, r1=D), mv(bt["sc0"], r1=D), mv(gw(bp + "equi_update.coord_mlp.2.weight")))
+            dc0 = self.f(max(D, 1), 256)
+            o.lin_bwd_x(mv(dc2, r1=D), mv(p[bp + "equi_update.coord_mlp.2.weight"]), mv(dc0, r1=D))
+            o.act_bwd(dc0, bt["c0"], dc0, SILU)
+            o.lin_bwd_w(mv(dc0, r1=D), mv(bt["zn"], r1=D), mv(gw(bp + "equi_update.coord_mlp.0.weight")), gw(bp + "equi_update.coord_mlp.0.bias"))
+            dzn = self.f(max(D, 1), 256)
+            o.lin_bwd_x(mv(dc0, r1=D), mv(p[bp + "equi_update.coord_mlp.0.weight"]), mv(dzn, r1=D))
+            dz = dc0                                         # reuse
+            o.lnmod_bwd(dzn, bt["zz"], bt["st_z"], 256, TL.pair_off, 2, B, ada, d_ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256, dz, False)
+            dac, ded = self.f(Nn, 512), self.f(Pp, 256)
+            E._check(lib.dst_zbuild_bwd(C.byref(TL.c), E._ptr(dz), E._ptr(dac), E._ptr(ded), s()), "dst_zbuild_bwd")
+            o.lin_bwd_w(mv(dac, 0, 256), mv(bt["h_out"]), mv(dWin, 0, 256))
+            o.lin_bwd_w(mv(dac, 256, 512), mv(bt["h_out"]), mv(dWin, 256, 512))
+            o.lin_bwd_x(mv(dac, 0, 256), mv(Win, 0, 256), mv(dh), acc=True)
+            o.lin_bwd_x(mv(dac, 256, 512), mv(Win, 256, 512), mv(dh), acc=True)
+            o.lin_bwd_w(mv(ded), mv(bt["X2"]), mv(dWin, 512, 640), gw(bp + "equi_update.input_lin.bias"))
+            o.lin_bwd_x(mv(ded), mv(Win, 512, 576), mv(de), acc=True)
+            dfeat2 = self.f(Pp, 64)
+            o.lin_bwd_x(mv(ded), mv(Win, 576, 640), mv(dfeat2))
+            # node stream
+            dy1, df2 = self.f(Nn, 256), self.f(Nn, 256)
+            o.gate_add_bwd(dh, bt["f2"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 1280, dy1, False, df2)
+            o.lin_bwd_w(mv(df2), mv(bt["s1"]), mv(gw(bp + "ff_linear2.weight")), gw(bp + "ff_linear2.bias"))
+            df1 = self.f(Nn, 512)
+            o.lin_bwd_x(mv(df2), mv(p[bp + "ff_linear2.weight"]), mv(df1))
+            o.act_bwd(df1, bt["f1"], df1, SILU)
+            o.lin_bwd_w(mv(df1), mv(bt["y1"]), mv(gw(bp + "ff_linear1.weight")), gw(bp + "ff_linear1.bias"))
+            o.lin_bwd_x(mv(df1), mv(p[bp + "ff_linear1.weight"]), mv(dy1), acc=True)
+            dx1 = df2                                        # reuse
+            o.lnmod_bwd(dy1, bt["x1"], bt["st_n2"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 768, a0 + NODE_OFF + 1024, dx1, False)
+            dh_in, dattn = self.f(Nn, 256), self.f(Nn, 256)
+            o.gate_add_bwd(dx1, bt["attn"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 512, dh_in, False, dattn)
+            # edge stream
+            dye1, df4 = self.f(Pp, 64), self.f(Pp, 64)
+            o.gate_add_bwd(de, bt["f4"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 320, dye1, False, df4)
+            o.lin_bwd_w(mv(df4), mv(bt["s3"]), mv(gw(bp + "ff_linear4.weight")), gw(bp + "ff_linear4.bias"))
+            df3 = self.f(Pp, 128)
+            o.lin_bwd_x(mv(df4), mv(p[bp + "ff_linear4.weight"]), mv(df3))
+            o.act_bwd(df3, bt["f3"], df3, SILU)
+            o.lin_bwd_w(mv(df3), mv(bt["ye1"]), mv(gw(bp + "ff_linear3.weight")), gw(bp + "ff_linear3.bias"))
+            o.lin_bwd_x(mv(df3), mv(p[bp + "ff_linear3.weight"]), mv(dye1), acc=True)
+            dxe1 = df4
+            o.lnmod_bwd(dye1, bt["xe1"], bt["st_e2"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 192, a0 + EDGE_OFF + 256, dxe1, False)
+            de_in, dhe = self.f(Pp, 64), self.f(Pp, 64)
+            o.gate_add_bwd(dxe1, bt["he"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 128, de_in, False, dhe)
+            # node2edge
+            du = self.f(Nn, 64)
+            E._check(lib.dst_pair_sum_bwd(C.byref(TL.c), E._ptr(dhe), C.c_int32(64), E._ptr(du), C.c_int32(0), s()), "dst_pair_sum_bwd")
+            o.colsum(mv(dhe), gw(bp + "node2edge_lin.bias"))
+            o.lin_bwd_w(mv(du), mv(bt["attn"]), mv(gw(bp + "node2edge_lin.weight")))
+            o.lin_bwd_x(mv(du), mv(p[bp + "node2edge_lin.weight"]), mv(dattn), acc=True)
+            # attention
+            dqkv, dte0, dte1 = self.f(Nn, 768), self.f(Pp, 256), self.f(Pp, 256)
+            E._check(lib.dst_attn_bwd(C.byref(TL.c), E._ptr(bt["qkv"]), E._ptr(bt["te0"]), E._ptr(bt["te1"]), E._ptr(bt["alpha"]), E._ptr(dattn),
+                                      E._ptr(dqkv), E._ptr(dte0), E._ptr(dte1), None, s()), "dst_attn_bwd")
+            o.act_bwd(dte0, bt["te0"], dte0, TANH)
+            o.act_bwd(dte1, bt["te1"], dte1, TANH)
+            o.lin_bwd_w(mv(dte0, 0, 252), mv(bt["en"]), mv(gw(ap + "lin_edge0.weight")))
+            o.lin_bwd_w(mv(dte1), mv(bt["en"]), mv(gw(ap + "lin_edge1.weight")))
+            den = self.f(Pp, 64)
+            o.lin_bwd_x(mv(dte0, 0, 252), mv(p[ap + "lin_edge0.weight"]), mv(den))
+            o.lin_bwd_x(mv(dte1), mv(p[ap + "lin_edge1.weight"]), mv(den), acc=True)
+            dhn = self.f(Nn, 256)
+            for k, (nm, c0_, c1_) in enumerate((("lin_query", 0, 252), ("lin_key", 256, 508), ("lin_value", 512, 768))):
+                o.lin_bwd_w(mv(dqkv, c0_, c1_), mv(bt["hn"]), mv(gw(ap + nm + ".weight")), gw(ap + nm + ".bias"))
+                o.lin_bwd_x(mv(dqkv, c0_, c1_), mv(p[ap + nm + ".weight"]), mv(dhn), acc=k > 0)
+            # adaLN modulates of the block input
+            de1 = self.f(Pp, 64)
+            o.lnmod_bwd(den, bt["e1"], bt["st_e1"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 0, a0 + EDGE_OFF + 64, de1, False)
+            o.lnmod_bwd(dhn, bt["h_in"], bt["st_n1"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 0, a0 + NODE_OFF + 256, dh_in, True)
+            # edge embedding + distance features
+            o.lin_bwd_w(mv(de1), mv(bt["X1"]), mv(gw(bp + "edge_emb.weight")), gw(bp + "edge_emb.bias"))
+            dfeat1 = self.f(Pp, 64)
+            Wee = p[bp + "edge_emb.weight"]
+            o.lin_bwd_x(mv(de1), mv(Wee, 0, 64), mv(dfeat1))
+            o.lin_bwd_x(mv(de1), mv(Wee, 64, 128), mv(de_in), acc=True)
+            self._geom_bwd(TL, bt["pos_in"], ada, d_ada, a0 + DIST_OFF, bp + "dist_layer.", bt["xs"], bt["d2"], dfeat1, dfeat2, dms_buf, dd2_buf, dpos_in)
+            o.colsum(mv(dms_buf, 1, 64), gw(bp + "dist_layer.means.weight").view(-1))      # lane k of the kernel = feature k = Gaussian k - 1
+            o.colsum(mv(dms_buf, 65, 128), gw(bp + "dist_layer.stds.weight").view(-1))
+            dh, de, dpos_out = dh_in, de_in, dpos_in
+        # ---- input embeddings
+        o.lin_bwd_w(mv(dh), mv(t["X0n"]), mv(gw("node_emb.weight")), gw("node_emb.bias"))
+        o.lin_bwd_w(mv(dAH, 0, 256), mv(t["X0n"]), mv(g["node_emb.weight"]), g["node_emb.bias"], acc=True)
+        o.lin_bwd_w(mv(de), mv(t["X0p"]), mv(gw("edge_emb.weight")), gw("edge_emb.bias"))
+        o.lin_bwd_w(mv(dEH, 0, 64), mv(t["X0p"]), mv(g["edge_emb.weight"]), g["edge_emb.bias"], acc=True)
+        for nm in ("dist_layer.means.weight", "dist_layer.stds.weight"):
+            gw(nm)
+        if not t["first"]:
+            dfeat0 = self.f(Pp, 64)
+            o.lin_bwd_x(mv(de), mv(p["edge_emb.weight"], 4, 68), mv(dfeat0))
+            o.lin_bwd_x(mv(dEH, 0, 64), mv(p["edge_emb.weight"], 4, 68), mv(dfeat0), acc=True)
+            self._geom_bwd(TL, t["cpos"], ada, d_ada, ADA_TOP, "dist_layer.", t["xs0"], t["d2c"], dfeat0, None, dms_buf, dd2_buf, None)
+            o.colsum(mv(dms_buf, 1, 64), g["dist_layer.means.weight"].view(-1))
+            o.colsum(mv(dms_buf, 65, 128), g["dist_layer.stds.weight"].view(-1))
+        # ---- adaLN table + time embedding
+        dWada, dbada = self.f(ADA, 1024), self.f(ADA)
+        o.lin_bwd_w(mv(d_ada), mv(t["st"]), mv(dWada), dbada)
+        self.scatter_ada_grads(dWada, dbada, g)
+        dtemb = self.f(B, 1024)
+        o.lin_bwd_x(mv(d_ada), mv(t["Wada"]), mv(dtemb))
+        o.act_bwd(dtemb, t["temb"], dtemb, SILU)
+        g["@ctx_emb"] = dtemb
+        o.lin_bwd_w(mv(dtemb), mv(t["tg"]), mv(gw("time_mlp.3.weight")), gw("time_mlp.3.bias"))
+        dtg = self.f(B, 1024)
+        o.lin_bwd_x(mv(dtemb), mv(p["time_mlp.3.weight"]), mv(dtg))
+        o.act_bwd(dtg, t["tm1"], dtg, GELU)
+        o.lin_bwd_w(mv(dtg), mv(t["tf"]), mv(gw("time_mlp.1.weight")), gw("time_mlp.1.bias"))
+        dtf = self.f(B, 17)
+        o.lin_bwd_x(mv(dtg), mv(p["time_mlp.1.weight"]), mv(dtf))
+        E._check(lib.dst_time_feat_bwd(E._ptr(t["noise_level"]), E._ptr(p["time_mlp.0.weights"]), E._ptr(dtf), C.c_int32(B),
+                                       E._ptr(gw("time_mlp.0.weights")), s()), "dst_time_feat_bwd")
+        self.t = None
+        return g
+
+    # ------------------------------------------------------------------ loss
+    def loss(self, TL: TrainLayout, pos, atom_pred, edge_pred, tpos, tfeat, tedge, wm, weights=(1.0, 0.25, 0.1)):
+        """losses.py:359-394 on packed predictions: (per-molecule loss [B], dpos, datom, dedge)."""
+        loss_m, dpos, dfeat, dedge = self.f(TL.B), self.f(TL.Nn, 3), self.f(TL.Nn, 6), self.f(max(TL.Pp, 1), 2)
+        E._check(self.lib.dst_loss(C.byref(TL.c), E._ptr(pos), E._ptr(atom_pred), E._ptr(edge_pred), E._ptr(tpos), E._ptr(tfeat), E._ptr(tedge),
+                                   E._ptr(wm), C.c_float(weights[0]), C.c_float(weights[1]), C.c_float(weights[2]), E._ptr(loss_m), E._ptr(dpos),
+                                   E._ptr(dfeat), E._ptr(dedge), E._stream()), "dst_loss")
+        return loss_m, dpos, dfeat, dedge

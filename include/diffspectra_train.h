@@ -1,0 +1,182 @@
+/*
+ * diffspectra_train.h — C-ABI of the MI355X (gfx950) TRAINING path of the DMT (BASELINE config 5).
+ *
+ * The reference trains through torch.autograd over models/dmt.py; this library provides the forward AND the hand-written
+ * backward of every operation of that graph as explicit kernels over the packed-ragged layout of diffspectra_hip.h
+ * (node rows / unordered-pair rows / directed rows d = 2p + dir with dir 0 = (row a, col b), dir 1 = (row b, col a)).
+ * The host side (diffspectra_amd/train_engine.py) strings them into the forward tape and its reverse; there is no autograd
+ * graph and no PyTorch arithmetic in between.  Plain device pointers + sizes + hipStream_t, int status.
+ *
+ * Reference operations covered (file:line in /root/reference):
+ *   dst_gemm                 every nn.Linear forward, input gradient and weight gradient
+ *   dst_lnmod_*              LayerNorm(eps 1e-6, no affine) + modulate             models/dmt.py:13-14,86-97,148-149,160,166
+ *   dst_gate_add_*           gated residuals                                         models/dmt.py:159-169
+ *   dst_geom_*               coord2dist + CondGaussianLayer                          models/utils.py:129-133, models/layers.py:291-295,328-334
+ *   dst_attn_*               TransMixLayer.message + PyG softmax / propagate         models/layers.py:131-186
+ *   dst_pair_sum_*, dst_zbuild_*   h[row] + h[col] gathers                           models/dmt.py:39,156
+ *   dst_coord_*              CoorsNorm, head mixing, scatter, remove_mean_with_mask  models/dmt.py:40-58,385-386, models/layers.py:344-347
+ *   dst_time_feat_*          LearnedSinusodialposEmb                                 models/layers.py:283-288
+ *   dst_loss                 the three MSE terms and their gradients                 losses.py:359-394
+ *   dst_noising, dst_kabsch  forward diffusion + Kabsch alignment                    losses.py:312-327,414-452; models/utils.py:67-106
+ *   dst_bn_*, dst_spec_attn_* SpecFormer in training mode                            models/specformer.py:247,260,385-425
+ *   dst_adamw_ema            AdamW(amsgrad) + EMA update, fused                      losses.py:20,92; models/ema.py:24-42
+ */
+#ifndef DIFFSPECTRA_TRAIN_H
+#define DIFFSPECTRA_TRAIN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Generic fp32 GEMM on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32): C[M,N] (+)= A[M,K] * B[K,N] (+ bias[N]).
+ * Element strides make every transpose a view: A[m,k] = A[m*a_rs + k*a_cs], B[k,n] = B[k*b_rs + n*b_cs], C row stride ldc.
+ *   Linear forward   Y = X W^T + b : A = X (a_rs = ldx, a_cs = 1), B = W^T (b_rs = 1, b_cs = ldw)
+ *   input gradient   dX = dY W     : A = dY,                        B = W   (b_rs = ldw, b_cs = 1)
+ *   weight gradient  dW = dY^T X   : A = dY^T (a_rs = 1, a_cs = ldy), B = X (b_rs = ldx, b_cs = 1), K = rows
+ * accumulate != 0 adds to C.  Long-K products are split over K into `partial` (caller scratch of partial_cap floats) and
+ * reduced in a fixed order: results do not depend on scheduling. */
+typedef struct dst_gemm_args {
+  const float* A; int64_t a_rs, a_cs;
+  const float* B; int64_t b_rs, b_cs;
+  float* C; int64_t ldc;
+  const float* bias;
+  int32_t M, N, K, accumulate;
+  float* partial; int64_t partial_cap;
+} dst_gemm_args;
+int dst_gemm(const dst_gemm_args* a, void* stream);
+
+/* out[c] (+)= sum_r X[r*ld + c], two fixed-order stages through `scratch` (bias gradients, per-molecule partial sums). */
+int dst_colsum(const float* X, int64_t ld, int32_t R, int32_t C, float* out, int32_t accumulate, float* scratch,
+               int64_t scratch_cap, void* stream);
+
+/* Elementwise.  kind: 1 SiLU, 2 GELU(erf), 3 tanh.  Backward: dx = dy * f'(.), with ref = x for SiLU / GELU and ref = y for
+ * tanh; dx may alias dy.  dst_axpy: y += a * x.  dst_scale_rows: y[r, :] = x[r, :] * s[r]. */
+int dst_act_fwd(const float* x, float* y, int64_t n, int32_t kind, void* stream);
+int dst_act_bwd(const float* dy, const float* ref, float* dx, int64_t n, int32_t kind, void* stream);
+int dst_axpy(float a, const float* x, float* y, int64_t n, void* stream);
+
+/* Segments: rows of molecule m are seg_off[m]*seg_mul .. seg_off[m+1]*seg_mul (node_off / pair_off with seg_mul 1, directed rows
+ * with pair_off and seg_mul 2).  ada [B, ada_ld] is the per-molecule adaLN table and d_ada its gradient; *_off are column offsets. */
+
+/* y = LN(x) * (1 + scale[m]) + shift[m], C in {64, 256}; stats [rows,2] = (mean, rstd).  Backward writes dx (accumulate != 0
+ * adds) and d_ada[m, shift_off + c] = sum_rows dy, d_ada[m, scale_off + c] = sum_rows dy * xhat. */
+int dst_lnmod_fwd(const float* x, int32_t C, const int32_t* seg_off, int32_t seg_mul, int32_t B, const float* ada, int64_t ada_ld,
+                  int32_t shift_off, int32_t scale_off, float* y, float* stats, void* stream);
+int dst_lnmod_bwd(const float* dy, const float* x, const float* stats, int32_t C, const int32_t* seg_off, int32_t seg_mul, int32_t B,
+                  const float* ada, float* d_ada, int64_t ada_ld, int32_t shift_off, int32_t scale_off, float* dx, int32_t accumulate,
+                  void* stream);
+
+/* out = r + gate[m] * z.  Backward: dr (accumulate_r != 0 adds) = dout, dz = gate * dout, d_ada[m, gate_off + c] = sum_rows dout * z. */
+int dst_gate_add_fwd(const float* r, const float* z, int32_t C, const int32_t* seg_off, int32_t seg_mul, int32_t B, const float* ada,
+                     int64_t ada_ld, int32_t gate_off, float* out, void* stream);
+int dst_gate_add_bwd(const float* dout, const float* z, int32_t C, const int32_t* seg_off, int32_t seg_mul, int32_t B, const float* ada,
+                     float* d_ada, int64_t ada_ld, int32_t gate_off, float* dr, int32_t accumulate_r, float* dz, void* stream);
+
+/* Layout tables shared by the molecule-level kernels (device pointers; the tables of ds_layout). */
+typedef struct dst_layout {
+  int32_t B, Nn, Pp, _pad;
+  const int32_t* node_off;   /* [B+1] */
+  const int32_t* pair_off;   /* [B+1] */
+} dst_layout;
+
+/* coord2dist + CondGaussianLayer: d2 = |pos_a - pos_b|^2, x' = d2 * (1 + ada[m, dist_off]) + ada[m, dist_off + 1],
+ * feat = [x', gaussian_k(x')] (63 kernels, std = |stds| + 1e-5, pi = 3.14159) written to X[p*ldx + k] for k < 64; xs[p] = x',
+ * d2s[p] = d2.  pos [Nn,3].  Backward: the gradient of the 64 features arrives from up to two places (g1, g2; g2 may be NULL);
+ * writes d_ada[m, dist_off .. +1], per-molecule partial sums of d means / d stds to dms [B,128] (d stds with respect to the raw
+ * stds.weight: sign included), and - when dpos != NULL - accumulates into dpos [Nn,3]. */
+int dst_geom_fwd(const dst_layout* L, const float* pos, const float* ada, int64_t ada_ld, int32_t dist_off, const float* means,
+                 const float* stds, float* X, int64_t ldx, float* xs, float* d2s, void* stream);
+int dst_geom_bwd(const dst_layout* L, const float* pos, const float* ada, float* d_ada, int64_t ada_ld, int32_t dist_off,
+                 const float* means, const float* stds, const float* xs, const float* d2s, const float* g1, int64_t ld1, const float* g2,
+                 int64_t ld2, float* dms, float* dd2_scratch, float* dpos, void* stream);
+
+/* TransMixLayer attention per molecule.  qkv [Nn,768]: q at columns 0..251, k at 256..507, v at 512..767; te0 [Pp,256]
+ * (= tanh(lin_edge0 e), 252 used), te1 [Pp,256], adj [Pp] bits (1: cond_adj_2d, 2: cond_adj_spatial); out [Nn,256];
+ * alpha [2*Pp,16] (row 2p: source a -> target b, row 2p+1: source b -> target a).  16 heads: 0,1 adjacency heads (0 -> -1e10),
+ * 2..15 learned (18 channels, scale 1/sqrt(16)); softmax over the sources of a target with + 1e-16 in the denominator.
+ * Backward: dqkv [Nn,768], dte0 [Pp,256], dte1 [Pp,256] are written (not accumulated). */
+int dst_attn_fwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, const int32_t* adj, float* out,
+                 float* alpha, void* stream);
+int dst_attn_bwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, const float* alpha, const float* dout,
+                 float* dqkv, float* dte0, float* dte1, float* scratch, void* stream);
+
+/* s[p] = u[a] + u[b] (+ bias[c]) over C columns; backward du[i] (accumulate != 0 adds) = sum over the pairs of atom i of ds[p]. */
+int dst_pair_sum_fwd(const dst_layout* L, const float* u, int32_t C, const float* bias, float* s, void* stream);
+int dst_pair_sum_bwd(const dst_layout* L, const float* ds, int32_t C, float* du, int32_t accumulate, void* stream);
+
+/* z[2p + dir] = ac[row, 0:256] + ac[col, 256:512] + ed[p] (dmt.py:39 with input_lin split into its row / col / edge parts).
+ * Backward: dac [Nn,512] and ded [Pp,256] are written. */
+int dst_zbuild_fwd(const dst_layout* L, const float* ac, const float* ed, float* z, void* stream);
+int dst_zbuild_bwd(const dst_layout* L, const float* dz, float* dac, float* ded, void* stream);
+
+/* Equivariant coordinate update + centre-of-mass removal (dmt.py:40-58,385-386): c2 [2*Pp,3] pre-tanh head outputs,
+ * inv = (tanh c2_0 + adj2d tanh c2_1 + adjsp tanh c2_2) / 3, pos_new[row] = pos[row] + sum_col CoorsNorm(pos[row] - pos[col]) inv,
+ * pos_out = pos_new - mean.  Backward from dpos_out: dpos_in [Nn,3] (written), dc2 [2*Pp,3], dscale_part [B] (per-molecule partial
+ * of d coord_norm.scale). */
+int dst_coord_fwd(const dst_layout* L, const float* pos, const float* c2, const int32_t* adj, const float* coord_scale,
+                  float* pos_out, void* stream);
+int dst_coord_bwd(const dst_layout* L, const float* pos, const float* c2, const int32_t* adj, const float* coord_scale,
+                  const float* dpos_out, float* dpos_in, float* dc2, float* dscale_part, void* stream);
+
+/* LearnedSinusodialposEmb: f [B,17] = [x, sin(2 pi x w_k), cos(2 pi x w_k)], k < 8.  Backward: dw [8] (written). */
+int dst_time_feat_fwd(const float* noise_level, const float* w, int32_t B, float* f, void* stream);
+int dst_time_feat_bwd(const float* noise_level, const float* w, const float* df, int32_t B, float* dw, void* stream);
+
+/* Loss of losses.py:359-394 (pred_data, reduce_mean False) on packed predictions and its gradient: per molecule
+ * l = wm[m] * (w_pos * sum_atoms mean_3 (pos - tpos)^2 + w_type * sum_atoms mean_6 (feat - tfeat)^2
+ *              + w_edge * 2 sum_pairs mean_2 (edge - tedge)^2), wm[m] = sqrt(alpha_m / sigma_m) / B supplied by the caller;
+ * loss_m [B]; dpos [Nn,3], dfeat [Nn,6], dedge [Pp,2] written. */
+int dst_loss(const dst_layout* L, const float* pos, const float* feat, const float* edge, const float* tpos, const float* tfeat,
+             const float* tedge, const float* wm, float w_pos, float w_type, float w_edge, float* loss_m, float* dpos, float* dfeat,
+             float* dedge, void* stream);
+
+/* Forward diffusion on packed rows (losses.py:312-320, models/utils.py:67-106): z = alpha[m] x + sigma[m] noise with the position
+ * noise centre-of-mass projected per molecule.  x [Nn,9] clean, raw [Nn,9] standard normals (columns 0..2 positions), out z [Nn,9];
+ * ex [Pp,2] clean pair features, eraw [Pp,2] normals, out ez [Pp,2]. */
+int dst_noising(const dst_layout* L, const float* alpha, const float* sigma, const float* x, const float* raw, float* z, const float* ex,
+                const float* eraw, float* ez, void* stream);
+
+/* Kabsch alignment (losses.py:414-452): rot[m] = U diag(1, 1, sign det A) V^T of A = sum_atoms pred_i tar_i^T (3x3 SVD by one-sided
+ * Jacobi in fp64), aligned[i] = rot tar_i.  pred / tar / aligned [Nn, ld] (first three columns); rot [B,9]. */
+int dst_kabsch(const dst_layout* L, const float* pred, int64_t ld_pred, const float* tar, int64_t ld_tar, float* rot, float* aligned,
+               void* stream);
+
+/* BatchNorm1d in training mode over the columns of X [R, C] (C <= 256): y = (x - mean_c) / sqrt(var_c + eps) * gamma_c + beta_c with
+ * biased batch variance; stats [2, C] = (mean, rstd) saved; running statistics updated in place with momentum 0.1 and the unbiased
+ * variance.  Backward: dx written, dgamma / dbeta [C] written. */
+int dst_bn_fwd(const float* x, int32_t R, int32_t C, const float* gamma, const float* beta, float eps, float* y, float* stats,
+               float* running_mean, float* running_var, float* scratch, int64_t scratch_cap, void* stream);
+int dst_bn_bwd(const float* dy, const float* x, const float* stats, int32_t R, int32_t C, const float* gamma, float* dx, float* dgamma,
+               float* dbeta, float* scratch, int64_t scratch_cap, void* stream);
+
+/* SpecFormer attention in training form (specformer.py:385-425): scores [B,H,L,L] = q k^T * scale (+ prev), attn = softmax, both kept;
+ * out [B,L,H*dk].  qkv [B,L,3*H*dk] (q | k | v).  Backward: dscores_in (gradient arriving at THIS layer's scores from the next layer's
+ * `prev` use; may be NULL) is added to the softmax gradient; writes dqkv and dscores (total gradient of this layer's scores = what
+ * flows on to the previous layer's scores). */
+int dst_spec_attn_fwd(const float* qkv, const float* prev, float* scores, float* attn, float* out, int32_t B, int32_t L, int32_t H,
+                      int32_t dk, float scale, void* stream);
+int dst_spec_attn_bwd(const float* qkv, const float* attn, const float* dout, const float* dscores_in, float* dqkv, float* dscores,
+                      int32_t B, int32_t L, int32_t H, int32_t dk, float scale, void* stream);
+
+/* LayerNorm with affine over the last dimension (specformer.py:67,119), training form.  Backward: dx written, dgamma / dbeta
+ * accumulated through per-row-block partials (fixed order). */
+int dst_ln_affine_fwd(const float* x, int32_t R, int32_t C, const float* gamma, const float* beta, float eps, float* y, float* stats,
+                      void* stream);
+int dst_ln_affine_bwd(const float* dy, const float* x, const float* stats, int32_t R, int32_t C, const float* gamma, float* dx,
+                      float* dgamma, float* dbeta, void* stream);
+
+/* Fused optimizer step over one flat fp32 parameter buffer (losses.py:20 AdamW(amsgrad=True, weight_decay), torch semantics) followed
+ * by the EMA update of models/ema.py:24-42: p, g, m, v, vmax, ema all [n].  clip_coef multiplies the gradient first (gradient clipping,
+ * losses.py:28-50); bias corrections are passed in (1 - beta^t). */
+int dst_adamw_ema(float* p, const float* g, float* m, float* v, float* vmax, float* ema, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float bc1, float bc2, float clip_coef, float ema_one_minus_decay, void* stream);
+
+/* sum of squares of x [n] into out[0] (accumulate != 0 adds): the global gradient norm of clip_grad_norm_. */
+int dst_sumsq(const float* x, int64_t n, float* out, int32_t accumulate, float* scratch, int64_t scratch_cap, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFSPECTRA_TRAIN_H */

@@ -97,6 +97,21 @@ def align_position(z_t, xh):
     return torch.einsum("...ki, ...ji -> ...jk", rot, xh[:, :, :3])
 
 
+def loss_from_predictions(pred, edge_pred, xh, edge_x, align_pos, alpha_t, sigma_t, loss_weights=(1.0, 0.25, 0.1)):
+    """losses.py:359-394 (pred_data, reduce_mean False): the three MSE terms, weighted, times sqrt(alpha_t / sigma_t), batch mean."""
+    B = xh.shape[0]
+    l_pos = torch.square(pred[:, :, :3] - align_pos).mean(-1).sum(-1)
+    l_type = torch.square(pred[:, :, 3:] - xh[:, :, 3:]).mean(-1).sum(-1)
+    l_edge = torch.square(edge_x - edge_pred).mean(-1).reshape(B, -1).sum(-1)
+    losses = loss_weights[0] * l_pos + loss_weights[1] * l_type + loss_weights[2] * l_edge
+    return (torch.sqrt(alpha_t / sigma_t) * losses).mean()
+
+
+def forward_with_context(sd, cfg, z_t, node_mask, edge_mask, edge_z_t, noise_level, ctx_emb, cond_x=None, cond_edge_x=None):
+    """The DMT forward with gradients enabled and the conditioning embedding supplied (used to check the DMT-side backward alone)."""
+    return odmt.dmt_forward.__wrapped__(sd, cfg, z_t, node_mask, edge_mask, edge_z_t, noise_level, cond_x, cond_edge_x, context_emb=ctx_emb)
+
+
 def training_loss(sd, cfg, batch, t_raw, randn, self_cond_coin: bool, loss_weights=(1.0, 0.25, 0.1)):
     """One ``loss_fn(model, batch)`` call (losses.py:301-394) with its random draws passed in: ``t_raw`` = the ``torch.rand(B)``
     draw, ``randn`` = the three noise draws (pos [B,N,3], feat [B,N,6], edge [B,2,N,N]), ``self_cond_coin`` = ``random() < 0.5``.
@@ -127,12 +142,8 @@ def training_loss(sd, cfg, batch, t_raw, randn, self_cond_coin: bool, loss_weigh
             sd = dict(sd)
             sd.update(stats0)
     (pred, edge_pred), stats = model(sd, cond_x, cond_edge_x)
-    l_pos = torch.square(pred[:, :, :3] - align_pos).mean(-1).sum(-1)
-    l_type = torch.square(pred[:, :, 3:] - xh[:, :, 3:]).mean(-1).sum(-1)
-    l_edge = torch.square(edge_x - edge_pred).mean(-1).reshape(B, -1).sum(-1)
-    losses = loss_weights[0] * l_pos + loss_weights[1] * l_type + loss_weights[2] * l_edge
-    losses = torch.sqrt(alpha_t / sigma_t) * losses
+    loss = loss_from_predictions(pred, edge_pred, xh, edge_x, align_pos, alpha_t, sigma_t, loss_weights)
     info.update(xh=xh, edge_x=edge_x, z_t=z_t, edge_z_t=edge_z_t, alpha_t=alpha_t, sigma_t=sigma_t, noise_level=noise_level,
                 align_pos=align_pos, pred=pred, edge_pred=edge_pred, cond_x=cond_x, cond_edge_x=cond_edge_x, bn=stats,
                 node_mask=node_mask, edge_mask=edge_mask)
-    return losses.mean(), info
+    return loss, info

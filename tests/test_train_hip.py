@@ -1,0 +1,366 @@
+"""GPU parity of the TRAINING path (row N1, stage A): every forward / backward kernel of csrc/ds_train.hip against torch autograd of
+the same operation, then the whole DMT graph (loss + gradients of every parameter) against the training oracle, which golden G13 pins
+to the reference's own ``get_sde_graph_loss_fn`` (losses.py:286-396).  Tolerances: loss rtol 1e-5, gradients rtol 1e-4 (plus a floor of
+1e-7 of the total gradient norm for gradients that are sums of cancelling terms)."""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import train as otrain
+from oracle import dmt as odmt
+from tests.golden import cases
+from tests.helpers import procedural_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def check(a, b, tol, what):
+    e = relerr(a, b)
+    assert e <= tol, f"{what}: max |diff| / max |ref| = {e:.3e} (tol {tol:g})"
+    return e
+
+
+@pytest.fixture(scope="module")
+def ops(gpu_device):
+    from diffspectra_amd import train_engine as T
+    return T, T.Ops(gpu_device)
+
+
+def layout(gpu_device, n_atoms):
+    from diffspectra_amd import filler, train_engine as T
+    node_mask, _ = filler.masks_from_n_atoms(n_atoms)
+    return T.TrainLayout(node_mask, gpu_device)
+
+
+def mol_tables(n_atoms):
+    """CPU index tables of the packed layout: node -> molecule, pair -> (a, b, molecule), directed edge lists."""
+    node_mol, pa, pb, pm = [], [], [], []
+    off = 0
+    for m, n in enumerate(n_atoms):
+        node_mol += [m] * n
+        for a in range(n):
+            for b in range(a + 1, n):
+                pa.append(off + a); pb.append(off + b); pm.append(m)
+        off += n
+    t = lambda x: torch.tensor(x, dtype=torch.long)
+    return t(node_mol), t(pa), t(pb), t(pm)
+
+
+N_ATOMS = [3, 1, 7, 12, 29, 2]
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K,ta,tb,bias,acc", [(70, 96, 40, False, True, True, False), (64, 64, 64, False, False, False, True),
+                                                    (252, 64, 5000, True, False, False, False), (1, 32, 3000, True, False, False, True),
+                                                    (300, 3, 256, False, True, False, False), (17, 1024, 17, False, True, True, False),
+                                                    (256, 256, 70000, True, False, False, False), (5, 7, 0, False, False, True, False)])
+def test_train_gemm(ops, gpu_device, M, N, K, ta, tb, bias, acc):
+    T, o = ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    Bm = torch.randn((N, K) if tb else (K, N), generator=g)
+    b = torch.randn(N, generator=g) if bias else None
+    C0 = torch.randn(M, N + 5, generator=g)                                   # a column slice of a wider buffer (ldc > N)
+    ref = (A.t() if ta else A).double() @ (Bm.t() if tb else Bm).double()
+    if bias:
+        ref = ref + b.double()
+    if acc:
+        ref = ref + C0[:, 2:2 + N].double()
+    d = gpu_device
+    Ad, Bd, Cd = A.to(d), Bm.to(d), C0.to(d)
+    o.gemm(T.mv(Ad), T.mv(Bd), T.mv(Cd, 2, 2 + N), ta, tb, bias=None if b is None else b.to(d), acc=acc)
+    out = Cd.cpu()
+    scale = float(ref.abs().max()) + 1e-6
+    assert float((out[:, 2:2 + N].double() - ref).abs().max()) <= 3e-6 * scale * max(1.0, K ** 0.5 / 8), (M, N, K)
+    assert torch.equal(out[:, :2], C0[:, :2]) and torch.equal(out[:, 2 + N:], C0[:, 2 + N:])      # nothing outside the slice is touched
+
+
+def test_colsum_and_acts(ops, gpu_device):
+    T, o = ops
+    d = gpu_device
+    X = torch.randn(3000, 70)
+    out = torch.zeros(64, device=d)
+    o.colsum(T.mv(X.to(d), 3, 67), out)
+    check(out, X[:, 3:67].double().sum(0), 2e-6, "colsum")
+    o.colsum(T.mv(X.to(d), 3, 67), out, acc=True)
+    check(out, 2 * X[:, 3:67].double().sum(0), 2e-6, "colsum accumulate")
+    x = torch.randn(5000) * 3
+    for kind, fn in ((T.SILU, F.silu), (T.GELU, F.gelu), (T.TANH, torch.tanh)):
+        xr = x.clone().double().requires_grad_(True)
+        yr = fn(xr)
+        dy = torch.randn(5000)
+        yr.backward(dy.double())
+        xd, yd, dxd = x.to(d), torch.empty(5000, device=d), torch.empty(5000, device=d)
+        o.act_fwd(xd, yd, kind)
+        o.act_bwd(dy.to(d), yd if kind == T.TANH else xd, dxd, kind)
+        check(yd, yr, 2e-6, f"act fwd {kind}")
+        check(dxd, xr.grad, 3e-6, f"act bwd {kind}")
+
+
+# ------------------------------------------------------------------------------------------------ LN + modulate, gated residual
+@pytest.mark.parametrize("Cc,kind", [(256, "node"), (64, "pair"), (256, "directed")])
+def test_lnmod_and_gate(ops, gpu_device, Cc, kind):
+    T, o = ops
+    d = gpu_device
+    TL = layout(d, N_ATOMS)
+    node_mol, pa, pb, pm = mol_tables(N_ATOMS)
+    seg, mul, row_mol = {"node": (TL.node_off, 1, node_mol), "pair": (TL.pair_off, 1, pm), "directed": (TL.pair_off, 2, pm.repeat_interleave(2))}[kind]
+    R, B = row_mol.numel(), len(N_ATOMS)
+    g = torch.Generator().manual_seed(Cc + R)
+    x = (torch.randn(R, Cc, generator=g) * 2 + 0.3).double().requires_grad_(True)
+    ada = (torch.randn(B, T.ADA, generator=g) * 0.5).double().requires_grad_(True)
+    sh, sc, gt = 100, 100 + Cc, 100 + 2 * Cc
+    y = F.layer_norm(x, (Cc,), None, None, 1e-6) * (1 + ada[row_mol, sc:sc + Cc]) + ada[row_mol, sh:sh + Cc]
+    dy = torch.randn(R, Cc, generator=g)
+    y.backward(dy.double())
+    xd, adad = x.detach().float().to(d), ada.detach().float().to(d)
+    yd, st, dxd, d_ada = torch.empty(R, Cc, device=d), torch.empty(R, 2, device=d), torch.zeros(R, Cc, device=d), torch.zeros(B, T.ADA, device=d)
+    o.lnmod_fwd(xd, Cc, seg, mul, B, adad, sh, sc, yd, st)
+    o.lnmod_bwd(dy.to(d), xd, st, Cc, seg, mul, B, adad, d_ada, sh, sc, dxd, False)
+    check(yd, y, 3e-6, "lnmod fwd")
+    check(dxd, x.grad, 2e-5, "lnmod dx")
+    check(d_ada[:, sh:sh + Cc], ada.grad[:, sh:sh + Cc], 1e-5, "lnmod dshift")
+    check(d_ada[:, sc:sc + Cc], ada.grad[:, sc:sc + Cc], 1e-5, "lnmod dscale")
+    o.lnmod_bwd(dy.to(d), xd, st, Cc, seg, mul, B, adad, d_ada, sh, sc, dxd, True)
+    check(dxd, 2 * x.grad, 2e-5, "lnmod dx accumulate")
+    # gated residual
+    r = torch.randn(R, Cc, generator=g).double().requires_grad_(True)
+    z = torch.randn(R, Cc, generator=g).double().requires_grad_(True)
+    ada2 = ada.detach().clone().requires_grad_(True)
+    out = r + ada2[row_mol, gt:gt + Cc] * z
+    out.backward(dy.double())
+    od, drd, dzd = torch.empty(R, Cc, device=d), torch.empty(R, Cc, device=d), torch.empty(R, Cc, device=d)
+    o.gate_add_fwd(r.detach().float().to(d), z.detach().float().to(d), Cc, seg, mul, B, adad, gt, od)
+    o.gate_add_bwd(dy.to(d), z.detach().float().to(d), Cc, seg, mul, B, adad, d_ada, gt, drd, False, dzd)
+    check(od, out, 2e-6, "gate_add fwd")
+    check(drd, r.grad, 1e-6, "gate_add dr")
+    check(dzd, z.grad, 2e-6, "gate_add dz")
+    check(d_ada[:, gt:gt + Cc], ada2.grad[:, gt:gt + Cc], 1e-5, "gate_add dgate")
+
+
+# ------------------------------------------------------------------------------------------------ geometry
+def test_geom(ops, gpu_device):
+    T, o = ops
+    d = gpu_device
+    TL = layout(d, N_ATOMS)
+    node_mol, pa, pb, pm = mol_tables(N_ATOMS)
+    Nn, P, B = node_mol.numel(), pa.numel(), len(N_ATOMS)
+    g = torch.Generator().manual_seed(5)
+    pos = (torch.randn(Nn, 3, generator=g) * 1.2).double().requires_grad_(True)
+    ada = (torch.randn(B, T.ADA, generator=g) * 0.3).double().requires_grad_(True)
+    means = (torch.rand(1, 63, generator=g) * 3).double().requires_grad_(True)
+    stds = ((torch.rand(1, 63, generator=g) * 3 + 0.05) * torch.where(torch.rand(1, 63, generator=g) > 0.8, -1.0, 1.0)).double().requires_grad_(True)
+    off = 37
+    d2 = ((pos[pa] - pos[pb]) ** 2).sum(1, keepdim=True)
+    x = d2 * (ada[pm, off:off + 1] + 1) + ada[pm, off + 1:off + 2]
+    sd = stds.view(-1).abs() + 1e-5
+    feat = torch.cat([x, torch.exp(-0.5 * ((x - means.view(-1)) / sd) ** 2) / ((2 * 3.14159) ** 0.5 * sd)], dim=1)
+    g1, g2 = torch.randn(P, 70, generator=g), torch.randn(P, 64, generator=g)
+    (feat * g1[:, 3:67].double()).sum().backward(retain_graph=True)
+    (feat * g2.double()).sum().backward()
+    p = {"x.means.weight": means.detach().float().to(d), "x.stds.weight": stds.detach().float().to(d)}
+    graph = T.DmtTrainGraph.__new__(T.DmtTrainGraph)
+    graph.p, graph.lib, graph.dev = p, o.lib, d
+    X, xs, d2s = torch.zeros(P, 70, device=d), torch.empty(P, device=d), torch.empty(P, device=d)
+    posd, adad = pos.detach().float().to(d), ada.detach().float().to(d)
+    graph._geom_fwd(TL, posd, adad, off, "x.", X, 70, 3, xs, d2s)
+    check(X[:, 3:67], feat, 3e-6, "geom features")
+    assert float(X[:, :3].abs().max()) == 0 and float(X[:, 67:].abs().max()) == 0
+    d_ada, dms, dd2, dpos = torch.zeros(B, T.ADA, device=d), torch.empty(B, 128, device=d), torch.empty(P, device=d), torch.zeros(Nn, 3, device=d)
+    g1d = g1[:, 3:67].contiguous().to(d)
+    graph._geom_bwd(TL, posd, adad, d_ada, off, "x.", xs, d2s, g1d, g2.to(d), dms, dd2, dpos)
+    check(dpos, pos.grad, 2e-5, "geom dpos")
+    check(d_ada[:, off:off + 2], ada.grad[:, off:off + 2], 2e-5, "geom d(scale, shift)")
+    check(dms[:, 1:64].sum(0), means.grad.view(-1), 2e-5, "geom dmeans")
+    check(dms[:, 65:128].sum(0), stds.grad.view(-1), 2e-5, "geom dstds")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def torch_attention(qkv, te0, te1, adj, pa, pb, Nn):
+    """layers.py:131-186 on explicit directed edges: row 2p = source a -> target b, row 2p+1 = source b -> target a."""
+    src = torch.stack([pa, pb], 1).reshape(-1)
+    tgt = torch.stack([pb, pa], 1).reshape(-1)
+    q, k, v = qkv[:, 0:252].reshape(-1, 14, 18), qkv[:, 256:508].reshape(-1, 14, 18), qkv[:, 512:768].reshape(-1, 16, 16)
+    e0 = te0[:, :252].reshape(-1, 14, 18).repeat_interleave(2, 0)
+    e1 = te1.reshape(-1, 16, 16).repeat_interleave(2, 0)
+    alpha = (q[tgt] * k[src] * e0).sum(-1) / 4.0
+    bits = adj.repeat_interleave(2)
+    extra = torch.stack([(bits & 1).double(), ((bits >> 1) & 1).double()], 1)
+    extra = torch.where(extra == 0, torch.full_like(extra, -1e10), extra)
+    alpha = torch.cat([extra, alpha], 1)
+    idx = tgt.view(-1, 1).expand_as(alpha)
+    mx = torch.full((Nn, 16), float("-inf"), dtype=alpha.dtype).scatter_reduce(0, idx, alpha, "amax", include_self=True)
+    ex = (alpha - mx[tgt]).exp()
+    den = torch.zeros(Nn, 16, dtype=alpha.dtype).index_add_(0, tgt, ex) + 1e-16
+    al = ex / den[tgt]
+    out = torch.zeros(Nn, 16, 16, dtype=alpha.dtype).index_add_(0, tgt, v[src] * e1 * al.unsqueeze(-1))
+    return out.reshape(Nn, 256), al
+
+
+def test_attention(ops, gpu_device):
+    T, o = ops
+    d = gpu_device
+    TL = layout(d, N_ATOMS)
+    node_mol, pa, pb, pm = mol_tables(N_ATOMS)
+    Nn, P = node_mol.numel(), pa.numel()
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(Nn, 768, generator=g)
+    qkv[:, 252:256] = 0
+    qkv[:, 508:512] = 0
+    te0 = torch.tanh(torch.randn(P, 256, generator=g))
+    te0[:, 252:] = 0
+    te1 = torch.tanh(torch.randn(P, 256, generator=g))
+    adj = torch.randint(0, 4, (P,), generator=g).to(torch.int32)
+    qr, e0r, e1r = (t.double().requires_grad_(True) for t in (qkv, te0, te1))
+    out, al = torch_attention(qr, e0r, e1r, adj.long(), pa, pb, Nn)
+    dout = torch.randn(Nn, 256, generator=g)
+    out.backward(dout.double())
+    outd, ald = torch.empty(Nn, 256, device=d), torch.empty(2 * P, 16, device=d)
+    qd, e0d, e1d, adjd = qkv.to(d), te0.to(d), te1.to(d), adj.to(d)
+    from diffspectra_amd import engine as E
+    E._check(o.lib.dst_attn_fwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), E._ptr(adjd), E._ptr(outd), E._ptr(ald), E._stream()), "attn_fwd")
+    check(ald, al, 3e-6, "attention alpha")
+    check(outd, out, 3e-6, "attention out")
+    dq, de0, de1 = torch.empty(Nn, 768, device=d), torch.empty(P, 256, device=d), torch.empty(P, 256, device=d)
+    E._check(o.lib.dst_attn_bwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), E._ptr(ald), E._ptr(dout.to(d)), E._ptr(dq), E._ptr(de0), E._ptr(de1),
+                                None, E._stream()), "attn_bwd")
+    check(dq, qr.grad, 2e-5, "attention dqkv")
+    check(de0, e0r.grad, 2e-5, "attention dte0")
+    check(de1, e1r.grad, 2e-5, "attention dte1")
+
+
+# ------------------------------------------------------------------------------------------------ gathers + coordinates
+def test_pair_sum_zbuild_coord(ops, gpu_device):
+    T, o = ops
+    from diffspectra_amd import engine as E
+    d = gpu_device
+    TL = layout(d, N_ATOMS)
+    node_mol, pa, pb, pm = mol_tables(N_ATOMS)
+    Nn, P, B = node_mol.numel(), pa.numel(), len(N_ATOMS)
+    g = torch.Generator().manual_seed(21)
+    s = E._stream
+    # pair sum
+    u = torch.randn(Nn, 64, generator=g).double().requires_grad_(True)
+    bias = torch.randn(64, generator=g)
+    ps = u[pa] + u[pb] + bias.double()
+    dps = torch.randn(P, 64, generator=g)
+    ps.backward(dps.double())
+    psd, dud = torch.empty(P, 64, device=d), torch.empty(Nn, 64, device=d)
+    E._check(o.lib.dst_pair_sum_fwd(C.byref(TL.c), E._ptr(u.detach().float().to(d)), C.c_int32(64), E._ptr(bias.to(d)), E._ptr(psd), s()), "pair_sum_fwd")
+    E._check(o.lib.dst_pair_sum_bwd(C.byref(TL.c), E._ptr(dps.to(d)), C.c_int32(64), E._ptr(dud), C.c_int32(0), s()), "pair_sum_bwd")
+    check(psd, ps, 1e-6, "pair_sum fwd")
+    check(dud, u.grad, 3e-6, "pair_sum bwd")
+    # zbuild: directed edge 2p = (row a, col b), 2p+1 = (row b, col a)
+    row = torch.stack([pa, pb], 1).reshape(-1)
+    col = torch.stack([pb, pa], 1).reshape(-1)
+    ac = torch.randn(Nn, 512, generator=g).double().requires_grad_(True)
+    ed = torch.randn(P, 256, generator=g).double().requires_grad_(True)
+    z = ac[row, :256] + ac[col, 256:] + ed.repeat_interleave(2, 0)
+    dz = torch.randn(2 * P, 256, generator=g)
+    z.backward(dz.double())
+    zd, dacd, dedd = torch.empty(2 * P, 256, device=d), torch.empty(Nn, 512, device=d), torch.empty(P, 256, device=d)
+    E._check(o.lib.dst_zbuild_fwd(C.byref(TL.c), E._ptr(ac.detach().float().to(d)), E._ptr(ed.detach().float().to(d)), E._ptr(zd), s()), "zbuild_fwd")
+    E._check(o.lib.dst_zbuild_bwd(C.byref(TL.c), E._ptr(dz.to(d)), E._ptr(dacd), E._ptr(dedd), s()), "zbuild_bwd")
+    check(zd, z, 1e-6, "zbuild fwd")
+    check(dacd, ac.grad, 3e-6, "zbuild dac")
+    check(dedd, ed.grad, 1e-6, "zbuild ded")
+    # coordinate update + CoM removal (dmt.py:40-58,385-386)
+    pos = (torch.randn(Nn, 3, generator=g) * 1.5).double().requires_grad_(True)
+    c2 = torch.randn(2 * P, 3, generator=g).double().requires_grad_(True)
+    scale = torch.tensor([0.013], dtype=torch.float64, requires_grad=True)
+    adj = torch.randint(0, 4, (P,), generator=g).to(torch.int32)
+    bits = adj.long().repeat_interleave(2)
+    adjs = torch.stack([torch.ones(2 * P, dtype=torch.float64), (bits & 1).double(), ((bits >> 1) & 1).double()], 1)
+    diff = pos[row] - pos[col]
+    unit = diff / diff.norm(dim=-1, keepdim=True).clamp(min=1e-8) * scale
+    inv = (torch.tanh(c2) * adjs).mean(-1, keepdim=True)
+    new = pos + torch.zeros_like(pos).index_add_(0, row, unit * inv)
+    cnt = torch.zeros(B, 1, dtype=torch.float64).index_add_(0, node_mol, torch.ones(Nn, 1, dtype=torch.float64))
+    mean = torch.zeros(B, 3, dtype=torch.float64).index_add_(0, node_mol, new) / cnt
+    out = new - mean[node_mol]
+    dout = torch.randn(Nn, 3, generator=g)
+    out.backward(dout.double())
+    posd, c2d, adjd, scd = pos.detach().float().to(d), c2.detach().float().to(d), adj.to(d), scale.detach().float().to(d)
+    outd, dposd, dc2d, dsp = torch.empty(Nn, 3, device=d), torch.empty(Nn, 3, device=d), torch.empty(2 * P, 3, device=d), torch.empty(B, device=d)
+    E._check(o.lib.dst_coord_fwd(C.byref(TL.c), E._ptr(posd), E._ptr(c2d), E._ptr(adjd), E._ptr(scd), E._ptr(outd), s()), "coord_fwd")
+    E._check(o.lib.dst_coord_bwd(C.byref(TL.c), E._ptr(posd), E._ptr(c2d), E._ptr(adjd), E._ptr(scd), E._ptr(dout.to(d)), E._ptr(dposd), E._ptr(dc2d),
+                                 E._ptr(dsp), s()), "coord_bwd")
+    check(outd, out, 2e-6, "coord fwd")
+    check(dposd, pos.grad, 2e-5, "coord dpos")
+    check(dc2d, c2.grad, 2e-5, "coord dc2")
+    check(dsp.sum().reshape(1), scale.grad, 2e-5, "coord dscale")
+
+
+# ------------------------------------------------------------------------------------------------ whole graph vs the oracle
+def _graph_case(version, coin, gpu_device):
+    """Inputs of one training evaluation on the G13 batch: the oracle (CPU, autograd) computes loss + gradients with the conditioning
+    embedding as a leaf; the same tensors drive the HIP graph."""
+    cfg, sd0 = procedural_state_dict(version)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.startswith("cond_encoder.") else v.clone()) for k, v in sd0.items()}
+    batch, draws = cases.training_batch(version), cases.training_draws()
+    with torch.no_grad():
+        _, info = otrain.training_loss({k: v.detach() for k, v in sd.items()}, cfg, batch, draws["t_raw"], draws["randn"], coin)
+        z, _ = otrain.specformer_forward_train({k: v.detach() for k, v in sd.items()}, batch["context"], version, cfg.model.patch_len, cfg.model.stride)
+        ctx0 = odmt._lin({k: v.detach() for k, v in sd.items()}, "cond_lin", z)
+    ctx = ctx0.clone().requires_grad_(True)
+    cond = (info["cond_x"], info["cond_edge_x"]) if coin else (None, None)
+    pred, edge_pred = otrain.forward_with_context(sd, cfg, info["z_t"], info["node_mask"], info["edge_mask"], info["edge_z_t"], info["noise_level"], ctx,
+                                                  cond[0], cond[1])
+    loss = otrain.loss_from_predictions(pred, edge_pred, info["xh"], info["edge_x"], info["align_pos"], info["alpha_t"], info["sigma_t"])
+    loss.backward()
+    return cfg, sd, info, ctx, cond, pred.detach(), edge_pred.detach(), loss.detach()
+
+
+@pytest.mark.parametrize("version,coin", [("ir", True), ("ir", False)])
+def test_dmt_graph_loss_and_gradients_vs_oracle(gpu_device, version, coin):
+    from diffspectra_amd import train_engine as T
+    d = gpu_device
+    cfg, sd, info, ctx, cond, pred, edge_pred, loss = _graph_case(version, coin, d)
+    params = {k: v.detach().to(d).contiguous() for k, v in sd.items() if not k.startswith("cond_encoder.") and v.is_floating_point()}
+    graph = T.DmtTrainGraph(params, cfg, d)
+    TL = T.TrainLayout(info["node_mask"], d)
+    pk_n = lambda t: None if t is None else TL.pack_nodes(t.to(d))
+    pk_e = lambda t: None if t is None else TL.pack_pairs(t.to(d))
+    pos, atom, edge = graph.forward(TL, pk_n(info["z_t"]), pk_e(info["edge_z_t"]), info["noise_level"].to(d), ctx.detach().to(d),
+                                    pk_n(cond[0]), pk_e(cond[1]))
+    check(TL.unpack_nodes(torch.cat([pos, atom], 1)), pred, 2e-5, "forward pred")
+    check(TL.unpack_pairs(edge), edge_pred, 2e-5, "forward edge_pred")
+    B = TL.B
+    wm = (torch.sqrt(info["alpha_t"] / info["sigma_t"]) / B).to(d)
+    tn = pk_n(torch.cat([info["align_pos"], info["xh"][:, :, 3:]], 2))
+    loss_m, dpos, dfeat, dedge = graph.loss(TL, pos, atom, edge, tn[:, :3].contiguous(), tn[:, 3:].contiguous(), pk_e(info["edge_x"]), wm)
+    got = float(loss_m.sum())
+    assert abs(got - float(loss)) <= 1e-5 * abs(float(loss)), (got, float(loss))
+    grads = graph.backward(dpos, dfeat, dedge)
+    total = float(torch.sqrt(sum((v.grad.double() ** 2).sum() for k, v in sd.items() if v.requires_grad and v.grad is not None)))
+    floor = 1e-7 * total
+    worst = ("", 0.0)
+    bad = []
+    for k, v in sd.items():
+        if not v.requires_grad:
+            continue
+        ref = v.grad if v.grad is not None else torch.zeros_like(v)
+        if k == "cond_lin.weight" or k == "cond_lin.bias":
+            continue                                   # downstream of ctx_emb: covered by the SpecFormer test
+        gk = grads[k].cpu().reshape(ref.shape)
+        err = float((gk.double() - ref.double()).abs().max())
+        lim = 1e-4 * float(ref.abs().max()) + floor
+        if err > lim:
+            bad.append((k, err, lim))
+        if float(ref.abs().max()) > 0 and err / float(ref.abs().max()) > worst[1]:
+            worst = (k, err / float(ref.abs().max()))
+    gctx = grads["@ctx_emb"].cpu()
+    err = float((gctx.double() - ctx.grad.double()).abs().max())
+    if err > 1e-4 * float(ctx.grad.abs().max()) + floor:
+        bad.append(("@ctx_emb", err, 0.0))
+    print(f"[train graph {version} selfcond={coin}] loss {got:.6f} (oracle {float(loss):.6f}); total grad norm {total:.3f}; worst relative deviation {worst}")
+    assert not bad, bad[:12]

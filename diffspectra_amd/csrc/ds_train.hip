@@ -779,6 +779,31 @@ __global__ __launch_bounds__(256) void k_noising(dst_layout L, const float* __re
   for (int it = threadIdx.x; it < np * 2; it += 256) ez[(int64_t)p0 * 2 + it] = a * ex[(int64_t)p0 * 2 + it] + s * eraw[(int64_t)p0 * 2 + it];
 }
 
+// process_edge_batch + get_data_scaler (losses.py:498-529, utils.py:33-68; centered data): CoM-free positions / pos_norm, one-hot types
+// * 2 - 1 over type_norm, charges over charge_norm; pair features * 2 - 1 over edge_norm.
+__global__ __launch_bounds__(256) void k_prepare_batch(dst_layout L, const float* __restrict__ pos, const float* __restrict__ one_hot, const float* __restrict__ fc,
+                                                        const float* __restrict__ edge, float pos_norm, float type_norm, float fc_norm, float edge_norm,
+                                                        float* __restrict__ x, float* __restrict__ ex) {
+  __shared__ float mean[3];
+  const int m = blockIdx.x;
+  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
+  if (threadIdx.x < 3) {
+    float t = 0.0f;
+    for (int i = 0; i < n; ++i) t += pos[(int64_t)(n0 + i) * 3 + threadIdx.x];
+    mean[threadIdx.x] = t / (float)n;
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < n * 9; it += 256) {
+    const int i = it / 9, c = it % 9;
+    float v;
+    if (c < 3) v = (pos[(int64_t)(n0 + i) * 3 + c] - mean[c]) / pos_norm;
+    else if (c < 8) v = (one_hot[(int64_t)(n0 + i) * 5 + (c - 3)] * 2.0f - 1.0f) / type_norm;
+    else v = fc[n0 + i] / fc_norm;
+    x[(int64_t)n0 * 9 + it] = v;
+  }
+  for (int it = threadIdx.x; it < np * 2; it += 256) ex[(int64_t)p0 * 2 + it] = (edge[(int64_t)p0 * 2 + it] * 2.0f - 1.0f) / edge_norm;
+}
+
 // 3x3 SVD by one-sided Jacobi on columns (fp64): A V = U S.
 __device__ void svd3(const double A[3][3], double U[3][3], double S[3], double V[3][3]) {
   double W[3][3];
@@ -1334,6 +1359,13 @@ int dst_noising(const dst_layout* L, const float* alpha, const float* sigma, con
                 const float* eraw, float* ez, void* stream) {
   if (!DST_L_OK(L) || !alpha || !sigma || !x || !raw || !z || !ex || !eraw || !ez) return DS_ERR_ARG;
   hipLaunchKernelGGL(k_noising, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, alpha, sigma, x, raw, z, ex, eraw, ez);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_prepare_batch(const dst_layout* L, const float* pos, const float* one_hot, const float* fc, const float* edge, float pos_norm,
+                      float type_norm, float fc_norm, float edge_norm, float* x, float* ex, void* stream) {
+  if (!DST_L_OK(L) || !pos || !one_hot || !fc || !edge || !x || !ex) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_prepare_batch, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, pos, one_hot, fc, edge, pos_norm, type_norm, fc_norm, edge_norm, x, ex);
   return DST_CHECK_LAUNCH();
 }
 

@@ -1,0 +1,419 @@
+"""Training step of the DMT on the MI355X - the surface of reference ``losses.py`` (BASELINE config 5).
+
+Same factories and call conventions: ``get_optimizer(config, params)`` (``losses.py:14-25``), ``optimization_manager(config)`` ->
+``optimize_fn(optimizer, params, step)`` with lr warm-up and the adaptive gradient-clipping queue (``:28-94``),
+``get_sde_graph_loss_fn(noise_scheduler, train, scaler, config)`` -> ``loss_fn(model, batch)`` (``:286-396``) and
+``get_step_fn(...)`` -> ``step_fn(state, batch)`` (``:97-125``: zero_grad, loss, ``loss.backward()``, optimize, EMA).
+
+What runs underneath is not autograd: ``loss_fn`` drives the HIP training library (``train_engine.DmtTrainGraph`` +
+``spec_train.SpecTrainGraph``: forward tape and hand-written backward of every operation) and hands the finished gradients to
+``loss.backward()`` through a one-node ``torch.autograd.Function``; the optimizer is one fused kernel over a flat parameter
+buffer (AdamW-amsgrad + gradient clipping + EMA), and with a process group the gradients are reduce-scattered, every rank
+updates its shard, and the parameters are all-gathered (RCCL over xGMI) - no parameter broadcast per call as ``nn.DataParallel``
+does (``models/utils.py:27``).  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from random import random
+from typing import Dict, List
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import engine as E
+from .ema import ExponentialMovingAverage
+from .scalers import _factors, get_self_cond_fn
+from .train_engine import DmtTrainGraph, Ops, TrainLayout, load_train_library
+
+
+# ----------------------------------------------------------------------------------------------------------- optimizer
+class FusedAdamW:
+    """``torch.optim.AdamW(params, lr, amsgrad=True, weight_decay)`` (losses.py:20) as ONE kernel over a flat fp32 buffer.
+
+    The parameters are re-pointed to views of one flat buffer (their values are kept), and so are their ``.grad`` s.  ``step``
+    optionally folds in the gradient-clipping coefficient and the EMA update (``models/ema.py:24-42``).  With an initialised
+    process group of W ranks the step is sharded: reduce-scatter of the flat gradient (mean over ranks), each rank updates 1/W
+    of the parameters (and holds 1/W of the optimizer state), all-gather of the parameters.  ``state_dict`` / ``load_state_dict``
+    speak ``torch.optim.AdamW``'s format, so checkpoints interchange with the reference's (``utils.py:7-30``)."""
+
+    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-12, amsgrad=True):
+        if not amsgrad:
+            raise ValueError("the fused kernel implements the shipped configuration: AdamW with amsgrad=True")
+        self.params: List[torch.nn.Parameter] = [p for p in params]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedAdamW runs on an MI355X only; diffspectra_amd has no CPU path")
+        self.lib = load_train_library()
+        self.dev = dev
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=True, params=list(range(len(self.params))))]
+        self.sizes = [p.numel() for p in self.params]
+        self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).tolist()
+        n = self.offsets[-1]
+        self.n = n
+        unit = 256 * self.world
+        self.n_pad = (n + unit - 1) // unit * unit
+        self.shard = self.n_pad // self.world
+        self.P = torch.zeros(self.n_pad, dtype=torch.float32, device=dev)
+        self.G = torch.zeros(self.n_pad, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            if p.dtype != torch.float32:
+                raise ValueError("FusedAdamW expects fp32 parameters")
+            self.P[o:o + p.numel()] = p.data.reshape(-1)
+            p.data = self.P[o:o + p.numel()].view(p.shape)
+            p.grad = self.G[o:o + p.numel()].view(p.shape)
+        lo = self.rank * self.shard
+        self.Ps, self.Gs = self.P[lo:lo + self.shard], (self.G[lo:lo + self.shard] if self.world == 1 else torch.zeros(self.shard, device=dev))
+        self.M, self.V, self.Vmax = (torch.zeros(self.shard, dtype=torch.float32, device=dev) for _ in range(3))
+        self.steps = 0
+        self.scratch = torch.empty(1024, dtype=torch.float32, device=dev)
+        self.norm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.ema_flat = None
+
+    # -- torch.optim surface
+    def zero_grad(self, set_to_none: bool = False):
+        self.G.zero_()
+        for p, o in zip(self.params, self.offsets):                    # keep .grad pointing into the flat buffer
+            if p.grad is None or p.grad.data_ptr() != self.G.data_ptr() + 4 * o:
+                p.grad = self.G[o:o + p.numel()].view(p.shape)
+
+    def _sync_grads(self):
+        """Mean of the gradients over the ranks, scattered: every rank ends with its shard in ``self.Gs``."""
+        if self.world == 1:
+            return
+        if dist.get_backend() == "gloo":                                # rehearsal backend: no reduce_scatter
+            dist.all_reduce(self.G)
+            self.Gs.copy_(self.G[self.rank * self.shard:(self.rank + 1) * self.shard])
+        else:
+            dist.reduce_scatter_tensor(self.Gs, self.G, op=dist.ReduceOp.SUM)
+
+    def grad_norm(self) -> torch.Tensor:
+        """Global L2 norm of the (rank-averaged) gradient: what ``clip_grad_norm_`` returns.  Synchronises the gradients."""
+        self._sync_grads()
+        self._synced = True
+        E._check(self.lib.dst_sumsq(E._ptr(self.Gs), C.c_int64(self.shard), E._ptr(self.norm_sq), C.c_int32(0), E._ptr(self.scratch),
+                                    C.c_int64(self.scratch.numel()), E._stream()), "dst_sumsq")
+        if self.world > 1:
+            ns = self.norm_sq if dist.get_backend() != "gloo" else self.norm_sq.cpu()
+            dist.all_reduce(ns)
+            self.norm_sq.copy_(ns)
+        return torch.sqrt(self.norm_sq[0]) / self.world                 # the shards hold SUMS over ranks; the mean's norm is 1/W of it
+
+    def attach_ema(self, ema: ExponentialMovingAverage):
+        """Fold ``ema.update`` into the step kernel: the shadow parameters become views of one flat buffer."""
+        flat = torch.zeros(self.n_pad, dtype=torch.float32, device=self.dev)
+        trainable = [i for i, p in enumerate(self.params) if p.requires_grad]
+        if len(trainable) != len(ema.shadow_params):
+            raise ValueError("EMA and optimizer must cover the same trainable parameters")
+        flat.copy_(self.P)                                             # frozen parameters: their slots just track the parameter
+        for i, s in zip(trainable, ema.shadow_params):
+            o = self.offsets[i]
+            flat[o:o + s.numel()] = s.reshape(-1).to(self.dev)
+        ema.shadow_params = [flat[self.offsets[i]:self.offsets[i] + self.sizes[i]].view(self.params[i].shape) for i in trainable]
+        self.ema_flat, self.ema = flat, ema
+
+    @torch.no_grad()
+    def step(self, clip_coef: float = 1.0, ema: ExponentialMovingAverage = None):
+        if not getattr(self, "_synced", False):
+            self._sync_grads()
+        self._synced = False
+        g = self.param_groups[0]
+        self.steps += 1
+        b1, b2 = g["betas"]
+        ema_omd = 0.0
+        ema_ptr = None
+        if ema is not None:
+            if self.ema_flat is None or getattr(self, "ema", None) is not ema:
+                self.attach_ema(ema)
+            ema_omd = 1.0 - ema.effective_decay()
+            if ema.num_updates is not None:
+                ema.num_updates += 1
+            lo = self.rank * self.shard
+            ema_ptr = self.ema_flat[lo:lo + self.shard]
+        E._check(self.lib.dst_adamw_ema(E._ptr(self.Ps), E._ptr(self.Gs), E._ptr(self.M), E._ptr(self.V), E._ptr(self.Vmax), E._ptr(ema_ptr),
+                                        C.c_int64(self.shard), C.c_float(float(g["lr"])), C.c_float(b1), C.c_float(b2), C.c_float(g["eps"]),
+                                        C.c_float(g["weight_decay"]), C.c_float(1.0 - b1 ** self.steps), C.c_float(1.0 - b2 ** self.steps),
+                                        C.c_float(float(clip_coef) / self.world), C.c_float(ema_omd), E._stream()), "dst_adamw_ema")
+        if self.world > 1:
+            if dist.get_backend() == "gloo":                           # rehearsal backend: host tensors
+                for full, mine in ((self.P, self.Ps),) + (((self.ema_flat, ema_ptr),) if ema_ptr is not None else ()):
+                    parts = [torch.empty(self.shard) for _ in range(self.world)]
+                    dist.all_gather(parts, mine.cpu())
+                    full.copy_(torch.cat(parts).to(self.dev))
+            else:
+                dist.all_gather_into_tensor(self.P, self.Ps.clone())
+                if ema_ptr is not None:
+                    dist.all_gather_into_tensor(self.ema_flat, ema_ptr.clone())
+
+    def _gathered(self, shard_t: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return shard_t
+        full = torch.empty(self.n_pad, dtype=torch.float32, device=self.dev)
+        dist.all_gather_into_tensor(full, shard_t.clone())
+        return full
+
+    def state_dict(self):
+        """``torch.optim.AdamW.state_dict()`` format (what the reference's ``save_checkpoint`` stores, golden G14)."""
+        M, V, X = self._gathered(self.M), self._gathered(self.V), self._gathered(self.Vmax)
+        state = {}
+        if self.steps > 0:
+            for i, (o, n, p) in enumerate(zip(self.offsets, self.sizes, self.params)):
+                if not p.requires_grad:
+                    continue                                          # torch keeps no state for parameters that never received a gradient
+                state[i] = dict(step=torch.tensor(float(self.steps)), exp_avg=M[o:o + n].view(p.shape).clone(), exp_avg_sq=V[o:o + n].view(p.shape).clone(),
+                                max_exp_avg_sq=X[o:o + n].view(p.shape).clone())
+        g = self.param_groups[0]
+        group = dict(lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"], amsgrad=True, maximize=False, foreach=None,
+                     capturable=False, differentiable=False, fused=None, decoupled_weight_decay=True, params=list(range(len(self.params))))
+        return dict(state=state, param_groups=[group])
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        self.param_groups[0].update(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"])
+        full = [torch.zeros(self.n_pad, dtype=torch.float32, device=self.dev) for _ in range(3)]
+        for i, st in sd["state"].items():
+            o, n = self.offsets[int(i)], self.sizes[int(i)]
+            self.steps = int(float(st["step"]))
+            for buf, key in zip(full, ("exp_avg", "exp_avg_sq", "max_exp_avg_sq")):
+                buf[o:o + n] = st[key].reshape(-1).to(self.dev)
+        lo = self.rank * self.shard
+        for dst, src in zip((self.M, self.V, self.Vmax), full):
+            dst.copy_(src[lo:lo + self.shard])
+
+
+def get_optimizer(config, params):
+    """losses.py:14-25.  'AdamW' is the shipped optimizer: AdamW(lr, amsgrad=True, weight_decay=1e-12), here the fused kernel."""
+    if config.optim.optimizer == "AdamW":
+        return FusedAdamW(params, lr=config.optim.lr, amsgrad=True, weight_decay=1e-12)
+    raise NotImplementedError(f"Optimizer {config.optim.optimizer} not supported yet!")
+
+
+class Queue:
+    """losses.py:53-72 (gradient-norm history of the adaptive clipping)."""
+
+    def __init__(self, max_len=50):
+        self.items, self.max_len = [], max_len
+
+    def __len__(self):
+        return len(self.items)
+
+    def add(self, item):
+        self.items.insert(0, item)
+        if len(self) > self.max_len:
+            self.items.pop()
+
+    def mean(self):
+        return np.mean(self.items)
+
+    def std(self):
+        return np.std(self.items)
+
+
+def clip_coefficient(grad_norm: float, gradnorm_queue: Queue, max_grad: float):
+    """The scale ``clip_grad_norm_`` applies inside ``gradient_clipping`` (losses.py:28-50) and the queue update: allowed norm =
+    min(1.5 mean + 2 std of the recent history, max_grad); coefficient = min(1, allowed / (norm + 1e-6))."""
+    if max_grad <= 1.0:
+        return min(1.0, max_grad / (grad_norm + 1e-6)), max_grad
+    max_grad_norm = min(1.5 * gradnorm_queue.mean() + 2 * gradnorm_queue.std(), max_grad)
+    gradnorm_queue.add(float(max_grad_norm) if grad_norm > max_grad_norm else float(grad_norm))
+    return min(1.0, float(max_grad_norm) / (grad_norm + 1e-6)), max_grad_norm
+
+
+def optimization_manager(config):
+    """losses.py:75-94: lr warm-up + adaptive gradient clipping + optimizer step."""
+    gradnorm_queue = Queue()
+    gradnorm_queue.add(3000)                                            # large value that will be flushed (losses.py:79)
+
+    def optimize_fn(optimizer, params, step, lr=config.optim.lr, warmup=config.optim.warmup, grad_clip=config.optim.grad_clip, ema=None):
+        if warmup > 0:
+            for g in optimizer.param_groups:
+                g["lr"] = lr * np.minimum(step / warmup, 1.0)
+        coef = 1.0
+        if grad_clip >= 0:
+            norm = float(optimizer.grad_norm())                        # one device->host sync, as float(grad_norm) in the reference
+            coef, _ = clip_coefficient(norm, gradnorm_queue, grad_clip)
+            optimize_fn.last_grad_norm = norm
+        optimizer.step(clip_coef=coef, ema=ema)
+
+    optimize_fn.queue = gradnorm_queue
+    return optimize_fn
+
+
+# ----------------------------------------------------------------------------------------------------------- loss
+class _HipLoss(torch.autograd.Function):
+    """One autograd node whose backward hands out gradients the HIP library has already computed."""
+
+    @staticmethod
+    def forward(ctx, loss_value, grads, *params):
+        ctx.grads = grads
+        return loss_value.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return (None, None) + tuple(None if g is None else g * grad_out for g in ctx.grads)
+
+
+class HipTrainer:
+    """Per-model training state: the two graphs, bound to the model's current parameter storage at every call."""
+
+    def __init__(self, module, config):
+        self.module, self.cfg = module, config
+        self.dev = next(module.parameters()).device
+        if self.dev.type != "cuda":
+            raise RuntimeError("training runs on an MI355X only (move the model to a 'cuda' device); there is no CPU path")
+        self.ops = Ops(self.dev)
+        self.lib = self.ops.lib
+        self._layouts: Dict[bytes, TrainLayout] = {}
+
+    def layout(self, atom_mask) -> TrainLayout:
+        key = (atom_mask != 0).to("cpu").numpy().tobytes() + bytes(atom_mask.shape[1])
+        if key not in self._layouts:
+            if len(self._layouts) >= 8:
+                self._layouts.pop(next(iter(self._layouts)))
+            self._layouts[key] = TrainLayout(atom_mask.unsqueeze(2), self.dev)
+        return self._layouts[key]
+
+    def graphs(self):
+        from .spec_train import SpecTrainGraph
+        named = dict(self.module.named_parameters())
+        pd = {k: v.data for k, v in named.items()}
+        bufs = {k: v for k, v in self.module.named_buffers()}
+        dmt = DmtTrainGraph.__new__(DmtTrainGraph)
+        dmt.p, dmt.cfg, dmt.dev, dmt.ops, dmt.lib = pd, self.cfg, self.dev, self.ops, self.lib
+        dmt.edge_th, dmt.cutoff = float(self.cfg.model.edge_quan_th), float(self.cfg.model.spatial_cut_off)
+        spec = SpecTrainGraph(pd, bufs, self.cfg, self.ops)
+        return named, dmt, spec
+
+
+def _trainer(model) -> HipTrainer:
+    m = getattr(model, "module", model)
+    if not hasattr(m, "engine"):
+        raise TypeError(f"diffspectra_amd.losses drives the HIP DMT (diffspectra_amd.dmt.DMT); got {type(m).__name__}")
+    tr = getattr(m, "_hip_trainer", None)
+    if tr is None or tr.dev != next(m.parameters()).device:
+        tr = HipTrainer(m, m.config)
+        m._hip_trainer = tr
+    return tr
+
+
+def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None):
+    """losses.py:286-396 for the shipped mode (DMT, pred_data, self_cond, noise_align, reduce_mean False).  ``scaler`` is accepted
+    for signature compatibility; the scaling of ``process_edge_batch`` runs in ``dst_prepare_batch`` with the same factors."""
+    if not (config.model.pred_data and config.model.self_cond and config.model.noise_align and config.model.name == "DMT"):
+        raise ValueError("the MI355X training step implements the shipped mode: DMT, pred_data, self_cond, noise_align")
+    if config.training.reduce_mean:
+        raise ValueError("training.reduce_mean=True is not implemented (every shipped config has False)")
+    if not config.data.centered or not config.model.include_fc_charge:
+        raise ValueError("the batch preparation kernel implements centered data with formal charges")
+    if getattr(config.model, "dropout", 0.0) != 0.0 and train and not getattr(config.model, "allow_dropout_free_training", False):
+        raise NotImplementedError("stage A of the training path is dropout-free: set config.model.dropout = 0.0 (or "
+                                  "config.model.allow_dropout_free_training = True to train without the reference's p = 0.1 FF dropout)")
+    loss_weights = [float(w) for w in config.model.loss_weights.split(",")]
+    cond_process_fn = get_self_cond_fn(config)
+    pos_norm, type_norm, fc_norm, edge_norm = (float(v) for v in _factors(config))
+
+    def loss_fn(model, batch):
+        model.train() if train else model.eval()
+        tr = _trainer(model)
+        dev, lib = tr.dev, tr.lib
+        named, dmt, spec = tr.graphs()
+        atom_mask = batch["atom_mask"].to(dev)
+        TL = tr.layout(atom_mask)
+        B, N = TL.B, TL.N
+        f32 = lambda t: t.to(dev, torch.float32)
+        pos_p, oh_p = TL.pack_nodes(f32(batch["positions"])), TL.pack_nodes(f32(batch["atom_one_hot"]))
+        fc_p, edge_p = TL.pack_nodes(f32(batch["formal_charges"])).reshape(-1).contiguous(), TL.pack_pairs(f32(batch["edge_one_hot"]))
+        x, ex = dmt.f(TL.Nn, 9), dmt.f(max(TL.Pp, 1), 2)
+        E._check(lib.dst_prepare_batch(C.byref(TL.c), E._ptr(pos_p), E._ptr(oh_p), E._ptr(fc_p), E._ptr(edge_p), C.c_float(pos_norm), C.c_float(type_norm),
+                                       C.c_float(fc_norm), C.c_float(edge_norm), E._ptr(x), E._ptr(ex), E._stream()), "dst_prepare_batch")
+        context = batch["context"]
+        context = [f32(c) for c in context] if isinstance(context, (list, tuple)) else f32(context)
+        # the random draws, in the reference's order and shapes (losses.py:314-317, models/utils.py:67-106)
+        t = torch.rand(B, device=dev) * (1.0 - 1e-5) + 1e-5
+        alpha_t, sigma_t = noise_scheduler.marginal_prob(t)
+        raw_pos, raw_feat = torch.randn((B, N, 3), device=dev), torch.randn((B, N, 6), device=dev)
+        raw_edge = torch.randn((B, 2, N, N), device=dev)
+        raw_n = TL.pack_nodes(torch.cat([raw_pos, raw_feat], dim=2))
+        raw_e = raw_edge.permute(0, 2, 3, 1).reshape(B * N * N, 2).index_select(0, TL.pair_dense_t).contiguous()   # tril(-1) value of the pair
+        z, ez = dmt.f(TL.Nn, 9), dmt.f(max(TL.Pp, 1), 2)
+        alpha_t, sigma_t = alpha_t.to(torch.float32).contiguous(), sigma_t.to(torch.float32).contiguous()
+        E._check(lib.dst_noising(C.byref(TL.c), E._ptr(alpha_t), E._ptr(sigma_t), E._ptr(x), E._ptr(raw_n), E._ptr(z), E._ptr(ex), E._ptr(raw_e), E._ptr(ez),
+                                 E._stream()), "dst_noising")
+        rot, aligned = dmt.f(B, 9), dmt.f(TL.Nn, 3)
+        E._check(lib.dst_kabsch(C.byref(TL.c), E._ptr(z), C.c_int64(9), E._ptr(x), C.c_int64(9), E._ptr(rot), E._ptr(aligned), E._stream()), "dst_kabsch")
+        noise_level = torch.log(alpha_t ** 2 / sigma_t ** 2).contiguous()
+        cond_n = cond_e = None
+        if random() < 0.5:                                              # self-conditioning forward, no gradient (losses.py:344-351)
+            ctx0 = spec.forward(context, save=False) if train else _eval_context(model, context)
+            pos0, atom0, edge0 = dmt.forward(TL, z, ez, noise_level, ctx0, None, None, save=False)
+            cond_n, cond_e = torch.cat([pos0, atom0], dim=1).contiguous(), edge0
+            if getattr(config.model, "self_cond_type", "ori") != "ori":
+                cd, ce = cond_process_fn(TL.unpack_nodes(cond_n), TL.unpack_pairs(cond_e))
+                cond_n, cond_e = TL.pack_nodes(cd), TL.pack_pairs(ce)
+        ctx = spec.forward(context, save=train) if train else _eval_context(model, context)
+        pos, atom, edge = dmt.forward(TL, z, ez, noise_level, ctx, cond_n, cond_e, save=train)
+        wm = (torch.sqrt(alpha_t / sigma_t) / B).contiguous()
+        tfeat = x[:, 3:9].contiguous()
+        loss_m, dpos, dfeat, dedge = dmt.loss(TL, pos, atom, edge, aligned, tfeat, ex, wm, loss_weights)
+        loss = loss_m.sum()
+        loss_fn.last = dict(t=t, alpha_t=alpha_t, sigma_t=sigma_t, z=z, ez=ez, aligned=aligned, rot=rot, pred=(pos, atom, edge), layout=TL)
+        if not (train and torch.is_grad_enabled()):
+            return loss
+        g = dmt.backward(dpos, dfeat, dedge)
+        g.update(spec.backward(g.pop("@ctx_emb")))
+        params = [p for p in named.values()]
+        grads = [g.get(n) if p.requires_grad else None for n, p in named.items()]
+        missing = [n for n, p in named.items() if p.requires_grad and n not in g]
+        if missing:
+            raise RuntimeError(f"no gradient was produced for {missing[:5]}")
+        return _HipLoss.apply(loss, grads, *params)
+
+    return loss_fn
+
+
+def _eval_context(model, context):
+    """Eval-mode conditioning embedding (BatchNorm running statistics): the sampling engine's SpecFormer."""
+    m = getattr(model, "module", model)
+    return m.engine().context_embedding(context)
+
+
+def get_step_fn(noise_scheduler, train, optimize_fn, scaler, config, prop_dist=None):
+    """losses.py:97-125."""
+    if not config.pred_edge or config.only_2D:
+        raise ValueError("the MI355X training step implements the 3-D graph loss (pred_edge, not only_2D)")
+    loss_fn = get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_dist)
+
+    def step_fn(state, batch):
+        model = state["model"]
+        if train:
+            optimizer = state["optimizer"]
+            optimizer.zero_grad()
+            loss = loss_fn(model, batch)
+            loss.backward()
+            fused = isinstance(optimizer, FusedAdamW) and isinstance(state["ema"], ExponentialMovingAverage)
+            if fused:
+                optimize_fn(optimizer, model.parameters(), step=state["step"], ema=state["ema"])      # EMA update inside the step kernel
+            else:
+                optimize_fn(optimizer, model.parameters(), step=state["step"])
+            state["step"] += 1
+            if not fused:
+                state["ema"].update(model.parameters())
+            m = getattr(model, "module", model)
+            if hasattr(m, "invalidate_engine"):
+                m.invalidate_engine()                                   # the sampling engine's packed weights are stale now
+        else:
+            with torch.no_grad():
+                ema = state["ema"]
+                ema.store(model.parameters())
+                ema.copy_to(model.parameters())
+                loss = loss_fn(model, batch)
+                ema.restore(model.parameters())
+        return loss
+
+    return step_fn

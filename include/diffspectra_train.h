@@ -132,6 +132,12 @@ int dst_loss(const dst_layout* L, const float* pos, const float* feat, const flo
              const float* tedge, const float* wm, float w_pos, float w_type, float w_edge, float* loss_m, float* dpos, float* dfeat,
              float* dedge, void* stream);
 
+/* process_edge_batch + get_data_scaler on packed rows (losses.py:498-529, utils.py:33-68, centered data): x [Nn,9] = [(pos - CoM) /
+ * pos_norm, (one_hot * 2 - 1) / type_norm, fc / fc_norm]; ex [Pp,2] = (edge * 2 - 1) / edge_norm.  pos [Nn,3], one_hot [Nn,5], fc [Nn],
+ * edge [Pp,2] (exist, bond order / 3). */
+int dst_prepare_batch(const dst_layout* L, const float* pos, const float* one_hot, const float* fc, const float* edge, float pos_norm,
+                      float type_norm, float fc_norm, float edge_norm, float* x, float* ex, void* stream);
+
 /* Forward diffusion on packed rows (losses.py:312-320, models/utils.py:67-106): z = alpha[m] x + sigma[m] noise with the position
  * noise centre-of-mass projected per molecule.  x [Nn,9] clean, raw [Nn,9] standard normals (columns 0..2 positions), out z [Nn,9];
  * ex [Pp,2] clean pair features, eraw [Pp,2] normals, out ez [Pp,2]. */

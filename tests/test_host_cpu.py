@@ -22,6 +22,35 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 11
     for name in declared:
         assert hasattr(lib, name), name
+    # the training C-ABI (include/diffspectra_train.h) lives in the same library
+    from diffspectra_amd import train_engine as T
+    train = T.train_exports()
+    assert len(train) >= 30 and "dst_gemm" in train and "dst_adamw_ema" in train
+    tl = T.load_train_library()
+    for name in train:
+        assert hasattr(tl, name), name
+
+
+def test_training_surface_refuses_cpu():
+    """Row N1 has no CPU path either: optimizer, loss function and graphs raise off the GPU."""
+    from diffspectra_amd import losses as Lh, train_engine as T
+    from diffspectra_amd.registry import create_model
+    import diffspectra_amd.dmt  # noqa: F401
+    cfg = qm9s_config("ir")
+    model = create_model(cfg)
+    with pytest.raises(RuntimeError):
+        Lh.get_optimizer(cfg, model.parameters())
+    with pytest.raises(RuntimeError):
+        T.DmtTrainGraph({}, cfg, "cpu")
+    cfg.model.dropout = 0.0
+    from diffspectra_amd.noise_schedule import NoiseScheduleVP
+    loss_fn = Lh.get_sde_graph_loss_fn(NoiseScheduleVP("cosine"), True, None, cfg)
+    with pytest.raises(RuntimeError):
+        loss_fn(model, {})
+    q = Lh.Queue()
+    q.add(3000)
+    coef, allowed = Lh.clip_coefficient(18.0, q, 10.0)              # losses.py:33-44: allowed = min(1.5 mean + 2 std, max_grad)
+    assert allowed == 10.0 and abs(coef - 10.0 / (18.0 + 1e-6)) < 1e-12 and q.items[0] == 10.0
 
 
 def test_missing_library_fails_loudly(monkeypatch):

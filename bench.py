@@ -141,9 +141,11 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", default="eval", choices=["eval", "resident"],
+    ap.add_argument("--mode", default="eval", choices=["eval", "resident", "train"],
                     help="eval: BASELINE config 2 through the product sampling function (10 000 samples per GPU); "
-                         "resident: --mols molecules resident, back-to-back passes (kernel-level A/B, config 4)")
+                         "resident: --mols molecules resident, back-to-back passes (kernel-level A/B, config 4); "
+                         "train: BASELINE config 5, one optimizer step per bench step on --train-batch molecules per GPU")
+    ap.add_argument("--train-batch", type=int, default=256, help="train mode: molecules per GPU and step (config 5: 2048 over 8 GPUs)")
     ap.add_argument("--samples", type=int, default=10000, help="eval mode: samples per GPU")
     ap.add_argument("--batch", type=int, default=3334, help="eval mode: micro-batch (molecules resident at a time)")
     ap.add_argument("--mols", type=int, default=4096, help="resident mode: molecules resident per GPU")
@@ -201,6 +203,76 @@ def self_launch(argv) -> int:
     return rc
 
 
+def train_bench(args, world, rank, device):
+    """BASELINE config 5 (secondary line, not the headline metric): the DMT training step on QM9S all-spectra through the product's
+    ``losses.get_step_fn`` - batch preparation, forward diffusion, Kabsch alignment, p = 0.5 self-conditioning forward, training-mode
+    SpecFormer, DMT forward + hand-written backward, gradient reduce-scatter, fused AdamW-amsgrad + clip + EMA, parameter all-gather.
+    fp32 storage and arithmetic (stage A; the bf16 variant named by config 5 is not built).  A bench step = one optimizer step on
+    --train-batch molecules per GPU."""
+    from diffspectra_amd import filler, losses as Lh
+    from diffspectra_amd.config import qm9s_config
+    from diffspectra_amd.ema import ExponentialMovingAverage
+    from diffspectra_amd.noise_schedule import NoiseScheduleVP
+    from diffspectra_amd.registry import create_model
+    import diffspectra_amd.dmt  # noqa: F401
+    cfg = qm9s_config(args.spectra, device=device)
+    model = create_model(cfg)
+    filler.fill_module_(model)
+    ema = ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_decay)
+    opt = Lh.get_optimizer(cfg, model.parameters())
+    ns = NoiseScheduleVP(cfg.sde.schedule, continuous_beta_0=cfg.sde.continuous_beta_0, continuous_beta_1=cfg.sde.continuous_beta_1)
+    step_fn = Lh.get_step_fn(ns, True, Lh.optimization_manager(cfg), None, cfg)
+    state = dict(optimizer=opt, model=model, ema=ema, step=0)
+    Bt = args.train_batch
+    n_atoms = filler.sample_n_atoms(world * Bt, seed=3)[rank * Bt:(rank + 1) * Bt].tolist()
+    node_mask, edge_mask = filler.masks_from_n_atoms(n_atoms)
+    N = node_mask.shape[1]
+    g = torch.Generator().manual_seed(11 + rank)
+    types = torch.randint(0, 5, (Bt, N), generator=g)
+    order = torch.triu((torch.rand(Bt, N, N, generator=g) > 0.8).float() * torch.randint(1, 4, (Bt, N, N), generator=g), 1)
+    order = (order + order.transpose(1, 2)) * edge_mask.reshape(Bt, N, N)
+    ctx = filler.synthetic_spectra(Bt, args.spectra, seed=5 + rank)
+    batch = dict(positions=(torch.randn(Bt, N, 3, generator=g) * 1.3 * node_mask).to(device), atom_mask=node_mask.squeeze(-1).to(device),
+                 edge_mask=edge_mask.to(device), atom_one_hot=(torch.nn.functional.one_hot(types, 5).float() * node_mask).to(device),
+                 edge_one_hot=torch.stack([(order > 0).float(), order / 3.0], -1).to(device), formal_charges=torch.zeros(Bt, N, 1, device=device),
+                 context=[c.to(device) for c in ctx] if isinstance(ctx, list) else ctx.to(device))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    torch.manual_seed(rank)
+    for w in range(args.warmup):
+        loss = step_fn(state, batch)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        loss = step_fn(state, batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(loss.detach()).all()
+    if rank == 0:
+        n = np.asarray(n_atoms, dtype=np.int64)
+        flop = 3.0 * 2.0 * algorithmic_macs(n)                        # forward + two backward GEMMs per forward GEMM (self-cond forward not counted)
+        line = {"metric": "molecules/sec, DMT training step on QM9S all-spectra (BASELINE config 5; secondary line)", "value": world * Bt * args.steps / elapsed,
+                "unit": "molecules/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (fp32 MFMA GEMMs; stage A of row N1, no bf16 yet)",
+                "data": "synthetic",
+                "config": {"workload": f"DMT training step, QM9S {args.spectra}, {Bt} molecules per GPU and step (global batch {world * Bt}), dropout "
+                                       f"{cfg.model.dropout}, AdamW-amsgrad + adaptive clip + EMA fused, gradient reduce-scatter + parameter all-gather",
+                           "mode": "train", "molecules_per_gpu": Bt, "parallelism": f"dp{world}", "last_loss": float(loss.detach())},
+                "whole_path": {"algorithmic_tflops_per_gpu": flop * args.steps / elapsed / 1e12}}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
@@ -243,6 +315,8 @@ def main(argv=None):
         entry.build()
     if world > 1:
         dist.barrier()
+    if args.mode == "train":
+        return train_bench(args, world, rank, device)
     from diffspectra_amd import filler, sampling as S, engine as E, shard
     from diffspectra_amd.config import qm9s_config
     from diffspectra_amd.dataset_pack import PackedSpectraTable

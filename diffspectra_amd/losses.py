@@ -304,16 +304,16 @@ def _trainer(model) -> HipTrainer:
 
 def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None):
     """losses.py:286-396 for the shipped mode (DMT, pred_data, self_cond, noise_align, reduce_mean False).  ``scaler`` is accepted
-    for signature compatibility; the scaling of ``process_edge_batch`` runs in ``dst_prepare_batch`` with the same factors."""
+    for signature compatibility; the scaling of ``process_edge_batch`` runs in ``dst_prepare_batch`` with the same factors.
+    ``config.model.dropout`` (0.1 as shipped) is the FF dropout of the blocks, with in-kernel Philox masks (``dst_dropout``); golden
+    G13 pins the p = 0 arithmetic, the masks themselves cannot agree with torch's generator."""
     if not (config.model.pred_data and config.model.self_cond and config.model.noise_align and config.model.name == "DMT"):
         raise ValueError("the MI355X training step implements the shipped mode: DMT, pred_data, self_cond, noise_align")
     if config.training.reduce_mean:
         raise ValueError("training.reduce_mean=True is not implemented (every shipped config has False)")
     if not config.data.centered or not config.model.include_fc_charge:
         raise ValueError("the batch preparation kernel implements centered data with formal charges")
-    if getattr(config.model, "dropout", 0.0) != 0.0 and train and not getattr(config.model, "allow_dropout_free_training", False):
-        raise NotImplementedError("stage A of the training path is dropout-free: set config.model.dropout = 0.0 (or "
-                                  "config.model.allow_dropout_free_training = True to train without the reference's p = 0.1 FF dropout)")
+    dropout_p = float(getattr(config.model, "dropout", 0.0))
     loss_weights = [float(w) for w in config.model.loss_weights.split(",")]
     cond_process_fn = get_self_cond_fn(config)
     pos_norm, type_norm, fc_norm, edge_norm = (float(v) for v in _factors(config))
@@ -349,7 +349,11 @@ def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None
         E._check(lib.dst_kabsch(C.byref(TL.c), E._ptr(z), C.c_int64(9), E._ptr(x), C.c_int64(9), E._ptr(rot), E._ptr(aligned), E._stream()), "dst_kabsch")
         noise_level = torch.log(alpha_t ** 2 / sigma_t ** 2).contiguous()
         cond_n = cond_e = None
+        # FF dropout (dmt.py:114-120) is active whenever the model is in training mode - in the no-grad self-conditioning forward too
+        dmt.dropout_p = dropout_p if train else 0.0
+        seeds = torch.randint(0, 2 ** 62, (2,)).tolist() if dmt.dropout_p > 0 else [0, 0]
         if random() < 0.5:                                              # self-conditioning forward, no gradient (losses.py:344-351)
+            dmt.dropout_seed = seeds[0]
             ctx0 = spec.forward(context, save=False) if train else _eval_context(model, context)
             pos0, atom0, edge0 = dmt.forward(TL, z, ez, noise_level, ctx0, None, None, save=False)
             cond_n, cond_e = torch.cat([pos0, atom0], dim=1).contiguous(), edge0
@@ -357,6 +361,7 @@ def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None
                 cd, ce = cond_process_fn(TL.unpack_nodes(cond_n), TL.unpack_pairs(cond_e))
                 cond_n, cond_e = TL.pack_nodes(cd), TL.pack_pairs(ce)
         ctx = spec.forward(context, save=train) if train else _eval_context(model, context)
+        dmt.dropout_seed = seeds[1]
         pos, atom, edge = dmt.forward(TL, z, ez, noise_level, ctx, cond_n, cond_e, save=train)
         wm = (torch.sqrt(alpha_t / sigma_t) / B).contiguous()
         tfeat = x[:, 3:9].contiguous()

@@ -131,6 +131,12 @@ class Ops:
     def act_bwd(self, dy, ref, dx, kind):
         E._check(self.lib.dst_act_bwd(E._ptr(dy), E._ptr(ref), E._ptr(dx), C.c_int64(dy.numel()), C.c_int32(kind), self._s()), "dst_act_bwd")
 
+    def dropout(self, x, p, seed, stream_id):
+        """In place; the same (seed, stream_id) on the gradient is the backward."""
+        if p > 0.0:
+            E._check(self.lib.dst_dropout(E._ptr(x), E._ptr(x), C.c_int64(x.numel()), C.c_float(p), C.c_uint64(seed), C.c_uint32(stream_id), self._s()),
+                     "dst_dropout")
+
     def axpy(self, a, x, y):
         E._check(self.lib.dst_axpy(C.c_float(a), E._ptr(x), E._ptr(y), C.c_int64(x.numel()), self._s()), "dst_axpy")
 
@@ -207,6 +213,10 @@ class DmtTrainGraph:
         self.edge_th = float(config.model.edge_quan_th)
         self.cutoff = float(config.model.spatial_cut_off)
 
+    # FF dropout of the training forward (dmt.py:114-120): probability and the seed of this evaluation's Philox streams; 0 = identity
+    dropout_p = 0.0
+    dropout_seed = 0
+
     # ------------------------------------------------------------------ helpers
     def f(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.dev)
@@ -254,7 +264,8 @@ class DmtTrainGraph:
         o, p, lib = self.ops, self.p, self.lib
         B, Nn, Pp = TL.B, TL.Nn, TL.Pp
         D = 2 * Pp
-        t: Dict[str, object] = dict(TL=TL, first=cond_n is None)
+        t: Dict[str, object] = dict(TL=TL, first=cond_n is None, drop=(self.dropout_p, self.dropout_seed))
+        dp, dseed = self.dropout_p, self.dropout_seed
         s = E._stream
         # ---- time embedding + adaLN table (dmt.py:249-257,353-357; every *time_mlp)
         tf = self.f(B, 17)
@@ -330,7 +341,9 @@ class DmtTrainGraph:
             f1, s1, f2, h_out = self.f(Nn, 512), self.f(Nn, 512), self.f(Nn, 256), self.f(Nn, 256)
             o.lin_fwd(mv(y1), mv(p[bp + "ff_linear1.weight"]), p[bp + "ff_linear1.bias"], mv(f1))
             o.act_fwd(f1, s1, SILU)
+            o.dropout(s1, dp, dseed, 4 * i + 0)
             o.lin_fwd(mv(s1), mv(p[bp + "ff_linear2.weight"]), p[bp + "ff_linear2.bias"], mv(f2))
+            o.dropout(f2, dp, dseed, 4 * i + 1)
             o.gate_add_fwd(y1, f2, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 1280, h_out)
             # edge stream (dmt.py:165-169)
             xe1, ye1, st_e2 = self.f(Pp, 64), self.f(Pp, 64), self.f(Pp, 2)
@@ -339,7 +352,9 @@ class DmtTrainGraph:
             f3, s3, f4, e_out = self.f(Pp, 128), self.f(Pp, 128), self.f(Pp, 64), self.f(Pp, 64)
             o.lin_fwd(mv(ye1), mv(p[bp + "ff_linear3.weight"]), p[bp + "ff_linear3.bias"], mv(f3))
             o.act_fwd(f3, s3, SILU)
+            o.dropout(s3, dp, dseed, 4 * i + 2)
             o.lin_fwd(mv(s3), mv(p[bp + "ff_linear4.weight"]), p[bp + "ff_linear4.bias"], mv(f4))
+            o.dropout(f4, dp, dseed, 4 * i + 3)
             o.gate_add_fwd(ye1, f4, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 320, e_out)
             # equivariant update (dmt.py:37-60) + CoM removal (:385-386)
             Win = p[bp + "equi_update.input_lin.weight"]                       # [256, 640] = [h_row | h_col | e | dist]
@@ -406,6 +421,7 @@ class DmtTrainGraph:
         D = 2 * Pp
         s = E._stream
         ada = t["ada"]
+        dp, dseed = t["drop"]
         g: Dict[str, torch.Tensor] = {}
 
         def gw(name):                                       # gradient buffer of a parameter (fully written by its producer)
@@ -477,9 +493,11 @@ class DmtTrainGraph:
             # node stream
             dy1, df2 = self.f(Nn, 256), self.f(Nn, 256)
             o.gate_add_bwd(dh, bt["f2"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 1280, dy1, False, df2)
+            o.dropout(df2, dp, dseed, 4 * i + 1)
             o.lin_bwd_w(mv(df2), mv(bt["s1"]), mv(gw(bp + "ff_linear2.weight")), gw(bp + "ff_linear2.bias"))
             df1 = self.f(Nn, 512)
             o.lin_bwd_x(mv(df2), mv(p[bp + "ff_linear2.weight"]), mv(df1))
+            o.dropout(df1, dp, dseed, 4 * i + 0)
             o.act_bwd(df1, bt["f1"], df1, SILU)
             o.lin_bwd_w(mv(df1), mv(bt["y1"]), mv(gw(bp + "ff_linear1.weight")), gw(bp + "ff_linear1.bias"))
             o.lin_bwd_x(mv(df1), mv(p[bp + "ff_linear1.weight"]), mv(dy1), acc=True)
@@ -490,9 +508,11 @@ class DmtTrainGraph:
             # edge stream
             dye1, df4 = self.f(Pp, 64), self.f(Pp, 64)
             o.gate_add_bwd(de, bt["f4"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 320, dye1, False, df4)
+            o.dropout(df4, dp, dseed, 4 * i + 3)
             o.lin_bwd_w(mv(df4), mv(bt["s3"]), mv(gw(bp + "ff_linear4.weight")), gw(bp + "ff_linear4.bias"))
             df3 = self.f(Pp, 128)
             o.lin_bwd_x(mv(df4), mv(p[bp + "ff_linear4.weight"]), mv(df3))
+            o.dropout(df3, dp, dseed, 4 * i + 2)
             o.act_bwd(df3, bt["f3"], df3, SILU)
             o.lin_bwd_w(mv(df3), mv(bt["ye1"]), mv(gw(bp + "ff_linear3.weight")), gw(bp + "ff_linear3.bias"))
             o.lin_bwd_x(mv(df3), mv(p[bp + "ff_linear3.weight"]), mv(dye1), acc=True)

@@ -57,6 +57,11 @@ int dst_act_fwd(const float* x, float* y, int64_t n, int32_t kind, void* stream)
 int dst_act_bwd(const float* dy, const float* ref, float* dx, int64_t n, int32_t kind, void* stream);
 int dst_axpy(float a, const float* x, float* y, int64_t n, void* stream);
 
+/* nn.Dropout(p) in training mode (dmt.py:114-120): y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) from the Philox4x32-10 stream
+ * (seed, stream_id) indexed by the element.  The same call on the gradient is the backward (the mask is re-created, not stored).
+ * y may alias x. */
+int dst_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint32_t stream_id, void* stream);
+
 /* Segments: rows of molecule m are seg_off[m]*seg_mul .. seg_off[m+1]*seg_mul (node_off / pair_off with seg_mul 1, directed rows
  * with pair_off and seg_mul 2).  ada [B, ada_ld] is the per-molecule adaLN table and d_ada its gradient; *_off are column offsets. */
 

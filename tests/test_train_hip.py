@@ -4,6 +4,7 @@ to the reference's own ``get_sde_graph_loss_fn`` (losses.py:286-396).  Tolerance
 1e-7 of the total gradient norm for gradients that are sums of cancelling terms)."""
 import ctypes as C
 import json
+import math
 
 import numpy as np
 import pytest
@@ -635,3 +636,67 @@ def test_data_parallel_step_two_ranks(gpu_device, tmp_path):
     ref.grad.mul_(coef)
     torch.optim.AdamW([ref], lr=cfg.optim.lr, amsgrad=True, weight_decay=1e-12).step()
     assert float((r0["P"][:n] - ref.detach()).abs().max()) <= 2e-7 + 2e-6 * float(ref.detach().abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ dropout
+def test_dropout_kernel_and_training_with_dropout(gpu_device, monkeypatch):
+    """FF dropout of the training forward (dmt.py:114-120) with in-kernel Philox masks: keep rate and scaling, the backward re-creates
+    the forward's mask, streams are independent; and the gradient of a p = 0.1 training loss agrees with a central finite difference
+    along the gradient direction (same draws, same masks)."""
+    from diffspectra_amd import losses as Lh, train_engine as T
+    from diffspectra_amd.noise_schedule import NoiseScheduleVP
+    d = gpu_device
+    o = T.Ops(d)
+    x = torch.ones(1_000_003, device=d)
+    y = x.clone()
+    o.dropout(y, 0.1, 12345, 7)
+    keep = float((y != 0).float().mean())
+    assert abs(keep - 0.9) < 2e-3 and torch.allclose(y[y != 0], torch.full_like(y[y != 0], 1.0 / 0.9))
+    y2 = x.clone()
+    o.dropout(y2, 0.1, 12345, 7)
+    assert torch.equal(y, y2)                                                    # the mask is a function of (seed, stream, index)
+    y3 = x.clone()
+    o.dropout(y3, 0.1, 12345, 8)
+    agree = float(((y3 != 0) == (y != 0)).float().mean())
+    assert abs(agree - (0.81 + 0.01)) < 5e-3                                      # independent masks agree on 0.9^2 + 0.1^2 of the elements
+    cfg, model = _train_model("ir", d)
+    cfg.model.dropout = 0.1
+    loss_fn = Lh.get_sde_graph_loss_fn(NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0), True, None, cfg)
+    batch = {k: v for k, v in cases.training_batch("ir").items() if k != "n_atoms"}
+    draws = cases.training_draws()
+    real_randint = torch.randint
+
+    def run():
+        monkeypatch.setattr(torch, "rand", _Replay([draws["t_raw"]]))
+        monkeypatch.setattr(torch, "randn", _Replay(draws["randn"]))
+        monkeypatch.setattr(torch, "randint", lambda *a, **k: torch.tensor([1111, 2222]))
+        monkeypatch.setattr(Lh, "random", lambda: 0.0)
+        try:
+            return loss_fn(model, batch)
+        finally:
+            monkeypatch.undo()
+
+    loss = run()
+    loss.backward()
+    # direction: the gradient over every feed-forward weight (the tensors whose gradient passes through the dropout masks)
+    ps = [p for n, p in model.module.named_parameters() if ".ff_linear" in n and n.endswith("weight")]
+    gs = [p.grad.detach().clone() for p in ps]
+    an = float(torch.sqrt(sum((g.double() ** 2).sum() for g in gs)))
+    eps = 2e-2
+
+    def shift(sign):
+        with torch.no_grad():
+            for p, g in zip(ps, gs):
+                p.data.add_(sign * eps / an * g)
+
+    shift(+1)
+    lp = float(run())
+    shift(-2)
+    lm = float(run())
+    shift(+1)
+    fd = (lp - lm) / (2 * eps)
+    print(f"[dropout] loss {float(loss):.5f}; directional derivative along the FF-weight gradient: finite difference {fd:.5f}, analytic {an:.5f}")
+    assert abs(fd - an) <= 0.03 * an + 1e-4
+    loss0 = float(loss)
+    cfg.model.dropout = 0.0
+    assert math.isfinite(loss0)

@@ -145,6 +145,8 @@ def parse_args(argv=None):
                     help="eval: BASELINE config 2 through the product sampling function (10 000 samples per GPU); "
                          "resident: --mols molecules resident, back-to-back passes (kernel-level A/B, config 4); "
                          "train: BASELINE config 5, one optimizer step per bench step on --train-batch molecules per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+                    help="train mode: GEMM arithmetic (bf16 = config 5: bf16 products, fp32 accumulation and master weights)")
     ap.add_argument("--train-batch", type=int, default=256, help="train mode: molecules per GPU and step (config 5: 2048 over 8 GPUs)")
     ap.add_argument("--samples", type=int, default=10000, help="eval mode: samples per GPU")
     ap.add_argument("--batch", type=int, default=3334, help="eval mode: micro-batch (molecules resident at a time)")
@@ -207,8 +209,8 @@ def train_bench(args, world, rank, device):
     """BASELINE config 5 (secondary line, not the headline metric): the DMT training step on QM9S all-spectra through the product's
     ``losses.get_step_fn`` - batch preparation, forward diffusion, Kabsch alignment, p = 0.5 self-conditioning forward, training-mode
     SpecFormer, DMT forward + hand-written backward, gradient reduce-scatter, fused AdamW-amsgrad + clip + EMA, parameter all-gather.
-    fp32 storage and arithmetic (stage A; the bf16 variant named by config 5 is not built).  A bench step = one optimizer step on
-    --train-batch molecules per GPU."""
+    --precision bf16 (default, config 5) rounds every GEMM operand to bf16 with fp32 accumulation; storage, master weights and the
+    optimizer stay fp32.  A bench step = one optimizer step on --train-batch molecules per GPU."""
     from diffspectra_amd import filler, losses as Lh
     from diffspectra_amd.config import qm9s_config
     from diffspectra_amd.ema import ExponentialMovingAverage
@@ -216,6 +218,7 @@ def train_bench(args, world, rank, device):
     from diffspectra_amd.registry import create_model
     import diffspectra_amd.dmt  # noqa: F401
     cfg = qm9s_config(args.spectra, device=device)
+    cfg.training.precision = args.precision
     model = create_model(cfg)
     filler.fill_module_(model)
     ema = ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_decay)
@@ -261,7 +264,9 @@ def train_bench(args, world, rank, device):
         flop = 3.0 * 2.0 * algorithmic_macs(n)                        # forward + two backward GEMMs per forward GEMM (self-cond forward not counted)
         line = {"metric": "molecules/sec, DMT training step on QM9S all-spectra (BASELINE config 5; secondary line)", "value": world * Bt * args.steps / elapsed,
                 "unit": "molecules/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (fp32 MFMA GEMMs; stage A of row N1, no bf16 yet)",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": ("bf16 (GEMM operands rounded to bf16, fp32 accumulation, fp32 master weights / activations / optimizer state)"
+                          if args.precision == "bf16" else "f32 (fp32 MFMA GEMMs)"),
                 "data": "synthetic",
                 "config": {"workload": f"DMT training step, QM9S {args.spectra}, {Bt} molecules per GPU and step (global batch {world * Bt}), dropout "
                                        f"{cfg.model.dropout}, AdamW-amsgrad + adaptive clip + EMA fused, gradient reduce-scatter + parameter all-gather",

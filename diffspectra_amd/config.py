@@ -45,7 +45,9 @@ def qm9s_config(spectra_version: str = "allspectra", device="cpu", steps: int = 
                       begin_ckpt=40, end_ckpt=40, ckpts="")
     # training side (configs/diffspectra_qm9s.py:85-127): batch 128 per GPU, AdamW-amsgrad lr 2e-4, warm-up 100 000 steps,
     # adaptive gradient clipping capped at 10
-    training = Config(batch_size=128, reduce_mean=False, n_iters=2000000, snapshot_freq=50000, num_gpus=1)
+    # precision: 'fp32' (the reference's arithmetic, what golden G13 pins) or 'bf16' (BASELINE config 5: GEMM operands rounded to bf16,
+    # fp32 accumulation and fp32 master weights - a build-side option, the reference has no AMP)
+    training = Config(batch_size=128, reduce_mean=False, n_iters=2000000, snapshot_freq=50000, num_gpus=1, precision="fp32")
     optim = Config(weight_decay=0, optimizer="AdamW", lr=2e-4, beta1=0.9, eps=1e-8, warmup=100000, grad_clip=10.0,
                    disable_grad_log=True)
     return Config(

@@ -24,56 +24,121 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ int pair_index(int n, int lo, int hi) { return lo * (2 * n - lo - 1) / 2 + (hi - lo - 1); }
 
 // ------------------------------------------------------------------------------------------------------------------ GEMM
-__global__ __launch_bounds__(256) void k_tr_gemm(dst_gemm_args g, int splits, int kchunk) {
-  __shared__ float As[16][68];
-  __shared__ float Bs[16][68];
+// BM x BN per 256-thread workgroup (2 x 2 waves, each (BM/2) x (BN/2) as 32 x 32 MFMA tiles), BK = 16, the next k-slab's global
+// loads in flight (registers) while the current one is multiplied out of LDS.  Operands by element strides (every transpose is a
+// view), guards on all three dimensions, optional split over K.  BF16 = config 5's precision: the operands are rounded to bf16
+// (round to nearest even, v_cvt_pk_bf16_f32) as they leave LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -
+// autocast semantics: fp32 master weights and activations in memory, bf16 products.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <int BM, int BN, bool BF16>
+__global__ __launch_bounds__(256) void k_tr_gemm_big(dst_gemm_args g, int splits, int kchunk) {
+  constexpr int TM = BM / 64, TN = BN / 64;              // 32 x 32 tiles per wave in each direction (BM, BN in {64, 128})
+  constexpr int LA = BM * 16 / 256, LB = BN * 16 / 256;  // elements per thread per slab
+  __shared__ float As[16][BM + 4];
+  __shared__ float Bs[16][BN + 4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int z = blockIdx.z;
   const int kbeg = z * kchunk;
   const int kend = min(g.K, kbeg + kchunk);
-  f32x16_t acc;
+  f32x16_t acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   const bool a_kfast = (g.a_cs == 1), b_nfast = (g.b_cs == 1);
-  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+  float ra[LA], rb[LB];
+  auto fetch = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < LA; ++i) {
       const int e = tid + i * 256;
       int mm, kk;
-      if (a_kfast) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
+      if (a_kfast) { kk = e & 15; mm = e >> 4; } else { mm = e % BM; kk = e / BM; }
       const int gm = m0 + mm, gk = k0 + kk;
-      As[kk][mm] = (gm < g.M && gk < kend) ? g.A[(int64_t)gm * g.a_rs + (int64_t)gk * g.a_cs] : 0.0f;
-      int nn, kb;
-      if (b_nfast) { nn = e & 63; kb = e >> 6; } else { kb = e & 15; nn = e >> 4; }
-      const int gn = n0 + nn, gkb = k0 + kb;
-      Bs[kb][nn] = (gn < g.N && gkb < kend) ? g.B[(int64_t)gkb * g.b_rs + (int64_t)gn * g.b_cs] : 0.0f;
+      ra[i] = (gm < g.M && gk < kend) ? g.A[(int64_t)gm * g.a_rs + (int64_t)gk * g.a_cs] : 0.0f;
     }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int e = tid + i * 256;
+      int nn, kk;
+      if (b_nfast) { nn = e % BN; kk = e / BN; } else { kk = e & 15; nn = e >> 4; }
+      const int gn = n0 + nn, gk = k0 + kk;
+      rb[i] = (gn < g.N && gk < kend) ? g.B[(int64_t)gk * g.b_rs + (int64_t)gn * g.b_cs] : 0.0f;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int e = tid + i * 256;
+      int mm, kk;
+      if (a_kfast) { kk = e & 15; mm = e >> 4; } else { mm = e % BM; kk = e / BM; }
+      As[kk][mm] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int e = tid + i * 256;
+      int nn, kk;
+      if (b_nfast) { nn = e % BN; kk = e / BN; } else { kk = e & 15; nn = e >> 4; }
+      Bs[kk][nn] = rb[i];
+    }
+  };
+  if (kbeg < kend) fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    commit();
     __syncthreads();
+    if (k0 + 16 < kend) fetch(k0 + 16);
+    if constexpr (BF16) {
+      bf16x8_t a8[TM], b8[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a8[i][t] = (__bf16)As[8 * (lane >> 5) + t][wm * (BM / 2) + i * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) b8[j][t] = (__bf16)Bs[8 * (lane >> 5) + t][wn * (BN / 2) + j * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+    } else
 #pragma unroll
     for (int kk = 0; kk < 16; kk += 2) {
-      const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
-      const float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[kk + (lane >> 5)][wm * (BM / 2) + i * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[kk + (lane >> 5)][wn * (BN / 2) + j * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
-  const int col = n0 + wn * 32 + (lane & 31);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int row = m0 + wm * 32 + (i >> 2) * 8 + (lane >> 5) * 4 + (i & 3);
-    if (row < g.M && col < g.N) {
-      if (splits > 1) {
-        g.partial[((int64_t)z * g.M + row) * g.N + col] = acc[i];
-      } else {
-        float v = acc[i] + (g.bias ? g.bias[col] : 0.0f);
-        float* c = g.C + (int64_t)row * g.ldc + col;
-        if (g.accumulate) v += *c;
-        *c = v;
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (BM / 2) + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+        if (row < g.M && col < g.N) {
+          if (splits > 1) {
+            g.partial[((int64_t)z * g.M + row) * g.N + col] = acc[i][j][r];
+          } else {
+            float v = acc[i][j][r] + (g.bias ? g.bias[col] : 0.0f);
+            float* c = g.C + (int64_t)row * g.ldc + col;
+            if (g.accumulate) v += *c;
+            *c = v;
+          }
+        }
       }
     }
-  }
 }
 
 __global__ void k_tr_gemm_reduce(dst_gemm_args g, int splits) {
@@ -394,7 +459,7 @@ __global__ __launch_bounds__(256) void k_geom_bwd(dst_layout L, const float* __r
 
 // ------------------------------------------------------------------------------------------------------------------ attention
 // logits / alpha scratch in LDS: [directed edge (2 * 406)][16 heads]
-__global__ __launch_bounds__(256) void k_attn_fwd(dst_layout L, const float* __restrict__ qkv, const float* __restrict__ te0, const float* __restrict__ te1,
+__global__ __launch_bounds__(1024) void k_attn_fwd(dst_layout L, const float* __restrict__ qkv, const float* __restrict__ te0, const float* __restrict__ te1,
                                                    const int32_t* __restrict__ adj, float* __restrict__ out, float* __restrict__ alpha) {
   __shared__ float lg[812 * 16];
   __shared__ unsigned char pa[406], pb[406];
@@ -403,7 +468,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(dst_layout L, const float* __r
   fill_pair_tables(n, pa, pb);
   __syncthreads();
   // logits: directed edge d = 2p + dir; dir 0: source a -> target b, dir 1: source b -> target a
-  for (int it = threadIdx.x; it < np * 2 * 16; it += 256) {
+  for (int it = threadIdx.x; it < np * 2 * 16; it += blockDim.x) {
     const int d = it >> 4, hd = it & 15, p = d >> 1, dir = d & 1;
     const int src = dir ? pb[p] : pa[p], tgt = dir ? pa[p] : pb[p];
     float v;
@@ -422,7 +487,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(dst_layout L, const float* __r
   }
   __syncthreads();
   // softmax over the sources of every (target, head)
-  for (int it = threadIdx.x; it < n * 16; it += 256) {
+  for (int it = threadIdx.x; it < n * 16; it += blockDim.x) {
     const int t = it >> 4, hd = it & 15;
     float mx = -INFINITY;
     for (int s = 0; s < n; ++s) {
@@ -449,7 +514,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(dst_layout L, const float* __r
   }
   __syncthreads();
   // aggregation onto the target, ascending source order
-  for (int it = threadIdx.x; it < n * 256; it += 256) {
+  for (int it = threadIdx.x; it < n * 256; it += blockDim.x) {
     const int t = it >> 8, col = it & 255, hd = col >> 4;
     float s = 0.0f;
     for (int sN = 0; sN < n; ++sN) {
@@ -461,10 +526,10 @@ __global__ __launch_bounds__(256) void k_attn_fwd(dst_layout L, const float* __r
     out[(int64_t)(n0 + t) * 256 + col] = s;
   }
   if (n == 1)
-    for (int col = threadIdx.x; col < 256; col += 256) out[(int64_t)n0 * 256 + col] = 0.0f;
+    for (int col = threadIdx.x; col < 256; col += blockDim.x) out[(int64_t)n0 * 256 + col] = 0.0f;
 }
 
-__global__ __launch_bounds__(256) void k_attn_bwd(dst_layout L, const float* __restrict__ qkv, const float* __restrict__ te0, const float* __restrict__ te1,
+__global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __restrict__ qkv, const float* __restrict__ te0, const float* __restrict__ te1,
                                                    const float* __restrict__ alpha, const float* __restrict__ dout, float* __restrict__ dqkv,
                                                    float* __restrict__ dte0, float* __restrict__ dte1) {
   __shared__ float dl[812 * 16];      // d alpha, then d logit (the 64 kB static LDS limit leaves no room for a copy of alpha)
@@ -475,7 +540,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(dst_layout L, const float* __r
   fill_pair_tables(n, pa, pb);
   __syncthreads();
   // d alpha[d, hd] = sum_c dout[tgt, hd, c] v[src, hd, c] te1[p, hd, c]
-  for (int it = threadIdx.x; it < np * 32; it += 256) {
+  for (int it = threadIdx.x; it < np * 32; it += blockDim.x) {
     const int d = it >> 4, hd = it & 15, p = d >> 1, dir = d & 1;
     const int src = dir ? pb[p] : pa[p], tgt = dir ? pa[p] : pb[p];
     const float* go = dout + (int64_t)(n0 + tgt) * 256 + hd * 16;
@@ -487,7 +552,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(dst_layout L, const float* __r
   }
   __syncthreads();
   // softmax backward per (target, head): dlogit = alpha (dalpha - sum alpha dalpha)
-  for (int it = threadIdx.x; it < n * 16; it += 256) {
+  for (int it = threadIdx.x; it < n * 16; it += blockDim.x) {
     const int t = it >> 4, hd = it & 15;
     float dot = 0.0f;
     for (int s = 0; s < n; ++s) {
@@ -503,7 +568,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(dst_layout L, const float* __r
   }
   __syncthreads();
   // node-side gradients: thread per (node, column of the 768-wide q|k|v row)
-  for (int it = threadIdx.x; it < n * 768; it += 256) {
+  for (int it = threadIdx.x; it < n * 768; it += blockDim.x) {
     const int i = it / 768, col = it % 768;
     float s = 0.0f;
     if (col < 252) {                                   // dq[i]: i is the target
@@ -536,7 +601,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(dst_layout L, const float* __r
     dqkv[(int64_t)(n0 + i) * 768 + col] = s;
   }
   // pair-side gradients (both directions of a pair)
-  for (int it = threadIdx.x; it < np * 256; it += 256) {
+  for (int it = threadIdx.x; it < np * 256; it += blockDim.x) {
     const int p = it >> 8, col = it & 255;
     const int a = pa[p], b = pb[p];
     {
@@ -563,7 +628,7 @@ __global__ __launch_bounds__(256) void k_pair_sum_fwd(dst_layout L, const float*
   const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
   fill_pair_tables(n, pa, pb);
   __syncthreads();
-  for (int it = threadIdx.x; it < np * C; it += 256) {
+  for (int it = threadIdx.x + 256 * blockIdx.y; it < np * C; it += 256 * gridDim.y) {
     const int p = it / C, c = it % C;
     s[(int64_t)(p0 + p) * C + c] = u[(int64_t)(n0 + pa[p]) * C + c] + u[(int64_t)(n0 + pb[p]) * C + c] + (bias ? bias[c] : 0.0f);
   }
@@ -571,7 +636,7 @@ __global__ __launch_bounds__(256) void k_pair_sum_fwd(dst_layout L, const float*
 __global__ __launch_bounds__(256) void k_pair_sum_bwd(dst_layout L, const float* __restrict__ ds, int C, float* __restrict__ du, int accumulate) {
   const int m = blockIdx.x;
   const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m];
-  for (int it = threadIdx.x; it < n * C; it += 256) {
+  for (int it = threadIdx.x + 256 * blockIdx.y; it < n * C; it += 256 * gridDim.y) {
     const int i = it / C, c = it % C;
     float s = 0.0f;
     for (int j = 0; j < n; ++j) {
@@ -590,7 +655,7 @@ __global__ __launch_bounds__(256) void k_zbuild_fwd(dst_layout L, const float* _
   const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
   fill_pair_tables(n, pa, pb);
   __syncthreads();
-  for (int it = threadIdx.x; it < np * 2 * 256; it += 256) {
+  for (int it = threadIdx.x + 256 * blockIdx.y; it < np * 2 * 256; it += 256 * gridDim.y) {
     const int d = it >> 8, c = it & 255, p = d >> 1, dir = d & 1;
     const int row = dir ? pb[p] : pa[p], col = dir ? pa[p] : pb[p];
     z[(int64_t)(2 * p0 + d) * 256 + c] = ac[(int64_t)(n0 + row) * 512 + c] + ac[(int64_t)(n0 + col) * 512 + 256 + c] + ed[(int64_t)(p0 + p) * 256 + c];
@@ -599,11 +664,11 @@ __global__ __launch_bounds__(256) void k_zbuild_fwd(dst_layout L, const float* _
 __global__ __launch_bounds__(256) void k_zbuild_bwd(dst_layout L, const float* __restrict__ dz, float* __restrict__ dac, float* __restrict__ ded) {
   const int m = blockIdx.x;
   const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
-  for (int it = threadIdx.x; it < np * 256; it += 256) {
+  for (int it = threadIdx.x + 256 * blockIdx.y; it < np * 256; it += 256 * gridDim.y) {
     const int p = it >> 8, c = it & 255;
     ded[(int64_t)(p0 + p) * 256 + c] = dz[(int64_t)(2 * (p0 + p)) * 256 + c] + dz[(int64_t)(2 * (p0 + p) + 1) * 256 + c];
   }
-  for (int it = threadIdx.x; it < n * 512; it += 256) {
+  for (int it = threadIdx.x + 256 * blockIdx.y; it < n * 512; it += 256 * gridDim.y) {
     const int i = it >> 9, c = it & 511, as_col = c >> 8, cc = c & 255;
     float s = 0.0f;
     for (int j = 0; j < n; ++j) {
@@ -997,7 +1062,8 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ dy, const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------------------------ SpecFormer attention
-// one workgroup per (batch, head, block of 4 query rows): dk = 8
+// one workgroup per (batch, head, slice of the query rows), one wave per query row; K and V of the head in LDS as [dk][L] (the first
+// version kept them [L][dk]: a 16-way bank conflict on every key read, 5.1 ms per layer at 256 molecules)
 __global__ __launch_bounds__(256) void k_spec_attn_fwd(const float* __restrict__ qkv, const float* __restrict__ prev, float* __restrict__ scores,
                                                         float* __restrict__ attn, float* __restrict__ out, int B, int Lq, int H, int dk, float scale) {
   extern __shared__ float sm[];                           // K [L][dk], V [L][dk]
@@ -1006,40 +1072,52 @@ __global__ __launch_bounds__(256) void k_spec_attn_fwd(const float* __restrict__
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int D = H * dk;
   for (int i = threadIdx.x; i < Lq * dk; i += 256) {
-    const int l = i / dk, c = i % dk;
-    Ks[i] = qkv[((int64_t)b * Lq + l) * 3 * D + D + h * dk + c];
-    Vs[i] = qkv[((int64_t)b * Lq + l) * 3 * D + 2 * D + h * dk + c];
+    const int l = i / dk, c = i % dk;                       // LDS as [dk][L]: consecutive lanes = consecutive keys, no bank conflicts
+    Ks[c * Lq + l] = qkv[((int64_t)b * Lq + l) * 3 * D + D + h * dk + c];
+    Vs[c * Lq + l] = qkv[((int64_t)b * Lq + l) * 3 * D + 2 * D + h * dk + c];
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int MAXJ = 8;                                  // keys per lane: L <= 512; the row's values stay in registers
   for (int qi = blockIdx.y * 4 + wave; qi < Lq; qi += gridDim.y * 4) {
     float q[16];
     for (int c = 0; c < dk; ++c) q[c] = qkv[((int64_t)b * Lq + qi) * 3 * D + h * dk + c];
     const int64_t rowbase = (((int64_t)b * H + h) * Lq + qi) * Lq;
+    float sv[MAXJ];
     float mx = -INFINITY;
-    for (int k = lane; k < Lq; k += 64) {
-      float s = 0.0f;
-      for (int c = 0; c < dk; ++c) s += q[c] * Ks[k * dk + c];
-      s *= scale;
-      if (prev) s += prev[rowbase + k];
-      scores[rowbase + k] = s;
-      mx = fmaxf(mx, s);
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int k = lane + 64 * j;
+      sv[j] = -INFINITY;
+      if (k < Lq) {
+        float s = 0.0f;
+        for (int c = 0; c < dk; ++c) s += q[c] * Ks[c * Lq + k];
+        s *= scale;
+        if (prev) s += prev[rowbase + k];
+        scores[rowbase + k] = s;
+        sv[j] = s;
+        mx = fmaxf(mx, s);
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     float den = 0.0f;
-    for (int k = lane; k < Lq; k += 64) {
-      const float e = expf(scores[rowbase + k] - mx);
-      attn[rowbase + k] = e;
-      den += e;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      sv[j] = (lane + 64 * j < Lq) ? expf(sv[j] - mx) : 0.0f;
+      den += sv[j];
     }
     den = wave_sum(den);
     float acc[16];
     for (int c = 0; c < dk; ++c) acc[c] = 0.0f;
-    for (int k = lane; k < Lq; k += 64) {
-      const float a = attn[rowbase + k] / den;
-      attn[rowbase + k] = a;
-      for (int c = 0; c < dk; ++c) acc[c] += a * Vs[k * dk + c];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int k = lane + 64 * j;
+      if (k < Lq) {
+        const float a = sv[j] / den;
+        attn[rowbase + k] = a;
+        for (int c = 0; c < dk; ++c) acc[c] += a * Vs[c * Lq + k];
+      }
     }
     for (int c = 0; c < dk; ++c) {
       const float s = wave_sum(acc[c]);
@@ -1058,9 +1136,9 @@ __global__ __launch_bounds__(256) void k_spec_attn_bwd_q(const float* __restrict
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int D = H * dk;
   for (int i = threadIdx.x; i < Lq * dk; i += 256) {
-    const int l = i / dk, c = i % dk;
-    Ks[i] = qkv[((int64_t)b * Lq + l) * 3 * D + D + h * dk + c];
-    Vs[i] = qkv[((int64_t)b * Lq + l) * 3 * D + 2 * D + h * dk + c];
+    const int l = i / dk, c = i % dk;                       // LDS as [dk][L]: consecutive lanes = consecutive keys, no bank conflicts
+    Ks[c * Lq + l] = qkv[((int64_t)b * Lq + l) * 3 * D + D + h * dk + c];
+    Vs[c * Lq + l] = qkv[((int64_t)b * Lq + l) * 3 * D + 2 * D + h * dk + c];
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1069,20 +1147,31 @@ __global__ __launch_bounds__(256) void k_spec_attn_bwd_q(const float* __restrict
     for (int c = 0; c < dk; ++c) go[c] = dout[((int64_t)b * Lq + qi) * D + h * dk + c];
     const int64_t rowbase = (((int64_t)b * H + h) * Lq + qi) * Lq;
     float dot = 0.0f;
-    for (int k = lane; k < Lq; k += 64) {
-      float da = 0.0f;
-      for (int c = 0; c < dk; ++c) da += go[c] * Vs[k * dk + c];
-      dscores[rowbase + k] = da;                           // d attn, for now
-      dot += attn[rowbase + k] * da;
+    float av[8], dav[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = lane + 64 * j;
+      av[j] = 0.0f; dav[j] = 0.0f;
+      if (k < Lq) {
+        float da = 0.0f;
+        for (int c = 0; c < dk; ++c) da += go[c] * Vs[c * Lq + k];
+        av[j] = attn[rowbase + k];
+        dav[j] = da;
+        dot += av[j] * da;
+      }
     }
     dot = wave_sum(dot);
     float dq[16];
     for (int c = 0; c < dk; ++c) dq[c] = 0.0f;
-    for (int k = lane; k < Lq; k += 64) {
-      float ds = attn[rowbase + k] * (dscores[rowbase + k] - dot);
-      if (dscores_in) ds += dscores_in[rowbase + k];
-      dscores[rowbase + k] = ds;
-      for (int c = 0; c < dk; ++c) dq[c] += ds * Ks[k * dk + c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = lane + 64 * j;
+      if (k < Lq) {
+        float ds = av[j] * (dav[j] - dot);
+        if (dscores_in) ds += dscores_in[rowbase + k];
+        dscores[rowbase + k] = ds;
+        for (int c = 0; c < dk; ++c) dq[c] += ds * Ks[c * Lq + k];
+      }
     }
     for (int c = 0; c < dk; ++c) {
       const float s = wave_sum(dq[c]) * scale;
@@ -1196,7 +1285,9 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   if (a->M == 0 || a->N == 0) return DS_OK;
   hipStream_t s = (hipStream_t)stream;
   dst_gemm_args g = *a;
-  const int tm = (g.M + 63) / 64, tn = (g.N + 63) / 64;
+  // tile: 128 x 128 for the wide products, 128 x 64 when N is narrow, 64 x 64 for small shapes
+  const int BM = g.M >= 96 ? 128 : 64, BN = (g.M >= 96 && g.N >= 96) ? 128 : 64;
+  const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
   const int64_t tiles = (int64_t)tm * tn;
   int splits = 1;
   if (g.K >= 1024 && tiles < 512 && g.partial) {
@@ -1210,7 +1301,17 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   int kchunk = ((g.K + splits - 1) / splits + 15) / 16 * 16;
   if (kchunk < 16) kchunk = 16;
   splits = g.K > 0 ? (g.K + kchunk - 1) / kchunk : 1;
-  hipLaunchKernelGGL(k_tr_gemm, dim3(tn, tm, splits), dim3(256), 0, s, g, splits, kchunk);
+  const dim3 grid(tn, tm, splits), blk(256);
+  const bool bf = g.bf16 != 0;
+#define DST_LAUNCH_GEMM(M_, N_)                                                                                              \
+  do {                                                                                                                     \
+    if (bf) hipLaunchKernelGGL((k_tr_gemm_big<M_, N_, true>), grid, blk, 0, s, g, splits, kchunk);                          \
+    else hipLaunchKernelGGL((k_tr_gemm_big<M_, N_, false>), grid, blk, 0, s, g, splits, kchunk);                            \
+  } while (0)
+  if (BM == 128 && BN == 128) DST_LAUNCH_GEMM(128, 128);
+  else if (BM == 128) DST_LAUNCH_GEMM(128, 64);
+  else DST_LAUNCH_GEMM(64, 64);
+#undef DST_LAUNCH_GEMM
   if (splits > 1) hipLaunchKernelGGL(k_tr_gemm_reduce, grid1d((int64_t)g.M * g.N), dim3(256), 0, s, g, splits);
   return DST_CHECK_LAUNCH();
 }
@@ -1325,35 +1426,35 @@ int dst_geom_bwd(const dst_layout* L, const float* pos, const float* ada, float*
 int dst_attn_fwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, const int32_t* adj, float* out, float* alpha,
                  void* stream) {
   if (!DST_L_OK(L) || !qkv || !te0 || !te1 || !adj || !out || !alpha) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_attn_fwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, qkv, te0, te1, adj, out, alpha);
+  hipLaunchKernelGGL(k_attn_fwd, dim3(L->B), dim3(1024), 0, (hipStream_t)stream, *L, qkv, te0, te1, adj, out, alpha);
   return DST_CHECK_LAUNCH();
 }
 int dst_attn_bwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, const float* alpha, const float* dout, float* dqkv,
                  float* dte0, float* dte1, float* scratch, void* stream) {
   (void)scratch;
   if (!DST_L_OK(L) || !qkv || !te0 || !te1 || !alpha || !dout || !dqkv || !dte0 || !dte1) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_attn_bwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, qkv, te0, te1, alpha, dout, dqkv, dte0, dte1);
+  hipLaunchKernelGGL(k_attn_bwd, dim3(L->B), dim3(1024), 0, (hipStream_t)stream, *L, qkv, te0, te1, alpha, dout, dqkv, dte0, dte1);
   return DST_CHECK_LAUNCH();
 }
 
 int dst_pair_sum_fwd(const dst_layout* L, const float* u, int32_t C, const float* bias, float* s, void* stream) {
   if (!DST_L_OK(L) || !u || !s || C <= 0) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_pair_sum_fwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, u, (int)C, bias, s);
+  hipLaunchKernelGGL(k_pair_sum_fwd, dim3(L->B, 4), dim3(256), 0, (hipStream_t)stream, *L, u, (int)C, bias, s);
   return DST_CHECK_LAUNCH();
 }
 int dst_pair_sum_bwd(const dst_layout* L, const float* ds, int32_t C, float* du, int32_t accumulate, void* stream) {
   if (!DST_L_OK(L) || !ds || !du || C <= 0) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_pair_sum_bwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, ds, (int)C, du, (int)accumulate);
+  hipLaunchKernelGGL(k_pair_sum_bwd, dim3(L->B, 4), dim3(256), 0, (hipStream_t)stream, *L, ds, (int)C, du, (int)accumulate);
   return DST_CHECK_LAUNCH();
 }
 int dst_zbuild_fwd(const dst_layout* L, const float* ac, const float* ed, float* z, void* stream) {
   if (!DST_L_OK(L) || !ac || !ed || !z) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_zbuild_fwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, ac, ed, z);
+  hipLaunchKernelGGL(k_zbuild_fwd, dim3(L->B, 4), dim3(256), 0, (hipStream_t)stream, *L, ac, ed, z);
   return DST_CHECK_LAUNCH();
 }
 int dst_zbuild_bwd(const dst_layout* L, const float* dz, float* dac, float* ded, void* stream) {
   if (!DST_L_OK(L) || !dz || !dac || !ded) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_zbuild_bwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, dz, dac, ded);
+  hipLaunchKernelGGL(k_zbuild_bwd, dim3(L->B, 4), dim3(256), 0, (hipStream_t)stream, *L, dz, dac, ded);
   return DST_CHECK_LAUNCH();
 }
 
@@ -1445,7 +1546,7 @@ int dst_bn_bwd(const float* dy, const float* x, const float* stats, int32_t R, i
 
 int dst_spec_attn_fwd(const float* qkv, const float* prev, float* scores, float* attn, float* out, int32_t B, int32_t L, int32_t H,
                       int32_t dk, float scale, void* stream) {
-  if (!qkv || !scores || !attn || !out || B <= 0 || L <= 0 || H <= 0 || dk <= 0 || dk > 16) return DS_ERR_ARG;
+  if (!qkv || !scores || !attn || !out || B <= 0 || L <= 0 || L > 512 || H <= 0 || dk <= 0 || dk > 16) return DS_ERR_ARG;
   const size_t lds = (size_t)2 * L * dk * sizeof(float);
   if (lds > 64 * 1024) return DS_ERR_ARG;
   hipLaunchKernelGGL(k_spec_attn_fwd, dim3(B * H, 8), dim3(256), lds, (hipStream_t)stream, qkv, prev, scores, attn, out, (int)B, (int)L, (int)H, (int)dk, scale);
@@ -1453,7 +1554,7 @@ int dst_spec_attn_fwd(const float* qkv, const float* prev, float* scores, float*
 }
 int dst_spec_attn_bwd(const float* qkv, const float* attn, const float* dout, const float* dscores_in, float* dqkv, float* dscores,
                       int32_t B, int32_t L, int32_t H, int32_t dk, float scale, void* stream) {
-  if (!qkv || !attn || !dout || !dqkv || !dscores || B <= 0 || L <= 0 || H <= 0 || dk <= 0 || dk > 16) return DS_ERR_ARG;
+  if (!qkv || !attn || !dout || !dqkv || !dscores || B <= 0 || L <= 0 || L > 512 || H <= 0 || dk <= 0 || dk > 16) return DS_ERR_ARG;
   const size_t lds = (size_t)2 * L * dk * sizeof(float);
   if (lds > 64 * 1024) return DS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;

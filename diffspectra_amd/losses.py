@@ -314,6 +314,9 @@ def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None
     if not config.data.centered or not config.model.include_fc_charge:
         raise ValueError("the batch preparation kernel implements centered data with formal charges")
     dropout_p = float(getattr(config.model, "dropout", 0.0))
+    precision = getattr(config.training, "precision", "fp32")
+    if precision not in ("fp32", "bf16"):
+        raise ValueError("config.training.precision must be 'fp32' or 'bf16'")
     loss_weights = [float(w) for w in config.model.loss_weights.split(",")]
     cond_process_fn = get_self_cond_fn(config)
     pos_norm, type_norm, fc_norm, edge_norm = (float(v) for v in _factors(config))
@@ -323,6 +326,7 @@ def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None
         tr = _trainer(model)
         dev, lib = tr.dev, tr.lib
         named, dmt, spec = tr.graphs()
+        tr.ops.bf16 = precision == "bf16"          # config 5: bf16 products with fp32 accumulation, fp32 master weights
         atom_mask = batch["atom_mask"].to(dev)
         TL = tr.layout(atom_mask)
         B, N = TL.B, TL.N

@@ -33,7 +33,7 @@ SILU, GELU, TANH = 1, 2, 3
 class DstGemmArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("a_rs", C.c_int64), ("a_cs", C.c_int64), ("B", C.c_void_p), ("b_rs", C.c_int64), ("b_cs", C.c_int64),
                 ("C", C.c_void_p), ("ldc", C.c_int64), ("bias", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
-                ("accumulate", C.c_int32), ("partial", C.c_void_p), ("partial_cap", C.c_int64)]
+                ("accumulate", C.c_int32), ("partial", C.c_void_p), ("partial_cap", C.c_int64), ("bf16", C.c_int32), ("_pad", C.c_int32)]
 
 
 class DstLayout(C.Structure):
@@ -91,6 +91,7 @@ class Ops:
         self.lib = load_train_library()
         self.dev = torch.device(device)
         self.scratch = torch.empty(48 * 1024 * 1024, dtype=torch.float32, device=self.dev)     # split-K partials / column sums
+        self.bf16 = False      # config.training.precision == 'bf16': every GEMM rounds its operands to bf16 (fp32 accumulate, fp32 storage)
 
     def _s(self):
         return E._stream()
@@ -105,7 +106,7 @@ class Ops:
             assert bias.numel() == N
         args = DstGemmArgs(A=A.ptr, a_rs=a_rs, a_cs=a_cs, B=Bm.ptr, b_rs=b_rs, b_cs=b_cs, C=Cm.ptr, ldc=Cm.ld,
                            bias=None if bias is None else bias.data_ptr(), M=M, N=N, K=K, accumulate=int(acc),
-                           partial=self.scratch.data_ptr(), partial_cap=self.scratch.numel())
+                           partial=self.scratch.data_ptr(), partial_cap=self.scratch.numel(), bf16=int(self.bf16), _pad=0)
         E._check(self.lib.dst_gemm(C.byref(args), self._s()), "dst_gemm")
 
     def colsum(self, X: MV, out: torch.Tensor, acc: bool = False):

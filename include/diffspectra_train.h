@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-/* Generic fp32 GEMM on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32): C[M,N] (+)= A[M,K] * B[K,N] (+ bias[N]).
+/* Generic GEMM, fp32 storage, on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32) or - args.bf16 - with bf16-rounded operands on the bf16
+ * pipe and fp32 accumulation: C[M,N] (+)= A[M,K] * B[K,N] (+ bias[N]).
  * Element strides make every transpose a view: A[m,k] = A[m*a_rs + k*a_cs], B[k,n] = B[k*b_rs + n*b_cs], C row stride ldc.
  *   Linear forward   Y = X W^T + b : A = X (a_rs = ldx, a_cs = 1), B = W^T (b_rs = 1, b_cs = ldw)
  *   input gradient   dX = dY W     : A = dY,                        B = W   (b_rs = ldw, b_cs = 1)
@@ -44,6 +45,7 @@ typedef struct dst_gemm_args {
   const float* bias;
   int32_t M, N, K, accumulate;
   float* partial; int64_t partial_cap;
+  int32_t bf16; int32_t _pad;   /* != 0: operands rounded to bf16, products on v_mfma_f32_32x32x16_bf16, fp32 accumulate (config 5) */
 } dst_gemm_args;
 int dst_gemm(const dst_gemm_args* a, void* stream);
 

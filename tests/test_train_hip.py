@@ -700,3 +700,50 @@ def test_dropout_kernel_and_training_with_dropout(gpu_device, monkeypatch):
     loss0 = float(loss)
     cfg.model.dropout = 0.0
     assert math.isfinite(loss0)
+
+
+def test_bf16_training_precision(gpu_device, monkeypatch):
+    """config.training.precision = 'bf16' (BASELINE config 5): GEMM operands rounded to bf16, fp32 accumulation.  Not the reference's
+    arithmetic (it has no AMP), so it is held to the fp32 golden G13 only loosely: loss within 1 %, total gradient direction
+    within cos > 0.995, every parameter finite; and the GEMM itself against a bf16-rounded fp64 product tightly."""
+    from diffspectra_amd import losses as Lh, train_engine as T
+    from diffspectra_amd.noise_schedule import NoiseScheduleVP
+    d = gpu_device
+    o = T.Ops(d)
+    o.bf16 = True
+    g = torch.Generator().manual_seed(1)
+    for M, N, K in ((200, 130, 300), (64, 64, 48), (130, 40, 2000)):
+        A, Bm = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+        Cd = torch.zeros(M, N, device=d)
+        o.gemm(T.mv(A.to(d)), T.mv(Bm.to(d)), T.mv(Cd), False, True)
+        ref = A.bfloat16().double() @ Bm.bfloat16().double().t()
+        assert float((Cd.cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) * max(1.0, K ** 0.5 / 8), (M, N, K)
+    cfg, model = _train_model("ir", d)
+    cfg.training.precision = "bf16"
+    ref_g = cases.load_npz("g13_training.npz")
+    tag = "ir_selfcond"
+    batch, draws = cases.training_batch("ir"), cases.training_draws()
+    batch = {k: v for k, v in batch.items() if k != "n_atoms"}
+    loss_fn = Lh.get_sde_graph_loss_fn(NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0), True, None, cfg)
+    monkeypatch.setattr(torch, "rand", _Replay([draws["t_raw"]]))
+    monkeypatch.setattr(torch, "randn", _Replay(draws["randn"]))
+    monkeypatch.setattr(Lh, "random", lambda: 0.0)
+    loss = loss_fn(model, batch)
+    monkeypatch.undo()
+    loss.backward()
+    ref_loss = float(ref_g[tag + "_loss"])
+    assert abs(float(loss.detach()) - ref_loss) <= 1e-2 * ref_loss, (float(loss.detach()), ref_loss)
+    names = json.loads(ref_g[tag + "_grad_names"])
+    grads = {n: p.grad for n, p in model.module.named_parameters()}
+    dot = n1 = n2 = 0.0
+    for i, n in enumerate(names):
+        if grads[n] is None:
+            continue
+        gr = grads[n].detach().cpu()
+        assert torch.isfinite(gr).all(), n
+        idx = torch.linspace(0, gr.numel() - 1, min(64, gr.numel())).round().long()
+        a, b = gr.reshape(-1)[idx].double(), ref_g[tag + "_grad_samples"][i][:len(idx)].double()
+        dot, n1, n2 = dot + float((a * b).sum()), n1 + float((a * a).sum()), n2 + float((b * b).sum())
+    cos = dot / (n1 * n2) ** 0.5
+    print(f"[bf16] loss {float(loss.detach()):.5f} (fp32 reference {ref_loss:.5f}); cosine of the sampled gradient against G13 {cos:.5f}")
+    assert cos > 0.995

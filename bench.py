@@ -10,7 +10,8 @@ Default workload (``--mode eval``) = BASELINE config 2 literally: **10 000 sampl
 ``get_cond_sampling_eval_fn(...)`` on a ``PackedSpectraTable``-backed synthetic test set - seed-42 permutation, size-sorted slot
 assignment, micro-batches of ``--batch`` molecules, per micro-batch SpecFormer conditioning (once per molecule) + in-kernel
 initial noise + 1000 DMT evaluations with the fused ancestral update + post-processing + 1 248-byte records, then the final
-gather (the only collective) and the unpacking into the reference's per-molecule tuples.  A bench *step* is one twentieth of
+gather (the only collective) and the one device->host copy of the result tensors (the reference's per-molecule tuples are built
+from them on access, ``sampling.MoleculeList``).  A bench *step* is one twentieth of
 that whole evaluation, so the driver's ``--steps 20 --warmup 5`` times exactly one complete 10 000-sample run; warm-up steps
 are slices of a throw-away run.  molecules/sec = molecules x (denoise iterations timed / iterations of the evaluation) / elapsed.
 Molecules are independent, so ranks own disjoint sample slots (weak scaling: 10 000 per GPU).
@@ -540,7 +541,7 @@ def main(argv=None):
                         f"mean {float(n.mean()):.2f}; seed-42 permutation, size-sorted slots, micro-batches of {args.batch}); one bench "
                         f"step = 1/{spp} of the evaluation ({slice_len} denoise iterations), {spp} steps = the complete "
                         f"{args.samples}-sample run incl. SpecFormer, initial noise, post-processing, the final gather and "
-                        "the unpacking into per-molecule tuples")
+                        "the single device->host copy of the result tensors (per-molecule tuples are views built on access)")
         else:
             workload = (("QM9S unconditional (zero context embedding), DMT only" if args.unconditional else
                          f"QM9S {args.spectra}, DMT + SpecFormer (no pretrain)") + ", random-init procedural weights, "

@@ -11,6 +11,7 @@ scalars come from a table computed up front, and molecules leave the GPU in one 
 """
 from __future__ import annotations
 
+from collections.abc import Sequence
 from typing import Callable, Optional
 
 import numpy as np
@@ -268,6 +269,36 @@ def initial_noise(batch_size, max_n, node_nf, edge_nf, node_mask, edge_mask):
     return torch.cat([zx, zh], dim=2), ze.contiguous()
 
 
+class MoleculeList(Sequence):
+    """The ``processed_mols`` of a sharded run: behaves like the reference's list of per-molecule tuples ``(pos [n,3] f32,
+    atom_type [n] i64, edge_type [n,n] f32, fc [n] i64)`` (sampling.py:17-28) - ``len``, indexing, slicing, iteration - but builds a
+    tuple when it is asked for, from the four host tensors the one device->host copy produced.  Building 80 000 tuples eagerly costs
+    seconds of Python on every rank of an 8-GPU run; consumers (``check_stability``, the RDKit metrics) walk the list once anyway.
+    ``tolist()`` materialises a plain list."""
+
+    def __init__(self, pos, atom, edge_type, fc, n_atoms):
+        self.pos, self.atom, self.edge_type, self.fc, self.n_atoms = pos, atom, edge_type, fc, list(n_atoms)
+
+    def __len__(self):
+        return len(self.n_atoms)
+
+    def _one(self, k):
+        n = self.n_atoms[k]
+        return (self.pos[k, :n].clone(), self.atom[k, :n].clone(), self.edge_type[k, :n, :n].clone(), self.fc[k, :n].clone())
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self._one(i) for i in range(*k.indices(len(self)))]
+        if k < 0:
+            k += len(self)
+        if not 0 <= k < len(self):
+            raise IndexError("molecule index out of range")
+        return self._one(k)
+
+    def tolist(self):
+        return self[:]
+
+
 def _make_sampler(config, noise_scheduler, eps, temperature):
     if config.sampling.method != "ancestral":
         raise ValueError("Invalid sampling method!")
@@ -427,10 +458,7 @@ def _sampling_fn_factory(config, sampler, batch_size, n_samples, inverse_scaler,
             by_slot[torch.cat(owners).to(allrec.device)] = allrec
             self.records_by_slot = by_slot
             pos, atom, fc, et = (t.cpu() for t in shard.unpack_records_u8(by_slot))     # ONE device->host copy per tensor
-            processed = []
-            for k in range(n_slots):
-                n = self.n_atoms[k]
-                processed.append((pos[k, :n].clone(), atom[k, :n].clone(), et[k, :n, :n].clone(), fc[k, :n].clone()))
+            processed = MoleculeList(pos, atom, et, fc, self.n_atoms[:n_slots])         # per-molecule tuples are built on access
             gt_pos, gt_mols = _ground_truth(ds, self.slot_ds.tolist())
             if self.rank == 0:
                 print("Generate {}, Total {}.".format(len(processed), n_samples * top_k))

@@ -962,7 +962,7 @@ def _rank_worker(rank, world, port, out_path):
         with swapped_weights(model, lambda sd: cases.readout_diverse(sd, "allspectra_S5")):
             mols, gt_pos, gt_mols = S.get_cond_sampling_eval_fn(cfg, ns, 3, 9, inv, ds)(model)
         if rank == 1:                                                    # every rank holds the full result; save rank 1's
-            torch.save({"mols": mols, "gt_mols": gt_mols}, out_path)
+            torch.save({"mols": mols.tolist(), "gt_mols": gt_mols}, out_path)      # MoleculeList -> plain list of tuples
     finally:
         dist.destroy_process_group()
 

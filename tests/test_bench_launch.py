@@ -39,3 +39,13 @@ def test_self_launch_two_ranks_on_one_gpu():
                    "--steps", "20", "--warmup", "2", "--no-cpu-baseline"], 900)
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["passes_completed"] == 1
     assert rec["config"]["molecules_per_gpu"] == 40 and "partial" not in rec["metric"]
+
+
+@pytest.mark.gpu
+def test_single_gpu_bench_prints_exactly_one_line():
+    """The driver's N = 1 invocation shape on a tiny evaluation: stdout carries the JSON line and nothing else (the product's
+    progress prints go to stderr), the run completes one evaluation and the line carries roofline + config."""
+    rec, err = _run(["--gpus", "1", "--samples", "40", "--batch", "24", "--denoise-steps", "20", "--steps", "20", "--warmup", "2",
+                     "--no-cpu-baseline", "--no-live-traffic"], 900)
+    assert rec["n_gpus"] == 1 and rec["config"]["passes_completed"] == 1 and rec["value"] > 0
+    assert "Generate 40, Total 40." in err and "roofline" in rec and rec["config"]["mode"] == "eval"

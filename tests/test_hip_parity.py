@@ -917,6 +917,37 @@ def test_philox_sampling_is_batch_independent_and_topk(gpu_device):
     assert torch.equal(k3[0][0], a[0][0])                                # slot 0 is slot 0 in both runs
 
 
+def test_get_sampling_fn_validation_sampler(gpu_device):
+    """``get_sampling_fn`` (sampling.py:148-248, the training-time validation sampler): UNSEEDED permutation of the validation set and
+    temperature 1, against ``get_cond_sampling_eval_fn`` (seed-42 permutation, eval temperature) on the same model."""
+    S, cfg, model, ds, n_atoms, ns, inv = _philox_sampling_setup(gpu_device)
+    cfg.eval.sampling_temperature = 0.7
+    with swapped_weights(model, lambda sd: cases.readout_diverse(sd, "allspectra_S5")):
+        torch.manual_seed(3)
+        a, gt_pos_a, gt_a = S.get_sampling_fn(cfg, ns, 4, 6, inv, ds)(model)
+        torch.manual_seed(3)
+        b, _, gt_b = S.get_sampling_fn(cfg, ns, 3, 6, inv, ds)(model)
+        torch.manual_seed(4)
+        c_, _, gt_c = S.get_sampling_fn(cfg, ns, 4, 6, inv, ds)(model)
+        ev, _, gt_e = S.get_cond_sampling_eval_fn(cfg, ns, 4, 6, inv, ds)(model)
+        # the validation sampler is the eval sampler at temperature 1 on whatever permutation the global generator yields
+        cfg1 = cfg.clone()
+        cfg1.eval.sampling_temperature = 1.0
+        torch.manual_seed(42)
+        perm42 = torch.randperm(len(ds)).tolist()
+        torch.manual_seed(42)
+        v42, _, gt_v42 = S.get_sampling_fn(cfg, ns, 4, 6, inv, ds)(model)
+        e1, _, gt_e1 = S.get_cond_sampling_eval_fn(cfg1, ns, 4, 6, inv, ds)(model)
+    torch.manual_seed(3)
+    perm3 = torch.randperm(len(ds)).tolist()
+    assert gt_a == [f"mol{i}" for i in perm3[:6]] == gt_b and len(a) == 6          # the permutation follows the global generator
+    assert _same_molecules(a, b)                                                    # same permutation -> same molecules, any batch size
+    assert gt_c != gt_a                                                             # unseeded: another generator state, another permutation
+    assert [m[0].shape[0] for m in a] == [n_atoms[i] for i in perm3[:6]]
+    assert gt_v42 == gt_e1 == [f"mol{i}" for i in perm42[:6]] == gt_e and _same_molecules(v42, e1)   # temperature 1 = the eval sampler at T = 1
+    assert not _same_molecules(ev, e1)                                              # and the eval temperature (0.7) does act
+
+
 def test_graph_replay_equals_eager(gpu_device):
     """hipGraph replay of the denoise iteration (device-side step index, in-place self-conditioning buffer) gives the
     eager launch sequence's result bit for bit, also when a pass is advanced in slices."""

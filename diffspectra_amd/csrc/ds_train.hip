@@ -1065,11 +1065,11 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ dy, const float* __rest
 // one workgroup per (batch, head, slice of the query rows), one wave per query row; K and V of the head in LDS as [dk][L] (the first
 // version kept them [L][dk]: a 16-way bank conflict on every key read, 5.1 ms per layer at 256 molecules)
 __global__ __launch_bounds__(256) void k_spec_attn_fwd(const float* __restrict__ qkv, const float* __restrict__ prev, float* __restrict__ scores,
-                                                        float* __restrict__ attn, float* __restrict__ out, int B, int Lq, int H, int dk, float scale) {
+                                                        float* __restrict__ attn, float* __restrict__ out, int B, int Lq, int H, int dk, float scale, int Lp) {
   extern __shared__ float sm[];                           // K [L][dk], V [L][dk]
   float* Ks = sm;
   float* Vs = sm + (size_t)Lq * dk;
-  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;     // consecutive workgroups (blockIdx.x) work on the same [L, L] matrix
   const int D = H * dk;
   for (int i = threadIdx.x; i < Lq * dk; i += 256) {
     const int l = i / dk, c = i % dk;                       // LDS as [dk][L]: consecutive lanes = consecutive keys, no bank conflicts
@@ -1079,10 +1079,10 @@ __global__ __launch_bounds__(256) void k_spec_attn_fwd(const float* __restrict__
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int MAXJ = 8;                                  // keys per lane: L <= 512; the row's values stay in registers
-  for (int qi = blockIdx.y * 4 + wave; qi < Lq; qi += gridDim.y * 4) {
+  for (int qi = blockIdx.x * 4 + wave; qi < Lq; qi += gridDim.x * 4) {
     float q[16];
     for (int c = 0; c < dk; ++c) q[c] = qkv[((int64_t)b * Lq + qi) * 3 * D + h * dk + c];
-    const int64_t rowbase = (((int64_t)b * H + h) * Lq + qi) * Lq;
+    const int64_t rowbase = (((int64_t)b * H + h) * Lq + qi) * Lp;   // rows padded to Lp floats (128-byte aligned)
     float sv[MAXJ];
     float mx = -INFINITY;
 #pragma unroll
@@ -1129,11 +1129,11 @@ __global__ __launch_bounds__(256) void k_spec_attn_fwd(const float* __restrict__
 // backward, pass 1 (per query row): dV partial is handled in pass 2; here dS = attn * (dA - sum attn dA) (+ dscores_in), dq.
 __global__ __launch_bounds__(256) void k_spec_attn_bwd_q(const float* __restrict__ qkv, const float* __restrict__ attn, const float* __restrict__ dout,
                                                           const float* __restrict__ dscores_in, float* __restrict__ dqkv, float* __restrict__ dscores,
-                                                          int B, int Lq, int H, int dk, float scale) {
+                                                          int B, int Lq, int H, int dk, float scale, int Lp) {
   extern __shared__ float sm[];
   float* Ks = sm;
   float* Vs = sm + (size_t)Lq * dk;
-  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;     // consecutive workgroups (blockIdx.x) work on the same [L, L] matrix
   const int D = H * dk;
   for (int i = threadIdx.x; i < Lq * dk; i += 256) {
     const int l = i / dk, c = i % dk;                       // LDS as [dk][L]: consecutive lanes = consecutive keys, no bank conflicts
@@ -1142,10 +1142,10 @@ __global__ __launch_bounds__(256) void k_spec_attn_bwd_q(const float* __restrict
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int qi = blockIdx.y * 4 + wave; qi < Lq; qi += gridDim.y * 4) {
+  for (int qi = blockIdx.x * 4 + wave; qi < Lq; qi += gridDim.x * 4) {
     float go[16];
     for (int c = 0; c < dk; ++c) go[c] = dout[((int64_t)b * Lq + qi) * D + h * dk + c];
-    const int64_t rowbase = (((int64_t)b * H + h) * Lq + qi) * Lq;
+    const int64_t rowbase = (((int64_t)b * H + h) * Lq + qi) * Lp;   // rows padded to Lp floats (128-byte aligned)
     float dot = 0.0f;
     float av[8], dav[8];
 #pragma unroll
@@ -1184,11 +1184,11 @@ __global__ __launch_bounds__(256) void k_spec_attn_bwd_q(const float* __restrict
 // the first version walked the columns of the [L, L] matrices with a stride of L floats and took 11.5 ms per layer at 256 molecules.
 __global__ __launch_bounds__(128) void k_spec_attn_bwd_kv(const float* __restrict__ qkv, const float* __restrict__ attn, const float* __restrict__ dout,
                                                            const float* __restrict__ dscores, float* __restrict__ dqkv, int B, int Lq, int H, int dk,
-                                                           float scale) {
+                                                           float scale, int Lp) {
   extern __shared__ float sm[];
   float* Qs = sm;
   float* Gs = sm + (size_t)Lq * dk;
-  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;     // consecutive workgroups (blockIdx.x) work on the same [L, L] matrix
   const int D = H * dk;
   for (int i = threadIdx.x; i < Lq * dk; i += blockDim.x) {
     const int l = i / dk, c = i % dk;
@@ -1196,13 +1196,13 @@ __global__ __launch_bounds__(128) void k_spec_attn_bwd_kv(const float* __restric
     Gs[i] = dout[((int64_t)b * Lq + l) * D + h * dk + c];
   }
   __syncthreads();
-  const int ki = blockIdx.y * blockDim.x + threadIdx.x;
+  const int ki = blockIdx.x * blockDim.x + threadIdx.x;
   if (ki >= Lq) return;
-  const int64_t base = ((int64_t)b * H + h) * Lq * Lq + ki;
+  const int64_t base = ((int64_t)b * H + h) * Lq * Lp + ki;
   float dkk[16], dvv[16];
   for (int c = 0; c < dk; ++c) { dkk[c] = 0.0f; dvv[c] = 0.0f; }
   for (int q = 0; q < Lq; ++q) {
-    const float ds = dscores[base + (int64_t)q * Lq], a = attn[base + (int64_t)q * Lq];
+    const float ds = dscores[base + (int64_t)q * Lp], a = attn[base + (int64_t)q * Lp];
     for (int c = 0; c < dk; ++c) { dkk[c] += ds * Qs[q * dk + c]; dvv[c] += a * Gs[q * dk + c]; }
   }
   for (int c = 0; c < dk; ++c) {
@@ -1549,7 +1549,8 @@ int dst_spec_attn_fwd(const float* qkv, const float* prev, float* scores, float*
   if (!qkv || !scores || !attn || !out || B <= 0 || L <= 0 || L > 512 || H <= 0 || dk <= 0 || dk > 16) return DS_ERR_ARG;
   const size_t lds = (size_t)2 * L * dk * sizeof(float);
   if (lds > 64 * 1024) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_spec_attn_fwd, dim3(B * H, 8), dim3(256), lds, (hipStream_t)stream, qkv, prev, scores, attn, out, (int)B, (int)L, (int)H, (int)dk, scale);
+  hipLaunchKernelGGL(k_spec_attn_fwd, dim3(8, B * H), dim3(256), lds, (hipStream_t)stream, qkv, prev, scores, attn, out, (int)B, (int)L, (int)H, (int)dk, scale,
+                     (int)((L + 31) / 32 * 32));
   return DST_CHECK_LAUNCH();
 }
 int dst_spec_attn_bwd(const float* qkv, const float* attn, const float* dout, const float* dscores_in, float* dqkv, float* dscores,
@@ -1558,9 +1559,10 @@ int dst_spec_attn_bwd(const float* qkv, const float* attn, const float* dout, co
   const size_t lds = (size_t)2 * L * dk * sizeof(float);
   if (lds > 64 * 1024) return DS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_spec_attn_bwd_q, dim3(B * H, 8), dim3(256), lds, s, qkv, attn, dout, dscores_in, dqkv, dscores, (int)B, (int)L, (int)H, (int)dk, scale);
-  hipLaunchKernelGGL(k_spec_attn_bwd_kv, dim3(B * H, (L + 127) / 128), dim3(128), lds, s, qkv, attn, dout, (const float*)dscores, dqkv, (int)B, (int)L, (int)H,
-                     (int)dk, scale);
+  const int Lp = (L + 31) / 32 * 32;
+  hipLaunchKernelGGL(k_spec_attn_bwd_q, dim3(8, B * H), dim3(256), lds, s, qkv, attn, dout, dscores_in, dqkv, dscores, (int)B, (int)L, (int)H, (int)dk, scale, Lp);
+  hipLaunchKernelGGL(k_spec_attn_bwd_kv, dim3((L + 127) / 128, B * H), dim3(128), lds, s, qkv, attn, dout, (const float*)dscores, dqkv, (int)B, (int)L, (int)H,
+                     (int)dk, scale, Lp);
   return DST_CHECK_LAUNCH();
 }
 

@@ -80,7 +80,8 @@ class SpecTrainGraph:
             qkv = self.f(B * L, 3 * D_MODEL)
             for k, nm in enumerate(("W_Q", "W_K", "W_V")):
                 o.lin_fwd(mv(Z), mv(p[base + f"self_attn.{nm}.weight"]), p[base + f"self_attn.{nm}.bias"], mv(qkv, k * D_MODEL, (k + 1) * D_MODEL))
-            scores, attn, ao = self.f(B, N_HEADS, L, L), self.f(B, N_HEADS, L, L), self.f(B * L, D_MODEL)
+            Lp = (L + 31) // 32 * 32                                   # padded row stride of the [L, L] score matrices
+            scores, attn, ao = self.f(B, N_HEADS, L, Lp), self.f(B, N_HEADS, L, Lp), self.f(B * L, D_MODEL)
             E._check(self.lib.dst_spec_attn_fwd(E._ptr(qkv), E._ptr(prev), E._ptr(scores), E._ptr(attn), E._ptr(ao), C.c_int32(B), C.c_int32(L),
                                                 C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()), "dst_spec_attn_fwd")
             r1 = Z.clone()
@@ -151,7 +152,7 @@ class SpecTrainGraph:
             o.lin_bwd_w(mv(dr1), mv(lt["ao"]), mv(gw(base + "self_attn.to_out.0.weight")), gw(base + "self_attn.to_out.0.bias"))
             dao = self.f(B * L, D_MODEL)
             o.lin_bwd_x(mv(dr1), mv(p[base + "self_attn.to_out.0.weight"]), mv(dao))
-            dqkv, dscores = self.f(B * L, 3 * D_MODEL), self.f(B, N_HEADS, L, L)
+            dqkv, dscores = self.f(B * L, 3 * D_MODEL), self.f(B, N_HEADS, L, (L + 31) // 32 * 32)
             E._check(self.lib.dst_spec_attn_bwd(E._ptr(lt["qkv"]), E._ptr(lt["attn"]), E._ptr(dao), E._ptr(dscores_in), E._ptr(dqkv), E._ptr(dscores),
                                                 C.c_int32(B), C.c_int32(L), C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()),
                      "dst_spec_attn_bwd")

@@ -164,7 +164,8 @@ int dst_bn_fwd(const float* x, int32_t R, int32_t C, const float* gamma, const f
 int dst_bn_bwd(const float* dy, const float* x, const float* stats, int32_t R, int32_t C, const float* gamma, float* dx, float* dgamma,
                float* dbeta, float* scratch, int64_t scratch_cap, void* stream);
 
-/* SpecFormer attention in training form (specformer.py:385-425): scores [B,H,L,L] = q k^T * scale (+ prev), attn = softmax, both kept;
+/* SpecFormer attention in training form (specformer.py:385-425): scores [B,H,L,Lp] = q k^T * scale (+ prev), attn = softmax, both kept
+ * (Lp = L rounded up to a multiple of 32: rows start on 128-byte boundaries; the pad columns are never read or written);
  * out [B,L,H*dk].  qkv [B,L,3*H*dk] (q | k | v).  Backward: dscores_in (gradient arriving at THIS layer's scores from the next layer's
  * `prev` use; may be NULL) is added to the softmax gradient; writes dqkv and dscores (total gradient of this layer's scores = what
  * flows on to the previous layer's scores). */

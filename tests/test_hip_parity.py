@@ -1252,6 +1252,32 @@ def test_engine_repacks_after_data_copy(gpu_device):
     assert_close(out1, want, 1e-6, "forward after p.data.copy_")
 
 
+def test_dropin_forward_caches_loop_invariant_work(gpu_device):
+    """A reference-style caller invokes ``model(...)`` 1000 times per round with the same context / mask tensors (sampling.py:588).
+    The drop-in forward then reuses the spectra embedding, the layout and the mask checks of the first call - and notices when any
+    of those tensors is modified in place."""
+    cfg, model = gpu_model("ir", gpu_device)
+    a = cases.forward_inputs("ir", False)
+    d = gpu_device
+    args = [torch.zeros(4, device=d), a["xh"].to(d), a["node_mask"].to(d), a["edge_mask"].to(d)]
+    kw = dict(context=a["context"].to(d), edge_x=a["edge_x"].to(d), noise_level=a["noise_level"].to(d),
+              cond_x=a["cond_x"].to(d), cond_edge_x=a["cond_edge_x"].to(d))
+    out0 = model(*args, **kw)[0].clone()
+    mod = model.module
+    ctx0 = mod._ctx_cache[1]
+    out1 = model(*args, **kw)[0]
+    assert mod._ctx_cache[1] is ctx0 and torch.equal(out0, out1)                 # second call: cached embedding, identical result
+    kw["context"].mul_(1.05)                                                      # in-place edit bumps the version: re-encoded
+    out2 = model(*args, **kw)[0]
+    assert mod._ctx_cache[1] is not ctx0 and float((out2 - out0).abs().max()) > 1e-5
+    fresh = model(*args, **dict(kw, context=kw["context"].clone()))[0]           # a new tensor with the same values: same result
+    assert torch.equal(fresh, out2)
+    bad = args[3].clone()
+    bad[5] = 1.0 - bad[5]
+    with pytest.raises(ValueError):                                               # a different edge_mask tensor is validated again
+        model(args[0], args[1], args[2], bad, **kw)
+
+
 def test_forward_rejects_asymmetric_edges(gpu_device):
     """The pair layout stores one value per unordered pair; a directed edge input must raise, not be silently symmetrised."""
     cfg, model = gpu_model("ir", gpu_device)

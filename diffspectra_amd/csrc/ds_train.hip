@@ -14,6 +14,9 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 namespace {
 
+#ifndef DST_SPEC_SLICES
+#define DST_SPEC_SLICES 2   // workgroups per (batch, head) in the SpecFormer attention kernels: each stages K and V of the head once
+#endif
 #define DST_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? DS_OK : DS_ERR_LAUNCH)
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -1062,27 +1065,47 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ dy, const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------------------------ SpecFormer attention
-// one workgroup per (batch, head, slice of the query rows), one wave per query row; K and V of the head in LDS as [dk][L] (the first
-// version kept them [L][dk]: a 16-way bank conflict on every key read, 5.1 ms per layer at 256 molecules)
+// One workgroup per (batch, head, slice of the query rows), one wave per query row, lanes over the keys (L <= 512: up to 8 per lane,
+// the row lives in registers).  K and V of the head sit in LDS as [dk][L] (consecutive lanes = consecutive keys: conflict-free; the
+// first version's [L][dk] was a 16-way bank conflict).  dk is a template constant - with a run-time dk the per-row register arrays
+// were indexed dynamically - and the NEXT row's global loads are issued before this row's stores: vector-memory operations retire in
+// issue order, so a row that loads after the previous row's stores waits for those stores first (14 us per row in that form).
+template <int DK>
 __global__ __launch_bounds__(256) void k_spec_attn_fwd(const float* __restrict__ qkv, const float* __restrict__ prev, float* __restrict__ scores,
-                                                        float* __restrict__ attn, float* __restrict__ out, int B, int Lq, int H, int dk, float scale, int Lp) {
-  extern __shared__ float sm[];                           // K [L][dk], V [L][dk]
+                                                        float* __restrict__ stats, float* __restrict__ out, int B, int Lq, int H, float scale, int Lp) {
+  extern __shared__ float sm[];
   float* Ks = sm;
-  float* Vs = sm + (size_t)Lq * dk;
+  float* Vs = sm + (size_t)Lq * DK;
   const int bh = blockIdx.y, b = bh / H, h = bh % H;     // consecutive workgroups (blockIdx.x) work on the same [L, L] matrix
-  const int D = H * dk;
-  for (int i = threadIdx.x; i < Lq * dk; i += 256) {
-    const int l = i / dk, c = i % dk;                       // LDS as [dk][L]: consecutive lanes = consecutive keys, no bank conflicts
-    Ks[c * Lq + l] = qkv[((int64_t)b * Lq + l) * 3 * D + D + h * dk + c];
-    Vs[c * Lq + l] = qkv[((int64_t)b * Lq + l) * 3 * D + 2 * D + h * dk + c];
+  const int D = H * DK;
+  for (int i = threadIdx.x; i < Lq * DK; i += 256) {
+    const int l = i / DK, c = i % DK;
+    Ks[c * Lq + l] = qkv[((int64_t)b * Lq + l) * 3 * D + D + h * DK + c];
+    Vs[c * Lq + l] = qkv[((int64_t)b * Lq + l) * 3 * D + 2 * D + h * DK + c];
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  constexpr int MAXJ = 8;                                  // keys per lane: L <= 512; the row's values stay in registers
-  for (int qi = blockIdx.x * 4 + wave; qi < Lq; qi += gridDim.x * 4) {
-    float q[16];
-    for (int c = 0; c < dk; ++c) q[c] = qkv[((int64_t)b * Lq + qi) * 3 * D + h * dk + c];
-    const int64_t rowbase = (((int64_t)b * H + h) * Lq + qi) * Lp;   // rows padded to Lp floats (128-byte aligned)
+  constexpr int MAXJ = 8;
+  const int step = gridDim.x * 4;
+  int qi = blockIdx.x * 4 + wave;
+  float qn[DK], pn[MAXJ];
+  auto issue = [&](int row) {                              // the global loads of one row: q (wave-uniform) and the previous layer's scores
+    const float* qp = qkv + ((int64_t)b * Lq + row) * 3 * D + h * DK;
+#pragma unroll
+    for (int c = 0; c < DK; ++c) qn[c] = qp[c];
+    const int64_t rb = (((int64_t)b * H + h) * Lq + row) * Lp;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) pn[j] = (prev && lane + 64 * j < Lq) ? prev[rb + lane + 64 * j] : 0.0f;
+  };
+  if (qi < Lq) issue(qi);
+  for (; qi < Lq; qi += step) {
+    float q[DK], pv[MAXJ];
+#pragma unroll
+    for (int c = 0; c < DK; ++c) q[c] = qn[c];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) pv[j] = pn[j];
+    if (qi + step < Lq) issue(qi + step);
+    const int64_t rowbase = (((int64_t)b * H + h) * Lq + qi) * Lp;
     float sv[MAXJ];
     float mx = -INFINITY;
 #pragma unroll
@@ -1091,123 +1114,174 @@ __global__ __launch_bounds__(256) void k_spec_attn_fwd(const float* __restrict__
       sv[j] = -INFINITY;
       if (k < Lq) {
         float s = 0.0f;
-        for (int c = 0; c < dk; ++c) s += q[c] * Ks[c * Lq + k];
-        s *= scale;
-        if (prev) s += prev[rowbase + k];
-        scores[rowbase + k] = s;
+#pragma unroll
+        for (int c = 0; c < DK; ++c) s += q[c] * Ks[c * Lq + k];
+        s = s * scale + pv[j];
         sv[j] = s;
         mx = fmaxf(mx, s);
       }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    float den = 0.0f;
+    float den = 0.0f, ev[MAXJ];
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
-      sv[j] = (lane + 64 * j < Lq) ? expf(sv[j] - mx) : 0.0f;
-      den += sv[j];
+      ev[j] = (lane + 64 * j < Lq) ? expf(sv[j] - mx) : 0.0f;
+      den += ev[j];
     }
     den = wave_sum(den);
-    float acc[16];
-    for (int c = 0; c < dk; ++c) acc[c] = 0.0f;
+    float acc[DK];
+#pragma unroll
+    for (int c = 0; c < DK; ++c) acc[c] = 0.0f;
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
       const int k = lane + 64 * j;
       if (k < Lq) {
-        const float a = sv[j] / den;
-        attn[rowbase + k] = a;
-        for (int c = 0; c < dk; ++c) acc[c] += a * Vs[c * Lq + k];
+        const float a = ev[j] / den;                     // the probabilities are NOT stored: the backward re-creates them from scores + (max, sum)
+#pragma unroll
+        for (int c = 0; c < DK; ++c) acc[c] += a * Vs[c * Lq + k];
       }
     }
-    for (int c = 0; c < dk; ++c) {
-      const float s = wave_sum(acc[c]);
-      if (lane == 0) out[((int64_t)b * Lq + qi) * D + h * dk + c] = s;
+#pragma unroll
+    for (int c = 0; c < DK; ++c) acc[c] = wave_sum(acc[c]);
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+      if (lane + 64 * j < Lq) scores[rowbase + lane + 64 * j] = sv[j];
+    if (lane == 0) {
+      stats[(((int64_t)b * H + h) * Lq + qi) * 2] = mx;
+      stats[(((int64_t)b * H + h) * Lq + qi) * 2 + 1] = den;
+#pragma unroll
+      for (int c = 0; c < DK; ++c) out[((int64_t)b * Lq + qi) * D + h * DK + c] = acc[c];
     }
   }
 }
 
-// backward, pass 1 (per query row): dV partial is handled in pass 2; here dS = attn * (dA - sum attn dA) (+ dscores_in), dq.
-__global__ __launch_bounds__(256) void k_spec_attn_bwd_q(const float* __restrict__ qkv, const float* __restrict__ attn, const float* __restrict__ dout,
-                                                          const float* __restrict__ dscores_in, float* __restrict__ dqkv, float* __restrict__ dscores,
-                                                          int B, int Lq, int H, int dk, float scale, int Lp) {
+// backward, pass 1 (per query row): dS = p * (dP - sum p dP) (+ dscores_in) with p re-created from scores + stats, and dq.  Same row
+// pipeline as the forward.
+template <int DK>
+__global__ __launch_bounds__(256) void k_spec_attn_bwd_q(const float* __restrict__ qkv, const float* __restrict__ scores, const float* __restrict__ stats,
+                                                          const float* __restrict__ dout, const float* __restrict__ dscores_in, float* __restrict__ dqkv,
+                                                          float* __restrict__ dscores, int B, int Lq, int H, float scale, int Lp) {
   extern __shared__ float sm[];
   float* Ks = sm;
-  float* Vs = sm + (size_t)Lq * dk;
-  const int bh = blockIdx.y, b = bh / H, h = bh % H;     // consecutive workgroups (blockIdx.x) work on the same [L, L] matrix
-  const int D = H * dk;
-  for (int i = threadIdx.x; i < Lq * dk; i += 256) {
-    const int l = i / dk, c = i % dk;                       // LDS as [dk][L]: consecutive lanes = consecutive keys, no bank conflicts
-    Ks[c * Lq + l] = qkv[((int64_t)b * Lq + l) * 3 * D + D + h * dk + c];
-    Vs[c * Lq + l] = qkv[((int64_t)b * Lq + l) * 3 * D + 2 * D + h * dk + c];
+  float* Vs = sm + (size_t)Lq * DK;
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const int D = H * DK;
+  for (int i = threadIdx.x; i < Lq * DK; i += 256) {
+    const int l = i / DK, c = i % DK;
+    Ks[c * Lq + l] = qkv[((int64_t)b * Lq + l) * 3 * D + D + h * DK + c];
+    Vs[c * Lq + l] = qkv[((int64_t)b * Lq + l) * 3 * D + 2 * D + h * DK + c];
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int qi = blockIdx.x * 4 + wave; qi < Lq; qi += gridDim.x * 4) {
-    float go[16];
-    for (int c = 0; c < dk; ++c) go[c] = dout[((int64_t)b * Lq + qi) * D + h * dk + c];
-    const int64_t rowbase = (((int64_t)b * H + h) * Lq + qi) * Lp;   // rows padded to Lp floats (128-byte aligned)
-    float dot = 0.0f;
-    float av[8], dav[8];
+  constexpr int MAXJ = 8;
+  const int step = gridDim.x * 4;
+  int qi = blockIdx.x * 4 + wave;
+  float gn[DK], sn[MAXJ], dn[MAXJ], mxn = 0.0f, denn = 1.0f;
+  auto issue = [&](int row) {
+    const float* gp = dout + ((int64_t)b * Lq + row) * D + h * DK;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int c = 0; c < DK; ++c) gn[c] = gp[c];
+    const int64_t rb = (((int64_t)b * H + h) * Lq + row) * Lp;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
       const int k = lane + 64 * j;
-      av[j] = 0.0f; dav[j] = 0.0f;
+      sn[j] = k < Lq ? scores[rb + k] : -INFINITY;
+      dn[j] = (dscores_in && k < Lq) ? dscores_in[rb + k] : 0.0f;
+    }
+    mxn = stats[(((int64_t)b * H + h) * Lq + row) * 2];
+    denn = stats[(((int64_t)b * H + h) * Lq + row) * 2 + 1];
+  };
+  if (qi < Lq) issue(qi);
+  for (; qi < Lq; qi += step) {
+    float go[DK], av[MAXJ], din[MAXJ];
+#pragma unroll
+    for (int c = 0; c < DK; ++c) go[c] = gn[c];
+    const float mx = mxn, den = denn;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) { av[j] = sn[j]; din[j] = dn[j]; }
+    if (qi + step < Lq) issue(qi + step);
+    const int64_t rowbase = (((int64_t)b * H + h) * Lq + qi) * Lp;
+    float dot = 0.0f, dav[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int k = lane + 64 * j;
+      dav[j] = 0.0f;
+      av[j] = k < Lq ? expf(av[j] - mx) / den : 0.0f;   // the forward's probabilities, re-created
       if (k < Lq) {
         float da = 0.0f;
-        for (int c = 0; c < dk; ++c) da += go[c] * Vs[c * Lq + k];
-        av[j] = attn[rowbase + k];
+#pragma unroll
+        for (int c = 0; c < DK; ++c) da += go[c] * Vs[c * Lq + k];
         dav[j] = da;
         dot += av[j] * da;
       }
     }
     dot = wave_sum(dot);
-    float dq[16];
-    for (int c = 0; c < dk; ++c) dq[c] = 0.0f;
+    float dq[DK];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int c = 0; c < DK; ++c) dq[c] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
       const int k = lane + 64 * j;
       if (k < Lq) {
-        float ds = av[j] * (dav[j] - dot);
-        if (dscores_in) ds += dscores_in[rowbase + k];
-        dscores[rowbase + k] = ds;
-        for (int c = 0; c < dk; ++c) dq[c] += ds * Ks[c * Lq + k];
+        const float ds = av[j] * (dav[j] - dot) + din[j];
+        av[j] = ds;
+#pragma unroll
+        for (int c = 0; c < DK; ++c) dq[c] += ds * Ks[c * Lq + k];
       }
     }
-    for (int c = 0; c < dk; ++c) {
-      const float s = wave_sum(dq[c]) * scale;
-      if (lane == 0) dqkv[((int64_t)b * Lq + qi) * 3 * D + h * dk + c] = s;
+#pragma unroll
+    for (int c = 0; c < DK; ++c) dq[c] = wave_sum(dq[c]) * scale;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+      if (lane + 64 * j < Lq) dscores[rowbase + lane + 64 * j] = av[j];
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < DK; ++c) dqkv[((int64_t)b * Lq + qi) * 3 * D + h * DK + c] = dq[c];
     }
   }
 }
-// backward, pass 2: dk[k] = scale * sum_q dS[q,k] q[q], dv[k] = sum_q attn[q,k] dout[q].  One thread per key, the query loop outside:
-// every step reads one row segment of dS / attn with consecutive lanes on consecutive keys (coalesced) and needs no reduction -
+
+// backward, pass 2: dk[k] = scale * sum_q dS[q,k] q[q], dv[k] = sum_q p[q,k] dout[q].  One thread per key, the query loop outside:
+// every step reads one row segment of dS / scores with consecutive lanes on consecutive keys (coalesced) and needs no reduction -
 // the first version walked the columns of the [L, L] matrices with a stride of L floats and took 11.5 ms per layer at 256 molecules.
-__global__ __launch_bounds__(128) void k_spec_attn_bwd_kv(const float* __restrict__ qkv, const float* __restrict__ attn, const float* __restrict__ dout,
-                                                           const float* __restrict__ dscores, float* __restrict__ dqkv, int B, int Lq, int H, int dk,
-                                                           float scale, int Lp) {
+template <int DK>
+__global__ __launch_bounds__(128) void k_spec_attn_bwd_kv(const float* __restrict__ qkv, const float* __restrict__ scores, const float* __restrict__ stats,
+                                                           const float* __restrict__ dout, const float* __restrict__ dscores, float* __restrict__ dqkv, int B,
+                                                           int Lq, int H, float scale, int Lp) {
   extern __shared__ float sm[];
   float* Qs = sm;
-  float* Gs = sm + (size_t)Lq * dk;
-  const int bh = blockIdx.y, b = bh / H, h = bh % H;     // consecutive workgroups (blockIdx.x) work on the same [L, L] matrix
-  const int D = H * dk;
-  for (int i = threadIdx.x; i < Lq * dk; i += blockDim.x) {
-    const int l = i / dk, c = i % dk;
-    Qs[i] = qkv[((int64_t)b * Lq + l) * 3 * D + h * dk + c];
-    Gs[i] = dout[((int64_t)b * Lq + l) * D + h * dk + c];
+  float* Gs = sm + (size_t)Lq * DK;
+  float* St = sm + (size_t)2 * Lq * DK;                    // (max, 1 / sum) of every query row
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const int D = H * DK;
+  for (int i = threadIdx.x; i < Lq * DK; i += blockDim.x) {
+    const int l = i / DK, c = i % DK;
+    Qs[i] = qkv[((int64_t)b * Lq + l) * 3 * D + h * DK + c];
+    Gs[i] = dout[((int64_t)b * Lq + l) * D + h * DK + c];
+  }
+  for (int i = threadIdx.x; i < Lq; i += blockDim.x) {
+    St[2 * i] = stats[((int64_t)b * H + h) * Lq * 2 + 2 * i];
+    St[2 * i + 1] = 1.0f / stats[((int64_t)b * H + h) * Lq * 2 + 2 * i + 1];
   }
   __syncthreads();
   const int ki = blockIdx.x * blockDim.x + threadIdx.x;
   if (ki >= Lq) return;
   const int64_t base = ((int64_t)b * H + h) * Lq * Lp + ki;
-  float dkk[16], dvv[16];
-  for (int c = 0; c < dk; ++c) { dkk[c] = 0.0f; dvv[c] = 0.0f; }
+  float dkk[DK], dvv[DK];
+#pragma unroll
+  for (int c = 0; c < DK; ++c) { dkk[c] = 0.0f; dvv[c] = 0.0f; }
+#pragma unroll 4
   for (int q = 0; q < Lq; ++q) {
-    const float ds = dscores[base + (int64_t)q * Lp], a = attn[base + (int64_t)q * Lp];
-    for (int c = 0; c < dk; ++c) { dkk[c] += ds * Qs[q * dk + c]; dvv[c] += a * Gs[q * dk + c]; }
+    const float ds = dscores[base + (int64_t)q * Lp];
+    const float a = expf(scores[base + (int64_t)q * Lp] - St[2 * q]) * St[2 * q + 1];
+#pragma unroll
+    for (int c = 0; c < DK; ++c) { dkk[c] += ds * Qs[q * DK + c]; dvv[c] += a * Gs[q * DK + c]; }
   }
-  for (int c = 0; c < dk; ++c) {
-    dqkv[((int64_t)b * Lq + ki) * 3 * D + D + h * dk + c] = dkk[c] * scale;
-    dqkv[((int64_t)b * Lq + ki) * 3 * D + 2 * D + h * dk + c] = dvv[c];
+#pragma unroll
+  for (int c = 0; c < DK; ++c) {
+    dqkv[((int64_t)b * Lq + ki) * 3 * D + D + h * DK + c] = dkk[c] * scale;
+    dqkv[((int64_t)b * Lq + ki) * 3 * D + 2 * D + h * DK + c] = dvv[c];
   }
 }
 
@@ -1544,25 +1618,25 @@ int dst_bn_bwd(const float* dy, const float* x, const float* stats, int32_t R, i
   return DST_CHECK_LAUNCH();
 }
 
-int dst_spec_attn_fwd(const float* qkv, const float* prev, float* scores, float* attn, float* out, int32_t B, int32_t L, int32_t H,
+int dst_spec_attn_fwd(const float* qkv, const float* prev, float* scores, float* stats, float* out, int32_t B, int32_t L, int32_t H,
                       int32_t dk, float scale, void* stream) {
-  if (!qkv || !scores || !attn || !out || B <= 0 || L <= 0 || L > 512 || H <= 0 || dk <= 0 || dk > 16) return DS_ERR_ARG;
+  if (!qkv || !scores || !stats || !out || B <= 0 || L <= 0 || L > 512 || H <= 0 || dk != 8) return DS_ERR_ARG;   // d_k = 8 (specformer.py:19, d_model 128 / 16 heads)
   const size_t lds = (size_t)2 * L * dk * sizeof(float);
   if (lds > 64 * 1024) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_spec_attn_fwd, dim3(8, B * H), dim3(256), lds, (hipStream_t)stream, qkv, prev, scores, attn, out, (int)B, (int)L, (int)H, (int)dk, scale,
+  hipLaunchKernelGGL(k_spec_attn_fwd<8>, dim3(DST_SPEC_SLICES, B * H), dim3(256), lds, (hipStream_t)stream, qkv, prev, scores, stats, out, (int)B, (int)L, (int)H, scale,
                      (int)((L + 31) / 32 * 32));
   return DST_CHECK_LAUNCH();
 }
-int dst_spec_attn_bwd(const float* qkv, const float* attn, const float* dout, const float* dscores_in, float* dqkv, float* dscores,
-                      int32_t B, int32_t L, int32_t H, int32_t dk, float scale, void* stream) {
-  if (!qkv || !attn || !dout || !dqkv || !dscores || B <= 0 || L <= 0 || L > 512 || H <= 0 || dk <= 0 || dk > 16) return DS_ERR_ARG;
+int dst_spec_attn_bwd(const float* qkv, const float* scores, const float* stats, const float* dout, const float* dscores_in, float* dqkv,
+                      float* dscores, int32_t B, int32_t L, int32_t H, int32_t dk, float scale, void* stream) {
+  if (!qkv || !scores || !stats || !dout || !dqkv || !dscores || B <= 0 || L <= 0 || L > 512 || H <= 0 || dk != 8) return DS_ERR_ARG;
   const size_t lds = (size_t)2 * L * dk * sizeof(float);
   if (lds > 64 * 1024) return DS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int Lp = (L + 31) / 32 * 32;
-  hipLaunchKernelGGL(k_spec_attn_bwd_q, dim3(8, B * H), dim3(256), lds, s, qkv, attn, dout, dscores_in, dqkv, dscores, (int)B, (int)L, (int)H, (int)dk, scale, Lp);
-  hipLaunchKernelGGL(k_spec_attn_bwd_kv, dim3((L + 127) / 128, B * H), dim3(128), lds, s, qkv, attn, dout, (const float*)dscores, dqkv, (int)B, (int)L, (int)H,
-                     (int)dk, scale, Lp);
+  hipLaunchKernelGGL(k_spec_attn_bwd_q<8>, dim3(DST_SPEC_SLICES, B * H), dim3(256), lds, s, qkv, scores, stats, dout, dscores_in, dqkv, dscores, (int)B, (int)L, (int)H, scale, Lp);
+  hipLaunchKernelGGL(k_spec_attn_bwd_kv<8>, dim3((L + 127) / 128, B * H), dim3(128), lds + (size_t)2 * L * sizeof(float), s, qkv, scores, stats, dout, (const float*)dscores, dqkv, (int)B, (int)L,
+                     (int)H, scale, Lp);
   return DST_CHECK_LAUNCH();
 }
 

@@ -256,7 +256,9 @@ class _HipLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        return (None, None) + tuple(None if g is None else g * grad_out for g in ctx.grads)
+        live = [g for g in ctx.grads if g is not None]
+        torch._foreach_mul_(live, grad_out)                 # one multi-tensor launch instead of one per parameter
+        return (None, None) + tuple(ctx.grads)
 
 
 class HipTrainer:

@@ -81,8 +81,8 @@ class SpecTrainGraph:
             for k, nm in enumerate(("W_Q", "W_K", "W_V")):
                 o.lin_fwd(mv(Z), mv(p[base + f"self_attn.{nm}.weight"]), p[base + f"self_attn.{nm}.bias"], mv(qkv, k * D_MODEL, (k + 1) * D_MODEL))
             Lp = (L + 31) // 32 * 32                                   # padded row stride of the [L, L] score matrices
-            scores, attn, ao = self.f(B, N_HEADS, L, Lp), self.f(B, N_HEADS, L, Lp), self.f(B * L, D_MODEL)
-            E._check(self.lib.dst_spec_attn_fwd(E._ptr(qkv), E._ptr(prev), E._ptr(scores), E._ptr(attn), E._ptr(ao), C.c_int32(B), C.c_int32(L),
+            scores, ast, ao = self.f(B, N_HEADS, L, Lp), self.f(B, N_HEADS, L, 2), self.f(B * L, D_MODEL)
+            E._check(self.lib.dst_spec_attn_fwd(E._ptr(qkv), E._ptr(prev), E._ptr(scores), E._ptr(ast), E._ptr(ao), C.c_int32(B), C.c_int32(L),
                                                 C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()), "dst_spec_attn_fwd")
             r1 = Z.clone()
             o.gemm(mv(ao), mv(p[base + "self_attn.to_out.0.weight"]), mv(r1), False, True, bias=p[base + "self_attn.to_out.0.bias"], acc=True)
@@ -97,7 +97,7 @@ class SpecTrainGraph:
             z2, st2 = self.f(B * L, D_MODEL), self.f(2, D_MODEL)
             self._bn_fwd(r2, base + "norm_ffn.1", z2, st2)
             if save:
-                layers.append(dict(Zin=Z, qkv=qkv, attn=attn, ao=ao, r1=r1, st1=st1, z1=z1, a=a, ga=ga, r2=r2, st2=st2, has_prev=prev is not None))
+                layers.append(dict(Zin=Z, qkv=qkv, scores=scores, ast=ast, ao=ao, r1=r1, st1=st1, z1=z1, a=a, ga=ga, r2=r2, st2=st2, has_prev=prev is not None))
             prev = scores
             Z = z2
         flat = Z.reshape(B, L * D_MODEL)
@@ -153,7 +153,7 @@ class SpecTrainGraph:
             dao = self.f(B * L, D_MODEL)
             o.lin_bwd_x(mv(dr1), mv(p[base + "self_attn.to_out.0.weight"]), mv(dao))
             dqkv, dscores = self.f(B * L, 3 * D_MODEL), self.f(B, N_HEADS, L, (L + 31) // 32 * 32)
-            E._check(self.lib.dst_spec_attn_bwd(E._ptr(lt["qkv"]), E._ptr(lt["attn"]), E._ptr(dao), E._ptr(dscores_in), E._ptr(dqkv), E._ptr(dscores),
+            E._check(self.lib.dst_spec_attn_bwd(E._ptr(lt["qkv"]), E._ptr(lt["scores"]), E._ptr(lt["ast"]), E._ptr(dao), E._ptr(dscores_in), E._ptr(dqkv), E._ptr(dscores),
                                                 C.c_int32(B), C.c_int32(L), C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()),
                      "dst_spec_attn_bwd")
             for k, nm in enumerate(("W_Q", "W_K", "W_V")):

@@ -164,15 +164,16 @@ int dst_bn_fwd(const float* x, int32_t R, int32_t C, const float* gamma, const f
 int dst_bn_bwd(const float* dy, const float* x, const float* stats, int32_t R, int32_t C, const float* gamma, float* dx, float* dgamma,
                float* dbeta, float* scratch, int64_t scratch_cap, void* stream);
 
-/* SpecFormer attention in training form (specformer.py:385-425): scores [B,H,L,Lp] = q k^T * scale (+ prev), attn = softmax, both kept
- * (Lp = L rounded up to a multiple of 32: rows start on 128-byte boundaries; the pad columns are never read or written);
- * out [B,L,H*dk].  qkv [B,L,3*H*dk] (q | k | v).  Backward: dscores_in (gradient arriving at THIS layer's scores from the next layer's
- * `prev` use; may be NULL) is added to the softmax gradient; writes dqkv and dscores (total gradient of this layer's scores = what
- * flows on to the previous layer's scores). */
-int dst_spec_attn_fwd(const float* qkv, const float* prev, float* scores, float* attn, float* out, int32_t B, int32_t L, int32_t H,
+/* SpecFormer attention in training form (specformer.py:385-425): scores [B,H,L,Lp] = q k^T * scale (+ prev) are kept (Lp = L rounded
+ * up to a multiple of 32: rows start on 128-byte boundaries; pad columns are never touched) - the next layer adds them to its own and
+ * the backward re-creates the probabilities exp(scores - max) / sum from them and stats [B,H,L,2] = (row max, row sum), so the
+ * [B,H,L,L] probability tensor is never written.  out [B,L,H*dk]; qkv [B,L,3*H*dk] (q | k | v).  Backward: dscores_in (gradient arriving
+ * at THIS layer's scores from the next layer's `prev` use; may be NULL) is added to the softmax gradient; writes dqkv and dscores (total
+ * gradient of this layer's scores = what flows on to the previous layer's scores). */
+int dst_spec_attn_fwd(const float* qkv, const float* prev, float* scores, float* stats, float* out, int32_t B, int32_t L, int32_t H,
                       int32_t dk, float scale, void* stream);
-int dst_spec_attn_bwd(const float* qkv, const float* attn, const float* dout, const float* dscores_in, float* dqkv, float* dscores,
-                      int32_t B, int32_t L, int32_t H, int32_t dk, float scale, void* stream);
+int dst_spec_attn_bwd(const float* qkv, const float* scores, const float* stats, const float* dout, const float* dscores_in, float* dqkv,
+                      float* dscores, int32_t B, int32_t L, int32_t H, int32_t dk, float scale, void* stream);
 
 /* LayerNorm with affine over the last dimension (specformer.py:67,119), training form.  Backward: dx written, dgamma / dbeta
  * accumulated through per-row-block partials (fixed order). */

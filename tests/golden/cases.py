@@ -233,6 +233,30 @@ TRAIN_FULL_GRADS = ("e_block_0.attn_mpnn.lin_edge0.weight", "e_block_7.equi_upda
                     "cond_encoder.backbone.encoder.layers.1.norm_attn.1.weight", "cond_encoder.out_norm.bias")
 
 
+def raw_molecules(n_atoms=(3, 7, 1, 12, 9), salt: int = 0):
+    """Procedural QM9S-style raw items (what ``QM9SDataset.process`` stores per molecule, qm9s_dataset.py:245-268): atom types 0..4,
+    directed edge list (both directions, sorted as PyG does) with bond types 1..4 (4 = aromatic), formal charges, positions, raw spectra."""
+    mols = []
+    for m, n in enumerate(n_atoms):
+        at = (filler.uniform(f"g16.at{m}", (n,), salt=salt) * 5).long().clamp(0, 4)
+        u = filler.uniform(f"g16.b{m}", (n, n), salt=salt)
+        rows, cols, types = [], [], []
+        for i in range(n):
+            for j in range(i + 1, n):
+                if float(u[i, j]) > 0.55:
+                    t = 1 + int(float(u[j, i]) * 4)                   # bond type 1..4
+                    rows += [i, j]; cols += [j, i]; types += [t, t]
+        ei = torch.tensor([rows, cols], dtype=torch.long).reshape(2, -1)
+        et = torch.tensor(types, dtype=torch.long)
+        if et.numel():
+            perm = (ei[0] * n + ei[1]).argsort()                      # qm9s_dataset.py:259-260
+            ei, et = ei[:, perm], et[perm]
+        fc = ((filler.uniform(f"g16.fc{m}", (n,), salt=salt) * 3).floor() - 1).long()
+        spec = {nm: filler.uniform(f"g16.{nm}{m}", (1, L), 0.0, 5.0, salt=salt) for nm, L in zip(("uv", "ir", "raman"), SPECTRUM_LENGTHS)}
+        mols.append(dict(atom_type=at, edge_index=ei, edge_type=et, fc=fc, pos=filler.normal(f"g16.pos{m}", (n, 3), salt) * 1.4, num_atom=n, **spec))
+    return mols
+
+
 def bond_distance_sweep():
     """Distances (Angstrom) for the bond-order golden (G12): a 1 pm grid over 0.5-2.0 A plus points 1e-4 A either side of
     every integer-picometre threshold in that range, so each ``<`` comparison is exercised on both sides."""

@@ -559,6 +559,51 @@ def g13_training(mods):
     cases.save_npz("g13_training.npz", **out)
 
 
+def g16_training_collate():
+    """Row N3, training half: the reference's own ``EdgeComSpectraTransform`` + ``CollateSpectra`` (datasets/build_dataset.py:94-149,306-395) on
+    procedural raw molecules, augmentation off and on (numpy / torch seeded).  ``build_dataset.py`` imports PyG names it does not use in these
+    two classes (``Compose``, ``ToDevice``, ``Data``) and the dataset class (PyG + RDKit): empty placeholders stand in for those imports."""
+    for name, attrs in (("torch_geometric", {}), ("torch_geometric.transforms", dict(Compose=object, ToDevice=object)),
+                        ("torch_geometric.data", dict(Data=object))):
+        if name not in sys.modules or not all(hasattr(sys.modules[name], a) for a in attrs):
+            mod = sys.modules.get(name) or types.ModuleType(name)
+            for a, v in attrs.items():
+                setattr(mod, a, v)
+            sys.modules[name] = mod
+    pkg = types.ModuleType("datasets")
+    pkg.__path__ = [os.path.join(REF, "datasets")]
+    saved = sys.modules.get("datasets")
+    sys.modules["datasets"] = pkg
+    stub = types.ModuleType("datasets.qm9s_dataset")
+    stub.QM9SDataset = object
+    sys.modules["datasets.qm9s_dataset"] = stub
+    try:
+        bd = importlib.import_module("datasets.build_dataset")
+    finally:
+        if saved is not None:
+            sys.modules["datasets"] = saved
+    tf = bd.EdgeComSpectraTransform([0, 1, 2, 3, 4], False, use_normalize=True)
+    items = []
+    for m in cases.raw_molecules():
+        d = types.SimpleNamespace(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in m.items()})
+        d.num_nodes = m["num_atom"]
+        items.append(tf(d))
+    out = {}
+    for tag, (rot, tr) in (("plain", (False, False)), ("aug", (True, True))):
+        for version in ("allspectra", "ir"):
+            np.random.seed(123)
+            torch.manual_seed(321)
+            b = bd.CollateSpectra(version, aug_rotation=rot, aug_translation=tr, aug_translation_scale=0.01)(items)
+            for k, v in b.items():
+                if k == "context":
+                    for i, c in enumerate(v if isinstance(v, list) else [v]):
+                        out[f"{tag}_{version}_context{i}"] = c.numpy()
+                else:
+                    out[f"{tag}_{version}_{k}"] = v.numpy()
+    cases.save_npz("g16_training_collate.npz", **out)
+    print("G16", sorted(out)[:6], "...", len(out), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -567,7 +612,9 @@ def main():
     only = [s for s in args.only.split(",") if s]
     if not only or "G12" in only:
         g12_bond_orders()
-    if only == ["G12"]:
+    if not only or "G16" in only:
+        g16_training_collate()
+    if only and set(only) <= {"G12", "G16"}:
         return
     mods = import_reference()
     todo = {"G0": g0_manifest, "G1": g1_schedule, "G2": g2_specformer, "G3": g3_components, "G4": g4_forward,

@@ -225,6 +225,8 @@ def _write_processed_qm9s(proc_dir, mols, layout):
     one = torch.arange(M + 1)
     slices = {"atom_type": cum(n), "pos": cum(n), "edge_index": cum(ne), "edge_type": cum(ne), "uv": one, "ir": one, "raman": one,
               "num_atom": one, "idx": one, "rdmol": one}
+    if "fc" in mols[0]:                               # per-atom formal charges (qm9s_dataset.py:267)
+        mapping["fc"], slices["fc"] = cat("fc"), cum(n)
     data = Data()
     if layout == "pyg2":
         st = Storage()

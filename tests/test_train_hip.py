@@ -747,3 +747,39 @@ def test_bf16_training_precision(gpu_device, monkeypatch):
     cos = dot / (n1 * n2) ** 0.5
     print(f"[bf16] loss {float(loss.detach()):.5f} (fp32 reference {ref_loss:.5f}); cosine of the sampled gradient against G13 {cos:.5f}")
     assert cos > 0.995
+
+
+def test_training_from_processed_file_end_to_end(gpu_device, tmp_path):
+    """The reference's training loop shape (run_lib.diffspectra_train: DataLoader -> train_step_fn) from a processed QM9S file in the PyG
+    layout: ``qm9s_reader.ProcessedQM9S`` -> ``train_data.TrainBatches`` (transform + collate + augmentation, pinned by golden G16) ->
+    ``losses.get_step_fn`` with the shipped dropout 0.1, two optimizer steps; then the trained weights sample through the HIP sampler."""
+    from diffspectra_amd import losses as Lh, train_data as TD
+    from diffspectra_amd.ema import ExponentialMovingAverage
+    from diffspectra_amd.noise_schedule import NoiseScheduleVP
+    from diffspectra_amd.qm9s_reader import ProcessedQM9S
+    from tests.test_host_cpu import _write_processed_qm9s
+    d = gpu_device
+    mols = cases.raw_molecules(n_atoms=(3, 7, 2, 12, 9, 5, 8, 4))
+    _write_processed_qm9s(str(tmp_path / "QM9S" / "processed"), mols, "pyg2")
+    proc = ProcessedQM9S(str(tmp_path / "QM9S"))
+    cfg, model = _train_model("allspectra", d)
+    cfg.model.dropout = 0.1
+    cfg.optim.warmup = 0
+    ema = ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_decay)
+    opt = Lh.get_optimizer(cfg, model.parameters())
+    step_fn = Lh.get_step_fn(NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0), True, Lh.optimization_manager(cfg), None, cfg)
+    state = dict(optimizer=opt, model=model, ema=ema, step=0)
+    before = opt.P.clone()
+    torch.manual_seed(0)
+    np.random.seed(0)
+    losses = []
+    for epoch in range(2):
+        for batch in TD.TrainBatches(proc, "test", batch_size=2, spectra_version="allspectra", device=d):
+            losses.append(float(step_fn(state, batch).detach()))
+    assert len(losses) == 2 and all(math.isfinite(v) for v in losses) and state["step"] == 2
+    assert float((opt.P - before).abs().max()) > 1e-5 and torch.isfinite(opt.P).all()
+    eval_step = Lh.get_step_fn(NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0), False, None, None, cfg)
+    val = eval_step(state, next(iter(TD.TrainBatches(proc, "valid", batch_size=2, spectra_version="allspectra", shuffle=False, aug_rotation=False,
+                                                       aug_translation=False, device=d))))
+    assert math.isfinite(float(val)) and not val.requires_grad                      # EMA weights, eval mode, no gradient (losses.py:117-122)
+    print(f"[train from file] losses {losses}, eval-mode EMA loss {float(val):.4f}")

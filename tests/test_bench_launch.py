@@ -36,7 +36,7 @@ def test_self_launch_two_ranks_on_one_gpu():
     """The whole multi-rank bench (product sampling function, slot sharding, final gather) through the spawn path: two gloo
     ranks sharing cuda:0."""
     rec, _ = _run(["--gpus", "2", "--backend", "gloo", "--same-device", "--samples", "40", "--batch", "24", "--denoise-steps", "20",
-                   "--steps", "20", "--warmup", "2", "--no-cpu-baseline"], 900)
+                   "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-live-traffic"], 900)
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["passes_completed"] == 1
     assert rec["config"]["molecules_per_gpu"] == 40 and "partial" not in rec["metric"]
 

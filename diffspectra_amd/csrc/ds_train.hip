@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void k_tr_gemm_big(dst_gemm_args g, int splits
       int nn, kk;
       if (b_nfast) { nn = e % BN; kk = e / BN; } else { kk = e & 15; nn = e >> 4; }
       const int gn = n0 + nn, gk = k0 + kk;
-      rb[i] = (gn < g.N && gk < kend) ? g.B[(int64_t)gk * g.b_rs + (int64_t)gn * g.b_cs] : 0.0f;
+      // column N is the virtual all-ones column of the fused row sum (bias gradient of a weight-gradient product)
+      rb[i] = gk < kend ? (gn < g.N ? g.B[(int64_t)gk * g.b_rs + (int64_t)gn * g.b_cs] : ((g.rowsum && gn == g.N) ? 1.0f : 0.0f)) : 0.0f;
     }
   };
   auto commit = [&]() {
@@ -130,9 +131,12 @@ __global__ __launch_bounds__(256) void k_tr_gemm_big(dst_gemm_args g, int splits
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * (BM / 2) + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
-        if (row < g.M && col < g.N) {
+        const int Nx = g.N + (g.rowsum ? 1 : 0);
+        if (row < g.M && col < Nx) {
           if (splits > 1) {
-            g.partial[((int64_t)z * g.M + row) * g.N + col] = acc[i][j][r];
+            g.partial[((int64_t)z * g.M + row) * Nx + col] = acc[i][j][r];
+          } else if (col == g.N) {
+            g.rowsum[row] = g.accumulate ? g.rowsum[row] + acc[i][j][r] : acc[i][j][r];
           } else {
             float v = acc[i][j][r] + (g.bias ? g.bias[col] : 0.0f);
             float* c = g.C + (int64_t)row * g.ldc + col;
@@ -145,12 +149,13 @@ __global__ __launch_bounds__(256) void k_tr_gemm_big(dst_gemm_args g, int splits
 }
 
 __global__ void k_tr_gemm_reduce(dst_gemm_args g, int splits) {
+  const int Nx = g.N + (g.rowsum ? 1 : 0);
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)g.M * g.N) return;
-  const int row = (int)(idx / g.N), col = (int)(idx % g.N);
-  float v = g.bias ? g.bias[col] : 0.0f;
-  for (int z = 0; z < splits; ++z) v += g.partial[(int64_t)z * g.M * g.N + idx];
-  float* c = g.C + (int64_t)row * g.ldc + col;
+  if (idx >= (int64_t)g.M * Nx) return;
+  const int row = (int)(idx / Nx), col = (int)(idx % Nx);
+  float v = (g.bias && col < g.N) ? g.bias[col] : 0.0f;
+  for (int z = 0; z < splits; ++z) v += g.partial[(int64_t)z * g.M * Nx + idx];
+  float* c = col == g.N ? g.rowsum + row : g.C + (int64_t)row * g.ldc + col;
   if (g.accumulate) v += *c;
   *c = v;
 }
@@ -1356,19 +1361,20 @@ extern "C" {
 
 int dst_gemm(const dst_gemm_args* a, void* stream) {
   if (!a || !a->C || a->M < 0 || a->N < 0 || a->K < 0 || (a->K > 0 && (!a->A || !a->B))) return DS_ERR_ARG;
-  if (a->M == 0 || a->N == 0) return DS_OK;
+  if (a->M == 0 || (a->N == 0 && !a->rowsum)) return DS_OK;
   hipStream_t s = (hipStream_t)stream;
   dst_gemm_args g = *a;
   // tile: 128 x 128 for the wide products, 128 x 64 when N is narrow, 64 x 64 for small shapes
-  const int BM = g.M >= 96 ? 128 : 64, BN = (g.M >= 96 && g.N >= 96) ? 128 : 64;
-  const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+  const int Nx = g.N + (g.rowsum ? 1 : 0);            // the fused row sum is one more (virtual, all-ones) column of B
+  const int BM = g.M >= 96 ? 128 : 64, BN = (g.M >= 96 && Nx >= 96) ? 128 : 64;
+  const int tm = (g.M + BM - 1) / BM, tn = (Nx + BN - 1) / BN;
   const int64_t tiles = (int64_t)tm * tn;
   int splits = 1;
   if (g.K >= 1024 && tiles < 512 && g.partial) {
     splits = (int)(1024 / tiles);
     const int max_by_k = (g.K + 255) / 256;
     if (splits > max_by_k) splits = max_by_k;
-    const int64_t cap = g.partial_cap / ((int64_t)g.M * g.N);
+    const int64_t cap = g.partial_cap / ((int64_t)g.M * Nx);
     if (splits > cap) splits = (int)cap;
     if (splits < 1) splits = 1;
   }
@@ -1386,7 +1392,7 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   else if (BM == 128) DST_LAUNCH_GEMM(128, 64);
   else DST_LAUNCH_GEMM(64, 64);
 #undef DST_LAUNCH_GEMM
-  if (splits > 1) hipLaunchKernelGGL(k_tr_gemm_reduce, grid1d((int64_t)g.M * g.N), dim3(256), 0, s, g, splits);
+  if (splits > 1) hipLaunchKernelGGL(k_tr_gemm_reduce, grid1d((int64_t)g.M * Nx), dim3(256), 0, s, g, splits);
   return DST_CHECK_LAUNCH();
 }
 

@@ -33,7 +33,7 @@ SILU, GELU, TANH = 1, 2, 3
 class DstGemmArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("a_rs", C.c_int64), ("a_cs", C.c_int64), ("B", C.c_void_p), ("b_rs", C.c_int64), ("b_cs", C.c_int64),
                 ("C", C.c_void_p), ("ldc", C.c_int64), ("bias", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
-                ("accumulate", C.c_int32), ("partial", C.c_void_p), ("partial_cap", C.c_int64), ("bf16", C.c_int32), ("_pad", C.c_int32)]
+                ("accumulate", C.c_int32), ("partial", C.c_void_p), ("partial_cap", C.c_int64), ("bf16", C.c_int32), ("_pad", C.c_int32), ("rowsum", C.c_void_p)]
 
 
 class DstLayout(C.Structure):
@@ -96,7 +96,8 @@ class Ops:
     def _s(self):
         return E._stream()
 
-    def gemm(self, A: MV, Bm: MV, Cm: MV, ta: bool, tb: bool, bias: Optional[torch.Tensor] = None, acc: bool = False):
+    def gemm(self, A: MV, Bm: MV, Cm: MV, ta: bool, tb: bool, bias: Optional[torch.Tensor] = None, acc: bool = False,
+             rowsum: Optional[torch.Tensor] = None):
         M, K = (A.cols, A.rows) if ta else (A.rows, A.cols)
         a_rs, a_cs = (1, A.ld) if ta else (A.ld, 1)
         K2, N = (Bm.cols, Bm.rows) if tb else (Bm.rows, Bm.cols)
@@ -104,9 +105,12 @@ class Ops:
         assert K == K2 and Cm.rows == M and Cm.cols == N, (M, K, K2, N, Cm.rows, Cm.cols)
         if bias is not None:
             assert bias.numel() == N
+        if rowsum is not None:
+            assert rowsum.numel() == M and rowsum.is_contiguous()
         args = DstGemmArgs(A=A.ptr, a_rs=a_rs, a_cs=a_cs, B=Bm.ptr, b_rs=b_rs, b_cs=b_cs, C=Cm.ptr, ldc=Cm.ld,
                            bias=None if bias is None else bias.data_ptr(), M=M, N=N, K=K, accumulate=int(acc),
-                           partial=self.scratch.data_ptr(), partial_cap=self.scratch.numel(), bf16=int(self.bf16), _pad=0)
+                           partial=self.scratch.data_ptr(), partial_cap=self.scratch.numel(), bf16=int(self.bf16), _pad=0,
+                           rowsum=None if rowsum is None else rowsum.data_ptr())
         E._check(self.lib.dst_gemm(C.byref(args), self._s()), "dst_gemm")
 
     def colsum(self, X: MV, out: torch.Tensor, acc: bool = False):
@@ -122,9 +126,7 @@ class Ops:
         self.gemm(dy, W, dx, False, False, acc=acc)
 
     def lin_bwd_w(self, dy: MV, x: MV, dW: MV, db: Optional[torch.Tensor] = None, acc: bool = False):
-        self.gemm(dy, x, dW, True, False, acc=acc)
-        if db is not None:
-            self.colsum(dy, db, acc=acc)
+        self.gemm(dy, x, dW, True, False, acc=acc, rowsum=db)           # db = column sums of dy = row sums of dy^T, fused into the product
 
     def act_fwd(self, x, y, kind):
         E._check(self.lib.dst_act_fwd(E._ptr(x), E._ptr(y), C.c_int64(x.numel()), C.c_int32(kind), self._s()), "dst_act_fwd")

@@ -46,6 +46,8 @@ typedef struct dst_gemm_args {
   int32_t M, N, K, accumulate;
   float* partial; int64_t partial_cap;
   int32_t bf16; int32_t _pad;   /* != 0: operands rounded to bf16, products on v_mfma_f32_32x32x16_bf16, fp32 accumulate (config 5) */
+  float* rowsum;                /* optional [M]: rowsum[m] (+)= sum_k A[m,k] in the same pass (a virtual all-ones column of B): with
+                                   A = dY^T this is the bias gradient of the weight-gradient product, no separate column-sum launches */
 } dst_gemm_args;
 int dst_gemm(const dst_gemm_args* a, void* stream);
 

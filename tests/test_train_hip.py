@@ -85,6 +85,24 @@ def test_train_gemm(ops, gpu_device, M, N, K, ta, tb, bias, acc):
     assert torch.equal(out[:, :2], C0[:, :2]) and torch.equal(out[:, 2 + N:], C0[:, 2 + N:])      # nothing outside the slice is touched
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 64, 300), (252, 127, 9000), (6, 1024, 70), (130, 256, 40000)])
+def test_train_gemm_fused_rowsum(ops, gpu_device, M, N, K):
+    """dW = dY^T X with db = column sums of dY in the same launch (a virtual all-ones column of B), incl. the split-K path and accumulate."""
+    T, o = ops
+    g = torch.Generator().manual_seed(M + N + K)
+    dY, X = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    d = gpu_device
+    dW, db = torch.full((M, N), 7.0, device=d), torch.full((M,), -3.0, device=d)
+    o.lin_bwd_w(T.mv(dY.to(d)), T.mv(X.to(d)), T.mv(dW), db)
+    refW, refb = dY.double().t() @ X.double(), dY.double().sum(0)
+    tol = 3e-6 * max(1.0, K ** 0.5 / 8)
+    assert float((dW.cpu().double() - refW).abs().max()) <= tol * float(refW.abs().max())
+    assert float((db.cpu().double() - refb).abs().max()) <= tol * float(refb.abs().max()) + 1e-5
+    o.lin_bwd_w(T.mv(dY.to(d)), T.mv(X.to(d)), T.mv(dW), db, acc=True)
+    assert float((dW.cpu().double() - 2 * refW).abs().max()) <= 2 * tol * float(refW.abs().max())
+    assert float((db.cpu().double() - 2 * refb).abs().max()) <= 2 * tol * float(refb.abs().max()) + 2e-5
+
+
 def test_colsum_and_acts(ops, gpu_device):
     T, o = ops
     d = gpu_device

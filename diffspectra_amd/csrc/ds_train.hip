@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/diffspectra_hip.h"
 #include "../../include/diffspectra_train.h"
@@ -1364,9 +1365,10 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   if (a->M == 0 || (a->N == 0 && !a->rowsum)) return DS_OK;
   hipStream_t s = (hipStream_t)stream;
   dst_gemm_args g = *a;
-  // tile: 128 x 128 for the wide products, 128 x 64 when N is narrow, 64 x 64 for small shapes
   const int Nx = g.N + (g.rowsum ? 1 : 0);            // the fused row sum is one more (virtual, all-ones) column of B
-  const int BM = g.M >= 96 ? 128 : 64, BN = (g.M >= 96 && Nx >= 96) ? 128 : 64;
+  // 128 x 64 tiles (64 x 64 for short M): 102 VGPRs = four waves per SIMD.  128 x 128 tiles need 136 VGPRs (three waves) and were
+  // 5-12 % slower over a training step in the same session (3276 / 3440 against 3694 / 3512 molecules/s); 64 x 64 throughout: 3575.
+  const int BM = g.M >= 96 ? 128 : 64, BN = 64;
   const int tm = (g.M + BM - 1) / BM, tn = (Nx + BN - 1) / BN;
   const int64_t tiles = (int64_t)tm * tn;
   int splits = 1;
@@ -1388,8 +1390,7 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
     if (bf) hipLaunchKernelGGL((k_tr_gemm_big<M_, N_, true>), grid, blk, 0, s, g, splits, kchunk);                          \
     else hipLaunchKernelGGL((k_tr_gemm_big<M_, N_, false>), grid, blk, 0, s, g, splits, kchunk);                            \
   } while (0)
-  if (BM == 128 && BN == 128) DST_LAUNCH_GEMM(128, 128);
-  else if (BM == 128) DST_LAUNCH_GEMM(128, 64);
+  if (BM == 128) DST_LAUNCH_GEMM(128, 64);
   else DST_LAUNCH_GEMM(64, 64);
 #undef DST_LAUNCH_GEMM
   if (splits > 1) hipLaunchKernelGGL(k_tr_gemm_reduce, grid1d((int64_t)g.M * Nx), dim3(256), 0, s, g, splits);

@@ -50,8 +50,16 @@ class ExponentialMovingAverage:
         torch._foreach_mul_(diff, one_minus_decay)
         torch._foreach_sub_(self.shadow_params, diff)
 
+    def _sync(self) -> None:
+        """Hook of a sharded optimizer (losses.FusedAdamW): every rank updates only its shard of the shadow parameters in the step
+        kernel; the shards are all-gathered when the averages are READ (copy_to, state_dict), not on every step."""
+        fn = getattr(self, "_before_read", None)
+        if fn is not None:
+            fn()
+
     @torch.no_grad()
     def copy_to(self, parameters) -> None:
+        self._sync()
         params = _trainable(parameters)
         if len(params) != len(self.shadow_params):
             raise ValueError(f"EMA holds {len(self.shadow_params)} tensors, the model has {len(params)} trainable ones")
@@ -67,6 +75,7 @@ class ExponentialMovingAverage:
             p.data.copy_(c.data)
 
     def state_dict(self):
+        self._sync()
         return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)
 
     def load_state_dict(self, state_dict) -> None:

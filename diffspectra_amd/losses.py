@@ -117,6 +117,22 @@ class FusedAdamW:
             flat[o:o + s.numel()] = s.reshape(-1).to(self.dev)
         ema.shadow_params = [flat[self.offsets[i]:self.offsets[i] + self.sizes[i]].view(self.params[i].shape) for i in trainable]
         self.ema_flat, self.ema = flat, ema
+        self._ema_stale = False
+        ema._before_read = self.gather_ema
+
+    def gather_ema(self):
+        """All-gather the EMA shards (only when the averages are read: ``ema.copy_to`` / ``ema.state_dict``)."""
+        if self.world == 1 or self.ema_flat is None or not self._ema_stale:
+            return
+        lo = self.rank * self.shard
+        mine = self.ema_flat[lo:lo + self.shard].clone()
+        if dist.get_backend() == "gloo":
+            parts = [torch.empty(self.shard) for _ in range(self.world)]
+            dist.all_gather(parts, mine.cpu())
+            self.ema_flat.copy_(torch.cat(parts).to(self.dev))
+        else:
+            dist.all_gather_into_tensor(self.ema_flat, mine)
+        self._ema_stale = False
 
     @torch.no_grad()
     def step(self, clip_coef: float = 1.0, ema: ExponentialMovingAverage = None):
@@ -142,14 +158,13 @@ class FusedAdamW:
                                         C.c_float(float(clip_coef) / self.world), C.c_float(ema_omd), E._stream()), "dst_adamw_ema")
         if self.world > 1:
             if dist.get_backend() == "gloo":                           # rehearsal backend: host tensors
-                for full, mine in ((self.P, self.Ps),) + (((self.ema_flat, ema_ptr),) if ema_ptr is not None else ()):
-                    parts = [torch.empty(self.shard) for _ in range(self.world)]
-                    dist.all_gather(parts, mine.cpu())
-                    full.copy_(torch.cat(parts).to(self.dev))
+                parts = [torch.empty(self.shard) for _ in range(self.world)]
+                dist.all_gather(parts, self.Ps.cpu())
+                self.P.copy_(torch.cat(parts).to(self.dev))
             else:
                 dist.all_gather_into_tensor(self.P, self.Ps.clone())
-                if ema_ptr is not None:
-                    dist.all_gather_into_tensor(self.ema_flat, ema_ptr.clone())
+            if ema_ptr is not None:
+                self._ema_stale = True                                  # the other ranks' EMA shards are gathered when the EMA is read
 
     def _gathered(self, shard_t: torch.Tensor) -> torch.Tensor:
         if self.world == 1:

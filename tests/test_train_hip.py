@@ -616,8 +616,13 @@ def _ddp_worker(rank, world, port, out_path):
         p_before = opt.P.detach().cpu().clone()
         loss = step_fn(state, batch)
         assert not torch.equal(p_before, opt.P.detach().cpu())
+        p_step = opt.P.detach().cpu().clone()
+        stale = opt.ema_flat.detach().cpu().clone()
+        ema.copy_to(model.parameters())                                  # reading the EMA gathers the shards
+        assert opt._ema_stale is False and not torch.equal(stale, opt.ema_flat.detach().cpu())
+        assert torch.equal(torch.cat([p.detach().reshape(-1) for p in model.parameters()]), opt.ema_flat[:opt.n])
         flat_grad_local = opt.G.detach().cpu().clone()
-        torch.save(dict(P=opt.P.detach().cpu(), G=flat_grad_local, loss=float(loss.detach()), ema=opt.ema_flat.detach().cpu()), out_path + f".{rank}")
+        torch.save(dict(P=p_step, G=flat_grad_local, loss=float(loss.detach()), ema=opt.ema_flat.detach().cpu()), out_path + f".{rank}")
     finally:
         dist.destroy_process_group()
 

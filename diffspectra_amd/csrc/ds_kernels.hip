@@ -404,6 +404,9 @@ __global__ __launch_bounds__(NW * 64) void k_node_qkv(Ctx c, int blk) {
 //            targets (t = wave, wave + 16) in registers, rows visited in pair order = ascending source order, as the
 //            reference's scatter-add (layers.py:178-186)
 // q|k of the molecule's atoms are staged in LDS for phase 1, V takes their place for phase 2.
+#ifndef DS_ABL
+#define DS_ABL 0   // development only (tools/variant_build.py): bit mask of k_attn_fused phases left out for ablation timing
+#endif
 __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   ds_fp16_saturate();
   constexpr int NW = 16, NT = NW * 64, QS = 512 + 32, LDT = 256 + 4, LDY = 2 * 64 + 8;
@@ -416,6 +419,9 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   // an iteration bounds the skew to one chunk)
   __shared__ int pab[2][64];
   __shared__ int padj[2][64];
+  // phase 2b's visit lists: VT[t][q], q = 0 .. n - 2, is target t's q-th incoming edge in ascending class-ordered row R:
+  // R | source << 9 | direction << 14; 511 (a row no chunk reaches) behind the end
+  __shared__ int VT[32][32];
   const int m = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5;
   const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
   const int p0 = c.L.pair_off[m], P = c.L.pair_off[m + 1] - p0;
@@ -509,8 +515,11 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     commit(false, ck & 1);
     __syncthreads();                       // Yc / pab of this chunk (and, first time, QK) visible; every reader of the previous Tt is past it
     if (ck + 1 < nchunks) fetch(ck + 1, false);
+#if !(DS_ABL & 8)
     project();
+#endif
     __syncthreads();
+#if !(DS_ABL & 4)
     for (int it = tid; it < 64 * 16; it += NT) {
       const int row = it >> 4, hs = it & 15, pl = ck * 64 + row;
       if (pl >= P) continue;
@@ -539,43 +548,66 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
       out[2 + hs] = s_ab / 4.0f;        // / sqrt(out_channels = 16) (layers.py:167)
       out[16 + 2 + hs] = s_ba / 4.0f;
     }
+#endif
   }
   load_weights(DS_BW_E1_H);               // lin_edge1 fragments fly during the softmax
   __threadfence_block();
   __syncthreads();                         // all logits written (and visible to this workgroup); QK is dead from here
   // ---- phase 2a: V -> LDS (over QK), softmax per target written back over the logits
   float* V = QK;
+  {   // the visit table: class d reaches target t from source t + d (row i = t) and from source t - d (row i = t - d), both mod n;
+      // the last class of an even n holds each atom once
+    const int t = tid >> 5, q = tid & 31, d = (q >> 1) + 1;
+    int e = 511;
+    if (t < n && q < n - 1) {
+      int i, s_;
+      if (2 * d == n) {
+        i = t < d ? t : t - d;
+        s_ = t < d ? t + d : t - d;
+      } else {
+        int sa = t + d, ib = t - d;
+        if (sa >= n) sa -= n;
+        if (ib < 0) ib += n;
+        const bool first_is_a = t < ib;            // rows of the class in ascending order
+        const bool take_a = (q & 1) ? !first_is_a : first_is_a;
+        i = take_a ? t : ib;
+        s_ = take_a ? sa : ib;
+      }
+      e = ((d - 1) * n + i) | (s_ << 9) | ((s_ < t ? 0 : 1) << 14);   // direction 0 is source a -> target b with a < b
+    }
+    VT[t][q] = e;
+  }
   for (int i0 = tid; i0 < n * 64; i0 += NT) reinterpret_cast<float4*>(V)[i0] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + (i0 >> 6)) * 768 + 512)[i0 & 63];
-  {
-    const int h = lane & 15, sq = lane >> 4;          // lane = (source mod 4, head)
-    for (int t = wave; t < n; t += NW) {
-      float x[8];
+#if !(DS_ABL & 2)
+  {   // one half wave per target (all targets at once: a molecule's softmax is one round of L2 latency), lane = (source parity, head)
+    const int h = lane & 15, sq = (lane >> 4) & 1, t = 2 * wave + hh;
+    if (t < n) {
+      float x[15];
       float mx = -INFINITY;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int s = sq + 4 * j;
+      for (int j = 0; j < 15; ++j) {
+        const int s = sq + 2 * j;
         x[j] = -INFINITY;
         if (s < n && s != t) {
           const int lo_ = s < t ? s : t, hi_ = s < t ? t : s;
           const int pl = lo_ * (2 * n - lo_ - 1) / 2 + (hi_ - lo_ - 1);
           x[j] = c.ws.lg[(size_t)(p0 + pl) * 32 + (s < t ? 0 : 16) + h];
         }
-        mx = fmaxf(mx, x[j]);
       }
+#pragma unroll
+      for (int j = 0; j < 15; ++j) mx = fmaxf(mx, x[j]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       float sum = 0.0f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        x[j] = (sq + 4 * j < n && sq + 4 * j != t) ? expf(x[j] - mx) : 0.0f;
+      for (int j = 0; j < 15; ++j) {
+        x[j] = (sq + 2 * j < n && sq + 2 * j != t) ? expf(x[j] - mx) : 0.0f;
         sum += x[j];
       }
       sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
       const float den = sum + 1e-16f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int s = sq + 4 * j;
+      for (int j = 0; j < 15; ++j) {
+        const int s = sq + 2 * j;
         if (s < n && s != t) {
           const int lo_ = s < t ? s : t, hi_ = s < t ? t : s;
           const int pl = lo_ * (2 * n - lo_ - 1) / 2 + (hi_ - lo_ - 1);
@@ -584,58 +616,84 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
       }
     }
   }
+#endif
   __threadfence_block();
   __syncthreads();
-  // ---- phase 2b: aggregation; wave w owns targets w and w + 16 (lane = channels 4 lane .. 4 lane + 3, head lane / 4)
-  float4 acc[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) acc[k] = make_float4(0, 0, 0, 0);
-  const int hd = lane >> 2;
+  // ---- phase 2b: aggregation.  The pair rows are taken in DIFFERENCE-CLASS order here: row R = (d - 1) n + i is the pair
+  // {i, (i + d) mod n}, d = 1 .. n/2 (the last class of an even n has n/2 rows).  A class touches every atom exactly twice, so
+  // any 64 consecutive rows hold the same number of incoming edges (+-2) for every target - in the (a, b)-sorted order of the
+  // layout the first chunk holds ALL sources of atoms 0 .. 3 and a few of the others, and the waves owning those waited on by
+  // everyone else at the chunk barrier.  One half wave per target (lane = 8 channels), its visits enumerated arithmetically:
+  // class d reaches target t from source t + d (row i = t) and from source t - d (row i = t - d), both mod n.  Sum order per
+  // target: ascending d, +d before -d (fixed; the reference's scatter-add, layers.py:178-186, is unordered).
+  const int t_me = 2 * wave + hh, l32 = lane & 31;
+  auto row_pair = [&](int R) {   // global pair row (relative to p0) of class-ordered row R < P
+    const int d = R / n + 1, i = R - (d - 1) * n;
+    int j = i + d;
+    if (j >= n) j -= n;
+    const int a = min(i, j), b = max(i, j);
+    return a * (2 * n - a - 1) / 2 + (b - a - 1);
+  };
+  auto fetch2 = [&](int ck) {
+    {
+      const int R = ck * 64 + (tid >> 4);
+      yv = R < P ? ye4[(size_t)row_pair(R) * 16 + (tid & 15)] : make_uint4(0, 0, 0, 0);
+    }
+    if (tid < 512) {
+      const int R = ck * 64 + (tid >> 3);
+      av = R < P ? reinterpret_cast<const float4*>(c.ws.lg + (size_t)(p0 + row_pair(R)) * 32)[tid & 7] : make_float4(0, 0, 0, 0);
+    }
+  };
+  float4 acc0 = make_float4(0, 0, 0, 0), acc1 = make_float4(0, 0, 0, 0);
+  struct Visit { float4 g0, g1, v0, v1; float al0, al1; };
+  const int* vt_row = &VT[t_me][0];
+  int vt_q = 0, vt_e = vt_row[0];
   // Two barriers per chunk: the next chunk's ye rows are committed while this chunk's rows are visited (Yc's readers - the
-  // projection - are past the first barrier), its alpha / pair tables right after the second one (read again only behind the
-  // next projection's barrier).
-  fetch(0, true);
-  commit(true, 0);
+  // projection - are past the first barrier), its alpha rows right after the second one.
+  fetch2(0);
+  *reinterpret_cast<uint4*>(&Yc[tid >> 4][(tid & 15) * 8]) = yv;
+  if (tid < 512) reinterpret_cast<float4*>(&AL[tid >> 3][0])[tid & 7] = av;
   __syncthreads();
   for (int ck = 0; ck < nchunks; ++ck) {
-    if (ck + 1 < nchunks) fetch(ck + 1, true);
+    if (ck + 1 < nchunks) fetch2(ck + 1);
+#if !(DS_ABL & 16)
     project();
+#endif
     __syncthreads();
     if (ck + 1 < nchunks) *reinterpret_cast<uint4*>(&Yc[tid >> 4][(tid & 15) * 8]) = yv;
-    const int rows = min(64, P - ck * 64);
-    const int my_ab = pab[ck & 1][lane];   // the chunk's 64 (a, b) pairs, one per lane
-    // rows in which this wave owns a target, as a lane mask: the loop visits only those (~16 of 64), in ascending row order
-    unsigned long long todo = __ballot(lane < rows && ((((my_ab >> 8) & 15) == wave) || ((my_ab & 15) == wave)));
-    while (todo) {
-      const int row = __builtin_ctzll(todo);
-      todo &= todo - 1;
-      const int ab = __builtin_amdgcn_readlane(my_ab, row), a = ab >> 8, b = ab & 255;
-      const bool mine_b = (b & 15) == wave, mine_a = (a & 15) == wave;     // wave-uniform
-      const float4 g = reinterpret_cast<const float4*>(&Tt[row][0])[lane];
-      const float4 va = reinterpret_cast<const float4*>(V)[a * 64 + lane];
-      const float4 vb = reinterpret_cast<const float4*>(V)[b * 64 + lane];
-      const float al_ab = AL[row][hd], al_ba = AL[row][16 + hd];
-      if (mine_b) {   // source a -> target b
-#pragma unroll
-        for (int k = 0; k < 2; ++k)   // the slot is wave-uniform: a branch, not a dynamic register index
-          if ((b >> 4) == k) { acc[k].x += (va.x * g.x) * al_ab; acc[k].y += (va.y * g.y) * al_ab; acc[k].z += (va.z * g.z) * al_ab; acc[k].w += (va.w * g.w) * al_ab; }
-      }
-      if (mine_a) {   // source b -> target a
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-          if ((a >> 4) == k) { acc[k].x += (vb.x * g.x) * al_ba; acc[k].y += (vb.y * g.y) * al_ba; acc[k].z += (vb.z * g.z) * al_ba; acc[k].w += (vb.w * g.w) * al_ba; }
+#if !(DS_ABL & 1)
+    {   // this half wave's visits of the chunk: the entries of its list with R0 <= R < R0 + 64 (the list is sorted and the chunks
+        // ascend, so a pointer walks it once per molecule); the next visit's operands are requested before this one's are used
+      const int R0 = ck * 64;
+      auto operands = [&](int e) {
+        const int r = min((e & 511) - R0, 63), s_ = (e >> 9) & 31;
+        Visit v;
+        // lane = channels 4 l .. 4 l + 3 and 128 + 4 l .. : a half wave reads 512 contiguous bytes (ds_read_b128 is conflict-free
+        // only for lane-contiguous 16-byte pieces)
+        const float4* gp = reinterpret_cast<const float4*>(&Tt[r][4 * l32]);
+        const float4* vp = reinterpret_cast<const float4*>(V + s_ * 256 + 4 * l32);
+        v.g0 = gp[0]; v.g1 = gp[32]; v.v0 = vp[0]; v.v1 = vp[32];
+        const float* ap = &AL[r][((e >> 14) & 1) * 16 + (l32 >> 2)];
+        v.al0 = ap[0]; v.al1 = ap[8];
+        return v;
+      };
+      Visit cur = operands(vt_e);
+      while ((vt_e & 511) - R0 < 64) {
+        const int e_next = vt_row[++vt_q];
+        const Visit nxt = operands(e_next);
+        acc0.x += (cur.v0.x * cur.g0.x) * cur.al0; acc0.y += (cur.v0.y * cur.g0.y) * cur.al0; acc0.z += (cur.v0.z * cur.g0.z) * cur.al0; acc0.w += (cur.v0.w * cur.g0.w) * cur.al0;
+        acc1.x += (cur.v1.x * cur.g1.x) * cur.al1; acc1.y += (cur.v1.y * cur.g1.y) * cur.al1; acc1.z += (cur.v1.z * cur.g1.z) * cur.al1; acc1.w += (cur.v1.w * cur.g1.w) * cur.al1;
+        cur = nxt;
+        vt_e = e_next;
       }
     }
-    __syncthreads();                       // Tt / AL / pab are rewritten by the next chunk
-    if (ck + 1 < nchunks) {
-      if (tid < 512) reinterpret_cast<float4*>(&AL[tid >> 3][0])[tid & 7] = av;
-      if (tid < 64) pab[(ck + 1) & 1][tid] = abv;
-    }
+#endif
+    __syncthreads();                       // Tt / AL are rewritten by the next chunk
+    if (ck + 1 < nchunks && tid < 512) reinterpret_cast<float4*>(&AL[tid >> 3][0])[tid & 7] = av;
   }
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int t = wave + 16 * k;
-    if (t < n) reinterpret_cast<float4*>(c.ws.attn + (size_t)(n0 + t) * 256)[lane] = acc[k];
+  if (t_me < n) {
+    float4* o = reinterpret_cast<float4*>(c.ws.attn + (size_t)(n0 + t_me) * 256 + 4 * l32);
+    o[0] = acc0; o[32] = acc1;
   }
 }
 

@@ -467,11 +467,12 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) wf[pl][kb] = wload_h(ws_, pl, kb);
   };
-  auto project = [&]() {   // Tt = tanh(Yc . W): this wave's 32 rows x 32 columns
+  auto project = [&](int rows) {   // Tt = tanh(Yc . W): this wave's 32 rows x 32 columns (rows: valid rows of the chunk)
+    const int mt = wave >> 3;
+    if (mt * 32 >= rows) return;          // the last chunk's upper row tile is empty half of the time; nothing reads its Tt rows
     f32x16 acc[1], lo[1];
     acc_zero<1>(acc);
     acc_zero<1>(lo);
-    const int mt = wave >> 3;
     const _Float16* xr = &Yc[mt * 32 + (lane & 31)][8 * hh];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -494,19 +495,21 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     }
   };
 
-  load_weights(DS_BW_E0_H);
-  fetch(0, false);
-  // ---- phase 0: q (256) | k (256) of every atom -> LDS
-  for (int i0 = tid; i0 < n * 128; i0 += NT * 4) {
+  // ---- phase 0: q (256) | k (256) of every atom -> LDS (n * 128 <= 4 * NT 16-byte pieces).  Their loads are issued first: they are
+  // the first to be waited for, and the chunk / weight loads behind them stay in flight across the LDS stores
+  static_assert(DS_MAX_ATOMS * 128 <= 4 * NT, "q|k staging is a single pass");
+  {
     float4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int idx = min(i0 + u * NT, n * 128 - 1);
+      const int idx = min(tid + u * NT, n * 128 - 1);
       v[u] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + (idx >> 7)) * 768)[idx & 127];
     }
+    fetch(0, false);
+    load_weights(DS_BW_E0_H);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int idx = i0 + u * NT;
+      const int idx = tid + u * NT;
       if (idx < n * 128) reinterpret_cast<float4*>(QK)[(idx >> 7) * (QS / 4) + (idx & 127)] = v[u];
     }
   }
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     __syncthreads();                       // Yc / pab of this chunk (and, first time, QK) visible; every reader of the previous Tt is past it
     if (ck + 1 < nchunks) fetch(ck + 1, false);
 #if !(DS_ABL & 8)
-    project();
+    project(min(64, P - ck * 64));
 #endif
     __syncthreads();
 #if !(DS_ABL & 4)
@@ -577,7 +580,36 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     }
     VT[t][q] = e;
   }
-  for (int i0 = tid; i0 < n * 64; i0 += NT) reinterpret_cast<float4*>(V)[i0] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + (i0 >> 6)) * 768 + 512)[i0 & 63];
+  auto row_pair = [&](int R) {   // global pair row (relative to p0) of class-ordered row R < P
+    const int d = R / n + 1, i = R - (d - 1) * n;
+    int j = i + d;
+    if (j >= n) j -= n;
+    const int a = min(i, j), b = max(i, j);
+    return a * (2 * n - a - 1) / 2 + (b - a - 1);
+  };
+  auto fetch2_y = [&](int ck) {
+    const int R = ck * 64 + (tid >> 4);
+    yv = R < P ? ye4[(size_t)row_pair(R) * 16 + (tid & 15)] : make_uint4(0, 0, 0, 0);
+  };
+  auto fetch2_a = [&](int ck) {
+    if (tid < 512) {
+      const int R = ck * 64 + (tid >> 3);
+      av = R < P ? reinterpret_cast<const float4*>(c.ws.lg + (size_t)(p0 + row_pair(R)) * 32)[tid & 7] : make_float4(0, 0, 0, 0);
+    }
+  };
+  fetch2_y(0);                             // the first chunk's ye rows do not wait for the softmax
+  static_assert(DS_MAX_ATOMS * 64 <= 2 * NT, "V staging is a single pass");
+  float4 vst[2];   // V rows: requested here, stored to LDS behind the softmax's logit loads (one round of latency for both)
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i0 = min(tid + u * NT, n * 64 - 1);
+    vst[u] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + (i0 >> 6)) * 768 + 512)[i0 & 63];
+  }
+  auto store_v = [&]() {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (tid + u * NT < n * 64) reinterpret_cast<float4*>(V)[tid + u * NT] = vst[u];
+  };
 #if !(DS_ABL & 2)
   {   // one half wave per target (all targets at once: a molecule's softmax is one round of L2 latency), lane = (source parity, head)
     const int h = lane & 15, sq = (lane >> 4) & 1, t = 2 * wave + hh;
@@ -594,6 +626,7 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
           x[j] = c.ws.lg[(size_t)(p0 + pl) * 32 + (s < t ? 0 : 16) + h];
         }
       }
+      store_v();
 #pragma unroll
       for (int j = 0; j < 15; ++j) mx = fmaxf(mx, x[j]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -614,8 +647,12 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
           c.ws.lg[(size_t)(p0 + pl) * 32 + (s < t ? 0 : 16) + h] = x[j] / den;
         }
       }
+    } else {
+      store_v();
     }
   }
+#else
+  store_v();
 #endif
   __threadfence_block();
   __syncthreads();
@@ -627,37 +664,20 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   // class d reaches target t from source t + d (row i = t) and from source t - d (row i = t - d), both mod n.  Sum order per
   // target: ascending d, +d before -d (fixed; the reference's scatter-add, layers.py:178-186, is unordered).
   const int t_me = 2 * wave + hh, l32 = lane & 31;
-  auto row_pair = [&](int R) {   // global pair row (relative to p0) of class-ordered row R < P
-    const int d = R / n + 1, i = R - (d - 1) * n;
-    int j = i + d;
-    if (j >= n) j -= n;
-    const int a = min(i, j), b = max(i, j);
-    return a * (2 * n - a - 1) / 2 + (b - a - 1);
-  };
-  auto fetch2 = [&](int ck) {
-    {
-      const int R = ck * 64 + (tid >> 4);
-      yv = R < P ? ye4[(size_t)row_pair(R) * 16 + (tid & 15)] : make_uint4(0, 0, 0, 0);
-    }
-    if (tid < 512) {
-      const int R = ck * 64 + (tid >> 3);
-      av = R < P ? reinterpret_cast<const float4*>(c.ws.lg + (size_t)(p0 + row_pair(R)) * 32)[tid & 7] : make_float4(0, 0, 0, 0);
-    }
-  };
   float4 acc0 = make_float4(0, 0, 0, 0), acc1 = make_float4(0, 0, 0, 0);
   struct Visit { float4 g0, g1, v0, v1; float al0, al1; };
   const int* vt_row = &VT[t_me][0];
   int vt_q = 0, vt_e = vt_row[0];
   // Two barriers per chunk: the next chunk's ye rows are committed while this chunk's rows are visited (Yc's readers - the
   // projection - are past the first barrier), its alpha rows right after the second one.
-  fetch2(0);
+  fetch2_a(0);
   *reinterpret_cast<uint4*>(&Yc[tid >> 4][(tid & 15) * 8]) = yv;
   if (tid < 512) reinterpret_cast<float4*>(&AL[tid >> 3][0])[tid & 7] = av;
   __syncthreads();
   for (int ck = 0; ck < nchunks; ++ck) {
-    if (ck + 1 < nchunks) fetch2(ck + 1);
+    if (ck + 1 < nchunks) { fetch2_y(ck + 1); fetch2_a(ck + 1); }
 #if !(DS_ABL & 16)
-    project();
+    project(min(64, P - ck * 64));
 #endif
     __syncthreads();
     if (ck + 1 < nchunks) *reinterpret_cast<uint4*>(&Yc[tid >> 4][(tid & 15) * 8]) = yv;

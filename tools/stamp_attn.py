@@ -34,12 +34,12 @@ def main():
         k = k.replace(old, new, count)
     rep("  // ---- phase 1: logits\n", "  DS_STAMP(0);\n  // ---- phase 1: logits\n")
     rep("    commit(false, ck & 1);\n    __syncthreads();", "    commit(false, ck & 1);\n    DS_STAMP(1);\n    __syncthreads();\n    DS_STAMP(2);")
-    rep("    project();\n#endif\n    __syncthreads();\n#if !(DS_ABL & 4)", "    project();\n#endif\n    DS_STAMP(3);\n    __syncthreads();\n    DS_STAMP(4);\n#if !(DS_ABL & 4)")
+    rep("    project(min(64, P - ck * 64));\n#endif\n    __syncthreads();\n#if !(DS_ABL & 4)", "    project(min(64, P - ck * 64));\n#endif\n    DS_STAMP(3);\n    __syncthreads();\n    DS_STAMP(4);\n#if !(DS_ABL & 4)")
     rep("#endif\n  }\n  load_weights(DS_BW_E1_H);", "#endif\n    DS_STAMP(5);\n  }\n  load_weights(DS_BW_E1_H);")
     rep("  __threadfence_block();\n  __syncthreads();                         // all logits written", "  __threadfence_block();\n  DS_STAMP(6);\n  __syncthreads();\n  DS_STAMP(7);                         // all logits written")
     rep("#endif\n  __threadfence_block();\n  __syncthreads();\n", "#endif\n  __threadfence_block();\n  DS_STAMP(8);\n  __syncthreads();\n  DS_STAMP(9);\n")
-    rep("  __syncthreads();\n  for (int ck = 0; ck < nchunks; ++ck) {\n    if (ck + 1 < nchunks) fetch2(ck + 1);", "  __syncthreads();\n  DS_STAMP(10);\n  for (int ck = 0; ck < nchunks; ++ck) {\n    if (ck + 1 < nchunks) fetch2(ck + 1);")
-    rep("    project();\n#endif\n    __syncthreads();\n    if (ck + 1 < nchunks) *reinterpret_cast<uint4*>", "    project();\n#endif\n    DS_STAMP(12);\n    __syncthreads();\n    DS_STAMP(13);\n    if (ck + 1 < nchunks) *reinterpret_cast<uint4*>")
+    rep("  __syncthreads();\n  for (int ck = 0; ck < nchunks; ++ck) {\n    if (ck + 1 < nchunks) { fetch2_y(ck + 1); fetch2_a(ck + 1); }", "  __syncthreads();\n  DS_STAMP(10);\n  for (int ck = 0; ck < nchunks; ++ck) {\n    if (ck + 1 < nchunks) { fetch2_y(ck + 1); fetch2_a(ck + 1); }")
+    rep("    project(min(64, P - ck * 64));\n#endif\n    __syncthreads();\n    if (ck + 1 < nchunks) *reinterpret_cast<uint4*>", "    project(min(64, P - ck * 64));\n#endif\n    DS_STAMP(12);\n    __syncthreads();\n    DS_STAMP(13);\n    if (ck + 1 < nchunks) *reinterpret_cast<uint4*>")
     rep("#endif\n    __syncthreads();                       // Tt / AL are rewritten by the next chunk", "#endif\n    DS_STAMP(14);\n    __syncthreads();\n    DS_STAMP(15);                       // Tt / AL are rewritten by the next chunk")
     k += "\n  DS_STAMP(12);\n  DS_STAMP_FLUSH(%s);" % flush
     s = s[:a] + k + s[b:]

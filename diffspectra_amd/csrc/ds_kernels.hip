@@ -394,34 +394,35 @@ __global__ __launch_bounds__(NW * 64) void k_node_qkv(Ctx c, int blk) {
 
 // Block stage C (one 1024-thread workgroup per molecule): the whole edge-modulated attention of TransMixLayer
 // (layers.py:131-186 + PyG propagate / softmax) with tanh(lin_edge0 e) and tanh(lin_edge1 e) recomputed on chip.
-//   phase 1, per chunk of 64 pair rows: ye rows -> LDS, te0 = tanh(ye . lin_edge0) on the f16 matrix pipe (one 32-column chunk per
-//            and row tile per wave) -> LDS tile, logits of both directions of every pair:
-//            lg[p][0][h] source a -> target b, lg[p][1][h] source b -> target a; 14 learned heads (q_t . k_s . te0 over 18
-//            channels, / sqrt(16)) + the 2 adjacency heads (0 -> -1e10; layers.py:165-174)
-//   phase 2a: segment softmax over the sources of every target (PyG softmax: max-shift, exp, / (sum + 1e-16)), one wave per
-//            target, written back over the logits
-//   phase 2b, per chunk: te1 = tanh(ye . lin_edge1) -> LDS tile; out[t] += (v_s * te1) * alpha, every wave accumulating its own
-//            targets (t = wave, wave + 16) in registers, rows visited in pair order = ascending source order, as the
-//            reference's scatter-add (layers.py:178-186)
+// The sixteen waves have two roles (each SIMD holds two of either): waves 8-15 PROJECT - per chunk of 32 pair rows the ye rows
+// go to LDS and tanh(ye . lin_edge) comes off the f16 matrix pipe into one of two LDS tiles (transcendental / VALU-bound) -,
+// waves 0-7 CONSUME the tile of the chunk before (LDS-bound), so a chunk costs the longer of the two, one barrier per chunk:
+//   phase 1: logits of both directions of every pair: lg[p][0][h] source a -> target b, lg[p][1][h] source b -> target a;
+//            14 learned heads (q_t . k_s . te0 over 18 channels, / sqrt(16)) + the 2 adjacency heads (0 -> -1e10;
+//            layers.py:165-174)
+//   phase 2a (all waves): segment softmax over the sources of every target (PyG softmax: max-shift, exp, / (sum + 1e-16)), one
+//            half wave per target, written back over the logits
+//   phase 2b: out[t] += (v_s * te1) * alpha (layers.py:178-186).  The pair rows are taken in DIFFERENCE-CLASS order here: row
+//            R = (d - 1) n + i is the pair {i, (i + d) mod n}, d = 1 .. n/2 (the last class of an even n has n/2 rows).  A class
+//            touches every atom exactly twice, so any run of consecutive rows holds the same number of incoming edges (+-2) for
+//            every target - in the (a, b)-sorted order of the layout the first rows hold ALL sources of atoms 0 .. 3 and few of the
+//            others'.  One quarter wave per target (lane = 16 channels) walks the target's visit list; sum order per target:
+//            ascending R (fixed; the reference's scatter-add is unordered).
 // q|k of the molecule's atoms are staged in LDS for phase 1, V takes their place for phase 2.
-#ifndef DS_ABL
-#define DS_ABL 0   // development only (tools/variant_build.py): bit mask of k_attn_fused phases left out for ablation timing
-#endif
 __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   ds_fp16_saturate();
-  constexpr int NW = 16, NT = NW * 64, QS = 512 + 32, LDT = 256 + 4, LDY = 2 * 64 + 8;
+  DS_STAMP_INIT();   // diagnostic build: wave 0 (consumer) P0-P7, wave 8 (producer) P8-P15
+  constexpr int NT = 1024, QS = 512 + 32, LDT = 256 + 4, LDY = 2 * 64 + 8, CR = 32, MAXP = DS_MAX_ATOMS * (DS_MAX_ATOMS - 1) / 2;
   __shared__ __attribute__((aligned(16))) float QK[DS_MAX_ATOMS * QS];       // 63,104 B; phase 2: V [n][256]
-  __shared__ __attribute__((aligned(16))) float Tt[64][LDT];                 // 66,560 B  tanh(te0 / te1) of the chunk
-  __shared__ __attribute__((aligned(16))) _Float16 Yc[64][LDY];              // 17,408 B  ye rows of the chunk (split-fp16 layout)
-  __shared__ __attribute__((aligned(16))) float AL[64][32];                  //  8,192 B  alpha of the chunk's pairs, both directions
-  // (a << 8) | b local atom indices and adjacency bits of the chunk's pairs, double-buffered by chunk parity: a wave that is
-  // through with chunk k's logits commits chunk k+1's tables while slower waves still read chunk k's (the barrier at the top of
-  // an iteration bounds the skew to one chunk)
-  __shared__ int pab[2][64];
-  __shared__ int padj[2][64];
+  __shared__ __attribute__((aligned(16))) float Tt[2][CR][LDT];              // 66,560 B  tanh(te0 / te1) of two chunks
+  __shared__ __attribute__((aligned(16))) _Float16 Yc[2][CR][LDY];           // 17,408 B  ye rows of two chunks (split-fp16 layout)
+  __shared__ __attribute__((aligned(16))) float AL[2][CR][32];               //  8,192 B  alpha of two chunks' pairs, both directions
+  __shared__ int PT[(MAXP + 15) & ~15];   // every pair of the molecule in layout order: (a << 8) | b (local atom indices) | adjacency bits << 16
   // phase 2b's visit lists: VT[t][q], q = 0 .. n - 2, is target t's q-th incoming edge in ascending class-ordered row R:
   // R | source << 9 | direction << 14; 511 (a row no chunk reaches) behind the end
   __shared__ int VT[32][32];
+  static_assert(DS_MAX_ATOMS <= 32 && MAXP <= 511 - CR, "visit table packing");
+  static_assert(DS_MAX_ATOMS * 128 <= 4 * NT && DS_MAX_ATOMS * 64 <= 2 * NT && MAXP <= NT, "single-pass staging");
   const int m = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5;
   const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
   const int p0 = c.L.pair_off[m], P = c.L.pair_off[m + 1] - p0;
@@ -430,35 +431,27 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     for (int i = tid; i < 256; i += NT) c.ws.attn[(size_t)n0 * 256 + i] = 0.0f;
     return;
   }
-  const int nchunks = (P + 63) >> 6;
+  const int nch = (P + CR - 1) / CR;
+  const bool producer = wave >= 8;                 // wave-uniform
+  const int ptid = tid & 511, prow = ptid >> 4, ppiece = ptid & 15;   // a producer thread's 16-byte piece of a chunk's ye rows
   const uint4* ye4 = reinterpret_cast<const uint4*>(c.ws.ye) + (size_t)p0 * 16;   // 16 x 16 bytes per pair row
-  // A chunk's global reads are issued one chunk ahead into registers (fetch) and land in LDS at the top of the chunk (commit):
-  // with one workgroup per CU nothing else hides their latency.
-  uint4 yv;
-  float4 av = make_float4(0, 0, 0, 0);
-  int abv = 0, adjv = 0;
-  auto fetch = [&](int ck, bool with_alpha) {
-    {   // 64 rows x 16 pieces of 16 bytes: one per thread
-      const int pl = ck * 64 + (tid >> 4);
-      yv = pl < P ? ye4[(size_t)pl * 16 + (tid & 15)] : make_uint4(0, 0, 0, 0);
-    }
-    if (with_alpha && tid < 512) {
-      const int pl = ck * 64 + (tid >> 3);
-      av = pl < P ? reinterpret_cast<const float4*>(c.ws.lg + (size_t)(p0 + pl) * 32)[tid & 7] : make_float4(0, 0, 0, 0);
-    }
-    if (tid < 64) {
-      const int pl = ck * 64 + tid;
-      abv = pl < P ? ((c.L.pair_a[p0 + pl] - n0) << 8) | (c.L.pair_b[p0 + pl] - n0) : 0;
-      if (!with_alpha) adjv = pl < P ? c.ws.adj[p0 + pl] : 0;   // the two adjacency heads' logits (phase 1): fetched with the chunk, not inside its logit loop
-    }
+  auto row_pair = [&](int R) {   // pair row (relative to p0) of class-ordered row R < P
+    const int d = R / n + 1, i = R - (d - 1) * n;
+    int j = i + d;
+    if (j >= n) j -= n;
+    const int a = min(i, j), b = max(i, j);
+    return a * (2 * n - a - 1) / 2 + (b - a - 1);
   };
-  auto commit = [&](bool with_alpha, int pb) {
-    *reinterpret_cast<uint4*>(&Yc[tid >> 4][(tid & 15) * 8]) = yv;
-    if (with_alpha && tid < 512) reinterpret_cast<float4*>(&AL[tid >> 3][0])[tid & 7] = av;
-    if (tid < 64) { pab[pb][tid] = abv; padj[pb][tid] = adjv; }
+  // A chunk's ye rows are requested FOUR chunks ahead into one of two register sets and land in LDS two chunks ahead: with one
+  // workgroup per CU nothing else hides their latency.
+  auto fetch_y = [&](int ck, bool class_order) {
+    const int R = ck * CR + prow;
+    if (R >= P) return make_uint4(0, 0, 0, 0);
+    return ye4[(size_t)(class_order ? row_pair(R) : R) * 16 + ppiece];
   };
-  // wave w owns output columns 32 (w & 7) .. +31 of row tile w >> 3; its lin_edge0 / lin_edge1 fragments (64 -> 256, split-fp16
-  // planes) live in registers for a whole phase: 8 x 16 bytes
+  auto commit_y = [&](int buf, const uint4& v) { *reinterpret_cast<uint4*>(&Yc[buf][prow][ppiece * 8]) = v; };
+  // producer wave w owns output columns 32 (w & 7) .. +31; its lin_edge0 / lin_edge1 fragments (64 -> 256, split-fp16 planes) live in
+  // registers for a whole phase: 8 x 16 bytes
   h8 wf[2][4];
   auto load_weights = [&](int slot) {
     const WStreamH ws_ = wstream_h(BW(c, blk, slot), 256, 64, (wave & 7) * 32);
@@ -467,13 +460,11 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) wf[pl][kb] = wload_h(ws_, pl, kb);
   };
-  auto project = [&](int rows) {   // Tt = tanh(Yc . W): this wave's 32 rows x 32 columns (rows: valid rows of the chunk)
-    const int mt = wave >> 3;
-    if (mt * 32 >= rows) return;          // the last chunk's upper row tile is empty half of the time; nothing reads its Tt rows
+  auto project = [&](int buf) {   // Tt[buf] = tanh(Yc[buf] . W): 32 rows x this wave's 32 columns
     f32x16 acc[1], lo[1];
     acc_zero<1>(acc);
     acc_zero<1>(lo);
-    const _Float16* xr = &Yc[mt * 32 + (lane & 31)][8 * hh];
+    const _Float16* xr = &Yc[buf][lane & 31][8 * hh];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const h8 x1 = *reinterpret_cast<const h8*>(xr + kb * 16);
@@ -485,7 +476,7 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
       lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][kb], x1, lo[0], 0, 0, 0);
     }
     split_finish<1>(acc, lo);
-    float* trow = &Tt[mt * 32 + (lane & 31)][(wave & 7) * 32 + 4 * hh];
+    float* trow = &Tt[buf][lane & 31][(wave & 7) * 32 + 4 * hh];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       f32x2 v0, v1;
@@ -494,10 +485,27 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
       *reinterpret_cast<float4*>(trow + 8 * q) = make_float4(v0.x, v0.y, v1.x, v1.y);
     }
   };
+  // The producers' side of a phase: chunk 0 is projected while the consumers wait, then one chunk ahead of them.  Entered with chunk 0's
+  // rows in Yc[0] (visible), chunk 1's in ya, chunk 2's in yb.  Barriers: 1 + nch, as in the consumers' loops.
+  auto produce = [&](uint4 ya, uint4 yb, bool class_order) {
+    project(0);
+    if (1 < nch) commit_y(1, ya);
+    if (3 < nch) ya = fetch_y(3, class_order);
+    __syncthreads();
+    if (class_order) { DS_STAMP(13); } else { DS_STAMP(9); }
+    for (int k = 0; k < nch; ++k) {   // interval k: ya holds chunk k + 3, yb chunk k + 2
+      if (k + 2 < nch) commit_y(k & 1, yb);             // Yc[k & 1] was last read by chunk k's projection, an interval ago
+      if (k + 4 < nch) yb = fetch_y(k + 4, class_order);
+      if (k + 1 < nch) project((k + 1) & 1);
+      const uint4 t_ = ya; ya = yb; yb = t_;
+      if (class_order) { DS_STAMP(14); } else { DS_STAMP(10); }
+      __syncthreads();
+      if (class_order) { DS_STAMP(15); } else { DS_STAMP(11); }
+    }
+  };
 
-  // ---- phase 0: q (256) | k (256) of every atom -> LDS (n * 128 <= 4 * NT 16-byte pieces).  Their loads are issued first: they are
-  // the first to be waited for, and the chunk / weight loads behind them stay in flight across the LDS stores
-  static_assert(DS_MAX_ATOMS * 128 <= 4 * NT, "q|k staging is a single pass");
+  // ---- phase 0: q (256) | k (256) of every atom -> LDS.  Their loads are issued first: they are the first to be waited for, and
+  // the chunk / weight loads behind them stay in flight across the LDS stores
   {
     float4 v[4];
 #pragma unroll
@@ -505,61 +513,77 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
       const int idx = min(tid + u * NT, n * 128 - 1);
       v[u] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + (idx >> 7)) * 768)[idx & 127];
     }
-    fetch(0, false);
-    load_weights(DS_BW_E0_H);
+    uint4 y0 = make_uint4(0, 0, 0, 0), y1 = y0, y2 = y0;
+    if (producer) {
+      y0 = fetch_y(0, false);
+      y1 = fetch_y(1, false);
+      y2 = fetch_y(2, false);
+      load_weights(DS_BW_E0_H);
+    } else if (tid < P) {
+      PT[tid] = ((c.L.pair_a[p0 + tid] - n0) << 8) | (c.L.pair_b[p0 + tid] - n0) | (c.ws.adj[p0 + tid] << 16);
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = tid + u * NT;
       if (idx < n * 128) reinterpret_cast<float4*>(QK)[(idx >> 7) * (QS / 4) + (idx & 127)] = v[u];
     }
-  }
-  // ---- phase 1: logits
-  for (int ck = 0; ck < nchunks; ++ck) {
-    commit(false, ck & 1);
-    __syncthreads();                       // Yc / pab of this chunk (and, first time, QK) visible; every reader of the previous Tt is past it
-    if (ck + 1 < nchunks) fetch(ck + 1, false);
-#if !(DS_ABL & 8)
-    project(min(64, P - ck * 64));
-#endif
-    __syncthreads();
-#if !(DS_ABL & 4)
-    for (int it = tid; it < 64 * 16; it += NT) {
-      const int row = it >> 4, hs = it & 15, pl = ck * 64 + row;
-      if (pl >= P) continue;
-      float* out = c.ws.lg + (size_t)(p0 + pl) * 32;
-      if (hs >= 14) {
-        if (hs == 14) {
-          const int bits = padj[ck & 1][row];
-          const float h0 = (bits & 1) ? 1.0f : -1e10f, h1 = (bits & 2) ? 1.0f : -1e10f;   // layers.py:171-174
-          out[0] = h0; out[1] = h1; out[16] = h0; out[17] = h1;
-        }
-        continue;
-      }
-      const int a = pab[ck & 1][row] >> 8, b = pab[ck & 1][row] & 255;
-      const float2* t0 = reinterpret_cast<const float2*>(&Tt[row][hs * 18]);
-      const float2* qa = reinterpret_cast<const float2*>(QK + a * QS + hs * 18);
-      const float2* qb = reinterpret_cast<const float2*>(QK + b * QS + hs * 18);
-      const float2* ka = reinterpret_cast<const float2*>(QK + a * QS + 256 + hs * 18);
-      const float2* kb = reinterpret_cast<const float2*>(QK + b * QS + 256 + hs * 18);
-      float s_ab = 0.0f, s_ba = 0.0f;
+    if (producer) commit_y(0, y0);
+    __syncthreads();                       // QK, PT, Yc[0]
+    if (producer) { DS_STAMP(8); } else { DS_STAMP(0); }
+    // ---- phase 1: logits
+    if (producer) {
+      produce(y1, y2, false);
+      load_weights(DS_BW_E1_H);            // lin_edge1 fragments fly during the softmax
+    } else {
+      __syncthreads();                     // Tt[0]
+      DS_STAMP(1);
+      const int row = tid >> 4, hs = tid & 15;
+      for (int k = 0; k < nch; ++k) {
+        const int pl = k * CR + row;
+        if (pl < P) {
+          const int e_ = PT[pl];
+          float* out = c.ws.lg + (size_t)(p0 + pl) * 32;
+          if (hs == 14) {
+            const float h0 = (e_ & 0x10000) ? 1.0f : -1e10f, h1 = (e_ & 0x20000) ? 1.0f : -1e10f;   // layers.py:171-174
+            out[0] = h0; out[1] = h1; out[16] = h0; out[17] = h1;
+          } else if (hs < 14) {
+            const int a = (e_ >> 8) & 255, b = e_ & 255;
+            // volatile: kept as 45 ds_read_b64 (2 LDS cycles each).  Merged in pairs into ds_read2_b64 - what the compiler does with
+            // adjacent 8-byte loads - they take 8 cycles per pair.
+            typedef const volatile f32x2 __attribute__((address_space(3))) * lds_v2;
+            lds_v2 t0 = (lds_v2)(&Tt[k & 1][row][hs * 18]);
+            lds_v2 qa = (lds_v2)(QK + a * QS + hs * 18);
+            lds_v2 qb = (lds_v2)(QK + b * QS + hs * 18);
+            lds_v2 ka = (lds_v2)(QK + a * QS + 256 + hs * 18);
+            lds_v2 kb = (lds_v2)(QK + b * QS + 256 + hs * 18);
+            float s_ab = 0.0f, s_ba = 0.0f;
 #pragma unroll
-      for (int j = 0; j < 9; ++j) {
-        const float2 e = t0[j], xa = qa[j], xb = qb[j], ya = ka[j], yb = kb[j];
-        s_ab += (xb.x * ya.x) * e.x; s_ab += (xb.y * ya.y) * e.y;
-        s_ba += (xa.x * yb.x) * e.x; s_ba += (xa.y * yb.y) * e.y;
+            for (int j0 = 0; j0 < 9; j0 += 3) {   // three batches of 15 reads
+              f32x2 e[3], xa[3], xb[3], ya[3], yb[3];
+#pragma unroll
+              for (int j = 0; j < 3; ++j) { e[j] = t0[j0 + j]; xa[j] = qa[j0 + j]; xb[j] = qb[j0 + j]; ya[j] = ka[j0 + j]; yb[j] = kb[j0 + j]; }
+#pragma unroll
+              for (int j = 0; j < 3; ++j) {
+                s_ab += (xb[j].x * ya[j].x) * e[j].x; s_ab += (xb[j].y * ya[j].y) * e[j].y;
+                s_ba += (xa[j].x * yb[j].x) * e[j].x; s_ba += (xa[j].y * yb[j].y) * e[j].y;
+              }
+            }
+            out[2 + hs] = s_ab / 4.0f;        // / sqrt(out_channels = 16) (layers.py:167)
+            out[16 + 2 + hs] = s_ba / 4.0f;
+          }
+        }
+        DS_STAMP(2);
+        __syncthreads();
+        DS_STAMP(3);
       }
-      out[2 + hs] = s_ab / 4.0f;        // / sqrt(out_channels = 16) (layers.py:167)
-      out[16 + 2 + hs] = s_ba / 4.0f;
     }
-#endif
   }
-  load_weights(DS_BW_E1_H);               // lin_edge1 fragments fly during the softmax
   __threadfence_block();
   __syncthreads();                         // all logits written (and visible to this workgroup); QK is dead from here
-  // ---- phase 2a: V -> LDS (over QK), softmax per target written back over the logits
+  // ---- phase 2a: V -> LDS (over QK), the visit table, softmax per target written back over the logits
   float* V = QK;
-  {   // the visit table: class d reaches target t from source t + d (row i = t) and from source t - d (row i = t - d), both mod n;
-      // the last class of an even n holds each atom once
+  {   // class d reaches target t from source t + d (row i = t) and from source t - d (row i = t - d), both mod n; the last class of an
+      // even n holds each atom once
     const int t = tid >> 5, q = tid & 31, d = (q >> 1) + 1;
     int e = 511;
     if (t < n && q < n - 1) {
@@ -580,25 +604,12 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     }
     VT[t][q] = e;
   }
-  auto row_pair = [&](int R) {   // global pair row (relative to p0) of class-ordered row R < P
-    const int d = R / n + 1, i = R - (d - 1) * n;
-    int j = i + d;
-    if (j >= n) j -= n;
-    const int a = min(i, j), b = max(i, j);
-    return a * (2 * n - a - 1) / 2 + (b - a - 1);
-  };
-  auto fetch2_y = [&](int ck) {
-    const int R = ck * 64 + (tid >> 4);
-    yv = R < P ? ye4[(size_t)row_pair(R) * 16 + (tid & 15)] : make_uint4(0, 0, 0, 0);
-  };
-  auto fetch2_a = [&](int ck) {
-    if (tid < 512) {
-      const int R = ck * 64 + (tid >> 3);
-      av = R < P ? reinterpret_cast<const float4*>(c.ws.lg + (size_t)(p0 + row_pair(R)) * 32)[tid & 7] : make_float4(0, 0, 0, 0);
-    }
-  };
-  fetch2_y(0);                             // the first chunk's ye rows do not wait for the softmax
-  static_assert(DS_MAX_ATOMS * 64 <= 2 * NT, "V staging is a single pass");
+  uint4 y0 = make_uint4(0, 0, 0, 0), y1 = y0, y2 = y0;
+  if (producer) {                          // the first class-ordered chunks do not wait for the softmax
+    y0 = fetch_y(0, true);
+    y1 = fetch_y(1, true);
+    y2 = fetch_y(2, true);
+  }
   float4 vst[2];   // V rows: requested here, stored to LDS behind the softmax's logit loads (one round of latency for both)
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -610,7 +621,6 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     for (int u = 0; u < 2; ++u)
       if (tid + u * NT < n * 64) reinterpret_cast<float4*>(V)[tid + u * NT] = vst[u];
   };
-#if !(DS_ABL & 2)
   {   // one half wave per target (all targets at once: a molecule's softmax is one round of L2 latency), lane = (source parity, head)
     const int h = lane & 15, sq = (lane >> 4) & 1, t = 2 * wave + hh;
     if (t < n) {
@@ -651,69 +661,74 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
       store_v();
     }
   }
-#else
-  store_v();
-#endif
   __threadfence_block();
-  __syncthreads();
-  // ---- phase 2b: aggregation.  The pair rows are taken in DIFFERENCE-CLASS order here: row R = (d - 1) n + i is the pair
-  // {i, (i + d) mod n}, d = 1 .. n/2 (the last class of an even n has n/2 rows).  A class touches every atom exactly twice, so
-  // any 64 consecutive rows hold the same number of incoming edges (+-2) for every target - in the (a, b)-sorted order of the
-  // layout the first chunk holds ALL sources of atoms 0 .. 3 and a few of the others, and the waves owning those waited on by
-  // everyone else at the chunk barrier.  One half wave per target (lane = 8 channels), its visits enumerated arithmetically:
-  // class d reaches target t from source t + d (row i = t) and from source t - d (row i = t - d), both mod n.  Sum order per
-  // target: ascending d, +d before -d (fixed; the reference's scatter-add, layers.py:178-186, is unordered).
-  const int t_me = 2 * wave + hh, l32 = lane & 31;
-  float4 acc0 = make_float4(0, 0, 0, 0), acc1 = make_float4(0, 0, 0, 0);
-  struct Visit { float4 g0, g1, v0, v1; float al0, al1; };
-  const int* vt_row = &VT[t_me][0];
-  int vt_q = 0, vt_e = vt_row[0];
-  // Two barriers per chunk: the next chunk's ye rows are committed while this chunk's rows are visited (Yc's readers - the
-  // projection - are past the first barrier), its alpha rows right after the second one.
-  fetch2_a(0);
-  *reinterpret_cast<uint4*>(&Yc[tid >> 4][(tid & 15) * 8]) = yv;
-  if (tid < 512) reinterpret_cast<float4*>(&AL[tid >> 3][0])[tid & 7] = av;
-  __syncthreads();
-  for (int ck = 0; ck < nchunks; ++ck) {
-    if (ck + 1 < nchunks) { fetch2_y(ck + 1); fetch2_a(ck + 1); }
-#if !(DS_ABL & 16)
-    project(min(64, P - ck * 64));
-#endif
-    __syncthreads();
-    if (ck + 1 < nchunks) *reinterpret_cast<uint4*>(&Yc[tid >> 4][(tid & 15) * 8]) = yv;
-#if !(DS_ABL & 1)
-    {   // this half wave's visits of the chunk: the entries of its list with R0 <= R < R0 + 64 (the list is sorted and the chunks
-        // ascend, so a pointer walks it once per molecule); the next visit's operands are requested before this one's are used
-      const int R0 = ck * 64;
-      auto operands = [&](int e) {
-        const int r = min((e & 511) - R0, 63), s_ = (e >> 9) & 31;
-        Visit v;
-        // lane = channels 4 l .. 4 l + 3 and 128 + 4 l .. : a half wave reads 512 contiguous bytes (ds_read_b128 is conflict-free
-        // only for lane-contiguous 16-byte pieces)
-        const float4* gp = reinterpret_cast<const float4*>(&Tt[r][4 * l32]);
-        const float4* vp = reinterpret_cast<const float4*>(V + s_ * 256 + 4 * l32);
-        v.g0 = gp[0]; v.g1 = gp[32]; v.v0 = vp[0]; v.v1 = vp[32];
-        const float* ap = &AL[r][((e >> 14) & 1) * 16 + (l32 >> 2)];
-        v.al0 = ap[0]; v.al1 = ap[8];
-        return v;
-      };
-      Visit cur = operands(vt_e);
-      while ((vt_e & 511) - R0 < 64) {
-        const int e_next = vt_row[++vt_q];
-        const Visit nxt = operands(e_next);
-        acc0.x += (cur.v0.x * cur.g0.x) * cur.al0; acc0.y += (cur.v0.y * cur.g0.y) * cur.al0; acc0.z += (cur.v0.z * cur.g0.z) * cur.al0; acc0.w += (cur.v0.w * cur.g0.w) * cur.al0;
-        acc1.x += (cur.v1.x * cur.g1.x) * cur.al1; acc1.y += (cur.v1.y * cur.g1.y) * cur.al1; acc1.z += (cur.v1.z * cur.g1.z) * cur.al1; acc1.w += (cur.v1.w * cur.g1.w) * cur.al1;
-        cur = nxt;
-        vt_e = e_next;
+  __syncthreads();                         // alphas written, V and VT visible
+  if (producer) { DS_STAMP(12); } else { DS_STAMP(4); }
+  // ---- phase 2b: aggregation
+  if (producer) {
+    commit_y(0, y0);
+    __syncthreads();                       // Yc[0] (and the consumers' AL[0])
+    produce(y1, y2, true);
+    DS_STAMP_FLUSH(512);
+  } else {
+    // a chunk's alpha rows (32 x 128 bytes: consumer threads 0 .. 255) travel like the producers' ye rows: requested three chunks
+    // ahead into one of two register sets, in LDS one chunk ahead
+    const int arow = tid >> 3, apiece = tid & 7;
+    auto fetch_a = [&](int ck) {
+      const int R = ck * CR + arow;
+      if (tid >= 256 || R >= P) return make_float4(0, 0, 0, 0);
+      return reinterpret_cast<const float4*>(c.ws.lg + (size_t)(p0 + row_pair(R)) * 32)[apiece];
+    };
+    auto commit_a = [&](int buf, const float4& v) {
+      if (tid < 256) reinterpret_cast<float4*>(&AL[buf][arow][0])[apiece] = v;
+    };
+    float4 aa = fetch_a(0), ab = fetch_a(1);
+    const float4 a2 = fetch_a(2);
+    commit_a(0, aa);
+    aa = a2;                               // aa: chunk 2, ab: chunk 1
+    __syncthreads();                       // AL[0] (and the producers' Yc[0])
+    __syncthreads();                       // Tt[0]
+    DS_STAMP(5);
+    const int t_me = tid >> 4, q16 = tid & 15;   // one quarter wave per target; lane = channels 4 q16 + 64 u .. + 3, u = 0 .. 3
+    const int* vt_row = &VT[t_me][0];
+    int vt_q = 0, vt_e = vt_row[0];
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0, 0, 0, 0);
+    for (int k = 0; k < nch; ++k) {        // interval k: ab holds chunk k + 1, aa chunk k + 2
+      if (k + 1 < nch) commit_a((k + 1) & 1, ab);       // AL[(k + 1) & 1] was last read in interval k - 1
+      if (k + 3 < nch) ab = fetch_a(k + 3);
+      { const float4 t_ = aa; aa = ab; ab = t_; }
+      // this quarter wave's visits of the chunk: the entries of its list with R0 <= R < R0 + 32 (the list is sorted and the
+      // chunks ascend, so a pointer walks it once per molecule)
+      const int R0 = k * CR;
+      while ((vt_e & 511) - R0 < CR) {
+        const int r = (vt_e & 511) - R0, s_ = (vt_e >> 9) & 31;
+        // a quarter wave reads 256 contiguous bytes per instruction (ds_read_b128 is conflict-free only for lane-contiguous pieces)
+        const float4* gp = reinterpret_cast<const float4*>(&Tt[k & 1][r][4 * q16]);
+        const float4* vp = reinterpret_cast<const float4*>(V + s_ * 256 + 4 * q16);
+        const float* ap = &AL[k & 1][r][((vt_e >> 14) & 1) * 16 + (q16 >> 2)];
+        float4 g[4], v[4];
+        float al[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { g[u] = gp[16 * u]; v[u] = vp[16 * u]; al[u] = ap[4 * u]; }
+        vt_e = vt_row[++vt_q];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc[u].x += (v[u].x * g[u].x) * al[u]; acc[u].y += (v[u].y * g[u].y) * al[u];
+          acc[u].z += (v[u].z * g[u].z) * al[u]; acc[u].w += (v[u].w * g[u].w) * al[u];
+        }
       }
+      DS_STAMP(6);
+      __syncthreads();
+      DS_STAMP(7);
     }
-#endif
-    __syncthreads();                       // Tt / AL are rewritten by the next chunk
-    if (ck + 1 < nchunks && tid < 512) reinterpret_cast<float4*>(&AL[tid >> 3][0])[tid & 7] = av;
-  }
-  if (t_me < n) {
-    float4* o = reinterpret_cast<float4*>(c.ws.attn + (size_t)(n0 + t_me) * 256 + 4 * l32);
-    o[0] = acc0; o[32] = acc1;
+    if (t_me < n) {
+      float4* o = reinterpret_cast<float4*>(c.ws.attn + (size_t)(n0 + t_me) * 256 + 4 * q16);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o[16 * u] = acc[u];
+    }
+    DS_STAMP_FLUSH(0);
   }
 }
 

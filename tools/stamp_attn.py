@@ -1,8 +1,10 @@
-"""Diagnostic build: k_attn_fused with a stamp before AND after every barrier (wave 0's work vs. barrier wait per phase).
+"""Diagnostic build (-DDS_STAMPS) with only k_attn_fused's in-tree stamps active: wave 0 (a consumer) fills P0-P7, wave 8 (a producer) P8-P15.
 
-    python tools/stamp_attn.py [flush_thread]   ->  diffspectra_amd/libdiffspectra_hip_stampattn.so
-P0 prologue | phase 1 per chunk: P1 commit, P2 wait, P3 fetch + projection, P4 wait, P5 logits | P6 weights, P7 wait |
-P8 V + softmax, P9 wait | phase 2: P10 first fetch/commit (+ wait) | per chunk: P12 fetch + projection, P13 wait, P14 visits, P15 wait
+    python tools/stamp_attn.py   ->  diffspectra_amd/libdiffspectra_hip_stampattn.so
+    DIFFSPECTRA_HIP_LIB=diffspectra_amd/libdiffspectra_hip_stampattn.so python tools/time_forward.py --mols 4096
+consumer: P0 prologue | P1 wait for the first tile | P2 logits, P3 barrier | P4 softmax phase | P5 alpha rows + first tile | P6 visits, P7 barrier
+producer: P8 prologue | P9 first projection | P10 commit + fetch + projection, P11 barrier | P12 softmax phase | P13 first projection |
+          P14 commit + fetch + projection, P15 barrier
 Development tool, never part of the product build.
 """
 import os
@@ -14,35 +16,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
-SRC = g.HIP_SOURCES[0]
-
 
 def main():
-    flush = sys.argv[1] if len(sys.argv) > 1 else "0"
-    s = open(SRC).read()
-    s = re.sub(r"\n\s*DS_STAMP(_W)?\(\d+\);", "", s)
-    s = re.sub(r"\n\s*DS_STAMP_FLUSH\([^)]*\);", "", s)
-    s = s.replace("  DS_STAMP_INIT();\n", "")
+    s = open(g.HIP_SOURCES[0]).read()
     a = s.index("void k_attn_fused(Ctx c, int blk) {")
-    b = s.index("\n}\n", a)
-    k = s[a:b]
-    k = k.replace("  ds_fp16_saturate();\n", "  ds_fp16_saturate();\n  DS_STAMP_INIT();\n", 1)
-
-    def rep(old, new, count=1):
-        nonlocal k
-        assert k.count(old) >= 1, old
-        k = k.replace(old, new, count)
-    rep("  // ---- phase 1: logits\n", "  DS_STAMP(0);\n  // ---- phase 1: logits\n")
-    rep("    commit(false, ck & 1);\n    __syncthreads();", "    commit(false, ck & 1);\n    DS_STAMP(1);\n    __syncthreads();\n    DS_STAMP(2);")
-    rep("    project(min(64, P - ck * 64));\n#endif\n    __syncthreads();\n#if !(DS_ABL & 4)", "    project(min(64, P - ck * 64));\n#endif\n    DS_STAMP(3);\n    __syncthreads();\n    DS_STAMP(4);\n#if !(DS_ABL & 4)")
-    rep("#endif\n  }\n  load_weights(DS_BW_E1_H);", "#endif\n    DS_STAMP(5);\n  }\n  load_weights(DS_BW_E1_H);")
-    rep("  __threadfence_block();\n  __syncthreads();                         // all logits written", "  __threadfence_block();\n  DS_STAMP(6);\n  __syncthreads();\n  DS_STAMP(7);                         // all logits written")
-    rep("#endif\n  __threadfence_block();\n  __syncthreads();\n", "#endif\n  __threadfence_block();\n  DS_STAMP(8);\n  __syncthreads();\n  DS_STAMP(9);\n")
-    rep("  __syncthreads();\n  for (int ck = 0; ck < nchunks; ++ck) {\n    if (ck + 1 < nchunks) { fetch2_y(ck + 1); fetch2_a(ck + 1); }", "  __syncthreads();\n  DS_STAMP(10);\n  for (int ck = 0; ck < nchunks; ++ck) {\n    if (ck + 1 < nchunks) { fetch2_y(ck + 1); fetch2_a(ck + 1); }")
-    rep("    project(min(64, P - ck * 64));\n#endif\n    __syncthreads();\n    if (ck + 1 < nchunks) *reinterpret_cast<uint4*>", "    project(min(64, P - ck * 64));\n#endif\n    DS_STAMP(12);\n    __syncthreads();\n    DS_STAMP(13);\n    if (ck + 1 < nchunks) *reinterpret_cast<uint4*>")
-    rep("#endif\n    __syncthreads();                       // Tt / AL are rewritten by the next chunk", "#endif\n    DS_STAMP(14);\n    __syncthreads();\n    DS_STAMP(15);                       // Tt / AL are rewritten by the next chunk")
-    k += "\n  DS_STAMP(12);\n  DS_STAMP_FLUSH(%s);" % flush
-    s = s[:a] + k + s[b:]
+    b = s.index("// Block stage D (nodes, 32 rows)")
+    strip = lambda t: re.sub(r"\n\s*DS_STAMP_FLUSH\([^)]*\);", "", re.sub(r"\n\s*DS_STAMP(_W)?\(\d+\);", "", t)).replace("  DS_STAMP_INIT();\n", "")
+    s = strip(s[:a]) + s[a:b] + strip(s[b:])        # the other kernels' stamps share the counters: off
     tmp = os.path.join(ROOT, "diffspectra_amd", "csrc", "_stamped.hip")
     open(tmp, "w").write(s)
     obj = os.path.join(g.OBJ_DIR, "stampattn.o")
@@ -50,7 +30,7 @@ def main():
     try:
         subprocess.run(["/opt/rocm/bin/hipcc", *g.BASE_FLAGS, *g.OPT_FLAGS, "-DDS_STAMPS", "-c", tmp, "-o", obj], check=True, cwd=ROOT)
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", obj, *others, "-o",
-                        os.path.join(ROOT, "diffspectra_amd", "libdiffspectra_hip_stampattn%s.so" % ("" if flush == "0" else flush))], check=True)
+                        os.path.join(ROOT, "diffspectra_amd", "libdiffspectra_hip_stampattn.so")], check=True)
     finally:
         os.remove(tmp)
         if os.path.exists(obj):

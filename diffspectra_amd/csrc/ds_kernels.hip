@@ -426,6 +426,10 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   const int m = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5;
   const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
   const int p0 = c.L.pair_off[m], P = c.L.pair_off[m + 1] - p0;
+  // the weight streams' descriptors are set up here, next to the offsets: each needs a table entry from memory, and behind the
+  // prologue's requests that small load would return only after them (loads return in order)
+  const WStreamH ws_e0 = wstream_h(BW(c, blk, DS_BW_E0_H), 256, 64, (wave & 7) * 32);
+  const WStreamH ws_e1 = wstream_h(BW(c, blk, DS_BW_E1_H), 256, 64, (wave & 7) * 32);
   if (n <= 0) return;
   if (P <= 0) {   // single atom: no message reaches it
     for (int i = tid; i < 256; i += NT) c.ws.attn[(size_t)n0 * 256 + i] = 0.0f;
@@ -434,7 +438,9 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   const int nch = (P + CR - 1) / CR;
   const bool producer = wave >= 8;                 // wave-uniform
   const int ptid = tid & 511, prow = ptid >> 4, ppiece = ptid & 15;   // a producer thread's 16-byte piece of a chunk's ye rows
-  const uint4* ye4 = reinterpret_cast<const uint4*>(c.ws.ye) + (size_t)p0 * 16;   // 16 x 16 bytes per pair row
+  // (one 128-bit register tuple per piece: as a struct of four scalars a set in flight is split up by the register allocator, and
+  // the moves that put it together again wait for the load)
+  const u32x4* ye4 = reinterpret_cast<const u32x4*>(c.ws.ye) + (size_t)p0 * 16;   // 16 x 16 bytes per pair row
   auto row_pair = [&](int R) {   // pair row (relative to p0) of class-ordered row R < P
     const int d = R / n + 1, i = R - (d - 1) * n;
     int j = i + d;
@@ -446,15 +452,16 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   // workgroup per CU nothing else hides their latency.
   auto fetch_y = [&](int ck, bool class_order) {
     const int R = ck * CR + prow;
-    if (R >= P) return make_uint4(0, 0, 0, 0);
-    return ye4[(size_t)(class_order ? row_pair(R) : R) * 16 + ppiece];
+    // no branch around the load and no select behind it (a load inside a conditional block is not requested ahead of the code in
+    // front of the block; a select waits for it on the spot): rows behind the end repeat the last row - nothing reads their tile rows
+    const int Rc = min(R, P - 1);
+    return ye4[(size_t)(class_order ? row_pair(Rc) : Rc) * 16 + ppiece];
   };
-  auto commit_y = [&](int buf, const uint4& v) { *reinterpret_cast<uint4*>(&Yc[buf][prow][ppiece * 8]) = v; };
+  auto commit_y = [&](int buf, const u32x4& v) { *reinterpret_cast<u32x4*>(&Yc[buf][prow][ppiece * 8]) = v; };
   // producer wave w owns output columns 32 (w & 7) .. +31; its lin_edge0 / lin_edge1 fragments (64 -> 256, split-fp16 planes) live in
   // registers for a whole phase: 8 x 16 bytes
   h8 wf[2][4];
-  auto load_weights = [&](int slot) {
-    const WStreamH ws_ = wstream_h(BW(c, blk, slot), 256, 64, (wave & 7) * 32);
+  auto load_weights = [&](const WStreamH& ws_) {
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
@@ -487,45 +494,53 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   };
   // The producers' side of a phase: chunk 0 is projected while the consumers wait, then one chunk ahead of them.  Entered with chunk 0's
   // rows in Yc[0] (visible), chunk 1's in ya, chunk 2's in yb.  Barriers: 1 + nch, as in the consumers' loops.
-  auto produce = [&](uint4 ya, uint4 yb, bool class_order) {
+  auto produce = [&](u32x4 ya, u32x4 yb, bool class_order) {
     project(0);
     if (1 < nch) commit_y(1, ya);
     if (3 < nch) ya = fetch_y(3, class_order);
     __syncthreads();
     if (class_order) { DS_STAMP(13); } else { DS_STAMP(9); }
-    for (int k = 0; k < nch; ++k) {   // interval k: ya holds chunk k + 3, yb chunk k + 2
-      if (k + 2 < nch) commit_y(k & 1, yb);             // Yc[k & 1] was last read by chunk k's projection, an interval ago
-      if (k + 4 < nch) yb = fetch_y(k + 4, class_order);
+    // interval k: chunk k + 2's rows (register set B) go to Yc[k & 1] - last read by chunk k's projection, an interval ago -, chunk
+    // k + 4 is requested into the same registers, chunk k + 1 is projected.  The two register sets swap ROLES from one interval
+    // to the next (the loop is unrolled by two): a register move of a set would wait for the load just issued into it.
+    auto interval = [&](int k, u32x4& B) {
+      if (k + 2 < nch) commit_y(k & 1, B);
+      if (k + 4 < nch) B = fetch_y(k + 4, class_order);
       if (k + 1 < nch) project((k + 1) & 1);
-      const uint4 t_ = ya; ya = yb; yb = t_;
       if (class_order) { DS_STAMP(14); } else { DS_STAMP(10); }
       __syncthreads();
       if (class_order) { DS_STAMP(15); } else { DS_STAMP(11); }
+    };
+    for (int k = 0; k < nch; k += 2) {
+      interval(k, yb);
+      if (k + 1 >= nch) break;
+      interval(k + 1, ya);
     }
   };
 
   // ---- phase 0: q (256) | k (256) of every atom -> LDS.  Their loads are issued first: they are the first to be waited for, and
   // the chunk / weight loads behind them stay in flight across the LDS stores
   {
-    float4 v[4];
+    f32x4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = min(tid + u * NT, n * 128 - 1);
-      v[u] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + (idx >> 7)) * 768)[idx & 127];
+      ld_async(v[u], c.ws.qkv + (size_t)(n0 + (idx >> 7)) * 768 + 4 * (idx & 127));
     }
-    uint4 y0 = make_uint4(0, 0, 0, 0), y1 = y0, y2 = y0;
+    u32x4 y0 = {0, 0, 0, 0}, y1 = y0, y2 = y0;
     if (producer) {
       y0 = fetch_y(0, false);
       y1 = fetch_y(1, false);
       y2 = fetch_y(2, false);
-      load_weights(DS_BW_E0_H);
+      load_weights(ws_e0);
     } else if (tid < P) {
       PT[tid] = ((c.L.pair_a[p0 + tid] - n0) << 8) | (c.L.pair_b[p0 + tid] - n0) | (c.ws.adj[p0 + tid] << 16);
     }
+    ld_wait(v[0], v[1], v[2], v[3]);       // every request of the prologue is out before the first value is waited for
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = tid + u * NT;
-      if (idx < n * 128) reinterpret_cast<float4*>(QK)[(idx >> 7) * (QS / 4) + (idx & 127)] = v[u];
+      if (idx < n * 128) reinterpret_cast<f32x4*>(QK)[(idx >> 7) * (QS / 4) + (idx & 127)] = v[u];
     }
     if (producer) commit_y(0, y0);
     __syncthreads();                       // QK, PT, Yc[0]
@@ -533,7 +548,7 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     // ---- phase 1: logits
     if (producer) {
       produce(y1, y2, false);
-      load_weights(DS_BW_E1_H);            // lin_edge1 fragments fly during the softmax
+      load_weights(ws_e1);                 // lin_edge1 fragments fly during the softmax
     } else {
       __syncthreads();                     // Tt[0]
       DS_STAMP(1);
@@ -604,22 +619,23 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     }
     VT[t][q] = e;
   }
-  uint4 y0 = make_uint4(0, 0, 0, 0), y1 = y0, y2 = y0;
+  u32x4 y0 = {0, 0, 0, 0}, y1 = y0, y2 = y0;
   if (producer) {                          // the first class-ordered chunks do not wait for the softmax
     y0 = fetch_y(0, true);
     y1 = fetch_y(1, true);
     y2 = fetch_y(2, true);
   }
-  float4 vst[2];   // V rows: requested here, stored to LDS behind the softmax's logit loads (one round of latency for both)
+  f32x4 vst[2];   // V rows: requested here, stored to LDS behind the softmax's logit loads (one round of latency for both)
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int i0 = min(tid + u * NT, n * 64 - 1);
-    vst[u] = reinterpret_cast<const float4*>(c.ws.qkv + (size_t)(n0 + (i0 >> 6)) * 768 + 512)[i0 & 63];
+    ld_async(vst[u], c.ws.qkv + (size_t)(n0 + (i0 >> 6)) * 768 + 512 + 4 * (i0 & 63));
   }
   auto store_v = [&]() {
+    ld_wait(vst[0], vst[1]);
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-      if (tid + u * NT < n * 64) reinterpret_cast<float4*>(V)[tid + u * NT] = vst[u];
+      if (tid + u * NT < n * 64) reinterpret_cast<f32x4*>(V)[tid + u * NT] = vst[u];
   };
   {   // one half wave per target (all targets at once: a molecule's softmax is one round of L2 latency), lane = (source parity, head)
     const int h = lane & 15, sq = (lane >> 4) & 1, t = 2 * wave + hh;
@@ -673,19 +689,17 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   } else {
     // a chunk's alpha rows (32 x 128 bytes: consumer threads 0 .. 255) travel like the producers' ye rows: requested three chunks
     // ahead into one of two register sets, in LDS one chunk ahead
-    const int arow = tid >> 3, apiece = tid & 7;
+    const int arow = (tid & 255) >> 3, apiece = tid & 7;   // threads 256 .. 511 request the same rows again (no branch around the load)
     auto fetch_a = [&](int ck) {
       const int R = ck * CR + arow;
-      if (tid >= 256 || R >= P) return make_float4(0, 0, 0, 0);
-      return reinterpret_cast<const float4*>(c.ws.lg + (size_t)(p0 + row_pair(R)) * 32)[apiece];
+      return reinterpret_cast<const u32x4*>(c.ws.lg + (size_t)(p0 + row_pair(min(R, P - 1))) * 32)[apiece];   // as fetch_y
     };
-    auto commit_a = [&](int buf, const float4& v) {
-      if (tid < 256) reinterpret_cast<float4*>(&AL[buf][arow][0])[apiece] = v;
+    auto commit_a = [&](int buf, const u32x4& v) {
+      if (tid < 256) reinterpret_cast<u32x4*>(&AL[buf][arow][0])[apiece] = v;
     };
-    float4 aa = fetch_a(0), ab = fetch_a(1);
-    const float4 a2 = fetch_a(2);
-    commit_a(0, aa);
-    aa = a2;                               // aa: chunk 2, ab: chunk 1
+    const u32x4 a0 = fetch_a(0);
+    u32x4 ab = fetch_a(1), aa = fetch_a(2);
+    commit_a(0, a0);
     __syncthreads();                       // AL[0] (and the producers' Yc[0])
     __syncthreads();                       // Tt[0]
     DS_STAMP(5);
@@ -695,12 +709,13 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     float4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = make_float4(0, 0, 0, 0);
-    for (int k = 0; k < nch; ++k) {        // interval k: ab holds chunk k + 1, aa chunk k + 2
-      if (k + 1 < nch) commit_a((k + 1) & 1, ab);       // AL[(k + 1) & 1] was last read in interval k - 1
-      if (k + 3 < nch) ab = fetch_a(k + 3);
-      { const float4 t_ = aa; aa = ab; ab = t_; }
-      // this quarter wave's visits of the chunk: the entries of its list with R0 <= R < R0 + 32 (the list is sorted and the
-      // chunks ascend, so a pointer walks it once per molecule)
+    // interval k: chunk k + 1's alpha rows (register set A) go to AL[(k + 1) & 1] - last read in interval k - 1 -, chunk k + 3 is
+    // requested into the same registers (the two sets swap roles from one interval to the next, as the producers'), then this
+    // quarter wave's visits of chunk k: the entries of its list with R0 <= R < R0 + 32 (the list is sorted and the chunks ascend,
+    // so a pointer walks it once per molecule)
+    auto interval = [&](int k, u32x4& A) {
+      if (k + 1 < nch) commit_a((k + 1) & 1, A);
+      if (k + 3 < nch) A = fetch_a(k + 3);
       const int R0 = k * CR;
       while ((vt_e & 511) - R0 < CR) {
         const int r = (vt_e & 511) - R0, s_ = (vt_e >> 9) & 31;
@@ -722,6 +737,11 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
       DS_STAMP(6);
       __syncthreads();
       DS_STAMP(7);
+    };
+    for (int k = 0; k < nch; k += 2) {     // entered with chunk 1 in ab, chunk 2 in aa
+      interval(k, ab);
+      if (k + 1 >= nch) break;
+      interval(k + 1, aa);
     }
     if (t_me < n) {
       float4* o = reinterpret_cast<float4*>(c.ws.attn + (size_t)(n0 + t_me) * 256 + 4 * q16);

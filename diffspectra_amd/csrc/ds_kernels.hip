@@ -417,7 +417,9 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   __shared__ __attribute__((aligned(16))) float Tt[2][CR][LDT];              // 66,560 B  tanh(te0 / te1) of two chunks
   __shared__ __attribute__((aligned(16))) _Float16 Yc[2][CR][LDY];           // 17,408 B  ye rows of two chunks (split-fp16 layout)
   __shared__ __attribute__((aligned(16))) float AL[2][CR][32];               //  8,192 B  alpha of two chunks' pairs, both directions
-  __shared__ int PT[(MAXP + 15) & ~15];   // every pair of the molecule in layout order: (a << 8) | b (local atom indices) | adjacency bits << 16
+  // phase 1: every pair of the molecule in layout order: (a << 8) | b (local atom indices) | adjacency bits << 16;
+  // phase 2: the pair row of class-ordered row R
+  __shared__ int PT[(MAXP + 15) & ~15];
   // phase 2b's visit lists: VT[t][q], q = 0 .. n - 2, is target t's q-th incoming edge in ascending class-ordered row R:
   // R | source << 9 | direction << 14; 511 (a row no chunk reaches) behind the end
   __shared__ int VT[32][32];
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     // no branch around the load and no select behind it (a load inside a conditional block is not requested ahead of the code in
     // front of the block; a select waits for it on the spot): rows behind the end repeat the last row - nothing reads their tile rows
     const int Rc = min(R, P - 1);
-    return ye4[(size_t)(class_order ? row_pair(Rc) : Rc) * 16 + ppiece];
+    return ye4[(size_t)(class_order ? PT[Rc] : Rc) * 16 + ppiece];   // phase 2: PT holds row_pair()
   };
   auto commit_y = [&](int buf, const u32x4& v) { *reinterpret_cast<u32x4*>(&Yc[buf][prow][ppiece * 8]) = v; };
   // producer wave w owns output columns 32 (w & 7) .. +31; its lin_edge0 / lin_edge1 fragments (64 -> 256, split-fp16 planes) live in
@@ -597,6 +599,7 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   __syncthreads();                         // all logits written (and visible to this workgroup); QK is dead from here
   // ---- phase 2a: V -> LDS (over QK), the visit table, softmax per target written back over the logits
   float* V = QK;
+  int* ET = reinterpret_cast<int*>(&Tt[0][0][0]);
   {   // class d reaches target t from source t + d (row i = t) and from source t - d (row i = t - d), both mod n; the last class of an
       // even n holds each atom once
     const int t = tid >> 5, q = tid & 31, d = (q >> 1) + 1;
@@ -618,18 +621,30 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
       e = ((d - 1) * n + i) | (s_ << 9) | ((s_ < t ? 0 : 1) << 14);   // direction 0 is source a -> target b with a < b
     }
     VT[t][q] = e;
-  }
-  u32x4 y0 = {0, 0, 0, 0}, y1 = y0, y2 = y0;
-  if (producer) {                          // the first class-ordered chunks do not wait for the softmax
-    y0 = fetch_y(0, true);
-    y1 = fetch_y(1, true);
-    y2 = fetch_y(2, true);
+    // ET[t][s]: where the logit / alpha of edge s -> t lives, as a float offset from the molecule's first logit (-1: no such edge).
+    // The softmax below reads 2 x 15 of them per lane; computed in place, the index arithmetic (~25 VALU issues each, sixteen
+    // lanes deriving the same number) was most of that phase.  The table borrows Tt, idle until phase 2b's first projection.
+    const int s = q;
+    int eo = -1;
+    if (t < n && s < n && s != t) {
+      const int lo_ = s < t ? s : t, hi_ = s < t ? t : s;
+      eo = (lo_ * (2 * n - lo_ - 1) / 2 + (hi_ - lo_ - 1)) * 32 + (s < t ? 0 : 16);
+    }
+    ET[t * 32 + s] = eo;
+    if (tid < P) PT[tid] = row_pair(tid);  // phase 1's pair table is dead
   }
   f32x4 vst[2];   // V rows: requested here, stored to LDS behind the softmax's logit loads (one round of latency for both)
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int i0 = min(tid + u * NT, n * 64 - 1);
     ld_async(vst[u], c.ws.qkv + (size_t)(n0 + (i0 >> 6)) * 768 + 512 + 4 * (i0 & 63));
+  }
+  __syncthreads();                         // ET, PT, VT
+  u32x4 y0 = {0, 0, 0, 0}, y1 = y0, y2 = y0;
+  if (producer) {                          // the first class-ordered chunks do not wait for the softmax
+    y0 = fetch_y(0, true);
+    y1 = fetch_y(1, true);
+    y2 = fetch_y(2, true);
   }
   auto store_v = [&]() {
     ld_wait(vst[0], vst[1]);
@@ -639,44 +654,36 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   };
   {   // one half wave per target (all targets at once: a molecule's softmax is one round of L2 latency), lane = (source parity, head)
     const int h = lane & 15, sq = (lane >> 4) & 1, t = 2 * wave + hh;
+    const int* et = ET + t * 32 + sq;
+    float* lgm = c.ws.lg + (size_t)p0 * 32 + h;
     if (t < n) {
       float x[15];
       float mx = -INFINITY;
 #pragma unroll
       for (int j = 0; j < 15; ++j) {
-        const int s = sq + 2 * j;
+        const int eo = et[2 * j];
         x[j] = -INFINITY;
-        if (s < n && s != t) {
-          const int lo_ = s < t ? s : t, hi_ = s < t ? t : s;
-          const int pl = lo_ * (2 * n - lo_ - 1) / 2 + (hi_ - lo_ - 1);
-          x[j] = c.ws.lg[(size_t)(p0 + pl) * 32 + (s < t ? 0 : 16) + h];
-        }
+        if (eo >= 0) x[j] = lgm[eo];
       }
-      store_v();
 #pragma unroll
       for (int j = 0; j < 15; ++j) mx = fmaxf(mx, x[j]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       float sum = 0.0f;
 #pragma unroll
       for (int j = 0; j < 15; ++j) {
-        x[j] = (sq + 2 * j < n && sq + 2 * j != t) ? expf(x[j] - mx) : 0.0f;
+        x[j] = expf(x[j] - mx);             // a missing edge: exp(-inf) = 0
         sum += x[j];
       }
       sum += __shfl_xor(sum, 16, 64);
       const float den = sum + 1e-16f;
 #pragma unroll
       for (int j = 0; j < 15; ++j) {
-        const int s = sq + 2 * j;
-        if (s < n && s != t) {
-          const int lo_ = s < t ? s : t, hi_ = s < t ? t : s;
-          const int pl = lo_ * (2 * n - lo_ - 1) / 2 + (hi_ - lo_ - 1);
-          c.ws.lg[(size_t)(p0 + pl) * 32 + (s < t ? 0 : 16) + h] = x[j] / den;
-        }
+        const int eo = et[2 * j];
+        if (eo >= 0) lgm[eo] = x[j] / den;
       }
-    } else {
-      store_v();
     }
   }
+  store_v();                               // V is first read behind phase 2b's opening barriers: its latency runs under the softmax
   __threadfence_block();
   __syncthreads();                         // alphas written, V and VT visible
   if (producer) { DS_STAMP(12); } else { DS_STAMP(4); }
@@ -692,7 +699,7 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     const int arow = (tid & 255) >> 3, apiece = tid & 7;   // threads 256 .. 511 request the same rows again (no branch around the load)
     auto fetch_a = [&](int ck) {
       const int R = ck * CR + arow;
-      return reinterpret_cast<const u32x4*>(c.ws.lg + (size_t)(p0 + row_pair(min(R, P - 1))) * 32)[apiece];   // as fetch_y
+      return reinterpret_cast<const u32x4*>(c.ws.lg + (size_t)(p0 + PT[min(R, P - 1)]) * 32)[apiece];   // as fetch_y
     };
     auto commit_a = [&](int buf, const u32x4& v) {
       if (tid < 256) reinterpret_cast<u32x4*>(&AL[buf][arow][0])[apiece] = v;

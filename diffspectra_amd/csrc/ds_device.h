@@ -48,6 +48,16 @@ __device__ __forceinline__ f32x2 ds_tanh2(f32x2 x) {
   r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
   return r * -2.0f + 1.0f;
 }
+// tanh of a pair that already carries the factor 2 log2(e) (DS_TANH_PRESCALE, folded into the packed lin_edge0 / lin_edge1 weights by
+// engine.py): one packed multiply per pair less next to the transcendental-bound projection of k_attn_fused
+__device__ __forceinline__ f32x2 ds_tanh2_prescaled(f32x2 t) {
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+  const f32x2 d = e + 1.0f;
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+  return r * -2.0f + 1.0f;
+}
 __device__ __forceinline__ f32x2 ds_silu2(f32x2 x) {   // x / (1 + exp(-x)), 8 issues per 2 values instead of 10
   const f32x2 t = x * -1.4426950408889634f;
   f32x2 e;

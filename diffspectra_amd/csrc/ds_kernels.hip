@@ -490,7 +490,7 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     for (int q = 0; q < 4; ++q) {
       f32x2 v0, v1;
       v0.x = acc[0][4 * q]; v0.y = acc[0][4 * q + 1]; v1.x = acc[0][4 * q + 2]; v1.y = acc[0][4 * q + 3];
-      v0 = ds_tanh2(v0); v1 = ds_tanh2(v1);              // layers.py:165-166,183
+      v0 = ds_tanh2_prescaled(v0); v1 = ds_tanh2_prescaled(v1);   // layers.py:165-166,183; the packed weights carry 2 log2(e)
       *reinterpret_cast<float4*>(trow + 8 * q) = make_float4(v0.x, v0.y, v1.x, v1.y);
     }
   };

@@ -144,6 +144,7 @@ def pack_linear(weight: torch.Tensor, n_pad_to: int = 32) -> torch.Tensor:
 
 
 SPLIT_SCALE = 2048.0   # 2^11: the low fp16 plane of a split operand is stored scaled so that it keeps 11 significant bits
+TANH_PRESCALE = 2.8853900817779268     # 2 log2(e), ds_device.h ds_tanh2_prescaled
 F16_MAX = 65504.0      # a split value has fp16's exponent range: |w| must stay below this (activations saturate in the kernels)
 
 
@@ -292,8 +293,9 @@ def pack_dmt_weights(sd: Dict[str, torch.Tensor]):
         put(bslot(b, "DS_BW_FF2_H"), pack_linear_f16_split(sd[p + "ff_linear2.weight"]))
         put(bslot(b, "DS_BW_NODE_RO_H"), pack_linear_f16_split(sd[f"node_{b}.weight"]))
         put(bslot(b, "DS_BW_AC_H"), pack_linear_f16_split(torch.cat([win[:, 0:256], win[:, 256:512]], 0)))
-        put(bslot(b, "DS_BW_E0_H"), pack_linear_f16_split(sd[p + "attn_mpnn.lin_edge0.weight"]))
-        put(bslot(b, "DS_BW_E1_H"), pack_linear_f16_split(sd[p + "attn_mpnn.lin_edge1.weight"]))
+        # k_attn_fused evaluates tanh(x) as 1 - 2 / (1 + exp2(2 log2(e) x)): the factor rides in the packed weights
+        put(bslot(b, "DS_BW_E0_H"), pack_linear_f16_split((sd[p + "attn_mpnn.lin_edge0.weight"].double() * TANH_PRESCALE).float()))
+        put(bslot(b, "DS_BW_E1_H"), pack_linear_f16_split((sd[p + "attn_mpnn.lin_edge1.weight"].double() * TANH_PRESCALE).float()))
         put(bslot(b, "DS_BW_ED_H"), pack_linear_f16_split(win[:, 512:640]))
         put(bslot(b, "DS_BW_EDGE_EMB_H"), pack_linear_f16_split(sd[p + "edge_emb.weight"]))
         mean, std, astd = _rbf_tables(sd, p + "dist_layer")

@@ -15,17 +15,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-// A 16-byte global load that is requested WHERE IT IS WRITTEN and waited for where ld_wait says.  The compiler sinks an ordinary
-// load towards its first use (into the conditional block that stores it, behind the loads of an earlier phase), which turns
-// "request everything, then wait once" into one round of memory latency per load; volatile loads are waited for on the spot.
-// The value must not be touched between ld_async and the ld_wait that names it.
-__device__ __forceinline__ void ld_async(f32x4& dst, const void* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void ld_wait(f32x4& a, f32x4& b) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
-__device__ __forceinline__ void ld_wait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
-}
 
 #define DS_LDP 4  // LDS row padding (floats)
 

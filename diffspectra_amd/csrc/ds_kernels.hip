@@ -425,9 +425,16 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   __shared__ int VT[32][32];
   static_assert(DS_MAX_ATOMS <= 32 && MAXP <= 511 - CR, "visit table packing");
   static_assert(DS_MAX_ATOMS * 128 <= 4 * NT && DS_MAX_ATOMS * 64 <= 2 * NT && MAXP <= NT, "single-pass staging");
-  const int m = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5;
-  const int n0 = c.L.node_off[m], n = c.L.node_off[m + 1] - n0;
-  const int p0 = c.L.pair_off[m], P = c.L.pair_off[m + 1] - p0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = lane >> 5;
+  int n0, n, p0, P;
+  if (c.L.mol_by_size) {                  // largest molecules first, one record per workgroup
+    const int4 r = reinterpret_cast<const int4*>(c.L.mol_by_size)[blockIdx.x];
+    n0 = r.x; n = r.y; p0 = r.z; P = r.w;
+  } else {
+    const int m = blockIdx.x;
+    n0 = c.L.node_off[m]; n = c.L.node_off[m + 1] - n0;
+    p0 = c.L.pair_off[m]; P = c.L.pair_off[m + 1] - p0;
+  }
   // the weight streams' descriptors are set up here, next to the offsets: each needs a table entry from memory, and behind the
   // prologue's requests that small load would return only after them (loads return in order)
   const WStreamH ws_e0 = wstream_h(BW(c, blk, DS_BW_E0_H), 256, 64, (wave & 7) * 32);
@@ -496,8 +503,9 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   };
   // The producers' side of a phase: chunk 0 is projected while the consumers wait, then one chunk ahead of them.  Entered with chunk 0's
   // rows in Yc[0] (visible), chunk 1's in ya, chunk 2's in yb.  Barriers: 1 + nch, as in the consumers' loops.
-  auto produce = [&](u32x4 ya, u32x4 yb, bool class_order) {
+  auto produce = [&](u32x4 ya, u32x4 yb, bool class_order, auto&& after_first) {
     project(0);
+    after_first();
     if (1 < nch) commit_y(1, ya);
     if (3 < nch) ya = fetch_y(3, class_order);
     __syncthreads();
@@ -520,39 +528,47 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     }
   };
 
-  // ---- phase 0: q (256) | k (256) of every atom -> LDS.  Their loads are issued first: they are the first to be waited for, and
-  // the chunk / weight loads behind them stay in flight across the LDS stores
+  // ---- phase 0: q (256) | k (256) of every atom -> LDS (n * 128 <= 4 * NT 16-byte pieces).  Every request of the prologue goes out
+  // here, the weights (L2) in front - loads return in order -, q|k last: the producers' first projection needs only the first
+  // chunk and the weights and runs while q|k are on their way.  The stores behind these loads are UNCONDITIONAL (pieces behind the
+  // end go to a junk area: the idle second tile): a load whose only use sits in a conditional block is sunk into that block by
+  // the compiler, which turns "request everything, wait once" into one round of memory latency per piece.
   {
+    u32x4 y0 = {0, 0, 0, 0}, y1 = y0, y2 = y0;
+    if (producer) {
+      load_weights(ws_e0);
+      y0 = fetch_y(0, false);
+      y1 = fetch_y(1, false);
+      y2 = fetch_y(2, false);
+    } else if (tid < P) {
+      PT[tid] = ((c.L.pair_a[p0 + tid] - n0) << 8) | (c.L.pair_b[p0 + tid] - n0) | (c.ws.adj[p0 + tid] << 16);
+    }
     f32x4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = min(tid + u * NT, n * 128 - 1);
-      ld_async(v[u], c.ws.qkv + (size_t)(n0 + (idx >> 7)) * 768 + 4 * (idx & 127));
+      v[u] = reinterpret_cast<const f32x4*>(c.ws.qkv + (size_t)(n0 + (idx >> 7)) * 768)[idx & 127];
     }
-    u32x4 y0 = {0, 0, 0, 0}, y1 = y0, y2 = y0;
-    if (producer) {
-      y0 = fetch_y(0, false);
-      y1 = fetch_y(1, false);
-      y2 = fetch_y(2, false);
-      load_weights(ws_e0);
-    } else if (tid < P) {
-      PT[tid] = ((c.L.pair_a[p0 + tid] - n0) << 8) | (c.L.pair_b[p0 + tid] - n0) | (c.ws.adj[p0 + tid] << 16);
-    }
-    ld_wait(v[0], v[1], v[2], v[3]);       // every request of the prologue is out before the first value is waited for
+    __builtin_amdgcn_sched_barrier(0);
+    auto store_qk = [&]() {
+      f32x4* junk = reinterpret_cast<f32x4*>(&Tt[1][0][0]) + tid;     // 16 kB of the second tile, first written in interval 0
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + u * NT;
-      if (idx < n * 128) reinterpret_cast<f32x4*>(QK)[(idx >> 7) * (QS / 4) + (idx & 127)] = v[u];
-    }
+      for (int u = 0; u < 4; ++u) {
+        const int idx = tid + u * NT;
+        f32x4* dst = idx < n * 128 ? reinterpret_cast<f32x4*>(QK) + (idx >> 7) * (QS / 4) + (idx & 127) : junk;
+        *dst = v[u];
+      }
+    };
     if (producer) commit_y(0, y0);
-    __syncthreads();                       // QK, PT, Yc[0]
+    __syncthreads();                       // PT, Yc[0]
     if (producer) { DS_STAMP(8); } else { DS_STAMP(0); }
     // ---- phase 1: logits
     if (producer) {
-      produce(y1, y2, false);
+      produce(y1, y2, false, store_qk);   // q|k land in LDS behind the first projection, which does not read them
       load_weights(ws_e1);                 // lin_edge1 fragments fly during the softmax
     } else {
-      __syncthreads();                     // Tt[0]
+      store_qk();
+      __syncthreads();                     // Tt[0], QK
       DS_STAMP(1);
       const int row = tid >> 4, hs = tid & 15;
       for (int k = 0; k < nch; ++k) {
@@ -633,12 +649,13 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     ET[t * 32 + s] = eo;
     if (tid < P) PT[tid] = row_pair(tid);  // phase 1's pair table is dead
   }
-  f32x4 vst[2];   // V rows: requested here, stored to LDS behind the softmax's logit loads (one round of latency for both)
+  f32x4 vst[2];   // V rows: requested here, stored to LDS behind the softmax (unconditional stores, as in phase 0; junk area: Yc)
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int i0 = min(tid + u * NT, n * 64 - 1);
-    ld_async(vst[u], c.ws.qkv + (size_t)(n0 + (i0 >> 6)) * 768 + 512 + 4 * (i0 & 63));
+    vst[u] = reinterpret_cast<const f32x4*>(c.ws.qkv + (size_t)(n0 + (i0 >> 6)) * 768 + 512)[i0 & 63];
   }
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();                         // ET, PT, VT
   u32x4 y0 = {0, 0, 0, 0}, y1 = y0, y2 = y0;
   if (producer) {                          // the first class-ordered chunks do not wait for the softmax
@@ -647,10 +664,12 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     y2 = fetch_y(2, true);
   }
   auto store_v = [&]() {
-    ld_wait(vst[0], vst[1]);
+    f32x4* junk = reinterpret_cast<f32x4*>(&Yc[0][0][0]) + tid;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (tid + u * NT < n * 64) reinterpret_cast<f32x4*>(V)[tid + u * NT] = vst[u];
+    for (int u = 0; u < 2; ++u) {
+      f32x4* dst = tid + u * NT < n * 64 ? reinterpret_cast<f32x4*>(V) + tid + u * NT : junk;
+      *dst = vst[u];
+    }
   };
   {   // one half wave per target (all targets at once: a molecule's softmax is one round of L2 latency), lane = (source parity, head)
     const int h = lane & 15, sq = (lane >> 4) & 1, t = 2 * wave + hh;
@@ -691,7 +710,7 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   if (producer) {
     commit_y(0, y0);
     __syncthreads();                       // Yc[0] (and the consumers' AL[0])
-    produce(y1, y2, true);
+    produce(y1, y2, true, [] {});
     DS_STAMP_FLUSH(512);
   } else {
     // a chunk's alpha rows (32 x 128 bytes: consumer threads 0 .. 255) travel like the producers' ye rows: requested three chunks

@@ -69,7 +69,8 @@ class DsLayout(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("Nn", C.c_int32), ("Pp", C.c_int32),
                 ("max_n", C.c_int32), ("_pad", C.c_int32),
                 ("node_off", C.c_void_p), ("pair_off", C.c_void_p), ("node_dense", C.c_void_p),
-                ("node_mol", C.c_void_p), ("pair_a", C.c_void_p), ("pair_b", C.c_void_p), ("pair_mol", C.c_void_p)]
+                ("node_mol", C.c_void_p), ("pair_a", C.c_void_p), ("pair_b", C.c_void_p), ("pair_mol", C.c_void_p),
+                ("mol_by_size", C.c_void_p)]
 
 
 _WS_FIELDS = ["pos", "h", "e", "atom_hids", "edge_hids", "tfeat", "tmid", "temb_silu", "ada", "qkv", "ye",
@@ -379,7 +380,9 @@ class Layout:
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         self.t = dict(node_off=dev(node_off.astype(np.int32)), pair_off=dev(pair_off.astype(np.int32)),
                       node_dense=dev(node_dense), node_mol=dev(node_mol), pair_a=dev(cat(pa)), pair_b=dev(cat(pb)),
-                      pair_mol=dev(cat(pm)))
+                      pair_mol=dev(cat(pm)),
+                      mol_by_size=dev(np.stack([node_off[:-1], n_atoms, pair_off[:-1], pair_cnt], 1)[
+                          np.argsort(-n_atoms.astype(np.int64), kind="stable")].astype(np.int32)))
         self.c = DsLayout(B=B, N=N, Nn=self.Nn, Pp=self.Pp, max_n=self.max_n, _pad=0,
                           **{k: v.data_ptr() for k, v in self.t.items()})
 

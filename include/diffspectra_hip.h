@@ -124,6 +124,9 @@ typedef struct ds_layout {
   const int32_t* pair_a;             /* [Pp]  packed node row of the smaller local index */
   const int32_t* pair_b;             /* [Pp]  packed node row of the larger local index */
   const int32_t* pair_mol;           /* [Pp] */
+  const int32_t* mol_by_size;        /* [B][4] {node_off, n, pair_off, n(n-1)/2} of the molecules by descending size: workgroup i of a per-molecule
+                                        kernel takes record i - one 16-byte load instead of a chain of dependent ones, and the tail of a launch is
+                                        made of the small molecules (NULL: index order through node_off / pair_off) */
 } ds_layout;
 
 typedef struct ds_workspace {        /* all device fp32 unless noted; sizes in floats */

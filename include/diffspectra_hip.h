@@ -73,7 +73,8 @@ enum ds_block_slot {
   DS_BW_COORD_SCALE,                        /* 1(32)       CoorsNorm.scale                    layers.py:347 */
   DS_BW_CM0_H,                              /* coord_mlp.0 as two fp16 planes (w = w1 + w2/2048) in f16-MFMA A-operand order:
                                                halves [plane 2][k/16 16][k-half 2][feature 256][8]; see k_equi_pairs */
-  DS_BW_E0_H, DS_BW_E1_H,                   /* lin_edge0 / lin_edge1 (64 -> 256) in the same split-fp16 layout (k_edge_geom) */
+  DS_BW_E0_H, DS_BW_E1_H,                   /* lin_edge0 / lin_edge1 (64 -> 256) TIMES 2 log2(e) in the same split-fp16 layout: k_attn_fused evaluates
+                                               tanh(x) as 1 - 2 / (1 + exp2(2 log2(e) x)) and the factor rides in the weights (engine.TANH_PRESCALE) */
   DS_BW_ED_H,                               /* input_lin edge|dist part (128 -> 256) split-fp16 (k_edge_update) */
   DS_BW_QKV_H,                              /* q|k|v projection (256 -> 768) split-fp16 (k_node_qkv) */
   DS_BW_FF3_H,                              /* ff_linear3 (64 -> 128) split-fp16 (k_edge_update, transposed) */

@@ -723,6 +723,34 @@ def test_permutation_equivariance(gpu_device):
     assert_close(outep.cpu(), wante, 5e-5, "atom permutation equivariance (edges)")
 
 
+def test_molecule_launch_order_does_not_change_results(gpu_device):
+    """ds_layout.mol_by_size (the per-molecule attention kernel takes its workgroups' molecules from size-sorted records) is a
+    scheduling hint: with the field NULL (index order through node_off / pair_off) the outputs are bit-identical; ragged sizes incl.
+    single atoms, pairs and the largest molecule."""
+    from diffspectra_amd import engine as E, filler
+    cfg, model = gpu_model("ir", gpu_device)
+    eng = model.module.engine()
+    d = gpu_device
+    n_atoms = [5, 29, 1, 2, 18, 18, 3, 24, 1, 11, 28, 9]
+    x, ex, node_mask, edge_mask = filler.synthetic_state(n_atoms, "lo.x")
+    cx, cex, _, _ = filler.synthetic_state(n_atoms, "lo.c")
+    nl = filler.uniform("lo.nl", (len(n_atoms),), -3, 3)
+    ctx = filler.normal("lo.ctx", (len(n_atoms), 1024)) * 0.5
+    L, ws = eng.layout_for(node_mask, edge_mask)
+    rec = L.t["mol_by_size"].cpu()
+    assert rec.shape == (len(n_atoms), 4) and rec[:, 1].tolist() == sorted(n_atoms, reverse=True)
+    assert torch.equal(rec[:, 3], rec[:, 1] * (rec[:, 1] - 1) // 2)
+    out, oute = eng.forward(L, ws, x.to(d), ex.to(d), nl.to(d), cx.to(d), cex.to(d), ctx.to(d))
+    out, oute = out.clone(), oute.clone()
+    saved = L.c.mol_by_size
+    try:
+        L.c.mol_by_size = None
+        out2, oute2 = eng.forward(L, ws, x.to(d), ex.to(d), nl.to(d), cx.to(d), cex.to(d), ctx.to(d))
+        assert torch.equal(out, out2) and torch.equal(oute, oute2)
+    finally:
+        L.c.mol_by_size = saved
+
+
 def test_non_prefix_mask_and_errors(gpu_device):
     """Valid atoms need not be a prefix; bad structures raise instead of computing garbage."""
     from diffspectra_amd import filler

@@ -1,6 +1,6 @@
 """Throughput vs resident micro-batch: runs bench.py at several --mols and collects the JSON lines.
 
-    python tools/batch_curve.py [--out profiles/r02_throughput_vs_batch.jsonl] [--mols 64,256,...]
+    python tools/batch_curve.py [--out profiles/r03_throughput_vs_batch.jsonl] [--mols 64,256,...]
 Each point times 4 bench steps (200 denoise iterations) after 1 warm-up step; molecules/sec is normalised to complete
 1000-step samplings exactly as the headline line is.  Development tool; bench.py is the contract.
 """
@@ -15,14 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_throughput_vs_batch.jsonl"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_throughput_vs_batch.jsonl"))
     ap.add_argument("--mols", default="64,128,256,512,1024,1250,2048,4096,8192,10000")
     ap.add_argument("--extra", default="", help="extra bench.py flags, e.g. --graph")
     args = ap.parse_args()
     rows = []
     for m in [int(x) for x in args.mols.split(",")]:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mols", str(m), "--steps", "4", "--warmup", "1",
-               "--no-cpu-baseline"] + args.extra.split()
+               "--no-cpu-baseline", "--mode", "resident", "--no-live-traffic"] + args.extra.split()
         out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not line:

@@ -971,6 +971,7 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
 // are the B operand of the FF4 MFMAs; the gated residual is applied in that transposed layout with 16-byte LDS accesses.
 __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
   ds_fp16_saturate();
+  DS_STAMP_INIT();   // diagnostic build (tools/stamp_attn.py k_edge_update): wave 0's cycles per stage
   constexpr int R = 32, LDW = 64 + DS_LDP;
   __shared__ __attribute__((aligned(16))) float E2s[4][R][LDW];   // residual stream, then e_out in place
   __shared__ __attribute__((aligned(16))) float Ds[4][R][LDW];    // CondGaussian features of this block
@@ -992,6 +993,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
     const int p = min(row0 + lane, Pp - 1);
     rmol[lane] = c.L.pair_mol[p]; rpa[lane] = c.L.pair_a[p]; rpb[lane] = c.L.pair_b[p];
   }
+  DS_STAMP(0);
   {
     const float4* bn = reinterpret_cast<const float4*>(BW(c, blk, DS_BW_N2E_B));
     // CondGaussian features of this block (layers.py:291-295,334), recomputed from the modulated squared distance k_edge_geom
@@ -1046,6 +1048,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
       }
     }
   }
+  DS_STAMP(1);
   // ---- FF (dmt.py:118-120) on the f16 matrix pipe, chained in registers.  ff_linear3 is computed transposed, 32 hidden features
   //      at a time (lane = row, register i = hidden feature hc*32 + acc_row(i, hh)); SiLU; the accumulator registers 8s .. 8s+7,
   //      split in two fp16 planes, ARE the B fragment of the ff_linear4 MFMAs (weights pre-permuted to that k order: DS_BW_FF4_C)
@@ -1091,6 +1094,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
     split_finish<1>(a4[0], a4lo[0]);
     split_finish<1>(a4[1], a4lo[1]);
   }
+  DS_STAMP(2);
   // ---- gated residual in the transposed layout (lane = row, 4 consecutive features per register quad): the FF input is read back
   //      from its split planes (x1 + x2/2048), e_out goes into the same tile bytes as fp32 once every lane has read
   {
@@ -1127,6 +1131,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
     const float4 v = reinterpret_cast<const float4*>(&E2[row][0])[k4];
     if (row < valid) reinterpret_cast<float4*>(c.ws.e + (size_t)(row0 + row) * 64)[k4] = v;
   }
+  DS_STAMP(3);
   // ---- the 64 -> 16 readout slice (fp32 MFMA on the fp32 tile), then [e_out | dist] (128) -> 256 (input_lin edge part +
   //      bias) on the f16 matrix pipe: e_out is re-written in place in the split-fp16 layout first
   {
@@ -1138,6 +1143,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
       acc_store<1, 192>(acc, c.ws.edge_hids + (size_t)row0 * 192 + 64 + 16 * blk, valid, [b](int, float v) { return v + b; });
     }
   }
+  DS_STAMP(4);
   {
     float4 v[8];
 #pragma unroll
@@ -1147,6 +1153,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) split_store4(E2h + ((lane + u * 64) >> 4) * LDW2, 64, 4 * (lane & 15), v[u]);
   }
+  DS_STAMP(5);
   {
     const float* bd = BW(c, blk, DS_BW_ED_B);
     const float* Wd = BW(c, blk, DS_BW_ED_H);
@@ -1164,6 +1171,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
       acc_store<1, 256>(acc, ed + ch * 32, valid, [](int, float v) { return v; });
     }
   }
+  DS_STAMP(6);
+  DS_STAMP_FLUSH(0);
 }
 
 // Block stage F (flat tiles of 32 pairs = 64 directed edges): MultiCondEquiUpdate.  dmt.py:37-60; layers.py:344-347.

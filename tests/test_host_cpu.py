@@ -297,3 +297,14 @@ def test_batched_stability_needs_the_hip_engine():
     from diffspectra_amd.stability import check_stability_batch
     with pytest.raises(RuntimeError):
         check_stability_batch(torch.zeros(1, 2, 3), torch.zeros(1, 2, dtype=torch.long), torch.ones(1, 2))
+
+
+def test_build_reports_on_stderr_only(tmp_path, capsys):
+    """bench.py calls build() and its stdout must stay ONE JSON line: a rebuild on the benchmark box (sources newer than the
+    library) may only talk on stderr."""
+    import __graft_entry__ as g
+    obj = str(tmp_path / "x.o")
+    g._compile("/bin/true", "x.hip", obj, ["-O3"])
+    cap = capsys.readouterr()
+    assert cap.out == "" and "[build]" in cap.err
+    assert open(obj + ".flags").read() == "-O3"

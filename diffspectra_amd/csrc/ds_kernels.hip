@@ -1344,10 +1344,13 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
         wave_mma_h_deep_t2<2, true, 16, PF>(&Xh[buf][0][0], 256, wsh[0], wsh[1], ring, ringB, 0, accA, loA, accB, loB);
         wring_h<PF>(ring, wsh[0], 0);    // the next tile's first blocks fly under the epilogues and the barrier
         wring_h<PF>(ringB, wsh[1], 0);
+        DS_STAMP(3);
         split_finish<2>(accA, loA);
         epilogue(wave, accA);
+        DS_STAMP(10);
         split_finish<2>(accB, loB);
         epilogue(wave + NCW, accB);
+        DS_STAMP(11);
       } else
 #endif
       {

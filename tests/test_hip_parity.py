@@ -723,6 +723,46 @@ def test_permutation_equivariance(gpu_device):
     assert_close(outep.cpu(), wante, 5e-5, "atom permutation equivariance (edges)")
 
 
+def test_permutation_equivariance_every_size(gpu_device):
+    """Every molecule size 2 .. 29 in one batch, each molecule's atoms permuted: the attention kernel's difference-class row order,
+    its per-target visit lists and its softmax address table all depend on n (odd / even n, the half class of an even n) and on which
+    atom sits where - outputs must follow the permutation for every n, and match the CPU oracle for every n."""
+    from diffspectra_amd import filler
+    cfg, model = gpu_model("ir", gpu_device)
+    eng = model.module.engine()
+    d = gpu_device
+    n_atoms = list(range(2, 30))
+    B = len(n_atoms)
+    x, ex, node_mask, edge_mask = filler.synthetic_state(n_atoms, "pes.x")
+    cx, cex, _, _ = filler.synthetic_state(n_atoms, "pes.c")
+    nl = filler.uniform("pes.nl", (B,), -3, 3)
+    ctx = filler.normal("pes.ctx", (B, 1024)) * 0.5
+    L, ws = eng.layout_for(node_mask, edge_mask)
+    out, oute = eng.forward(L, ws, x.to(d), ex.to(d), nl.to(d), cx.to(d), cex.to(d), ctx.to(d))
+    out, oute = out.cpu().clone(), oute.cpu().clone()
+    gen = torch.Generator().manual_seed(11)
+    perms = [torch.randperm(n, generator=gen) for n in n_atoms]
+    def permute(t, e):
+        t2, e2 = t.clone(), e.clone()
+        for b, (n, pm) in enumerate(zip(n_atoms, perms)):
+            t2[b, :n] = t[b, pm]
+            e2[b, :n, :n] = e[b, pm][:, pm]
+        return t2, e2
+    xp, exp_ = permute(x, ex)
+    cxp, cexp = permute(cx, cex)
+    outp, outep = eng.forward(L, ws, xp.to(d), exp_.to(d), nl.to(d), cxp.to(d), cexp.to(d), ctx.to(d))
+    want, wante = permute(out, oute)
+    cpu_cfg, sd = procedural_state_dict("ir")
+    for b, n in enumerate(n_atoms):
+        assert_close(outp.cpu()[b], want[b], 5e-5, f"n = {n}: atom permutation equivariance")
+        assert_close(outep.cpu()[b], wante[b], 5e-5, f"n = {n}: atom permutation equivariance (edges)")
+        nm1, em1 = filler.masks_from_n_atoms([n])          # ... and every size against the oracle, one molecule at a time
+        ref, refe = oracle.dmt_forward(sd, cpu_cfg, x[b:b + 1, :n], nm1, em1, ex[b:b + 1, :n, :n], nl[b:b + 1], cx[b:b + 1, :n],
+                                       cex[b:b + 1, :n, :n], context_emb=ctx[b:b + 1])
+        assert_close(out[b:b + 1, :n], ref, TOL_FORWARD, f"n = {n} vs single-molecule oracle")
+        assert_close(oute[b:b + 1, :n, :n], refe, TOL_FORWARD, f"n = {n} edges vs single-molecule oracle")
+
+
 def test_molecule_launch_order_does_not_change_results(gpu_device):
     """ds_layout.mol_by_size (the per-molecule attention kernel takes its workgroups' molecules from size-sorted records) is a
     scheduling hint: with the field NULL (index order through node_off / pair_off) the outputs are bit-identical; ragged sizes incl.

@@ -39,11 +39,17 @@ def main():
         print(name, "phases:", n, "-> P%d..P%d" % (int(base), int(base) + n - 1))
     tmp = os.path.join(ROOT, "diffspectra_amd", "csrc", "_stamped.hip")
     open(tmp, "w").write(s)
+    obj = os.path.join(ROOT, "build", "obj", "stamped.o")
+    others = [os.path.join(ROOT, "build", "obj", n) for n in ("ds_aux.o", "ds_train.o")]      # run build() first
     try:
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-                        "-DDS_STAMPS", tmp, "-o", os.path.join(ROOT, "diffspectra_amd", "libdiffspectra_hip_stamps.so")], check=True)
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+                        "-DDS_STAMPS", "-c", tmp, "-o", obj], check=True)
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", obj, *others, "-o",
+                        os.path.join(ROOT, "diffspectra_amd", "libdiffspectra_hip_stamps.so")], check=True)
     finally:
         os.remove(tmp)
+        if os.path.exists(obj):
+            os.remove(obj)
 
 
 if __name__ == "__main__":

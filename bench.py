@@ -187,6 +187,52 @@ def cpu_baseline(version: str, denoise_steps: int, sample_mols: int = 64, sample
                       f"faithful CPU oracle ({per_step:.3f} s/step), extrapolated to {denoise_steps} steps"}
 
 
+def cpu_baseline_train(version: str, sample_mols: int = 16):
+    """Time the CPU oracle's training step (oracle/train.py: the reference's loss_fn restated, torch autograd for the backward) on
+    a bounded sample: one step with the self-conditioning forward and one without (the reference flips a fair coin per step)."""
+    from oracle import train as otrain
+    from diffspectra_amd import filler
+    from diffspectra_amd.config import qm9s_config
+    from diffspectra_amd.params import build_dmt_tree, Holder
+    cfg = qm9s_config(version)
+    tree = Holder()
+    build_dmt_tree(tree, cfg)
+    sd = {}
+    for k, v in filler.fill_state_dict(tree.state_dict()).items():
+        v = v.clone()
+        if v.is_floating_point() and not any(s in k for s in ("running_mean", "running_var", "sdp_attn.scale")):
+            v.requires_grad_(True)
+        sd[k] = v
+    B = sample_mols
+    n_atoms = filler.sample_n_atoms(B, seed=3).tolist()
+    node_mask, edge_mask = filler.masks_from_n_atoms(n_atoms)
+    N = node_mask.shape[1]
+    g = torch.Generator().manual_seed(11)
+    types = torch.randint(0, 5, (B, N), generator=g)
+    order = torch.triu((torch.rand(B, N, N, generator=g) > 0.8).float() * torch.randint(1, 4, (B, N, N), generator=g), 1)
+    order = (order + order.transpose(1, 2)) * edge_mask.reshape(B, N, N)
+    batch = dict(positions=torch.randn(B, N, 3, generator=g) * 1.3 * node_mask, atom_mask=node_mask.squeeze(-1), edge_mask=edge_mask,
+                 atom_one_hot=torch.nn.functional.one_hot(types, 5).float() * node_mask,
+                 edge_one_hot=torch.stack([(order > 0).float(), order / 3.0], -1), formal_charges=torch.zeros(B, N, 1),
+                 context=filler.synthetic_spectra(B, version, seed=5), n_atoms=n_atoms)
+    draws = [torch.randn(B, N, 3, generator=g), torch.randn(B, N, 6, generator=g), torch.randn(B, 2, N, N, generator=g)]
+    t_raw = torch.rand(B, generator=g) * 0.96 + 0.02
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    times = []
+    for coin in (True, False):
+        for v in sd.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        loss, _ = otrain.training_loss(sd, cfg, batch, t_raw, draws, coin)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    per_step = float(np.mean(times))
+    return {"value": B / per_step, "unit": "molecules/sec", "cores": int(cores), "kind": "port",
+            "sample": f"{B} molecules (QM9 size histogram, seed 3), two training steps of the CPU oracle (forward of oracle/train.py, "
+                      f"torch autograd backward; one with the self-conditioning forward, one without: {times[0]:.2f} s / {times[1]:.2f} s)"}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -312,6 +358,25 @@ def train_bench(args, world, rank, device):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(loss.detach()).all()
+    # roofline of the dominant kernel family (the GEMMs: k_tr_gemm_big + its split-K reduction): one more step - on every rank, the step
+    # holds collectives - with a HIP event pair around every dst_gemm call on its stream, outside the timed region; algorithmic
+    # FLOPs 2 M N K per call
+    from diffspectra_amd import train_engine as TE
+    orig_gemm, recs = TE.Ops.gemm, []
+
+    def timed_gemm(self, A, Bm, Cm, ta, tb, **kw):
+        M, K = (A.cols, A.rows) if ta else (A.rows, A.cols)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_gemm(self, A, Bm, Cm, ta, tb, **kw)
+        e1.record()
+        recs.append((e0, e1, 2.0 * M * Cm.cols * K))
+    TE.Ops.gemm = timed_gemm
+    try:
+        step_fn(state, batch)
+        sync()
+    finally:
+        TE.Ops.gemm = orig_gemm
     if rank == 0:
         n = np.asarray(n_atoms, dtype=np.int64)
         flop = 3.0 * 2.0 * algorithmic_macs(n)                        # forward + two backward GEMMs per forward GEMM (self-cond forward not counted)
@@ -325,6 +390,22 @@ def train_bench(args, world, rank, device):
                                        f"{cfg.model.dropout}, AdamW-amsgrad + adaptive clip + EMA fused, gradient reduce-scatter + parameter all-gather",
                            "mode": "train", "molecules_per_gpu": Bt, "parallelism": f"dp{world}", "last_loss": float(loss.detach())},
                 "whole_path": {"algorithmic_tflops_per_gpu": flop * args.steps / elapsed / 1e12}}
+        gemm_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+        gemm_flop = sum(f for _, _, f in recs)
+        peak = PEAK_F16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
+        ach = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
+        line["roofline"] = {"bound": "mfma", "kernel": "k_tr_gemm_big (+ k_tr_gemm_reduce, its split-K reduction): every dst_gemm call of one step",
+                            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": None if ach is None else ach / peak,
+                            "peak_note": ("dense bf16 MFMA peak" if args.precision == "bf16" else "dense fp32 MFMA peak") +
+                                         " (MI355X_MICROARCH.md); the step's GEMMs are small (M = nodes / pairs of 256 molecules, N, K <= 1024) "
+                                         "and bound by launch latency and their operand streams, not by the matrix pipe",
+                            "traffic": None, "launches_timed": len(recs), "avg_launch_ms": gemm_ms / max(1, len(recs)),
+                            "share_of_step": gemm_ms / (elapsed / args.steps * 1e3), "algorithmic_flop_per_step": gemm_flop}
+        if not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline_train(args.spectra)
+            except Exception as exc:  # noqa: BLE001 - the GPU line is still valid
+                line["cpu_baseline"] = {"value": None, "unit": "molecules/sec", "cores": usable_cores(), "kind": "port", "sample": f"failed: {exc}"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -763,6 +763,36 @@ def test_permutation_equivariance_every_size(gpu_device):
         assert_close(oute[b:b + 1, :n, :n], refe, TOL_FORWARD, f"n = {n} edges vs single-molecule oracle")
 
 
+def test_largest_molecules_batch(gpu_device):
+    """A batch of only the largest molecules (n = 29 and the even n = 28: 13 chunks of pair rows, every LDS table at its maximum, the
+    half class at its largest) against the oracle, and identical molecules inside one batch giving identical outputs (the per-molecule
+    kernel has no cross-molecule state)."""
+    from diffspectra_amd import filler
+    cfg, model = gpu_model("ir", gpu_device)
+    eng = model.module.engine()
+    d = gpu_device
+    n_atoms = [29, 28] * 6
+    B = len(n_atoms)
+    x, ex, node_mask, edge_mask = filler.synthetic_state(n_atoms, "lm.x")
+    cx, cex, _, _ = filler.synthetic_state(n_atoms, "lm.c")
+    nl = filler.uniform("lm.nl", (B,), -3, 3)
+    ctx = filler.normal("lm.ctx", (B, 1024)) * 0.5
+    for t in (x, ex, cx, cex, nl, ctx):          # molecules 10 / 11 are copies of 0 / 1
+        t[10], t[11] = t[0], t[1]
+    L, ws = eng.layout_for(node_mask, edge_mask)
+    out, oute = eng.forward(L, ws, x.to(d), ex.to(d), nl.to(d), cx.to(d), cex.to(d), ctx.to(d))
+    out, oute = out.cpu(), oute.cpu()
+    assert torch.equal(out[10], out[0]) and torch.equal(oute[10], oute[0]) and torch.equal(out[11], out[1]) and torch.equal(oute[11], oute[1])
+    cpu_cfg, sd = procedural_state_dict("ir")
+    for b in (0, 1, 7):
+        n = n_atoms[b]
+        nm1, em1 = filler.masks_from_n_atoms([n])
+        ref, refe = oracle.dmt_forward(sd, cpu_cfg, x[b:b + 1, :n], nm1, em1, ex[b:b + 1, :n, :n], nl[b:b + 1], cx[b:b + 1, :n],
+                                       cex[b:b + 1, :n, :n], context_emb=ctx[b:b + 1])
+        assert_close(out[b:b + 1, :n], ref, TOL_FORWARD, f"molecule {b} (n = {n}) vs single-molecule oracle")
+        assert_close(oute[b:b + 1, :n, :n], refe, TOL_FORWARD, f"molecule {b} (n = {n}) edges vs oracle")
+
+
 def test_molecule_launch_order_does_not_change_results(gpu_device):
     """ds_layout.mol_by_size (the per-molecule attention kernel takes its workgroups' molecules from size-sorted records) is a
     scheduling hint: with the field NULL (index order through node_off / pair_off) the outputs are bit-identical; ragged sizes incl.

@@ -131,14 +131,15 @@ class DMT(nn.Module):
             raise TypeError("DMT.forward needs `context` (spectra); pass context_emb to the engine for a zero context")
         # The reference re-encodes the loop-invariant spectra on every call (dmt.py:348-350; 62 % of its forward time).  A caller that
         # passes the SAME context tensors again (its sampler does, 1000 times per round) gets the embedding of the first call: keyed
-        # on the tensors' storage + version counters and on the weights the engine was packed from.
+        # on the tensor objects + version counters and on the weights the engine was packed from.
         ctx_list = context if isinstance(context, (list, tuple)) else [context]
-        ckey = (self._engine_key, tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in ctx_list))
         cached = getattr(self, "_ctx_cache", None)
-        if cached is not None and cached[0] == ckey:
-            ctx = cached[1]
+        # keyed on the tensor OBJECTS (held by the cache, so their addresses cannot be re-issued) + their version counters
+        if (cached is not None and cached[0] == self._engine_key and len(cached[1]) == len(ctx_list)
+                and all(a is b and v == b._version for (a, v), b in zip(cached[1], ctx_list))):
+            ctx = cached[2]
         else:
             ctx = eng.context_embedding(context)
-            self._ctx_cache = (ckey, ctx)
+            self._ctx_cache = (self._engine_key, [(t, t._version) for t in ctx_list], ctx)
         out_xh, out_edge = eng.forward(L, ws, xh, edge_x, noise_level, cond_x, cond_edge_x, ctx)
         return out_xh.to(xh.dtype), out_edge.to(edge_x.dtype)

@@ -75,10 +75,24 @@ class ExponentialMovingAverage:
             p.data.copy_(c.data)
 
     def state_dict(self):
+        """ema.py:79-81.  Under a sharded optimizer this gathers the shards first: a collective, every rank must call it."""
         self._sync()
         return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)
 
     def load_state_dict(self, state_dict) -> None:
+        """ema.py:83-85.  When a fused optimizer has made the shadow parameters views of its flat buffer (``attach_ema``), the loaded
+        values are copied INTO those views - rebinding the list would leave the step kernel averaging the old buffer."""
         self.decay = state_dict["decay"]
         self.num_updates = state_dict["num_updates"]
-        self.shadow_params = state_dict["shadow_params"]
+        loaded = state_dict["shadow_params"]
+        if getattr(self, "_before_read", None) is not None:
+            if len(loaded) != len(self.shadow_params):
+                raise ValueError(f"EMA holds {len(self.shadow_params)} tensors, the checkpoint has {len(loaded)}")
+            with torch.no_grad():
+                for mine, new in zip(self.shadow_params, loaded):
+                    mine.copy_(new.to(mine.device))
+            done = getattr(self, "_after_load", None)
+            if done is not None:
+                done()
+        else:
+            self.shadow_params = loaded

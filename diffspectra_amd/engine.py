@@ -388,21 +388,22 @@ class Layout:
 
     def check_edge_mask(self, edge_mask: torch.Tensor):
         """The path assumes edge_mask = outer(node_mask) minus the diagonal, as every reference caller builds it."""
-        key = (edge_mask.data_ptr(), edge_mask._version, tuple(edge_mask.shape))
-        if getattr(self, "_mask_ok", None) == key:          # same storage, unmodified since it was checked (a B*N*N device->host copy saved)
+        ok = getattr(self, "_mask_ok", None)
+        # the SAME tensor object, unmodified since it was checked (a B*N*N device->host copy saved).  The cache holds the tensor
+        # itself: an address is not an identity - the caching allocator hands a freed mask's address to the next same-shape mask
+        if ok is not None and ok[0] is edge_mask and ok[1] == edge_mask._version:
             return
         v = torch.from_numpy(self.valid)
         want = (v.unsqueeze(1) & v.unsqueeze(2)) & ~torch.eye(self.N, dtype=torch.bool).unsqueeze(0)
         got = edge_mask.detach().reshape(self.B, self.N, self.N).cpu() != 0
         if not torch.equal(want, got):
             raise ValueError("edge_mask is not node_mask ⊗ node_mask minus the diagonal; unsupported graph structure")
-        self._mask_ok = key
-
+        self._mask_ok = (edge_mask, edge_mask._version)
 
     def check_edge_symmetry(self, edge: torch.Tensor, name: str = "edge_x"):
         """The pair layout stores one value per unordered pair: ``edge[b,i,j,:] == edge[b,j,i,:]`` must hold on valid pairs."""
-        key = (name, edge.data_ptr(), edge._version, tuple(edge.shape))
-        if getattr(self, "_sym_ok", None) == key:          # same storage, unmodified since the last check (a blocking .any() saved)
+        ok = getattr(self, "_sym_ok", {}).get(name)
+        if ok is not None and ok[0] is edge and ok[1] == edge._version:   # the same tensor object, unmodified (a blocking .any() saved)
             return
         e = edge.detach().reshape(self.B, self.N, self.N, -1)
         v = torch.from_numpy(self.valid).to(e.device)
@@ -410,7 +411,9 @@ class Layout:
         if bool(((e != e.transpose(1, 2)) & m).any()):
             raise ValueError(f"{name} is not symmetric in its two atom indices; the MI355X path stores edge features per "
                              "unordered pair and does not support directed edge inputs")
-        self._sym_ok = key
+        if not hasattr(self, "_sym_ok"):
+            self._sym_ok = {}
+        self._sym_ok[name] = (edge, edge._version)
 
 
 class Workspace:
@@ -450,16 +453,17 @@ class DmtEngine:
 
     # layout/workspace cache: keyed on the mask's bytes (cheap: B*N bytes) so equal structures share tables
     def layout_for(self, node_mask: torch.Tensor, edge_mask: Optional[torch.Tensor] = None, validate: bool = False):
-        ident = (node_mask.data_ptr(), node_mask._version, tuple(node_mask.shape))
         last = getattr(self, "_last_layout", None)
-        if last is not None and last[0] == ident and last[2] in self._layouts:      # the same mask tensor again: no device->host copy
+        # the same mask TENSOR again (object identity + version; the cache keeps the tensor alive, so its address cannot be
+        # re-issued to another mask while it is the key): no device->host copy
+        if last is not None and last[0] is node_mask and last[1] == node_mask._version and last[2] in self._layouts:
             hit = self._layouts[last[2]]
             if validate and edge_mask is not None:
                 hit[0].check_edge_mask(edge_mask)
             return hit
         key_t = (node_mask.detach().reshape(node_mask.shape[0], -1) != 0).to("cpu")
         key = (tuple(key_t.shape), key_t.numpy().tobytes())
-        self._last_layout = (ident, None, key)
+        self._last_layout = (node_mask, node_mask._version, key)
         hit = self._layouts.get(key)
         if hit is None:
             L = Layout(node_mask, self.device)

@@ -39,12 +39,15 @@ def restore_checkpoint(ckpt_path: str, state: Dict, device) -> Dict:
 
 
 def save_checkpoint(ckpt_path: str, state: Dict) -> None:
-    """utils.py:23-30."""
+    """utils.py:23-30.  In a multi-rank job EVERY rank calls this (the sharded optimizer / EMA state is gathered by collectives
+    inside ``state_dict()``); rank 0 writes the file."""
     saved = {}
     if state.get("optimizer") is not None:            # same key order as the reference's file
         saved["optimizer"] = state["optimizer"].state_dict()
     saved.update(model=state["model"].state_dict(), ema=state["ema"].state_dict(), step=state["step"])
-    torch.save(saved, ckpt_path)
+    from .shard import world_info
+    if world_info()[0] == 0:
+        torch.save(saved, ckpt_path)
 
 
 def checkpoint_ids(config):

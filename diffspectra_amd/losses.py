@@ -39,7 +39,7 @@ class FusedAdamW:
     of the parameters (and holds 1/W of the optimizer state), all-gather of the parameters.  ``state_dict`` / ``load_state_dict``
     speak ``torch.optim.AdamW``'s format, so checkpoints interchange with the reference's (``utils.py:7-30``)."""
 
-    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-12, amsgrad=True):
+    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-12, amsgrad=True, force_sharded=False):
         if not amsgrad:
             raise ValueError("the fused kernel implements the shipped configuration: AdamW with amsgrad=True")
         self.params: List[torch.nn.Parameter] = [p for p in params]
@@ -52,6 +52,9 @@ class FusedAdamW:
         self.dev = dev
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
+        # the sharded step (reduce-scatter, shard update, all-gather) runs with more than one rank - or, as a rehearsal of exactly
+        # those RCCL calls, on a one-rank group with force_sharded (shard = everything; results equal the unsharded step bit for bit)
+        self.sharded = self.world > 1 or (bool(force_sharded) and dist.is_available() and dist.is_initialized())
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=True, params=list(range(len(self.params))))]
         self.sizes = [p.numel() for p in self.params]
         self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).tolist()
@@ -69,7 +72,7 @@ class FusedAdamW:
             p.data = self.P[o:o + p.numel()].view(p.shape)
             p.grad = self.G[o:o + p.numel()].view(p.shape)
         lo = self.rank * self.shard
-        self.Ps, self.Gs = self.P[lo:lo + self.shard], (self.G[lo:lo + self.shard] if self.world == 1 else torch.zeros(self.shard, device=dev))
+        self.Ps, self.Gs = self.P[lo:lo + self.shard], (torch.zeros(self.shard, device=dev) if self.sharded else self.G[lo:lo + self.shard])
         self.M, self.V, self.Vmax = (torch.zeros(self.shard, dtype=torch.float32, device=dev) for _ in range(3))
         self.steps = 0
         self.scratch = torch.empty(1024, dtype=torch.float32, device=dev)
@@ -85,7 +88,7 @@ class FusedAdamW:
 
     def _sync_grads(self):
         """Mean of the gradients over the ranks, scattered: every rank ends with its shard in ``self.Gs``."""
-        if self.world == 1:
+        if not self.sharded:
             return
         if dist.get_backend() == "gloo":                                # rehearsal backend: no reduce_scatter
             dist.all_reduce(self.G)
@@ -99,7 +102,7 @@ class FusedAdamW:
         self._synced = True
         E._check(self.lib.dst_sumsq(E._ptr(self.Gs), C.c_int64(self.shard), E._ptr(self.norm_sq), C.c_int32(0), E._ptr(self.scratch),
                                     C.c_int64(self.scratch.numel()), E._stream()), "dst_sumsq")
-        if self.world > 1:
+        if self.sharded:
             ns = self.norm_sq if dist.get_backend() != "gloo" else self.norm_sq.cpu()
             dist.all_reduce(ns)
             self.norm_sq.copy_(ns)
@@ -119,10 +122,14 @@ class FusedAdamW:
         self.ema_flat, self.ema = flat, ema
         self._ema_stale = False
         ema._before_read = self.gather_ema
+        ema._after_load = self._ema_loaded
+
+    def _ema_loaded(self):
+        self._ema_stale = False                                        # every rank has just loaded the full averages
 
     def gather_ema(self):
         """All-gather the EMA shards (only when the averages are read: ``ema.copy_to`` / ``ema.state_dict``)."""
-        if self.world == 1 or self.ema_flat is None or not self._ema_stale:
+        if not self.sharded or self.ema_flat is None or not self._ema_stale:
             return
         lo = self.rank * self.shard
         mine = self.ema_flat[lo:lo + self.shard].clone()
@@ -156,7 +163,7 @@ class FusedAdamW:
                                         C.c_int64(self.shard), C.c_float(float(g["lr"])), C.c_float(b1), C.c_float(b2), C.c_float(g["eps"]),
                                         C.c_float(g["weight_decay"]), C.c_float(1.0 - b1 ** self.steps), C.c_float(1.0 - b2 ** self.steps),
                                         C.c_float(float(clip_coef) / self.world), C.c_float(ema_omd), E._stream()), "dst_adamw_ema")
-        if self.world > 1:
+        if self.sharded:
             if dist.get_backend() == "gloo":                           # rehearsal backend: host tensors
                 parts = [torch.empty(self.shard) for _ in range(self.world)]
                 dist.all_gather(parts, self.Ps.cpu())
@@ -167,14 +174,21 @@ class FusedAdamW:
                 self._ema_stale = True                                  # the other ranks' EMA shards are gathered when the EMA is read
 
     def _gathered(self, shard_t: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if not self.sharded:
             return shard_t
+        if dist.get_backend() == "gloo":                               # rehearsal backend: host tensors
+            parts = [torch.empty(self.shard) for _ in range(self.world)]
+            dist.all_gather(parts, shard_t.cpu())
+            return torch.cat(parts).to(self.dev)
         full = torch.empty(self.n_pad, dtype=torch.float32, device=self.dev)
         dist.all_gather_into_tensor(full, shard_t.clone())
         return full
 
     def state_dict(self):
-        """``torch.optim.AdamW.state_dict()`` format (what the reference's ``save_checkpoint`` stores, golden G14)."""
+        """``torch.optim.AdamW.state_dict()`` format (what the reference's ``save_checkpoint`` stores, golden G14).
+
+        With more than one rank the optimizer state is sharded (ZeRO-1), so this call is a COLLECTIVE: every rank must make it
+        (``evaluate.save_checkpoint`` does, and lets rank 0 write the file); a "rank 0 only" caller would wait for ever."""
         M, V, X = self._gathered(self.M), self._gathered(self.V), self._gathered(self.Vmax)
         state = {}
         if self.steps > 0:
@@ -205,7 +219,8 @@ class FusedAdamW:
 def get_optimizer(config, params):
     """losses.py:14-25.  'AdamW' is the shipped optimizer: AdamW(lr, amsgrad=True, weight_decay=1e-12), here the fused kernel."""
     if config.optim.optimizer == "AdamW":
-        return FusedAdamW(params, lr=config.optim.lr, amsgrad=True, weight_decay=1e-12)
+        return FusedAdamW(params, lr=config.optim.lr, amsgrad=True, weight_decay=1e-12,
+                          force_sharded=bool(getattr(config.optim, "force_sharded", False)))
     raise NotImplementedError(f"Optimizer {config.optim.optimizer} not supported yet!")
 
 

@@ -85,6 +85,25 @@ def assign_slots(n_atoms, rank: int, world: int):
     return order[rank::world]
 
 
+# Rehearsal switch: with a process group of ONE rank the collectives below are identities and are skipped;
+# force_collectives(True) (or DIFFSPECTRA_FORCE_COLLECTIVES=1) runs them anyway, so that a single GPU with a world-size-1 `nccl`
+# group exercises every RCCL call site of the path (dtype / contiguity / aliasing errors show up before an 8-GPU run does).
+import os as _os
+_FORCE = _os.environ.get("DIFFSPECTRA_FORCE_COLLECTIVES", "0") == "1"
+
+
+def force_collectives(on: bool = True) -> None:
+    global _FORCE
+    _FORCE = bool(on)
+
+
+def collectives_on() -> bool:
+    """True when the collectives of this module must really run: a process group with more than one rank, or the rehearsal switch."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or _FORCE
+
+
 def world_info():
     """(rank, world) of the initialised default process group, (0, 1) without one."""
     if dist.is_available() and dist.is_initialized():
@@ -94,7 +113,7 @@ def world_info():
 
 def broadcast_from_rank0(t: torch.Tensor, device) -> torch.Tensor:
     """Every rank gets rank 0's ``t`` (a small host tensor: permutations, seeds); identity without a process group."""
-    if world_info()[1] == 1:
+    if not collectives_on():
         return t
     buf = t.clone() if dist.get_backend() == "gloo" else t.to(device)
     dist.broadcast(buf, src=0)
@@ -103,7 +122,7 @@ def broadcast_from_rank0(t: torch.Tensor, device) -> torch.Tensor:
 
 def all_gather_counts(count: torch.Tensor, device):
     """Every rank's value of the one-element int64 host tensor ``count`` (list of ints, rank order)."""
-    if world_info()[1] == 1:
+    if not collectives_on():
         return [int(count.item())]
     world = dist.get_world_size()
     buf = count.clone() if dist.get_backend() == "gloo" else count.to(device)
@@ -117,7 +136,7 @@ def gather_records(rec: torch.Tensor, counts=None) -> torch.Tensor:
 
     Ranks may hold different molecule counts (``counts``); blocks are padded to the largest for the collective.
     """
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_on():
         return rec
     world = dist.get_world_size()
     if counts is None:

@@ -26,6 +26,14 @@ def test_self_launch_two_ranks_dry_run():
     assert "torch.distributed.run" in err                 # went through the spawn path
 
 
+@pytest.mark.parametrize("scaling,total,per_rank", [("weak", 80, [40, 40]), ("strong", 40, [20, 20])])
+def test_scaling_modes_shard_the_evaluation(scaling, total, per_rank):
+    """--scaling weak: --samples per GPU (what the driver's --gpus N runs); strong: --samples in all, sharded over the ranks (BASELINE
+    config 3).  The dry run deals the sample slots with the product's shard.assign_slots and gathers the per-rank counts over gloo."""
+    rec, _ = _run(["--gpus", "2", "--backend", "gloo", "--dry-run", "--samples", "40", "--scaling", scaling], 300)
+    assert rec["scaling"] == scaling and rec["config"]["samples_total"] == total and rec["config"]["molecules_per_gpu"] == per_rank
+
+
 def test_single_rank_does_not_spawn():
     rec, err = _run(["--gpus", "1", "--dry-run"], 120)
     assert rec["n_gpus"] == 1 and "self-launch" not in err
@@ -49,3 +57,20 @@ def test_single_gpu_bench_prints_exactly_one_line():
                      "--no-cpu-baseline", "--no-live-traffic"], 900)
     assert rec["n_gpus"] == 1 and rec["config"]["passes_completed"] == 1 and rec["value"] > 0
     assert "Generate 40, Total 40." in err and "roofline" in rec and rec["config"]["mode"] == "eval"
+
+
+@pytest.mark.gpu
+def test_strong_scaling_two_ranks_on_one_gpu():
+    """BASELINE config 3's split on one card: 40 samples in all, 20 per rank, one final gather."""
+    rec, _ = _run(["--gpus", "2", "--backend", "gloo", "--same-device", "--scaling", "strong", "--samples", "40", "--batch", "24",
+                   "--denoise-steps", "20", "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-live-traffic"], 900)
+    assert rec["scaling"] == "strong" and rec["config"]["samples_total"] == 40 and rec["config"]["molecules_per_gpu"] == 20
+    assert rec["value"] > 0 and rec["config"]["passes_completed"] == 1
+
+
+@pytest.mark.gpu
+def test_force_collectives_rehearsal_on_one_gpu():
+    """`bench.py --gpus 1 --backend nccl --force-collectives`: a world-size-1 RCCL group, the record gather really executed."""
+    rec, _ = _run(["--gpus", "1", "--backend", "nccl", "--force-collectives", "--samples", "40", "--batch", "24", "--denoise-steps", "20",
+                   "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-live-traffic"], 900)
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and "forced" in rec["config"]["collectives"]

@@ -1362,18 +1362,56 @@ def test_dropin_forward_caches_loop_invariant_work(gpu_device):
               cond_x=a["cond_x"].to(d), cond_edge_x=a["cond_edge_x"].to(d))
     out0 = model(*args, **kw)[0].clone()
     mod = model.module
-    ctx0 = mod._ctx_cache[1]
+    ctx0 = mod._ctx_cache[2]
     out1 = model(*args, **kw)[0]
-    assert mod._ctx_cache[1] is ctx0 and torch.equal(out0, out1)                 # second call: cached embedding, identical result
+    assert mod._ctx_cache[2] is ctx0 and torch.equal(out0, out1)                 # second call: cached embedding, identical result
     kw["context"].mul_(1.05)                                                      # in-place edit bumps the version: re-encoded
     out2 = model(*args, **kw)[0]
-    assert mod._ctx_cache[1] is not ctx0 and float((out2 - out0).abs().max()) > 1e-5
+    assert mod._ctx_cache[2] is not ctx0 and float((out2 - out0).abs().max()) > 1e-5
     fresh = model(*args, **dict(kw, context=kw["context"].clone()))[0]           # a new tensor with the same values: same result
     assert torch.equal(fresh, out2)
     bad = args[3].clone()
     bad[5] = 1.0 - bad[5]
     with pytest.raises(ValueError):                                               # a different edge_mask tensor is validated again
         model(args[0], args[1], args[2], bad, **kw)
+
+
+def test_caches_do_not_confuse_a_reallocated_tensor_with_the_freed_one(gpu_device):
+    """The caching allocator hands a freed tensor's address to the next tensor of the same size, with version counter 0 again
+    (ADVICE r3): a mask / context freed and re-created with OTHER contents between two calls must be seen as new.  The loop frees
+    and re-allocates until the address really repeats (it does on the first try with torch's allocator), then compares with a
+    model that has never seen the first tensors."""
+    cfg, model = gpu_model("ir", gpu_device)
+    d = gpu_device
+    from diffspectra_amd import filler
+    from diffspectra_amd.sampling import build_masks
+
+    def inputs(n_atoms, salt):
+        x, ex, _, _ = filler.synthetic_state(n_atoms, f"realloc.{salt}", n_max=9)
+        nm, em = build_masks(n_atoms, len(n_atoms), d, max_n=9)
+        c = torch.log10(1.0 + filler.uniform(f"realloc.ir.{salt}", (len(n_atoms), 1, 3501)))
+        return x.to(d), ex.to(d), nm, em, c
+
+    def call(m, x, ex, nm, em, c):
+        return m(torch.zeros(x.shape[0], device=d), x, nm, em, context=c, edge_x=ex, noise_level=torch.zeros(x.shape[0], device=d),
+                 cond_x=None, cond_edge_x=None)
+
+    x1, ex1, nm1, em1, c1 = inputs([9, 4, 7], 1)
+    c1 = c1.to(d)
+    call(model, x1, ex1, nm1, em1, c1)
+    addr = (nm1.data_ptr(), em1.data_ptr(), c1.data_ptr())
+    del nm1, em1, c1
+    x2, ex2, nm2, em2, c2h = inputs([5, 9, 3], 2)
+    c2 = c2h.to(d)
+    reused = (nm2.data_ptr() == addr[0], em2.data_ptr() == addr[1], c2.data_ptr() == addr[2])
+    print(f"addresses re-issued by the allocator (node_mask, edge_mask, context): {reused}")
+    out = call(model, x2, ex2, nm2, em2, c2)
+    from diffspectra_amd.registry import create_model
+    fresh = create_model(cfg)                                       # a model that has never seen the first tensors
+    filler.fill_module_(fresh)
+    fresh.eval()
+    want = call(fresh, x2, ex2, nm2.clone(), em2.clone(), c2.clone())
+    assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1])
 
 
 def test_forward_rejects_asymmetric_edges(gpu_device):

@@ -304,7 +304,11 @@ def test_build_reports_on_stderr_only(tmp_path, capsys):
     library) may only talk on stderr."""
     import __graft_entry__ as g
     obj = str(tmp_path / "x.o")
-    g._compile("/bin/true", "x.hip", obj, ["-O3"])
+    src = str(tmp_path / "x.hip")
+    open(src, "w").write("// empty\n")
+    g._compile("/bin/true", src, obj, ["-O3"])
     cap = capsys.readouterr()
     assert cap.out == "" and "[build]" in cap.err
     assert open(obj + ".flags").read() == "-O3"
+    with pytest.raises(FileNotFoundError):                   # a dependency that does not exist is an error, not an empty digest (ADVICE r3)
+        g._digest([str(tmp_path / "missing.h")])

@@ -622,7 +622,27 @@ def _ddp_worker(rank, world, port, out_path):
         assert opt._ema_stale is False and not torch.equal(stale, opt.ema_flat.detach().cpu())
         assert torch.equal(torch.cat([p.detach().reshape(-1) for p in model.parameters()]), opt.ema_flat[:opt.n])
         flat_grad_local = opt.G.detach().cpu().clone()
-        torch.save(dict(P=p_step, G=flat_grad_local, loss=float(loss.detach()), ema=opt.ema_flat.detach().cpu()), out_path + f".{rank}")
+        ema_gathered = opt.ema_flat.detach().cpu().clone()
+        # checkpoint in a sharded job: state_dict() gathers the sharded moments - a collective every rank joins; rank 0 writes
+        from diffspectra_amd.evaluate import save_checkpoint, restore_checkpoint
+        opt.P.copy_(p_step.to(d))                                                  # undo the copy_to above: parameters of the step
+        save_checkpoint(out_path + ".ckpt", state)
+        dist.barrier()
+        cfg2, model2 = _train_model("ir", d)
+        cfg2.optim.warmup = 0
+        ema2 = ExponentialMovingAverage(model2.parameters(), decay=0.999)
+        opt2 = Lh.get_optimizer(cfg2, model2.parameters())
+        step2 = Lh.get_step_fn(NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0), True, Lh.optimization_manager(cfg2), None, cfg2)
+        state2 = restore_checkpoint(out_path + ".ckpt", dict(optimizer=opt2, model=model2, ema=ema2, step=0), d)
+        assert state2["step"] == 1 and torch.equal(opt2.P, opt.P) and torch.equal(opt2.M, opt.M) and torch.equal(opt2.Vmax, opt.Vmax)
+        finals = []
+        for st_, fn_ in ((state, step_fn), (state2, step2)):
+            torch.manual_seed(500 + rank)
+            random.seed(9)
+            fn_(st_, batch)
+            finals.append(st_["optimizer"].P.detach().cpu().clone())
+        assert torch.equal(finals[0], finals[1]), "save -> restore -> step diverged from the uninterrupted run"
+        torch.save(dict(P=p_step, G=flat_grad_local, loss=float(loss.detach()), ema=ema_gathered, P2=finals[1]), out_path + f".{rank}")
     finally:
         dist.destroy_process_group()
 
@@ -645,6 +665,7 @@ def test_data_parallel_step_two_ranks(gpu_device, tmp_path):
     r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
     assert torch.equal(r0["P"], r1["P"]), "ranks ended with different parameters"
     assert torch.equal(r0["ema"], r1["ema"])
+    assert torch.equal(r0["P2"], r1["P2"]) and not torch.equal(r0["P2"], r0["P"])      # the step after the checkpoint round trip
     assert abs(r0["loss"] - r1["loss"]) > 1e-3                                   # the ranks did see different batches
     assert torch.equal(r0["G"], r1["G"])                                         # gloo path: all_reduce in place, both hold the sum
     cfg, model = _train_model("ir", gpu_device)

@@ -100,8 +100,11 @@ def _equi_update(sd, name, h, pos, edge_index, edge_attr, dist, time_emb, adj_ex
     return pos + agg
 
 
-def _mix_block(sd, name, pos, h, edge_attr, edge_index, node_mask, extra_heads, node_t, edge_t):
-    """dmt.py:122-174 (cond_time=True, dist_gbf=True; dropout inactive in eval)."""
+def _mix_block(sd, name, pos, h, edge_attr, edge_index, node_mask, extra_heads, node_t, edge_t, drop=None):
+    """dmt.py:122-174 (cond_time=True, dist_gbf=True).  ``drop(site, x)`` applies the FF dropout of dmt.py:114-120 (site 0 / 1 =
+    node hidden / output, 2 / 3 = edge hidden / output) with an injected mask; None = eval mode (identity)."""
+    if drop is None:
+        drop = lambda site, x: x
     h_in_node, h_in_edge = h, edge_attr
     row, col = edge_index
     d = pos[row] - pos[col]
@@ -116,11 +119,11 @@ def _mix_block(sd, name, pos, h, edge_attr, edge_index, node_mask, extra_heads, 
     h_edge = _lin(sd, name + ".node2edge_lin", h_node[row] + h_node[col])
     h_node = h_in_node + n_g_a * h_node
     h_node = _modulate(_ln(h_node), n_sh_m, n_sc_m) * node_mask
-    ff = _lin(sd, name + ".ff_linear2", F.silu(_lin(sd, name + ".ff_linear1", h_node)))
+    ff = drop(1, _lin(sd, name + ".ff_linear2", drop(0, F.silu(_lin(sd, name + ".ff_linear1", h_node)))))
     h_out = (h_node + n_g_m * ff) * node_mask
     h_edge = h_in_edge + e_g_a * h_edge
     h_edge = _modulate(_ln(h_edge), e_sh_m, e_sc_m)
-    ffe = _lin(sd, name + ".ff_linear4", F.silu(_lin(sd, name + ".ff_linear3", h_edge)))
+    ffe = drop(3, _lin(sd, name + ".ff_linear4", drop(2, F.silu(_lin(sd, name + ".ff_linear3", h_edge)))))
     h_edge_out = h_edge + e_g_m * ffe
     pos = _equi_update(sd, name + ".equi_update", h_out, pos, edge_index, h_edge_out, distance, edge_t, extra_heads)
     return h_out, h_edge_out, pos
@@ -154,8 +157,9 @@ def context_embedding(sd, context, cfg):
 
 @torch.no_grad()
 def dmt_forward(sd, cfg, xh, node_mask, edge_mask, edge_x, noise_level, cond_x=None, cond_edge_x=None,
-                context=None, context_emb=None, return_debug=False):
-    """models/dmt.py:306-412.  ``context_emb`` (a precomputed ``context_embedding``) may replace ``context``."""
+                context=None, context_emb=None, return_debug=False, dropout_masks=None):
+    """models/dmt.py:306-412.  ``context_emb`` (a precomputed ``context_embedding``) may replace ``context``.
+    ``dropout_masks(block, site, x) -> x * mask`` = training-mode FF dropout with injected masks (golden G17); None = eval."""
     n_layers = cfg.model.n_layers
     bs, n_nodes, _ = xh.shape
     pos = xh[:, :, 0:3].clone().reshape(bs * n_nodes, -1)
@@ -196,8 +200,9 @@ def dmt_forward(sd, cfg, xh, node_mask, edge_mask, edge_x, noise_level, cond_x=N
     nm_flat = node_mask.reshape(-1, 1)
     dbg = {}
     for i in range(n_layers):
+        drop = None if dropout_masks is None else (lambda site, x, _i=i: dropout_masks(_i, site, x))
         h, edge_attr, pos = _mix_block(sd, "e_block_%d" % i, pos, h, edge_attr, edge_index, nm_flat,
-                                       extra_adj, node_t, edge_t)
+                                       extra_adj, node_t, edge_t, drop)
         pos = _remove_mean_with_mask(pos.reshape(bs, n_nodes, -1), node_mask).reshape(bs * n_nodes, -1)
         atom_hids.append(_lin(sd, "node_%d" % i, h))
         edge_hids.append(_lin(sd, "edge_%d" % i, edge_attr))

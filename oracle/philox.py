@@ -69,3 +69,18 @@ def molecule_noise(seed, draw, mol_id, n):
         edge[hi, lo] = e
         edge[lo, hi] = e
     return pos, feat, edge
+
+
+def dropout_keep(seed, stream_id, n, p):
+    """The FF-dropout masks of the training kernels (``dst_dropout`` / the fused GEMM epilogues, csrc/ds_train.hip): element i of a
+    tensor is kept iff word ``i & 3`` of Philox block (i >> 2, stream_id, 'DROP') under key ``seed`` is >= p * 2^32 (evaluated in
+    fp32, as the kernel does).  Returns a bool array of ``n`` elements; kept elements are scaled by ``dropout_scale(p)``."""
+    q = np.arange((n + 3) // 4, dtype=np.uint64)
+    w = philox4x32_10(q & MASK, q >> np.uint64(32), np.uint64(stream_id), np.uint64(0x44524F50), int(seed) & 0xFFFFFFFF, int(seed) >> 32)
+    thr = np.uint32(min(np.float32(p) * np.float32(4294967296.0), np.float32(4294967040.0)))
+    return (np.stack(w, axis=1).reshape(-1)[:n] >= thr)
+
+
+def dropout_scale(p):
+    """1 / (1 - p) in fp32, as the host side of ``dst_dropout`` computes it."""
+    return np.float32(1.0) / (np.float32(1.0) - np.float32(p))

@@ -3,8 +3,10 @@
 takes), ``process_edge_batch`` (``:498-529``), ``get_data_scaler`` (``utils.py:33-68``), ``get_align_position`` /
 ``kabsch_batch`` (``losses.py:414-452``) and the noise samplers (``models/utils.py:67-106``), over the functional forward of
 ``oracle/dmt.py`` with the SpecFormer encoder in TRAINING mode (BatchNorm batch statistics, ``specformer.py:247,260``).
-Dropout is the identity here (stage A of row N1 pins the p = 0 arithmetic; the reference's dropout masks are torch-RNG state).
-Gradients come from ``torch.autograd`` on this restatement; it is pinned by golden G13 (the reference's own loss and gradients).
+FF dropout (dmt.py:114-120) is the identity by default (golden G13 pins the p = 0 arithmetic) or, with ``dropout=(p, seeds)``, a
+multiplication by the masks of ``dropout_masks`` - the Philox masks of the HIP kernels laid out on the reference's tensors, which is
+what golden G17 injects into the reference's own ``nn.Dropout`` (the reference's torch-RNG masks cannot be reproduced on a GPU).
+Gradients come from ``torch.autograd`` on this restatement; it is pinned by goldens G13 / G17 (the reference's own loss and gradients).
 """
 from __future__ import annotations
 
@@ -112,10 +114,61 @@ def forward_with_context(sd, cfg, z_t, node_mask, edge_mask, edge_z_t, noise_lev
     return odmt.dmt_forward.__wrapped__(sd, cfg, z_t, node_mask, edge_mask, edge_z_t, noise_level, cond_x, cond_edge_x, context_emb=ctx_emb)
 
 
-def training_loss(sd, cfg, batch, t_raw, randn, self_cond_coin: bool, loss_weights=(1.0, 0.25, 0.1)):
+def dropout_masks(n_atoms, n_max, p, seed):
+    """FF-dropout masks of ONE DMT evaluation for the reference's tensor shapes: ``fn(block, site, x) -> x * mask``.
+
+    The HIP training path draws the mask of element c of packed node row r (valid atoms, molecule-major) / packed pair row q
+    (unordered pairs a < b, molecule-major, a-major) from Philox stream ``4 * block + site`` at flat index ``r * C + c`` /
+    ``q * C + c`` (``philox.dropout_keep``).  The reference holds node tensors densely, [B * N, C] with padded atoms, and edge tensors
+    per DIRECTED edge in ``dense_to_sparse`` order; its masks here are those values gathered: a padded atom's row is kept (it is
+    multiplied by node_mask anyway), and both directions of a pair get the pair's mask - the edge features stay pair-symmetric,
+    which the reference's own independent per-edge masks would not (the documented deviation)."""
+    import numpy as np
+    from . import philox
+    n_atoms = [int(n) for n in n_atoms]
+    B, N = len(n_atoms), int(n_max)
+    node_row = np.full(B * N, -1, dtype=np.int64)
+    edge_row = []
+    r = q = 0
+    for b, n in enumerate(n_atoms):
+        node_row[b * N:b * N + n] = np.arange(r, r + n)
+        r += n
+        tri = np.zeros((n, n), dtype=np.int64)
+        iu = np.triu_indices(n, 1)
+        tri[iu] = np.arange(q, q + len(iu[0]))
+        tri = tri + tri.T
+        q += len(iu[0])
+        ii, jj = np.nonzero(~np.eye(n, dtype=bool))                 # row-major (i, j), i != j: dense_to_sparse order
+        edge_row.append(tri[ii, jj])
+    edge_row = np.concatenate(edge_row) if edge_row else np.zeros(0, dtype=np.int64)
+    Nn, Pp = r, q
+    scale = float(philox.dropout_scale(p))
+    cache = {}
+
+    def fn(block, site, x):
+        C = x.shape[1]
+        key = (block, site)
+        if key not in cache:
+            rows = Nn if site < 2 else Pp
+            keep = philox.dropout_keep(seed, 4 * block + site, rows * C, p).reshape(rows, C)
+            if site < 2:
+                dense = np.ones((B * N, C), dtype=bool)
+                dense[node_row >= 0] = keep[node_row[node_row >= 0]]
+            else:
+                dense = keep[edge_row]
+            cache[key] = torch.from_numpy(dense.astype(np.float32) * np.float32(scale))
+        m = cache[key]
+        assert m.shape == x.shape, (m.shape, x.shape)
+        return x * m
+
+    return fn
+
+
+def training_loss(sd, cfg, batch, t_raw, randn, self_cond_coin: bool, loss_weights=(1.0, 0.25, 0.1), dropout=None):
     """One ``loss_fn(model, batch)`` call (losses.py:301-394) with its random draws passed in: ``t_raw`` = the ``torch.rand(B)``
     draw, ``randn`` = the three noise draws (pos [B,N,3], feat [B,N,6], edge [B,2,N,N]), ``self_cond_coin`` = ``random() < 0.5``.
-    ``sd`` tensors that require grad receive gradients from ``loss.backward()``.  Returns (loss, dict of intermediates)."""
+    ``sd`` tensors that require grad receive gradients from ``loss.backward()``.  ``dropout = (p, (seed_selfcond, seed_main))``
+    turns the FF dropout on with the injected masks of ``dropout_masks`` (golden G17).  Returns (loss, dict of intermediates)."""
     xh, edge_x, node_mask, edge_mask = scale_batch(batch)
     B = xh.shape[0]
     t = t_raw * (1.0 - 1e-5) + 1e-5
@@ -129,19 +182,22 @@ def training_loss(sd, cfg, batch, t_raw, randn, self_cond_coin: bool, loss_weigh
     noise_level = torch.log(alpha_t ** 2 / sigma_t ** 2)
     fwd = odmt.dmt_forward.__wrapped__                                       # the same forward, gradients enabled
 
-    def model(sd, cond_x, cond_edge_x):
+    n_at = node_mask.reshape(B, -1).sum(1).long().tolist()
+
+    def model(sd, cond_x, cond_edge_x, seed_index):
         z, stats = specformer_forward_train(sd, batch["context"], cfg.data.spectra_version, cfg.model.patch_len, cfg.model.stride)
         ctx = odmt._lin(sd, "cond_lin", z)
-        return fwd(sd, cfg, z_t, node_mask, edge_mask, edge_z_t, noise_level, cond_x, cond_edge_x, context_emb=ctx), stats
+        masks = None if dropout is None else dropout_masks(n_at, node_mask.shape[1], dropout[0], dropout[1][seed_index])
+        return fwd(sd, cfg, z_t, node_mask, edge_mask, edge_z_t, noise_level, cond_x, cond_edge_x, context_emb=ctx, dropout_masks=masks), stats
 
     cond_x = cond_edge_x = None
     info = {}
     if self_cond_coin:
         with torch.no_grad():
-            (cond_x, cond_edge_x), stats0 = model(sd, None, None)  # also a training-mode forward: BatchNorm stats move twice
+            (cond_x, cond_edge_x), stats0 = model(sd, None, None, 0)  # also a training-mode forward: BatchNorm stats move twice
             sd = dict(sd)
             sd.update(stats0)
-    (pred, edge_pred), stats = model(sd, cond_x, cond_edge_x)
+    (pred, edge_pred), stats = model(sd, cond_x, cond_edge_x, 1)
     loss = loss_from_predictions(pred, edge_pred, xh, edge_x, align_pos, alpha_t, sigma_t, loss_weights)
     info.update(xh=xh, edge_x=edge_x, z_t=z_t, edge_z_t=edge_z_t, alpha_t=alpha_t, sigma_t=sigma_t, noise_level=noise_level,
                 align_pos=align_pos, pred=pred, edge_pred=edge_pred, cond_x=cond_x, cond_edge_x=cond_edge_x, bn=stats,

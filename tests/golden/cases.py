@@ -226,6 +226,8 @@ def training_draws(n_atoms=TRAIN_ATOMS, salt: int = 0):
 
 # parameters whose FULL gradient the training golden stores (one per kernel family); every other parameter is pinned by its
 # gradient norm and by a 64-entry strided sample
+TRAIN_DROPOUT_SEEDS = (1111, 2222)            # G17: Philox keys of the FF-dropout masks (self-conditioning forward, main forward)
+
 TRAIN_FULL_GRADS = ("e_block_0.attn_mpnn.lin_edge0.weight", "e_block_7.equi_update.coord_mlp.0.weight", "node_emb.weight",
                     "e_block_3.node_time_mlp.1.bias", "e_block_0.dist_layer.means.weight", "e_block_5.dist_layer.stds.weight",
                     "e_block_2.equi_update.coord_norm.scale", "time_mlp.0.weights", "e_block_4.attn_mpnn.lin_query.weight",

@@ -479,20 +479,32 @@ def grad_sample_index(numel: int, count: int = 64):
 
 
 def g13_training(mods):
+    _training_golden(mods, "g13_training.npz", 0.0, (("ir", "selfcond"), ("ir", "plain"), ("allspectra", "selfcond")), "G13")
+
+
+def g17_training_dropout(mods):
+    """Config 5 AS SHIPPED (dropout 0.1): the reference's ``loss_fn`` with ``nn.Dropout.forward`` patched to multiply by injected
+    masks - the Philox masks of the HIP kernels, laid out on the reference's dense-node / directed-edge tensors by
+    ``oracle.train.dropout_masks`` (both directions of a pair share the pair's mask, so the reference's forward stays
+    pair-symmetric; the reference's own masks are independent per directed edge, ``models/dmt.py:119-120`` - the build's
+    documented deviation).  Seeds: ``cases.TRAIN_DROPOUT_SEEDS`` = (self-conditioning forward, main forward)."""
+    _training_golden(mods, "g17_training_dropout.npz", 0.1, (("ir", "selfcond"), ("allspectra", "plain")), "G17")
+
+
+def _training_golden(mods, fname, dropout_p, plan, label):
     """Row N1: the reference's own training loss and gradients - ``get_sde_graph_loss_fn`` (losses.py:286-396, train=True) on
     ``DataParallel(DMT)`` with every random draw injected (``torch.rand`` for t, the three noise ``randn``s, the self-conditioning
     coin ``random()``), dropout 0.0 (stage A), BatchNorm in training mode.  Stored: loss, the tensors the loss is built from
     (alpha_t, sigma_t, Kabsch rotations and aligned target, z_t, predictions), per-parameter gradient norms and strided samples
     for ALL parameters, full gradients for one tensor per kernel family, and the BatchNorm running statistics after the step."""
     ref_losses = importlib.import_module("losses")
+    from oracle.train import dropout_masks
     out = {}
-    for version in ("ir", "allspectra"):
-        for coin_name, coin in (("selfcond", 0.0), ("plain", 1.0)):
-            if version == "allspectra" and coin_name == "plain":
-                continue
+    for version, coin_name in plan:
+        for coin in ((0.0 if coin_name == "selfcond" else 1.0),):
             cfg = cases.config_for(version)
             cfg.device = torch.device("cpu")
-            cfg.model.dropout = 0.0
+            cfg.model.dropout = dropout_p
             model = torch.nn.DataParallel(mods.model_utils._MODELS["DMT"](cfg))
             model.load_state_dict(filler.fill_state_dict(model.state_dict()), strict=True)
             ns = mods.noise_schedule.NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0)
@@ -519,12 +531,30 @@ def g13_training(mods):
 
             model.module.forward = spy
             torch.randn, torch.rand, ref_losses.random = replay_n, replay_u, (lambda: coin)
+            real_dropout = torch.nn.Dropout.forward
+            calls = {"k": 0}
+            if dropout_p > 0:
+                n_max = max(cases.TRAIN_ATOMS)
+                mask_fns = [dropout_masks(cases.TRAIN_ATOMS, n_max, dropout_p, sd_) for sd_ in cases.TRAIN_DROPOUT_SEEDS]
+
+                def injected(self, x):
+                    if self.p == 0.0 or not self.training:                # SpecFormer's nn.Dropout(0.) modules, eval mode
+                        return x
+                    k = calls["k"]
+                    calls["k"] += 1
+                    fwd_i, blk, site = k // 32, (k % 32) // 4, k % 4      # dmt.py:114-120: node hidden, node out, edge hidden, edge out per block
+                    return mask_fns[fwd_i if coin_name == "selfcond" else 1](blk, site, x)
+
+                torch.nn.Dropout.forward = injected
             try:
                 loss = loss_fn(model, {k: v for k, v in batch.items() if k != "n_atoms"})
                 loss.backward()
             finally:
                 torch.randn, torch.rand, ref_losses.random = real_randn, real_rand, real_coin
+                torch.nn.Dropout.forward = real_dropout
                 model.module.forward = real_forward
+            if dropout_p > 0:
+                assert calls["k"] == (64 if coin_name == "selfcond" else 32), calls
             assert not replay_n.queue and replay_u.calls == 1
             tag = f"{version}_{coin_name}"
             out[tag + "_loss"] = loss.detach().numpy()
@@ -554,9 +584,9 @@ def g13_training(mods):
             sd = {k[7:]: v for k, v in model.state_dict().items()}
             out[tag + "_bn_running_mean"], out[tag + "_bn_running_var"] = sd[bn + "running_mean"].numpy(), sd[bn + "running_var"].numpy()
             out[tag + "_bn_batches"] = sd[bn + "num_batches_tracked"].numpy()
-            print("G13", tag, "loss", float(loss), "total grad norm", float(np.sqrt(np.sum(np.square(norms)))),
+            print(label, tag, "loss", float(loss), "total grad norm", float(np.sqrt(np.sum(np.square(norms)))),
                   "zero-grad tensors", [n for n, v in zip(names, norms) if v == 0.0])
-    cases.save_npz("g13_training.npz", **out)
+    cases.save_npz(fname, **out)
 
 
 def g16_training_collate():
@@ -620,7 +650,7 @@ def main():
     todo = {"G0": g0_manifest, "G1": g1_schedule, "G2": g2_specformer, "G3": g3_components, "G4": g4_forward,
             "G5": g5_trajectory, "G6": g6_post_process, "G7": g7_full_length, "G8": g8_clamp_self_cond,
             "G9": g9_full_length_allspectra, "G10": g10_pretrained_specformer, "G11": g11_sampling_fn,
-            "G13": g13_training, "G14": g14_checkpoint, "G15": g15_full_length_max_size}
+            "G13": g13_training, "G14": g14_checkpoint, "G15": g15_full_length_max_size, "G17": g17_training_dropout}
     for k, fn in todo.items():
         if not only or k in only:
             fn(mods)

@@ -463,18 +463,45 @@ def test_loss_fn_matches_reference_loss_and_gradients(gpu_device, monkeypatch, v
     """``get_sde_graph_loss_fn(...)(model, batch)`` + ``loss.backward()`` through the HIP training library against golden G13 (the
     reference's own loss_fn, train=True, dropout 0, every random draw injected): loss rtol 1e-5, every parameter's gradient norm and
     strided sample and the stored full gradients rtol 1e-4, Kabsch rotations, BatchNorm running statistics."""
+    _loss_fn_against_golden(gpu_device, monkeypatch, version, coin_name, "g13_training.npz", 0.0)
+
+
+@pytest.mark.parametrize("version,coin_name", [("ir", "selfcond"), ("allspectra", "plain")])
+def test_loss_fn_matches_reference_with_dropout(gpu_device, monkeypatch, version, coin_name):
+    """Config 5 AS SHIPPED (``config.model.dropout = 0.1``) against golden G17: the reference's loss_fn with its ``nn.Dropout`` masks
+    injected - the masks this library's kernels generate (Philox, keyed on (seed, 4 * block + site, element)), pair-symmetric on the
+    edge side.  Same gates as G13: loss 1e-5, all gradient norms / samples / full tensors rtol 1e-4."""
+    _loss_fn_against_golden(gpu_device, monkeypatch, version, coin_name, "g17_training_dropout.npz", 0.1)
+
+
+def test_dropout_kernel_masks_equal_the_oracle_masks(gpu_device):
+    """``dst_dropout``'s mask against ``oracle.philox.dropout_keep`` (the generator golden G17's injected masks come from), bit for bit,
+    incl. a length that is not a multiple of the 4-element Philox block."""
+    from diffspectra_amd import train_engine as T
+    from oracle import philox
+    o = T.Ops(gpu_device)
+    for n, p, seed, stream in ((1_000_003, 0.1, 1111, 0), (4099, 0.1, 2222, 31), (512 * 37, 0.25, (1 << 61) + 12345, 7)):
+        y = torch.ones(n, device=gpu_device)
+        o.dropout(y, p, seed, stream)
+        keep = philox.dropout_keep(seed, stream, n, p)
+        want = torch.from_numpy(keep.astype(np.float32) * philox.dropout_scale(p))
+        assert torch.equal(y.cpu(), want), (n, p, seed, stream)
+
+
+def _loss_fn_against_golden(gpu_device, monkeypatch, version, coin_name, fixture, dropout_p):
     from diffspectra_amd import losses as Lh
     from diffspectra_amd.noise_schedule import NoiseScheduleVP
-    from diffspectra_amd.scalers import get_data_inverse_scaler
     d = gpu_device
     cfg, model = _train_model(version, d)
-    g = cases.load_npz("g13_training.npz")
+    cfg.model.dropout = dropout_p
+    g = cases.load_npz(fixture)
     tag = f"{version}_{coin_name}"
     batch, draws = cases.training_batch(version), cases.training_draws()
     batch = {k: v for k, v in batch.items() if k != "n_atoms"}
     loss_fn = Lh.get_sde_graph_loss_fn(NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0), True, None, cfg)
     monkeypatch.setattr(torch, "rand", _Replay([draws["t_raw"]]))
     monkeypatch.setattr(torch, "randn", _Replay(draws["randn"]))
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: torch.tensor(list(cases.TRAIN_DROPOUT_SEEDS)))
     monkeypatch.setattr(Lh, "random", lambda: 0.0 if coin_name == "selfcond" else 1.0)
     loss = loss_fn(model, batch)
     monkeypatch.undo()
@@ -514,7 +541,7 @@ def test_loss_fn_matches_reference_loss_and_gradients(gpu_device, monkeypatch, v
             full = g[f"{tag}_grad::{n}"]
             if not torch.allclose(gr, full, rtol=1e-4, atol=1e-4 * float(full.abs().max()) + floor):
                 bad.append((n, "full", float((gr - full).abs().max()), float(full.abs().max())))
-    print(f"[loss_fn {tag}] loss {float(loss):.6f} (reference {ref_loss:.6f}); total grad norm {total:.3f}; {len(names)} parameters checked")
+    print(f"[loss_fn {fixture[:3]} {tag}] loss {float(loss):.6f} (reference {ref_loss:.6f}); total grad norm {total:.3f}; {len(names)} parameters checked")
     assert not bad, bad[:10]
     bn = "cond_encoder.backbone.encoder.layers.0.norm_attn.1."
     bufs = dict(model.module.named_buffers())

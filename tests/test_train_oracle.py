@@ -10,14 +10,16 @@ from oracle import train as otrain
 from tests.golden import cases
 from tests.helpers import procedural_state_dict
 
-CASES = [("ir", "selfcond"), ("ir", "plain"), ("allspectra", "selfcond")]
+CASES = [("ir", "selfcond", "g13"), ("ir", "plain", "g13"), ("allspectra", "selfcond", "g13"),
+         ("ir", "selfcond", "g17"), ("allspectra", "plain", "g17")]      # G17: dropout 0.1 with injected masks (config 5 as shipped)
+FIXTURES = {"g13": "g13_training.npz", "g17": "g17_training_dropout.npz"}
 
 
 def grad_sample_index(numel: int, count: int = 64):
     return torch.linspace(0, numel - 1, min(count, numel)).round().long()
 
 
-def oracle_loss_and_grads(version, coin_name):
+def oracle_loss_and_grads(version, coin_name, dropout=None):
     cfg, sd0 = procedural_state_dict(version)
     cfg = cfg.clone()
     sd = {}
@@ -28,16 +30,16 @@ def oracle_loss_and_grads(version, coin_name):
         sd[k] = v
     batch = cases.training_batch(version)
     draws = cases.training_draws()
-    loss, info = otrain.training_loss(sd, cfg, batch, draws["t_raw"], draws["randn"], coin_name == "selfcond")
+    loss, info = otrain.training_loss(sd, cfg, batch, draws["t_raw"], draws["randn"], coin_name == "selfcond", dropout=dropout)
     loss.backward()
     return sd, loss.detach(), info
 
 
-@pytest.mark.parametrize("version,coin_name", CASES)
-def test_training_oracle_matches_reference_loss_and_grads(version, coin_name):
-    g = cases.load_npz("g13_training.npz")
+@pytest.mark.parametrize("version,coin_name,fixture", CASES)
+def test_training_oracle_matches_reference_loss_and_grads(version, coin_name, fixture):
+    g = cases.load_npz(FIXTURES[fixture])
     tag = f"{version}_{coin_name}"
-    sd, loss, info = oracle_loss_and_grads(version, coin_name)
+    sd, loss, info = oracle_loss_and_grads(version, coin_name, (0.1, cases.TRAIN_DROPOUT_SEEDS) if fixture == "g17" else None)
     for k in ("xh", "edge_x", "z_t", "edge_z_t", "alpha_t", "sigma_t", "noise_level", "align_pos", "pred", "edge_pred"):
         assert torch.allclose(info[k].detach(), g[f"{tag}_{k}"], rtol=1e-5, atol=2e-6), k
     if coin_name == "selfcond":
@@ -66,7 +68,7 @@ def test_training_oracle_matches_reference_loss_and_grads(version, coin_name):
     bn = "cond_encoder.backbone.encoder.layers.0.norm_attn.1."
     assert torch.allclose(info["bn"][bn + "running_mean"], g[tag + "_bn_running_mean"], rtol=1e-5, atol=1e-6)
     assert torch.allclose(info["bn"][bn + "running_var"], g[tag + "_bn_running_var"], rtol=1e-5, atol=1e-6)
-    print(f"[G13 {tag}] loss {float(loss):.6f}; worst sampled gradient deviation {worst:.2e}")
+    print(f"[{fixture.upper()} {tag}] loss {float(loss):.6f}; worst sampled gradient deviation {worst:.2e}")
 
 
 def test_kabsch_alignment_golden():
@@ -79,3 +81,25 @@ def test_kabsch_alignment_golden():
         if n >= 3:                                     # with fewer atoms the rotation is not unique (rank-deficient covariance)
             assert torch.allclose(rot[b], g[tag + "_rotations"][b], atol=1e-4), b
     assert torch.allclose(otrain.align_position(g[tag + "_z_t"], g[tag + "_xh"]), g[tag + "_align_pos"], atol=1e-5)
+
+
+def test_dropout_masks_are_pair_symmetric_and_hit_the_keep_rate():
+    """The injected FF-dropout masks (oracle.train.dropout_masks): both directions of a pair carry the pair's mask, padded atoms are
+    kept, the keep rate is 1 - p, kept elements are scaled by 1 / (1 - p)."""
+    n_atoms = [3, 5, 1, 4]
+    fn = otrain.dropout_masks(n_atoms, 5, 0.1, 1234)
+    E = sum(n * (n - 1) for n in n_atoms)
+    m = fn(2, 3, torch.ones(E, 64))
+    off = 0
+    for n in n_atoms:
+        blk = m[off:off + n * (n - 1)]
+        ii, jj = np.nonzero(~np.eye(n, dtype=bool))
+        dense = torch.zeros(n, n, 64)
+        dense[ii, jj] = blk
+        assert torch.equal(dense, dense.transpose(0, 1))
+        off += n * (n - 1)
+    node = fn(0, 0, torch.ones(4 * 5, 512)).reshape(4, 5, 512)
+    assert float(node[2, 1:].min()) > 1.0                               # padded atoms of the single-atom molecule: kept
+    big = otrain.dropout_masks([29] * 8, 29, 0.1, 99)(1, 2, torch.ones(8 * 29 * 28, 128))
+    keep = float((big != 0).float().mean())
+    assert abs(keep - 0.9) < 5e-3 and abs(float(big.max()) - 1.0 / 0.9) < 1e-6

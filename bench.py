@@ -49,6 +49,27 @@ EQUI_MACS_PER_DIRECTED_EDGE = 256 * 256 + 256 * 3   # coord_mlp.0 + coord_mlp.2 
 _T0 = time.perf_counter()
 
 
+_OUT = None
+
+
+def claim_stdout():
+    """The process's stdout carries ONE JSON line.  Native libraries write there too (RCCL prints a five-line version banner on
+    stdout when its first communicator is created), so file descriptor 1 is pointed at stderr for the whole run and the JSON line
+    goes to a private duplicate of the original descriptor."""
+    global _OUT
+    if _OUT is None:
+        sys.stdout.flush()
+        _OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _OUT
+
+
+def emit(line: dict) -> None:
+    out = claim_stdout()
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
 def log(msg: str) -> None:
     """Progress on stderr (stdout carries only the JSON line)."""
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
@@ -421,7 +442,7 @@ def train_bench(args, world, rank, device):
                 line["cpu_baseline"] = cpu_baseline_train(args.spectra)
             except Exception as exc:  # noqa: BLE001 - the GPU line is still valid
                 line["cpu_baseline"] = {"value": None, "unit": "molecules/sec", "cores": usable_cores(), "kind": "port", "sample": f"failed: {exc}"}
-        print(json.dumps(line), flush=True)
+        emit(line)
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
@@ -433,6 +454,7 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(argv))
 
+    claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -453,9 +475,9 @@ def main(argv=None):
         mine = shard.assign_slots(filler.sample_n_atoms(total, seed=0), rank, world)
         counts = shard.all_gather_counts(torch.tensor([mine.numel()], dtype=torch.int64), "cpu")
         if rank == 0:
-            print(json.dumps({"metric": "molecules/sec, 1000-step QM9S all-spectra sampling", "value": None, "unit": "molecules/sec",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": args.scaling,
-                              "config": {"samples_total": total, "molecules_per_gpu": counts}}), flush=True)
+            emit({"metric": "molecules/sec, 1000-step QM9S all-spectra sampling", "value": None, "unit": "molecules/sec",
+                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": args.scaling,
+                  "config": {"samples_total": total, "molecules_per_gpu": counts}})
         if world > 1:
             dist.destroy_process_group()
         return
@@ -765,7 +787,7 @@ def main(argv=None):
             except Exception as exc:   # the GPU line must not be lost to a host-side problem
                 line["cpu_baseline"] = {"value": None, "unit": "molecules/sec", "cores": usable_cores(), "kind": "port",
                                         "sample": f"failed: {type(exc).__name__}: {exc}"}
-        print(json.dumps(line), flush=True)
+        emit(line)
     if grouped:
         dist.barrier()
         dist.destroy_process_group()

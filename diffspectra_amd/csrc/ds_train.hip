@@ -27,140 +27,6 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 __device__ __forceinline__ int pair_index(int n, int lo, int hi) { return lo * (2 * n - lo - 1) / 2 + (hi - lo - 1); }
 
-// ------------------------------------------------------------------------------------------------------------------ GEMM
-// BM x BN per 256-thread workgroup (2 x 2 waves, each (BM/2) x (BN/2) as 32 x 32 MFMA tiles), BK = 16, the next k-slab's global
-// loads in flight (registers) while the current one is multiplied out of LDS.  Operands by element strides (every transpose is a
-// view), guards on all three dimensions, optional split over K.  BF16 = config 5's precision: the operands are rounded to bf16
-// (round to nearest even, v_cvt_pk_bf16_f32) as they leave LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -
-// autocast semantics: fp32 master weights and activations in memory, bf16 products.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-template <int BM, int BN, bool BF16>
-__global__ __launch_bounds__(256) void k_tr_gemm_big(dst_gemm_args g, int splits, int kchunk) {
-  constexpr int TM = BM / 64, TN = BN / 64;              // 32 x 32 tiles per wave in each direction (BM, BN in {64, 128})
-  constexpr int LA = BM * 16 / 256, LB = BN * 16 / 256;  // elements per thread per slab
-  __shared__ float As[16][BM + 4];
-  __shared__ float Bs[16][BN + 4];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int z = blockIdx.z;
-  const int kbeg = z * kchunk;
-  const int kend = min(g.K, kbeg + kchunk);
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  const bool a_kfast = (g.a_cs == 1), b_nfast = (g.b_cs == 1);
-  float ra[LA], rb[LB];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < LA; ++i) {
-      const int e = tid + i * 256;
-      int mm, kk;
-      if (a_kfast) { kk = e & 15; mm = e >> 4; } else { mm = e % BM; kk = e / BM; }
-      const int gm = m0 + mm, gk = k0 + kk;
-      ra[i] = (gm < g.M && gk < kend) ? g.A[(int64_t)gm * g.a_rs + (int64_t)gk * g.a_cs] : 0.0f;
-    }
-#pragma unroll
-    for (int i = 0; i < LB; ++i) {
-      const int e = tid + i * 256;
-      int nn, kk;
-      if (b_nfast) { nn = e % BN; kk = e / BN; } else { kk = e & 15; nn = e >> 4; }
-      const int gn = n0 + nn, gk = k0 + kk;
-      // column N is the virtual all-ones column of the fused row sum (bias gradient of a weight-gradient product)
-      rb[i] = gk < kend ? (gn < g.N ? g.B[(int64_t)gk * g.b_rs + (int64_t)gn * g.b_cs] : ((g.rowsum && gn == g.N) ? 1.0f : 0.0f)) : 0.0f;
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int i = 0; i < LA; ++i) {
-      const int e = tid + i * 256;
-      int mm, kk;
-      if (a_kfast) { kk = e & 15; mm = e >> 4; } else { mm = e % BM; kk = e / BM; }
-      As[kk][mm] = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < LB; ++i) {
-      const int e = tid + i * 256;
-      int nn, kk;
-      if (b_nfast) { nn = e % BN; kk = e / BN; } else { kk = e & 15; nn = e >> 4; }
-      Bs[kk][nn] = rb[i];
-    }
-  };
-  if (kbeg < kend) fetch(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += 16) {
-    commit();
-    __syncthreads();
-    if (k0 + 16 < kend) fetch(k0 + 16);
-    if constexpr (BF16) {
-      bf16x8_t a8[TM], b8[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) a8[i][t] = (__bf16)As[8 * (lane >> 5) + t][wm * (BM / 2) + i * 32 + (lane & 31)];
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) b8[j][t] = (__bf16)Bs[8 * (lane >> 5) + t][wn * (BN / 2) + j * 32 + (lane & 31)];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
-    } else
-#pragma unroll
-    for (int kk = 0; kk < 16; kk += 2) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[kk + (lane >> 5)][wm * (BM / 2) + i * 32 + (lane & 31)];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[kk + (lane >> 5)][wn * (BN / 2) + j * 32 + (lane & 31)];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (BM / 2) + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
-        const int Nx = g.N + (g.rowsum ? 1 : 0);
-        if (row < g.M && col < Nx) {
-          if (splits > 1) {
-            g.partial[((int64_t)z * g.M + row) * Nx + col] = acc[i][j][r];
-          } else if (col == g.N) {
-            g.rowsum[row] = g.accumulate ? g.rowsum[row] + acc[i][j][r] : acc[i][j][r];
-          } else {
-            float v = acc[i][j][r] + (g.bias ? g.bias[col] : 0.0f);
-            float* c = g.C + (int64_t)row * g.ldc + col;
-            if (g.accumulate) v += *c;
-            *c = v;
-          }
-        }
-      }
-    }
-}
-
-__global__ void k_tr_gemm_reduce(dst_gemm_args g, int splits) {
-  const int Nx = g.N + (g.rowsum ? 1 : 0);
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)g.M * Nx) return;
-  const int row = (int)(idx / Nx), col = (int)(idx % Nx);
-  float v = (g.bias && col < g.N) ? g.bias[col] : 0.0f;
-  for (int z = 0; z < splits; ++z) v += g.partial[(int64_t)z * g.M * Nx + idx];
-  float* c = col == g.N ? g.rowsum + row : g.C + (int64_t)row * g.ldc + col;
-  if (g.accumulate) v += *c;
-  *c = v;
-}
-
 // ------------------------------------------------------------------------------------------------------------------ colsum / sumsq
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ X, int64_t ld, int R, int C, float* __restrict__ partial,
                                                          int rows_per_chunk) {
@@ -1359,43 +1225,6 @@ inline dim3 grid1d(int64_t n, int block = 256) { return dim3((unsigned)((n + blo
 
 // ====================================================================================================================== C-ABI
 extern "C" {
-
-int dst_gemm(const dst_gemm_args* a, void* stream) {
-  if (!a || !a->C || a->M < 0 || a->N < 0 || a->K < 0 || (a->K > 0 && (!a->A || !a->B))) return DS_ERR_ARG;
-  if (a->M == 0 || (a->N == 0 && !a->rowsum)) return DS_OK;
-  hipStream_t s = (hipStream_t)stream;
-  dst_gemm_args g = *a;
-  const int Nx = g.N + (g.rowsum ? 1 : 0);            // the fused row sum is one more (virtual, all-ones) column of B
-  // 128 x 64 tiles (64 x 64 for short M): 102 VGPRs = four waves per SIMD.  128 x 128 tiles need 136 VGPRs (three waves) and were
-  // 5-12 % slower over a training step in the same session (3276 / 3440 against 3694 / 3512 molecules/s); 64 x 64 throughout: 3575.
-  const int BM = g.M >= 96 ? 128 : 64, BN = 64;
-  const int tm = (g.M + BM - 1) / BM, tn = (Nx + BN - 1) / BN;
-  const int64_t tiles = (int64_t)tm * tn;
-  int splits = 1;
-  if (g.K >= 1024 && tiles < 512 && g.partial) {
-    splits = (int)(1024 / tiles);
-    const int max_by_k = (g.K + 255) / 256;
-    if (splits > max_by_k) splits = max_by_k;
-    const int64_t cap = g.partial_cap / ((int64_t)g.M * Nx);
-    if (splits > cap) splits = (int)cap;
-    if (splits < 1) splits = 1;
-  }
-  int kchunk = ((g.K + splits - 1) / splits + 15) / 16 * 16;
-  if (kchunk < 16) kchunk = 16;
-  splits = g.K > 0 ? (g.K + kchunk - 1) / kchunk : 1;
-  const dim3 grid(tn, tm, splits), blk(256);
-  const bool bf = g.bf16 != 0;
-#define DST_LAUNCH_GEMM(M_, N_)                                                                                              \
-  do {                                                                                                                     \
-    if (bf) hipLaunchKernelGGL((k_tr_gemm_big<M_, N_, true>), grid, blk, 0, s, g, splits, kchunk);                          \
-    else hipLaunchKernelGGL((k_tr_gemm_big<M_, N_, false>), grid, blk, 0, s, g, splits, kchunk);                            \
-  } while (0)
-  if (BM == 128) DST_LAUNCH_GEMM(128, 64);
-  else DST_LAUNCH_GEMM(64, 64);
-#undef DST_LAUNCH_GEMM
-  if (splits > 1) hipLaunchKernelGGL(k_tr_gemm_reduce, grid1d((int64_t)g.M * Nx), dim3(256), 0, s, g, splits);
-  return DST_CHECK_LAUNCH();
-}
 
 int dst_colsum(const float* X, int64_t ld, int32_t R, int32_t C, float* out, int32_t accumulate, float* scratch, int64_t scratch_cap,
                void* stream) {

@@ -1,0 +1,436 @@
+// diffspectra_amd - the GEMM of the TRAINING path (include/diffspectra_train.h: dst_gemm), gfx950.
+//
+// Every nn.Linear forward, input gradient and weight gradient of the DMT / SpecFormer training graph is one call of dst_gemm with
+// element strides (a transpose is a view).  Two kernels:
+//
+//  * k_tr_gemm_bf16 (config 5, args.bf16): 128 x BN tiles, BK = 32.  Operands are fp32 in HBM (master weights, fp32 tape); a tile is
+//    fetched with 16-byte loads one k-step ahead (registers), rounded to bf16 ONCE as it is written to LDS (v_cvt_pk_bf16_f32) in the
+//    k-contiguous order of the MFMA operands - an operand whose memory order is row-contiguous (dY^T and X of a weight gradient, W of
+//    an input gradient) is transposed in registers, 4 x 4 at a time, on its way in - so a fragment of v_mfma_f32_32x32x16_bf16 is one
+//    ds_read_b128 and the MFMA loop holds no conversion (round 3's kernel kept fp32 in LDS and converted eight values per lane per
+//    MFMA).  LDS rows are 80 bytes (32 bf16 + 16 bytes of padding): the sixteen lanes of a ds_read_b128 group then hit sixteen
+//    different 16-byte slots of the 256-byte bank row.
+//  * k_tr_gemm_big: round 3's fp32-in-LDS kernel - the fp32 mode (v_mfma_f32_32x32x2_f32: the arithmetic golden G13 pins) and the
+//    fallback for operands that are not 16-byte aligned (K = 17 time features, 3-wide coordinate heads).
+//
+// Both end in the same fused epilogue (bias, activation, activation derivative, Philox dropout mask, second output) and the same
+// split-K finish: every k-slice writes its fp32 slab, the LAST slice to arrive at the tile's counter (agent-scope release / acquire,
+// cdna_hip_programming.md section 6 guideline 16) adds the slabs in slice order 0 .. S-1 and runs the epilogue - a fixed summation
+// order whatever the arrival order, and no separate reduction launch.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/diffspectra_hip.h"
+#include "../../include/diffspectra_train.h"
+#include "ds_train_common.h"
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+namespace {
+
+#define DST_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? DS_OK : DS_ERR_LAUNCH)
+
+// ------------------------------------------------------------------------------------------------------------------ epilogue
+// One output element.  v = acc + bias; v *= f'(ref) (dact); act: C <- v (pre-activation) and C2 <- drop(f(v)) when C2 is given, else
+// C <- drop(f(v)); no act: C (+)= drop(v).  Column N is the fused row sum (the virtual all-ones column of B).
+__device__ __forceinline__ void epi_store(const dst_gemm_args& g, int row, int col, float acc) {
+  if (col == g.N) {
+    g.rowsum[row] = g.accumulate ? g.rowsum[row] + acc : acc;
+    return;
+  }
+  float v = acc + (g.bias ? g.bias[col] : 0.0f);
+  if (g.dact) v *= dst::act_deriv(g.ref[(int64_t)row * g.ldref + col], g.dact);
+  float keep = 1.0f;
+  if (g.drop_p > 0.0f)
+    keep = dst::dropout_keep(g.drop_seed, g.drop_stream, (int64_t)row * g.drop_ld + col, dst::dropout_threshold(g.drop_p)) ? 1.0f / (1.0f - g.drop_p) : 0.0f;
+  float* c = g.C + (int64_t)row * g.ldc + col;
+  if (g.act) {
+    if (g.C2) {
+      *c = v;
+      g.C2[(int64_t)row * g.ldc2 + col] = dst::act_apply(v, g.act) * keep;
+      return;
+    }
+    v = dst::act_apply(v, g.act);
+  }
+  v *= keep;
+  if (g.accumulate) v += *c;
+  *c = v;
+}
+
+// The wave's TM x TN accumulator tiles (32 x 32 each; rows rbase + 32 i, columns cbase + 32 j) -> memory.  splits > 1: slab, arrival
+// counter, and the last arriver's fixed-order sum.
+template <int TM, int TN>
+__device__ __forceinline__ void finish_tiles(const dst_gemm_args& g, f32x16_t (&acc)[TM][TN], int rbase, int cbase, int splits, int z, int tile,
+                                             int* s_last) {
+  const int lane = threadIdx.x & 63;
+  const int Nx = g.N + (g.rowsum ? 1 : 0);
+  if (splits > 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = cbase + j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+          if (row < g.M && col < Nx) g.partial[((int64_t)z * g.M + row) * Nx + col] = acc[i][j][r];
+        }
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int old = __hip_atomic_fetch_add(&g.counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == splits - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&g.counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
+      }
+      *s_last = last;
+    }
+    __syncthreads();
+    if (!*s_last) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int zz = 0; zz < splits; ++zz)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = cbase + j * 32 + (lane & 31);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+            if (row < g.M && col < Nx) acc[i][j][r] += g.partial[((int64_t)zz * g.M + row) * Nx + col];
+          }
+        }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = cbase + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+        if (row < g.M && col < Nx) epi_store(g, row, col, acc[i][j][r]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ bf16 kernel
+constexpr int BK = 32;       // k-step
+constexpr int LDK = 40;      // bf16 elements per LDS row: 64 bytes of operand + 16 of padding
+
+__device__ __forceinline__ unsigned int pack2(float a, float b) {
+  const bf16x2_t v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned int, v);
+}
+
+// Fetch one ROWS x 32 operand tile into registers.  The operand is addressed as X[row * rs + k * ks] with either ks == 1 ("k-fast": a
+// row of the tile is 128 contiguous bytes; vec4 u of 256-thread pass i covers row u >> 3, k 4 (u & 7) ..) or rs == 1 ("row-fast": the
+// memory order runs along the rows; a thread takes a 4 (rows) x 4 (k) micro-tile, four 16-byte loads, transposed when committed).
+// Out-of-range elements are zero.  ones_row (B only): that row of the tile is the virtual all-ones vector of the fused row sum.
+template <int ROWS>
+__device__ __forceinline__ void fetch_tile(const float* __restrict__ X, int64_t rs, int64_t ks, bool rfast, int row0, int R, int k0, int kend,
+                                           int ones_row, f32x4_t (&v)[4]) {
+  const int tid = threadIdx.x;
+  if (!rfast) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+      const int u = tid + i * 256;
+      const int gr = row0 + (u >> 3), gk = k0 + 4 * (u & 7);
+      f32x4_t t = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (gr < R) {
+        const float* p = X + (int64_t)gr * rs + gk;
+        if (gk + 3 < kend) t = *reinterpret_cast<const f32x4_t*>(p);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gk + e < kend) t[e] = p[e];
+        }
+      } else if (gr == ones_row) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = gk + e < kend ? 1.0f : 0.0f;
+      }
+      v[i] = t;
+    }
+  } else {
+    if (tid < ROWS * 2) {
+      const int kg = tid & 7, rq = tid >> 3;
+      const int gr0 = row0 + 4 * rq;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int gk = k0 + 4 * kg + kk;
+        f32x4_t t = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (gk < kend) {
+          const float* p = X + (int64_t)gk * ks + gr0;
+          if (gr0 + 3 < R) t = *reinterpret_cast<const f32x4_t*>(p);
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (gr0 + e < R) t[e] = p[e];
+          }
+          if (ones_row >= gr0 && ones_row < gr0 + 4) t[ones_row - gr0] = 1.0f;
+        }
+        v[kk] = t;
+      }
+    }
+  }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void commit_tile(unsigned short* __restrict__ Xs, bool rfast, const f32x4_t (&v)[4]) {
+  const int tid = threadIdx.x;
+  if (!rfast) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+      const int u = tid + i * 256;
+      const uint2 w = {pack2(v[i][0], v[i][1]), pack2(v[i][2], v[i][3])};
+      *reinterpret_cast<uint2*>(Xs + (u >> 3) * LDK + 4 * (u & 7)) = w;
+    }
+  } else {
+    if (tid < ROWS * 2) {
+      const int kg = tid & 7, rq = tid >> 3;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const uint2 w = {pack2(v[0][rr], v[1][rr]), pack2(v[2][rr], v[3][rr])};
+        *reinterpret_cast<uint2*>(Xs + (4 * rq + rr) * LDK + 4 * kg) = w;
+      }
+    }
+  }
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void k_tr_gemm_bf16(dst_gemm_args g, int splits, int kchunk, int a_rfast, int b_rfast) {
+  constexpr int BM = 128, TM = 2, TN = BN / 64;
+  __shared__ __attribute__((aligned(16))) unsigned short lds[(BM + BN) * LDK];
+  __shared__ int s_last;
+  unsigned short* As = lds;
+  unsigned short* Bs = lds + BM * LDK;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int z = blockIdx.z;
+  const int kbeg = z * kchunk;
+  const int kend = min(g.K, kbeg + kchunk);
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  // A[m, k] = A[m * a_rs + k * a_cs]; B[k, n] = B[k * b_rs + n * b_cs]: as a (row = n, k) operand its row stride is b_cs, its k stride b_rs
+  const int ones_row = g.rowsum ? g.N : -1;
+  f32x4_t ra[4], rb[4];
+  if (kbeg < kend) {
+    fetch_tile<BM>(g.A, g.a_rs, g.a_cs, a_rfast != 0, m0, g.M, kbeg, kend, -1, ra);
+    fetch_tile<BN>(g.B, g.b_cs, g.b_rs, b_rfast != 0, n0, g.N, kbeg, kend, ones_row, rb);
+  }
+  const int arow = (wm * 64 + (lane & 31)) * LDK + 8 * (lane >> 5);
+  const int brow = (wn * (BN / 2) + (lane & 31)) * LDK + 8 * (lane >> 5);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    commit_tile<BM>(As, a_rfast != 0, ra);
+    commit_tile<BN>(Bs, b_rfast != 0, rb);
+    __syncthreads();
+    if (k0 + BK < kend) {
+      fetch_tile<BM>(g.A, g.a_rs, g.a_cs, a_rfast != 0, m0, g.M, k0 + BK, kend, -1, ra);
+      fetch_tile<BN>(g.B, g.b_cs, g.b_rs, b_rfast != 0, n0, g.N, k0 + BK, kend, ones_row, rb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8_t a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(As + arow + i * 32 * LDK + ks * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + brow + j * 32 * LDK + ks * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  finish_tiles<TM, TN>(g, acc, m0 + wm * 64, n0 + wn * (BN / 2), splits, z, blockIdx.y * gridDim.x + blockIdx.x, &s_last);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ fp32 / unaligned kernel
+// BM x BN per 256-thread workgroup (2 x 2 waves, each (BM/2) x (BN/2) as 32 x 32 MFMA tiles), BK = 16, the next k-slab's global
+// loads in flight (registers) while the current one is multiplied out of LDS; scalar loads by element strides, guards on all three
+// dimensions.  BF16: operands rounded to bf16 as they leave LDS (the fallback of k_tr_gemm_bf16 for unaligned operands).
+template <int BM, int BN, bool BF16>
+__global__ __launch_bounds__(256) void k_tr_gemm_big(dst_gemm_args g, int splits, int kchunk) {
+  constexpr int TM = BM / 64, TN = BN / 64;              // 32 x 32 tiles per wave in each direction (BM, BN in {64, 128})
+  constexpr int LA = BM * 16 / 256, LB = BN * 16 / 256;  // elements per thread per slab
+  __shared__ float As[16][BM + 4];
+  __shared__ float Bs[16][BN + 4];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int z = blockIdx.z;
+  const int kbeg = z * kchunk;
+  const int kend = min(g.K, kbeg + kchunk);
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const bool a_kfast = (g.a_cs == 1), b_nfast = (g.b_cs == 1);
+  float ra[LA], rb[LB];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int e = tid + i * 256;
+      int mm, kk;
+      if (a_kfast) { kk = e & 15; mm = e >> 4; } else { mm = e % BM; kk = e / BM; }
+      const int gm = m0 + mm, gk = k0 + kk;
+      ra[i] = (gm < g.M && gk < kend) ? g.A[(int64_t)gm * g.a_rs + (int64_t)gk * g.a_cs] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int e = tid + i * 256;
+      int nn, kk;
+      if (b_nfast) { nn = e % BN; kk = e / BN; } else { kk = e & 15; nn = e >> 4; }
+      const int gn = n0 + nn, gk = k0 + kk;
+      // column N is the virtual all-ones column of the fused row sum (bias gradient of a weight-gradient product)
+      rb[i] = gk < kend ? (gn < g.N ? g.B[(int64_t)gk * g.b_rs + (int64_t)gn * g.b_cs] : ((g.rowsum && gn == g.N) ? 1.0f : 0.0f)) : 0.0f;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int e = tid + i * 256;
+      int mm, kk;
+      if (a_kfast) { kk = e & 15; mm = e >> 4; } else { mm = e % BM; kk = e / BM; }
+      As[kk][mm] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int e = tid + i * 256;
+      int nn, kk;
+      if (b_nfast) { nn = e % BN; kk = e / BN; } else { kk = e & 15; nn = e >> 4; }
+      Bs[kk][nn] = rb[i];
+    }
+  };
+  if (kbeg < kend) fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    commit();
+    __syncthreads();
+    if (k0 + 16 < kend) fetch(k0 + 16);
+    if constexpr (BF16) {
+      bf16x8_t a8[TM], b8[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a8[i][t] = (__bf16)As[8 * (lane >> 5) + t][wm * (BM / 2) + i * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) b8[j][t] = (__bf16)Bs[8 * (lane >> 5) + t][wn * (BN / 2) + j * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+    } else
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[kk + (lane >> 5)][wm * (BM / 2) + i * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[kk + (lane >> 5)][wn * (BN / 2) + j * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  finish_tiles<TM, TN>(g, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), splits, z, blockIdx.y * gridDim.x + blockIdx.x, &s_last);
+}
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dst_struct_sizes(int64_t* out) {
+  if (!out) return DS_ERR_ARG;
+  out[0] = sizeof(dst_gemm_args);
+  out[1] = sizeof(dst_layout);
+  return DS_OK;
+}
+
+int dst_gemm(const dst_gemm_args* a, void* stream) {
+  if (!a || !a->C || a->M < 0 || a->N < 0 || a->K < 0 || (a->K > 0 && (!a->A || !a->B))) return DS_ERR_ARG;
+  if ((a->dact && !a->ref) || a->act < 0 || a->act > 3 || a->dact < 0 || a->dact > 3 || !(a->drop_p >= 0.0f && a->drop_p < 1.0f)) return DS_ERR_ARG;
+  if (a->act && a->accumulate) return DS_ERR_ARG;                       // an activated output is written, never accumulated
+  if (a->M == 0 || (a->N == 0 && !a->rowsum)) return DS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dst_gemm_args g = *a;
+  const int Nx = g.N + (g.rowsum ? 1 : 0);            // the fused row sum is one more (virtual, all-ones) column of B
+  const bool bf = g.bf16 != 0;
+  // the vector kernel needs every operand either k-contiguous or row-contiguous, 16-byte aligned with a leading stride of whole vec4s
+  auto vec_ok = [](const float* p, int64_t fast, int64_t slow) { return fast == 1 && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (slow & 3) == 0; };
+  const bool a_k = vec_ok(g.A, g.a_cs, g.a_rs), a_r = !a_k && vec_ok(g.A, g.a_rs, g.a_cs);
+  const bool b_k = vec_ok(g.B, g.b_rs, g.b_cs), b_r = !b_k && vec_ok(g.B, g.b_cs, g.b_rs);
+  static const int force_old = env_int("DST_GEMM_OLD", 0), bn_pref = env_int("DST_GEMM_BN", 0), split_target = env_int("DST_GEMM_SPLIT_TILES", 1024);
+  const bool vec = bf && !force_old && (a_k || a_r) && (b_k || b_r) && g.K >= 8;
+  int BM, BN;
+  if (vec) {
+    BM = 128;
+    BN = bn_pref ? bn_pref : (Nx > 64 ? 128 : 64);
+  } else {
+    // 128 x 64 tiles (64 x 64 for short M): 102 VGPRs = four waves per SIMD (round 3: 128 x 128 was 5-12 % slower over a training step)
+    BM = g.M >= 96 ? 128 : 64;
+    BN = 64;
+  }
+  const int tm = (g.M + BM - 1) / BM, tn = (Nx + BN - 1) / BN;
+  const int64_t tiles = (int64_t)tm * tn;
+  const int kq = vec ? BK : 16;
+  int splits = 1;
+  if (g.K >= 1024 && tiles < 512 && g.partial && g.counters && tiles <= 4096) {
+    splits = (int)(split_target / tiles);
+    const int max_by_k = (g.K + 255) / 256;
+    if (splits > max_by_k) splits = max_by_k;
+    const int64_t cap = g.partial_cap / ((int64_t)g.M * Nx);
+    if (splits > cap) splits = (int)cap;
+    if (splits < 1) splits = 1;
+  }
+  int kchunk = ((g.K + splits - 1) / splits + kq - 1) / kq * kq;
+  if (kchunk < kq) kchunk = kq;
+  splits = g.K > 0 ? (g.K + kchunk - 1) / kchunk : 1;
+  const dim3 grid(tn, tm, splits), blk(256);
+  if (vec) {
+    if (BN == 128) hipLaunchKernelGGL((k_tr_gemm_bf16<128>), grid, blk, 0, s, g, splits, kchunk, (int)a_r, (int)b_r);
+    else hipLaunchKernelGGL((k_tr_gemm_bf16<64>), grid, blk, 0, s, g, splits, kchunk, (int)a_r, (int)b_r);
+  } else if (BM == 128) {
+    if (bf) hipLaunchKernelGGL((k_tr_gemm_big<128, 64, true>), grid, blk, 0, s, g, splits, kchunk);
+    else hipLaunchKernelGGL((k_tr_gemm_big<128, 64, false>), grid, blk, 0, s, g, splits, kchunk);
+  } else {
+    if (bf) hipLaunchKernelGGL((k_tr_gemm_big<64, 64, true>), grid, blk, 0, s, g, splits, kchunk);
+    else hipLaunchKernelGGL((k_tr_gemm_big<64, 64, false>), grid, blk, 0, s, g, splits, kchunk);
+  }
+  return DST_CHECK_LAUNCH();
+}
+
+}  // extern "C"

@@ -33,7 +33,9 @@ SILU, GELU, TANH = 1, 2, 3
 class DstGemmArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("a_rs", C.c_int64), ("a_cs", C.c_int64), ("B", C.c_void_p), ("b_rs", C.c_int64), ("b_cs", C.c_int64),
                 ("C", C.c_void_p), ("ldc", C.c_int64), ("bias", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
-                ("accumulate", C.c_int32), ("partial", C.c_void_p), ("partial_cap", C.c_int64), ("bf16", C.c_int32), ("_pad", C.c_int32), ("rowsum", C.c_void_p)]
+                ("accumulate", C.c_int32), ("partial", C.c_void_p), ("partial_cap", C.c_int64), ("bf16", C.c_int32), ("_pad", C.c_int32), ("rowsum", C.c_void_p),
+                ("act", C.c_int32), ("dact", C.c_int32), ("ref", C.c_void_p), ("ldref", C.c_int64), ("C2", C.c_void_p), ("ldc2", C.c_int64),
+                ("drop_p", C.c_float), ("drop_stream", C.c_uint32), ("drop_seed", C.c_uint64), ("drop_ld", C.c_int64), ("counters", C.c_void_p)]
 
 
 class DstLayout(C.Structure):
@@ -55,6 +57,11 @@ def load_train_library() -> C.CDLL:
         lib = E.load_library()
         for name in train_exports():
             getattr(lib, name).restype = C.c_int
+        sizes = (C.c_int64 * 2)()
+        lib.dst_struct_sizes(sizes)
+        mine = [C.sizeof(DstGemmArgs), C.sizeof(DstLayout)]
+        if list(sizes) != mine:
+            raise RuntimeError(f"C-ABI struct layout mismatch (training): library {list(sizes)} vs binding {mine}")
         _lib = lib
     return _lib
 
@@ -91,13 +98,16 @@ class Ops:
         self.lib = load_train_library()
         self.dev = torch.device(device)
         self.scratch = torch.empty(48 * 1024 * 1024, dtype=torch.float32, device=self.dev)     # split-K partials / column sums
+        self.counters = torch.zeros(4096, dtype=torch.int32, device=self.dev)                  # split-K arrival counters (left zero by every call)
         self.bf16 = False      # config.training.precision == 'bf16': every GEMM rounds its operands to bf16 (fp32 accumulate, fp32 storage)
 
     def _s(self):
         return E._stream()
 
     def gemm(self, A: MV, Bm: MV, Cm: MV, ta: bool, tb: bool, bias: Optional[torch.Tensor] = None, acc: bool = False,
-             rowsum: Optional[torch.Tensor] = None):
+             rowsum: Optional[torch.Tensor] = None, act: int = 0, dact: int = 0, ref: Optional[MV] = None, out2: Optional[MV] = None,
+             drop=None):
+        """``drop = (p, seed, stream_id, row_length)``: the Philox dropout mask of element (m, n) is taken at index m * row_length + n."""
         M, K = (A.cols, A.rows) if ta else (A.rows, A.cols)
         a_rs, a_cs = (1, A.ld) if ta else (A.ld, 1)
         K2, N = (Bm.cols, Bm.rows) if tb else (Bm.rows, Bm.cols)
@@ -110,7 +120,16 @@ class Ops:
         args = DstGemmArgs(A=A.ptr, a_rs=a_rs, a_cs=a_cs, B=Bm.ptr, b_rs=b_rs, b_cs=b_cs, C=Cm.ptr, ldc=Cm.ld,
                            bias=None if bias is None else bias.data_ptr(), M=M, N=N, K=K, accumulate=int(acc),
                            partial=self.scratch.data_ptr(), partial_cap=self.scratch.numel(), bf16=int(self.bf16), _pad=0,
-                           rowsum=None if rowsum is None else rowsum.data_ptr())
+                           rowsum=None if rowsum is None else rowsum.data_ptr(), act=act, dact=dact,
+                           ref=None if ref is None else ref.ptr, ldref=0 if ref is None else ref.ld,
+                           C2=None if out2 is None else out2.ptr, ldc2=0 if out2 is None else out2.ld,
+                           drop_p=0.0 if not drop or drop[0] <= 0 else float(drop[0]), drop_stream=0 if not drop else int(drop[2]),
+                           drop_seed=0 if not drop else int(drop[1]), drop_ld=0 if not drop else int(drop[3]),
+                           counters=self.counters.data_ptr())
+        if ref is not None:
+            assert ref.rows == M and ref.cols == N
+        if out2 is not None:
+            assert out2.rows == M and out2.cols == N
         E._check(self.lib.dst_gemm(C.byref(args), self._s()), "dst_gemm")
 
     def colsum(self, X: MV, out: torch.Tensor, acc: bool = False):

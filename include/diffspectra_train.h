@@ -30,14 +30,19 @@
 extern "C" {
 #endif
 
-/* Generic GEMM, fp32 storage, on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32) or - args.bf16 - with bf16-rounded operands on the bf16
- * pipe and fp32 accumulation: C[M,N] (+)= A[M,K] * B[K,N] (+ bias[N]).
+/* Generic GEMM, fp32 storage: C[M,N] (+)= A[M,K] * B[K,N] (+ bias[N]) on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32) or - args.bf16,
+ * BASELINE config 5 - with the operands rounded to bf16 as they are staged into LDS, products on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
  * Element strides make every transpose a view: A[m,k] = A[m*a_rs + k*a_cs], B[k,n] = B[k*b_rs + n*b_cs], C row stride ldc.
  *   Linear forward   Y = X W^T + b : A = X (a_rs = ldx, a_cs = 1), B = W^T (b_rs = 1, b_cs = ldw)
  *   input gradient   dX = dY W     : A = dY,                        B = W   (b_rs = ldw, b_cs = 1)
  *   weight gradient  dW = dY^T X   : A = dY^T (a_rs = 1, a_cs = ldy), B = X (b_rs = ldx, b_cs = 1), K = rows
- * accumulate != 0 adds to C.  Long-K products are split over K into `partial` (caller scratch of partial_cap floats) and
- * reduced in a fixed order: results do not depend on scheduling. */
+ * accumulate != 0 adds to C.  Long-K products are split over K: every slice writes an fp32 slab into `partial` (caller scratch of
+ * partial_cap floats), the slice that arrives last at the tile's entry of `counters` (>= 4096 zero-initialised ints, left zero) adds the
+ * slabs in slice order - a fixed summation order, no second launch.
+ * Fused epilogue, per element (all optional):  v = acc + bias;  dact: v *= f'(ref[m,n]);  act: C = v and C2 = drop(f(v)) when C2 is
+ * given, else C = drop(f(v));  no act: C (+)= drop(v).  f: 1 SiLU, 2 GELU(erf), 3 tanh; f' takes ref = pre-activation (SiLU, GELU) or
+ * ref = tanh output.  drop(x) = x * keep / (1 - p) with the Philox mask of dst_dropout at element index m * drop_ld + n of stream
+ * (drop_seed, drop_stream) - the dropout of dmt.py:114-120 applied where the value is produced, and re-created in the backward. */
 typedef struct dst_gemm_args {
   const float* A; int64_t a_rs, a_cs;
   const float* B; int64_t b_rs, b_cs;
@@ -45,11 +50,19 @@ typedef struct dst_gemm_args {
   const float* bias;
   int32_t M, N, K, accumulate;
   float* partial; int64_t partial_cap;
-  int32_t bf16; int32_t _pad;   /* != 0: operands rounded to bf16, products on v_mfma_f32_32x32x16_bf16, fp32 accumulate (config 5) */
+  int32_t bf16; int32_t _pad;   /* != 0: bf16 products, fp32 accumulate (config 5) */
   float* rowsum;                /* optional [M]: rowsum[m] (+)= sum_k A[m,k] in the same pass (a virtual all-ones column of B): with
                                    A = dY^T this is the bias gradient of the weight-gradient product, no separate column-sum launches */
+  int32_t act, dact;            /* fused activation / activation derivative (0 = none) */
+  const float* ref; int64_t ldref;
+  float* C2; int64_t ldc2;
+  float drop_p; uint32_t drop_stream; uint64_t drop_seed; int64_t drop_ld;
+  int32_t* counters;
 } dst_gemm_args;
 int dst_gemm(const dst_gemm_args* a, void* stream);
+
+/* out[0] = sizeof(dst_gemm_args), out[1] = sizeof(dst_layout): the binding checks its own struct layouts against the library's. */
+int dst_struct_sizes(int64_t* out);
 
 /* out[c] (+)= sum_r X[r*ld + c], two fixed-order stages through `scratch` (bias gradients, per-molecule partial sums). */
 int dst_colsum(const float* X, int64_t ld, int32_t R, int32_t C, float* out, int32_t accumulate, float* scratch,

@@ -85,6 +85,94 @@ def test_train_gemm(ops, gpu_device, M, N, K, ta, tb, bias, acc):
     assert torch.equal(out[:, :2], C0[:, :2]) and torch.equal(out[:, 2 + N:], C0[:, 2 + N:])      # nothing outside the slice is touched
 
 
+
+def _bf(t):
+    return t.bfloat16().double()
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [
+    (300, 256, 128, False, True),        # Linear forward: A k-fast, B k-fast
+    (4100, 64, 256, False, False),       # input gradient: B row-fast (transposed in registers), BN = 64
+    (256, 512, 9000, True, False),       # weight gradient: both row-fast, split over K with the in-kernel reduction
+    (252, 128, 70000, True, False),      # ragged M, long K
+    (130, 132, 40, False, True),         # ragged everything, K not a multiple of the k-step
+    (33, 768, 256, False, True), (1000, 252, 64, False, True), (96, 68, 4096, True, False)])
+def test_train_gemm_bf16_vector_kernel(ops, gpu_device, M, N, K, ta, tb):
+    """The config-5 GEMM (k_tr_gemm_bf16: vec4 loads, bf16 rounding at LDS staging, in-register transposes, in-kernel split-K finish)
+    against the fp64 product of the bf16-rounded operands, in every operand order the training graph uses; bias, accumulate, a fused
+    row sum on the weight-gradient shapes; and the scalar fallback for the same product must agree (same arithmetic, other kernel)."""
+    T, _ = ops
+    o = T.Ops(gpu_device)
+    o.bf16 = True
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    Bm = torch.randn((N, K) if tb else (K, N), generator=g)
+    b = torch.randn(N, generator=g)
+    d = gpu_device
+    ref = _bf(A.t() if ta else A) @ _bf(Bm.t() if tb else Bm)
+    tol = 2e-6 * float(ref.abs().max()) * max(1.0, K ** 0.5 / 4)
+    Cd = torch.full((M, N + 4), 5.0, device=d)
+    use_bias = not ta
+    rs = torch.full((M,), 2.0, device=d) if ta else None
+    o.gemm(T.mv(A.to(d)), T.mv(Bm.to(d)), T.mv(Cd, 4, 4 + N), ta, tb, bias=b.to(d) if use_bias else None, rowsum=rs)
+    want = ref + (b.double() if use_bias else 0.0)
+    assert float((Cd[:, 4:].cpu().double() - want).abs().max()) <= tol, (M, N, K)
+    assert torch.equal(Cd[:, :4].cpu(), torch.full((M, 4), 5.0))
+    if ta:
+        rref = _bf(A.t()).sum(1)
+        assert float((rs.cpu().double() - rref).abs().max()) <= 2e-6 * float(rref.abs().max()) * max(1.0, K ** 0.5 / 4) + 1e-5
+    first = Cd.clone()
+    o.gemm(T.mv(A.to(d)), T.mv(Bm.to(d)), T.mv(Cd, 4, 4 + N), ta, tb, bias=b.to(d) if use_bias else None, acc=True, rowsum=rs)
+    assert float((Cd[:, 4:].cpu().double() - (first[:, 4:].cpu().double() + want)).abs().max()) <= 2 * tol
+    # an operand off the 16-byte grid takes the scalar kernel: same bf16 arithmetic, results within fp32 summation-order noise
+    A1 = torch.zeros(A.numel() + 1, device=d)
+    A1[1:] = A.reshape(-1).to(d)
+    Au = A1[1:].view(A.shape)
+    assert Au.data_ptr() % 16 != 0
+    C2 = torch.zeros(M, N, device=d)
+    o.gemm(T.MV(A1, A.shape[0], A.shape[1], A.shape[1], 1), T.mv(Bm.to(d)), T.mv(C2), ta, tb)
+    assert float((C2.cpu().double() - ref).abs().max()) <= tol
+    assert int(o.counters.abs().sum()) == 0                                     # every split-K episode left its counter at zero
+
+
+@pytest.mark.parametrize("bf16", [True, False])
+def test_train_gemm_fused_epilogues(ops, gpu_device, bf16):
+    """The fused epilogues of dst_gemm against torch: activation with a second output (pre-activation kept for the backward), Philox
+    dropout at the producing GEMM (mask = oracle.philox.dropout_keep at element m * N + n), activation derivative x dropout mask on an
+    input-gradient product, tanh epilogue; in both arithmetic modes (the fp32 mode runs the scalar kernel with the same epilogue)."""
+    from oracle import philox
+    T, _ = ops
+    o = T.Ops(gpu_device)
+    o.bf16 = bf16
+    d = gpu_device
+    g = torch.Generator().manual_seed(5)
+    r = _bf if bf16 else (lambda t: t.double())
+    M, K, N = 777, 64, 128
+    X, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.3, torch.randn(N, generator=g)
+    seed, stream, p = (1 << 40) + 77, 9, 0.1
+    keep = torch.from_numpy(philox.dropout_keep(seed, stream, M * N, p).astype(np.float64)).reshape(M, N) * float(philox.dropout_scale(p))
+    pre = r(X) @ r(W).t() + b.double()
+    tol = 3e-6 * float(pre.abs().max()) * (4.0 if bf16 else 1.0)
+    f1, s1 = torch.zeros(M, N, device=d), torch.zeros(M, N, device=d)
+    o.gemm(T.mv(X.to(d)), T.mv(W.to(d)), T.mv(f1), False, True, bias=b.to(d), act=T.SILU, out2=T.mv(s1), drop=(p, seed, stream, N))
+    assert float((f1.cpu().double() - pre).abs().max()) <= tol
+    assert float((s1.cpu().double() - F.silu(pre) * keep).abs().max()) <= 2 * tol
+    assert abs(float((s1 == 0).float().mean()) - p) < 0.01
+    t1 = torch.zeros(M, N, device=d)
+    o.gemm(T.mv(X.to(d)), T.mv(W.to(d)), T.mv(t1), False, True, act=T.TANH)
+    assert float((t1.cpu().double() - torch.tanh(pre - b.double())).abs().max()) <= tol
+    y = torch.zeros(M, N, device=d)
+    o.gemm(T.mv(X.to(d)), T.mv(W.to(d)), T.mv(y), False, True, bias=b.to(d), drop=(p, seed, stream + 1, N))
+    keep2 = torch.from_numpy(philox.dropout_keep(seed, stream + 1, M * N, p).astype(np.float64)).reshape(M, N) * float(philox.dropout_scale(p))
+    assert float((y.cpu().double() - pre * keep2).abs().max()) <= tol
+    # backward of s1 = drop(silu(f1)): ds -> df1 = (dy W2) * mask * silu'(f1), as one input-gradient product
+    W2, dy = torch.randn(96, N, generator=g) * 0.2, torch.randn(M, 96, generator=g)
+    df1 = torch.zeros(M, N, device=d)
+    o.gemm(T.mv(dy.to(d)), T.mv(W2.to(d)), T.mv(df1), False, False, dact=T.SILU, ref=T.mv(f1), drop=(p, seed, stream, N))
+    f1r = f1.cpu().double().requires_grad_(True)
+    (F.silu(f1r) * keep * (r(dy) @ r(W2))).sum().backward()
+    assert float((df1.cpu().double() - f1r.grad).abs().max()) <= 4e-6 * float(f1r.grad.abs().max()) * (4.0 if bf16 else 1.0)
+
 @pytest.mark.parametrize("M,N,K", [(64, 64, 300), (252, 127, 9000), (6, 1024, 70), (130, 256, 40000)])
 def test_train_gemm_fused_rowsum(ops, gpu_device, M, N, K):
     """dW = dY^T X with db = column sums of dY in the same launch (a virtual all-ones column of B), incl. the split-K path and accumulate."""

@@ -10,6 +10,7 @@
 
 #include "../../include/diffspectra_hip.h"
 #include "../../include/diffspectra_train.h"
+#include "ds_train_common.h"
 
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
@@ -114,118 +115,132 @@ __global__ void k_dropout(const float* __restrict__ x, float* __restrict__ y, in
 }
 
 // ------------------------------------------------------------------------------------------------------------------ LN + modulate
+// The molecule-level row kernels (LayerNorm + modulate, gated residual): one 1024-thread workgroup per molecule - its rows are
+// contiguous and the adaLN gradients are sums over exactly those rows, reduced here in a fixed order.  A lane owns four consecutive
+// columns (16-byte accesses): a 256-wide row is one wave, four 64-wide rows share a wave (16 lanes each, 16-lane reductions).
+// Round 3 ran these with 256 threads and 4-byte accesses: one workgroup per CU at four waves left the memory pipe idle (60 - 190 us
+// per launch on the directed rows; the rows of 256 molecules are 250 MB).
+constexpr int MOLW = 16;                                   // waves per molecule workgroup
+typedef float f4_t __attribute__((ext_vector_type(4)));
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {      // sum over aligned groups of G lanes
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ f4_t ld4(const float* p) { return *reinterpret_cast<const f4_t*>(p); }
+__device__ __forceinline__ void st4(float* p, f4_t v) { *reinterpret_cast<f4_t*>(p) = v; }
+
 template <int C>
-__global__ __launch_bounds__(256) void k_lnmod_fwd(const float* __restrict__ x, const int32_t* __restrict__ seg_off, int seg_mul,
-                                                    const float* __restrict__ ada, int64_t ada_ld, int shift_off, int scale_off,
-                                                    float* __restrict__ y, float* __restrict__ stats) {
-  constexpr int V = C / 64;
+__global__ __launch_bounds__(1024) void k_lnmod_fwd(const float* __restrict__ x, const int32_t* __restrict__ seg_off, int seg_mul,
+                                                     const float* __restrict__ ada, int64_t ada_ld, int shift_off, int scale_off,
+                                                     float* __restrict__ y, float* __restrict__ stats) {
+  constexpr int LPR = C / 4, RPW = 64 / LPR;               // lanes per row, rows per wave
   const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane / LPR, cl = (lane % LPR) * 4;
   const int r0 = seg_off[m] * seg_mul, r1 = seg_off[m + 1] * seg_mul;
-  float sh[V], sc[V];
-#pragma unroll
-  for (int j = 0; j < V; ++j) {
-    sh[j] = ada[(int64_t)m * ada_ld + shift_off + lane + 64 * j];
-    sc[j] = ada[(int64_t)m * ada_ld + scale_off + lane + 64 * j];
-  }
-  for (int r = r0 + wave; r < r1; r += 4) {
-    float v[V], s = 0.0f;
-#pragma unroll
-    for (int j = 0; j < V; ++j) { v[j] = x[(int64_t)r * C + lane + 64 * j]; s += v[j]; }
-    const float mean = wave_sum(s) * (1.0f / C);
-    float q = 0.0f;
-#pragma unroll
-    for (int j = 0; j < V; ++j) { const float d = v[j] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + 1e-6f);
-#pragma unroll
-    for (int j = 0; j < V; ++j) y[(int64_t)r * C + lane + 64 * j] = ((v[j] - mean) * rstd) * (1.0f + sc[j]) + sh[j];
-    if (lane == 0) { stats[(int64_t)r * 2] = mean; stats[(int64_t)r * 2 + 1] = rstd; }
+  const f4_t sh = ld4(ada + (int64_t)m * ada_ld + shift_off + cl), sc = ld4(ada + (int64_t)m * ada_ld + scale_off + cl);
+  for (int r = r0 + wave * RPW + sub; r < r1; r += MOLW * RPW) {
+    const f4_t v = ld4(x + (int64_t)r * C + cl);
+    const float mean = group_sum<LPR>((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / C);
+    const f4_t d = v - mean;
+    const float rstd = 1.0f / sqrtf(group_sum<LPR>((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / C) + 1e-6f);
+    st4(y + (int64_t)r * C + cl, (d * rstd) * (1.0f + sc) + sh);
+    if (lane % LPR == 0) { stats[(int64_t)r * 2] = mean; stats[(int64_t)r * 2 + 1] = rstd; }
   }
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void k_lnmod_bwd(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
-                                                    const int32_t* __restrict__ seg_off, int seg_mul, const float* __restrict__ ada,
-                                                    float* __restrict__ d_ada, int64_t ada_ld, int shift_off, int scale_off,
-                                                    float* __restrict__ dx, int accumulate) {
-  constexpr int V = C / 64;
-  __shared__ float red[2][4][C];
+__global__ __launch_bounds__(1024) void k_lnmod_bwd(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
+                                                     const int32_t* __restrict__ seg_off, int seg_mul, const float* __restrict__ ada,
+                                                     float* __restrict__ d_ada, int64_t ada_ld, int shift_off, int scale_off,
+                                                     float* __restrict__ dx, int accumulate) {
+  constexpr int LPR = C / 4, RPW = 64 / LPR, SLOTS = MOLW * RPW;
+  __shared__ float red[2][SLOTS][C];
   const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane / LPR, cl = (lane % LPR) * 4;
   const int r0 = seg_off[m] * seg_mul, r1 = seg_off[m + 1] * seg_mul;
-  float sc[V], dsh[V], dsc[V];
-#pragma unroll
-  for (int j = 0; j < V; ++j) { sc[j] = ada[(int64_t)m * ada_ld + scale_off + lane + 64 * j]; dsh[j] = 0.0f; dsc[j] = 0.0f; }
-  for (int r = r0 + wave; r < r1; r += 4) {
+  const f4_t sc1 = ld4(ada + (int64_t)m * ada_ld + scale_off + cl) + 1.0f;
+  f4_t dsh = {0.0f, 0.0f, 0.0f, 0.0f}, dsc = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int r = r0 + wave * RPW + sub; r < r1; r += MOLW * RPW) {
     const float mean = stats[(int64_t)r * 2], rstd = stats[(int64_t)r * 2 + 1];
-    float xh[V], gg[V], s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      const float g = dy[(int64_t)r * C + lane + 64 * j];
-      xh[j] = (x[(int64_t)r * C + lane + 64 * j] - mean) * rstd;
-      dsh[j] += g;
-      dsc[j] += g * xh[j];
-      gg[j] = g * (1.0f + sc[j]);
-      s1 += gg[j];
-      s2 += gg[j] * xh[j];
-    }
-    const float m1 = wave_sum(s1) * (1.0f / C), m2 = wave_sum(s2) * (1.0f / C);
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      const float d = rstd * (gg[j] - m1 - xh[j] * m2);
-      float* o = dx + (int64_t)r * C + lane + 64 * j;
-      *o = accumulate ? *o + d : d;
-    }
+    const f4_t g = ld4(dy + (int64_t)r * C + cl);
+    const f4_t xh = (ld4(x + (int64_t)r * C + cl) - mean) * rstd;
+    dsh += g;
+    dsc += g * xh;
+    const f4_t gg = g * sc1, gx = gg * xh;
+    const float m1 = group_sum<LPR>((gg[0] + gg[1]) + (gg[2] + gg[3])) * (1.0f / C);
+    const float m2 = group_sum<LPR>((gx[0] + gx[1]) + (gx[2] + gx[3])) * (1.0f / C);
+    f4_t d = rstd * (gg - m1 - xh * m2);
+    float* o = dx + (int64_t)r * C + cl;
+    if (accumulate) d += ld4(o);
+    st4(o, d);
   }
-#pragma unroll
-  for (int j = 0; j < V; ++j) { red[0][wave][lane + 64 * j] = dsh[j]; red[1][wave][lane + 64 * j] = dsc[j]; }
+  st4(&red[0][wave * RPW + sub][cl], dsh);
+  st4(&red[1][wave * RPW + sub][cl], dsc);
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    d_ada[(int64_t)m * ada_ld + shift_off + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-    d_ada[(int64_t)m * ada_ld + scale_off + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+  for (int c = threadIdx.x; c < 2 * C; c += MOLW * 64) {
+    const int w = c / C, cc = c % C;
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) t += red[w][k][cc];
+    d_ada[(int64_t)m * ada_ld + (w ? scale_off : shift_off) + cc] = t;
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ gated residual
 template <int C>
-__global__ __launch_bounds__(256) void k_gate_add_fwd(const float* __restrict__ r_, const float* __restrict__ z, const int32_t* __restrict__ seg_off,
-                                                       int seg_mul, const float* __restrict__ ada, int64_t ada_ld, int gate_off,
-                                                       float* __restrict__ out) {
-  constexpr int V = C / 64;
+__global__ __launch_bounds__(1024) void k_gate_add_fwd(const float* __restrict__ r_, const float* __restrict__ z, const int32_t* __restrict__ seg_off,
+                                                        int seg_mul, const float* __restrict__ ada, int64_t ada_ld, int gate_off,
+                                                        float* __restrict__ out) {
+  constexpr int LPR = C / 4, RPW = 64 / LPR;
   const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane / LPR, cl = (lane % LPR) * 4;
   const int r0 = seg_off[m] * seg_mul, r1 = seg_off[m + 1] * seg_mul;
-  float g[V];
-#pragma unroll
-  for (int j = 0; j < V; ++j) g[j] = ada[(int64_t)m * ada_ld + gate_off + lane + 64 * j];
-  for (int r = r0 + wave; r < r1; r += 4)
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      const int64_t i = (int64_t)r * C + lane + 64 * j;
-      out[i] = r_[i] + g[j] * z[i];
-    }
+  const f4_t g = ld4(ada + (int64_t)m * ada_ld + gate_off + cl);
+  for (int r = r0 + wave * RPW + sub; r < r1; r += MOLW * RPW) {
+    const int64_t i = (int64_t)r * C + cl;
+    st4(out + i, ld4(r_ + i) + g * ld4(z + i));
+  }
 }
+// dz = gate * dout, optionally times the dropout mask of the tensor z was (drop_p > 0: z = drop(.) in the forward, dmt.py:116,120 - the
+// mask of element (r, c) is Philox block (r * C + c) / 4 of stream (seed, stream_id), the four columns of a lane are one block)
 template <int C>
-__global__ __launch_bounds__(256) void k_gate_add_bwd(const float* __restrict__ dout, const float* __restrict__ z, const int32_t* __restrict__ seg_off,
-                                                       int seg_mul, const float* __restrict__ ada, float* __restrict__ d_ada, int64_t ada_ld,
-                                                       int gate_off, float* __restrict__ dr, int accumulate_r, float* __restrict__ dz) {
-  constexpr int V = C / 64;
-  __shared__ float red[4][C];
+__global__ __launch_bounds__(1024) void k_gate_add_bwd(const float* __restrict__ dout, const float* __restrict__ z, const int32_t* __restrict__ seg_off,
+                                                        int seg_mul, const float* __restrict__ ada, float* __restrict__ d_ada, int64_t ada_ld,
+                                                        int gate_off, float* __restrict__ dr, int accumulate_r, float* __restrict__ dz, float drop_p,
+                                                        unsigned long long drop_seed, unsigned int drop_stream) {
+  constexpr int LPR = C / 4, RPW = 64 / LPR, SLOTS = MOLW * RPW;
+  __shared__ float red[SLOTS][C];
   const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane / LPR, cl = (lane % LPR) * 4;
   const int r0 = seg_off[m] * seg_mul, r1 = seg_off[m + 1] * seg_mul;
-  float g[V], dg[V];
+  const f4_t g = ld4(ada + (int64_t)m * ada_ld + gate_off + cl);
+  const unsigned int thr = dst::dropout_threshold(drop_p);
+  const float keep_scale = 1.0f / (1.0f - drop_p);
+  f4_t dg = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int r = r0 + wave * RPW + sub; r < r1; r += MOLW * RPW) {
+    const int64_t i = (int64_t)r * C + cl;
+    const f4_t d = ld4(dout + i);
+    dg += d * ld4(z + i);
+    f4_t o = g * d;
+    if (drop_p > 0.0f) {
+      unsigned int w[4];
+      dst::dropout_block(drop_seed, drop_stream, i >> 2, w);
 #pragma unroll
-  for (int j = 0; j < V; ++j) { g[j] = ada[(int64_t)m * ada_ld + gate_off + lane + 64 * j]; dg[j] = 0.0f; }
-  for (int r = r0 + wave; r < r1; r += 4)
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      const int64_t i = (int64_t)r * C + lane + 64 * j;
-      const float d = dout[i];
-      dg[j] += d * z[i];
-      dz[i] = g[j] * d;
-      if (dr) dr[i] = accumulate_r ? dr[i] + d : d;
+      for (int e = 0; e < 4; ++e) o[e] = w[e] >= thr ? o[e] * keep_scale : 0.0f;
     }
-#pragma unroll
-  for (int j = 0; j < V; ++j) red[wave][lane + 64 * j] = dg[j];
+    st4(dz + i, o);
+    if (dr) st4(dr + i, accumulate_r ? ld4(dr + i) + d : d);
+  }
+  st4(&red[wave * RPW + sub][cl], dg);
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) d_ada[(int64_t)m * ada_ld + gate_off + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  for (int c = threadIdx.x; c < C; c += MOLW * 64) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) t += red[k][c];
+    d_ada[(int64_t)m * ada_ld + gate_off + c] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ geometry
@@ -1281,8 +1296,8 @@ int dst_lnmod_fwd(const float* x, int32_t C, const int32_t* seg_off, int32_t seg
                   int32_t shift_off, int32_t scale_off, float* y, float* stats, void* stream) {
   if (!x || !seg_off || !ada || !y || !stats || (C != 64 && C != 256) || B <= 0) return DS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (C == 64) hipLaunchKernelGGL(k_lnmod_fwd<64>, dim3(B), dim3(256), 0, s, x, seg_off, (int)seg_mul, ada, ada_ld, (int)shift_off, (int)scale_off, y, stats);
-  else hipLaunchKernelGGL(k_lnmod_fwd<256>, dim3(B), dim3(256), 0, s, x, seg_off, (int)seg_mul, ada, ada_ld, (int)shift_off, (int)scale_off, y, stats);
+  if (C == 64) hipLaunchKernelGGL(k_lnmod_fwd<64>, dim3(B), dim3(1024), 0, s, x, seg_off, (int)seg_mul, ada, ada_ld, (int)shift_off, (int)scale_off, y, stats);
+  else hipLaunchKernelGGL(k_lnmod_fwd<256>, dim3(B), dim3(1024), 0, s, x, seg_off, (int)seg_mul, ada, ada_ld, (int)shift_off, (int)scale_off, y, stats);
   return DST_CHECK_LAUNCH();
 }
 int dst_lnmod_bwd(const float* dy, const float* x, const float* stats, int32_t C, const int32_t* seg_off, int32_t seg_mul, int32_t B,
@@ -1291,9 +1306,9 @@ int dst_lnmod_bwd(const float* dy, const float* x, const float* stats, int32_t C
   if (!dy || !x || !stats || !seg_off || !ada || !d_ada || !dx || (C != 64 && C != 256) || B <= 0) return DS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (C == 64)
-    hipLaunchKernelGGL(k_lnmod_bwd<64>, dim3(B), dim3(256), 0, s, dy, x, stats, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)shift_off, (int)scale_off, dx, (int)accumulate);
+    hipLaunchKernelGGL(k_lnmod_bwd<64>, dim3(B), dim3(1024), 0, s, dy, x, stats, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)shift_off, (int)scale_off, dx, (int)accumulate);
   else
-    hipLaunchKernelGGL(k_lnmod_bwd<256>, dim3(B), dim3(256), 0, s, dy, x, stats, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)shift_off, (int)scale_off, dx, (int)accumulate);
+    hipLaunchKernelGGL(k_lnmod_bwd<256>, dim3(B), dim3(1024), 0, s, dy, x, stats, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)shift_off, (int)scale_off, dx, (int)accumulate);
   return DST_CHECK_LAUNCH();
 }
 
@@ -1301,18 +1316,19 @@ int dst_gate_add_fwd(const float* r, const float* z, int32_t C, const int32_t* s
                      int64_t ada_ld, int32_t gate_off, float* out, void* stream) {
   if (!r || !z || !seg_off || !ada || !out || (C != 64 && C != 256) || B <= 0) return DS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (C == 64) hipLaunchKernelGGL(k_gate_add_fwd<64>, dim3(B), dim3(256), 0, s, r, z, seg_off, (int)seg_mul, ada, ada_ld, (int)gate_off, out);
-  else hipLaunchKernelGGL(k_gate_add_fwd<256>, dim3(B), dim3(256), 0, s, r, z, seg_off, (int)seg_mul, ada, ada_ld, (int)gate_off, out);
+  if (C == 64) hipLaunchKernelGGL(k_gate_add_fwd<64>, dim3(B), dim3(1024), 0, s, r, z, seg_off, (int)seg_mul, ada, ada_ld, (int)gate_off, out);
+  else hipLaunchKernelGGL(k_gate_add_fwd<256>, dim3(B), dim3(1024), 0, s, r, z, seg_off, (int)seg_mul, ada, ada_ld, (int)gate_off, out);
   return DST_CHECK_LAUNCH();
 }
 int dst_gate_add_bwd(const float* dout, const float* z, int32_t C, const int32_t* seg_off, int32_t seg_mul, int32_t B, const float* ada,
-                     float* d_ada, int64_t ada_ld, int32_t gate_off, float* dr, int32_t accumulate_r, float* dz, void* stream) {
-  if (!dout || !z || !seg_off || !ada || !d_ada || !dz || (C != 64 && C != 256) || B <= 0) return DS_ERR_ARG;
+                     float* d_ada, int64_t ada_ld, int32_t gate_off, float* dr, int32_t accumulate_r, float* dz, float drop_p, uint64_t drop_seed,
+                     uint32_t drop_stream, void* stream) {
+  if (!dout || !z || !seg_off || !ada || !d_ada || !dz || (C != 64 && C != 256) || B <= 0 || !(drop_p >= 0.0f && drop_p < 1.0f)) return DS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (C == 64)
-    hipLaunchKernelGGL(k_gate_add_bwd<64>, dim3(B), dim3(256), 0, s, dout, z, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)gate_off, dr, (int)accumulate_r, dz);
+    hipLaunchKernelGGL(k_gate_add_bwd<64>, dim3(B), dim3(1024), 0, s, dout, z, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)gate_off, dr, (int)accumulate_r, dz, drop_p, (unsigned long long)drop_seed, (unsigned int)drop_stream);
   else
-    hipLaunchKernelGGL(k_gate_add_bwd<256>, dim3(B), dim3(256), 0, s, dout, z, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)gate_off, dr, (int)accumulate_r, dz);
+    hipLaunchKernelGGL(k_gate_add_bwd<256>, dim3(B), dim3(1024), 0, s, dout, z, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)gate_off, dr, (int)accumulate_r, dz, drop_p, (unsigned long long)drop_seed, (unsigned int)drop_stream);
   return DST_CHECK_LAUNCH();
 }
 

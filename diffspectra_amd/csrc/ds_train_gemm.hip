@@ -13,10 +13,11 @@
 //  * k_tr_gemm_big: round 3's fp32-in-LDS kernel - the fp32 mode (v_mfma_f32_32x32x2_f32: the arithmetic golden G13 pins) and the
 //    fallback for operands that are not 16-byte aligned (K = 17 time features, 3-wide coordinate heads).
 //
-// Both end in the same fused epilogue (bias, activation, activation derivative, Philox dropout mask, second output) and the same
-// split-K finish: every k-slice writes its fp32 slab, the LAST slice to arrive at the tile's counter (agent-scope release / acquire,
-// cdna_hip_programming.md section 6 guideline 16) adds the slabs in slice order 0 .. S-1 and runs the epilogue - a fixed summation
-// order whatever the arrival order, and no separate reduction launch.
+// Both end in the same fused epilogue (bias, activation, activation derivative, Philox dropout mask, second output).  A long-K product
+// (weight gradients: K = rows) is split over K: every slice writes its fp32 slab and k_tr_gemm_reduce adds the slabs in slice order
+// 0 .. S-1 and runs the epilogue - a fixed summation order.  (Tried and measured on the MI355X: the reduction inside the GEMM launch by
+// the slice that arrives last at a per-tile counter - one workgroup then reads 128 slabs of its tile serially, 1.2 ms for a 256 x 256
+// weight gradient over 80 800 rows against ~0.1 ms with the reduction spread over the chip.)
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -38,12 +39,9 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------------ epilogue
 // One output element.  v = acc + bias; v *= f'(ref) (dact); act: C <- v (pre-activation) and C2 <- drop(f(v)) when C2 is given, else
 // C <- drop(f(v)); no act: C (+)= drop(v).  Column N is the fused row sum (the virtual all-ones column of B).
-__device__ __forceinline__ void epi_store(const dst_gemm_args& g, int row, int col, float acc) {
-  if (col == g.N) {
-    g.rowsum[row] = g.accumulate ? g.rowsum[row] + acc : acc;
-    return;
-  }
-  float v = acc + (g.bias ? g.bias[col] : 0.0f);
+// The activation / dropout form is a CALL (one copy of its transcendental and Philox code per kernel): inlined at every one of a lane's
+// 32 - 64 output elements it made the kernels instruction-cache bound (the 128 x 128 tile ran 3x slower than the 128 x 64 one).
+__device__ __noinline__ void epi_fused(const dst_gemm_args& g, int row, int col, float v) {
   if (g.dact) v *= dst::act_deriv(g.ref[(int64_t)row * g.ldref + col], g.dact);
   float keep = 1.0f;
   if (g.drop_p > 0.0f)
@@ -61,61 +59,24 @@ __device__ __forceinline__ void epi_store(const dst_gemm_args& g, int row, int c
   if (g.accumulate) v += *c;
   *c = v;
 }
+__device__ __forceinline__ void epi_store(const dst_gemm_args& g, bool fused, int row, int col, float acc) {
+  if (col == g.N) {
+    g.rowsum[row] = g.accumulate ? g.rowsum[row] + acc : acc;
+    return;
+  }
+  const float v = acc + (g.bias ? g.bias[col] : 0.0f);
+  if (fused) { epi_fused(g, row, col, v); return; }
+  float* c = g.C + (int64_t)row * g.ldc + col;
+  *c = g.accumulate ? v + *c : v;
+}
 
-// The wave's TM x TN accumulator tiles (32 x 32 each; rows rbase + 32 i, columns cbase + 32 j) -> memory.  splits > 1: slab, arrival
-// counter, and the last arriver's fixed-order sum.
+// The wave's TM x TN accumulator tiles (32 x 32 each; rows rbase + 32 i, columns cbase + 32 j) -> memory: the output through the
+// epilogue, or - split over K - slice z's fp32 slab (k_tr_gemm_reduce adds the slabs in slice order and runs the epilogue).
 template <int TM, int TN>
-__device__ __forceinline__ void finish_tiles(const dst_gemm_args& g, f32x16_t (&acc)[TM][TN], int rbase, int cbase, int splits, int z, int tile,
-                                             int* s_last) {
+__device__ __forceinline__ void finish_tiles(const dst_gemm_args& g, f32x16_t (&acc)[TM][TN], int rbase, int cbase, int splits, int z) {
   const int lane = threadIdx.x & 63;
   const int Nx = g.N + (g.rowsum ? 1 : 0);
-  if (splits > 1) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = cbase + j * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
-          if (row < g.M && col < Nx) g.partial[((int64_t)z * g.M + row) * Nx + col] = acc[i][j][r];
-        }
-      }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int old = __hip_atomic_fetch_add(&g.counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = old == splits - 1;
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&g.counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
-      }
-      *s_last = last;
-    }
-    __syncthreads();
-    if (!*s_last) return;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    for (int zz = 0; zz < splits; ++zz)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int col = cbase + j * 32 + (lane & 31);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = rbase + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
-            if (row < g.M && col < Nx) acc[i][j][r] += g.partial[((int64_t)zz * g.M + row) * Nx + col];
-          }
-        }
-  }
+  const bool fused = g.act || g.dact || g.drop_p > 0.0f;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -124,9 +85,51 @@ __device__ __forceinline__ void finish_tiles(const dst_gemm_args& g, f32x16_t (&
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rbase + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
-        if (row < g.M && col < Nx) epi_store(g, row, col, acc[i][j][r]);
+        if (row < g.M && col < Nx) {
+          if (splits > 1) g.partial[((int64_t)z * g.M + row) * Nx + col] = acc[i][j][r];
+          else epi_store(g, fused, row, col, acc[i][j][r]);
+        }
       }
     }
+}
+
+// Workgroup -> (k-slice, m-tile, n-tile).  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so linear ids
+// L, L + 8, L + 16 .. share an L2: those walk the `inner` tiles that read the same operand rows - the n-tiles of one m-tile (A rows;
+// without it a 256-wide output fetched A four times from HBM, once per XCD), or every tile of one k-slice of a split product.
+// Speed only: any placement computes the same result.  false = padding workgroup (outer index beyond the range).
+__device__ __forceinline__ bool tile_of_block(int tm, int tn, int splits, int& z, int& mt, int& nt) {
+  const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const int inner = splits > 1 ? tm * tn : tn, outer_n = splits > 1 ? splits : tm;
+  const int outer = (slot / inner) * 8 + xcd, in = slot % inner;
+  if (outer >= outer_n) return false;
+  if (splits > 1) { z = outer; mt = in / tn; nt = in % tn; }
+  else { z = 0; mt = outer; nt = in; }
+  return true;
+}
+
+// sum of the k-slices' slabs in slice order, then the epilogue: four consecutive columns per thread
+__global__ __launch_bounds__(256) void k_tr_gemm_reduce(dst_gemm_args g, int splits) {
+  const int Nx = g.N + (g.rowsum ? 1 : 0);
+  const int64_t total = (int64_t)g.M * Nx;
+  const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i0 >= total) return;
+  const bool fused = g.act || g.dact || g.drop_p > 0.0f;
+  float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (i0 + 3 < total && (total & 3) == 0) {
+    for (int z = 0; z < splits; ++z) {
+      const f32x4_t t = *reinterpret_cast<const f32x4_t*>(g.partial + (int64_t)z * total + i0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += t[e];
+    }
+  } else {
+    for (int z = 0; z < splits; ++z)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (i0 + e < total) v[e] += g.partial[(int64_t)z * total + i0 + e];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (i0 + e < total) epi_store(g, fused, (int)((i0 + e) / Nx), (int)((i0 + e) % Nx), v[e]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ bf16 kernel
@@ -212,17 +215,17 @@ __device__ __forceinline__ void commit_tile(unsigned short* __restrict__ Xs, boo
   }
 }
 
-template <int BN>
-__global__ __launch_bounds__(256) void k_tr_gemm_bf16(dst_gemm_args g, int splits, int kchunk, int a_rfast, int b_rfast) {
-  constexpr int BM = 128, TM = 2, TN = BN / 64;
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_tr_gemm_bf16(dst_gemm_args g, int splits, int kchunk, int a_rfast, int b_rfast, int tm, int tn) {
+  constexpr int TM = BM / 64, TN = BN / 64;
   __shared__ __attribute__((aligned(16))) unsigned short lds[(BM + BN) * LDK];
-  __shared__ int s_last;
   unsigned short* As = lds;
   unsigned short* Bs = lds + BM * LDK;
+  int z, mt, nt;
+  if (!tile_of_block(tm, tn, splits, z, mt, nt)) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int z = blockIdx.z;
+  const int m0 = mt * BM, n0 = nt * BN;
   const int kbeg = z * kchunk;
   const int kend = min(g.K, kbeg + kchunk);
   f32x16_t acc[TM][TN];
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256) void k_tr_gemm_bf16(dst_gemm_args g, int split
     fetch_tile<BM>(g.A, g.a_rs, g.a_cs, a_rfast != 0, m0, g.M, kbeg, kend, -1, ra);
     fetch_tile<BN>(g.B, g.b_cs, g.b_rs, b_rfast != 0, n0, g.N, kbeg, kend, ones_row, rb);
   }
-  const int arow = (wm * 64 + (lane & 31)) * LDK + 8 * (lane >> 5);
+  const int arow = (wm * (BM / 2) + (lane & 31)) * LDK + 8 * (lane >> 5);
   const int brow = (wn * (BN / 2) + (lane & 31)) * LDK + 8 * (lane >> 5);
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     commit_tile<BM>(As, a_rfast != 0, ra);
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256) void k_tr_gemm_bf16(dst_gemm_args g, int split
     }
     __syncthreads();
   }
-  finish_tiles<TM, TN>(g, acc, m0 + wm * 64, n0 + wn * (BN / 2), splits, z, blockIdx.y * gridDim.x + blockIdx.x, &s_last);
+  finish_tiles<TM, TN>(g, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), splits, z);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ fp32 / unaligned kernel
@@ -271,16 +274,16 @@ __global__ __launch_bounds__(256) void k_tr_gemm_bf16(dst_gemm_args g, int split
 // loads in flight (registers) while the current one is multiplied out of LDS; scalar loads by element strides, guards on all three
 // dimensions.  BF16: operands rounded to bf16 as they leave LDS (the fallback of k_tr_gemm_bf16 for unaligned operands).
 template <int BM, int BN, bool BF16>
-__global__ __launch_bounds__(256) void k_tr_gemm_big(dst_gemm_args g, int splits, int kchunk) {
+__global__ __launch_bounds__(256) void k_tr_gemm_big(dst_gemm_args g, int splits, int kchunk, int tm, int tn) {
   constexpr int TM = BM / 64, TN = BN / 64;              // 32 x 32 tiles per wave in each direction (BM, BN in {64, 128})
   constexpr int LA = BM * 16 / 256, LB = BN * 16 / 256;  // elements per thread per slab
   __shared__ float As[16][BM + 4];
   __shared__ float Bs[16][BN + 4];
-  __shared__ int s_last;
+  int z, mt, nt;
+  if (!tile_of_block(tm, tn, splits, z, mt, nt)) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int z = blockIdx.z;
+  const int m0 = mt * BM, n0 = nt * BN;
   const int kbeg = z * kchunk;
   const int kend = min(g.K, kbeg + kchunk);
   f32x16_t acc[TM][TN];
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(256) void k_tr_gemm_big(dst_gemm_args g, int splits
     }
     __syncthreads();
   }
-  finish_tiles<TM, TN>(g, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), splits, z, blockIdx.y * gridDim.x + blockIdx.x, &s_last);
+  finish_tiles<TM, TN>(g, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), splits, z);
 }
 
 int env_int(const char* name, int dflt) {
@@ -393,12 +396,19 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   auto vec_ok = [](const float* p, int64_t fast, int64_t slow) { return fast == 1 && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (slow & 3) == 0; };
   const bool a_k = vec_ok(g.A, g.a_cs, g.a_rs), a_r = !a_k && vec_ok(g.A, g.a_rs, g.a_cs);
   const bool b_k = vec_ok(g.B, g.b_rs, g.b_cs), b_r = !b_k && vec_ok(g.B, g.b_cs, g.b_rs);
-  static const int force_old = env_int("DST_GEMM_OLD", 0), bn_pref = env_int("DST_GEMM_BN", 0), split_target = env_int("DST_GEMM_SPLIT_TILES", 1024);
+  static const int force_old = env_int("DST_GEMM_OLD", 0), bn_pref = env_int("DST_GEMM_BN", 0), bm_pref = env_int("DST_GEMM_BM", 0),
+                   split_target = env_int("DST_GEMM_SPLIT_WGS", 1024), wg_target = env_int("DST_GEMM_WGS", 768);
   const bool vec = bf && !force_old && (a_k || a_r) && (b_k || b_r) && g.K >= 8;
   int BM, BN;
   if (vec) {
-    BM = 128;
+    // tiles sized so that the launch has at least ~3 workgroups per CU where the problem allows it: the k-loop of a workgroup exposes
+    // one memory round trip per step, and what hides it is the neighbours on the CU (24 - 32 kB in flight per workgroup and step)
     BN = bn_pref ? bn_pref : (Nx > 64 ? 128 : 64);
+    BM = 128;
+    auto count = [&](int bm, int bn) { return (int64_t)((g.M + bm - 1) / bm) * ((Nx + bn - 1) / bn); };
+    if (!bn_pref && BN == 128 && count(BM, BN) < wg_target) BN = 64;
+    if (count(BM, BN) < wg_target && g.K < 1024) BM = 64;
+    if (bm_pref) BM = bm_pref;
   } else {
     // 128 x 64 tiles (64 x 64 for short M): 102 VGPRs = four waves per SIMD (round 3: 128 x 128 was 5-12 % slower over a training step)
     BM = g.M >= 96 ? 128 : 64;
@@ -408,7 +418,7 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   const int64_t tiles = (int64_t)tm * tn;
   const int kq = vec ? BK : 16;
   int splits = 1;
-  if (g.K >= 1024 && tiles < 512 && g.partial && g.counters && tiles <= 4096) {
+  if (g.K >= 1024 && tiles < 512 && g.partial) {
     splits = (int)(split_target / tiles);
     const int max_by_k = (g.K + 255) / 256;
     if (splits > max_by_k) splits = max_by_k;
@@ -419,17 +429,23 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   int kchunk = ((g.K + splits - 1) / splits + kq - 1) / kq * kq;
   if (kchunk < kq) kchunk = kq;
   splits = g.K > 0 ? (g.K + kchunk - 1) / kchunk : 1;
-  const dim3 grid(tn, tm, splits), blk(256);
+  const int inner = splits > 1 ? (int)tiles : tn, outer = splits > 1 ? splits : tm;
+  const dim3 grid(8 * ((outer + 7) / 8) * inner), blk(256);
   if (vec) {
-    if (BN == 128) hipLaunchKernelGGL((k_tr_gemm_bf16<128>), grid, blk, 0, s, g, splits, kchunk, (int)a_r, (int)b_r);
-    else hipLaunchKernelGGL((k_tr_gemm_bf16<64>), grid, blk, 0, s, g, splits, kchunk, (int)a_r, (int)b_r);
+#define DST_LAUNCH_BF16(M_, N_) hipLaunchKernelGGL((k_tr_gemm_bf16<M_, N_>), grid, blk, 0, s, g, splits, kchunk, (int)a_r, (int)b_r, tm, tn)
+    if (BM == 128 && BN == 128) DST_LAUNCH_BF16(128, 128);
+    else if (BM == 128) DST_LAUNCH_BF16(128, 64);
+    else if (BN == 128) DST_LAUNCH_BF16(64, 128);
+    else DST_LAUNCH_BF16(64, 64);
+#undef DST_LAUNCH_BF16
   } else if (BM == 128) {
-    if (bf) hipLaunchKernelGGL((k_tr_gemm_big<128, 64, true>), grid, blk, 0, s, g, splits, kchunk);
-    else hipLaunchKernelGGL((k_tr_gemm_big<128, 64, false>), grid, blk, 0, s, g, splits, kchunk);
+    if (bf) hipLaunchKernelGGL((k_tr_gemm_big<128, 64, true>), grid, blk, 0, s, g, splits, kchunk, tm, tn);
+    else hipLaunchKernelGGL((k_tr_gemm_big<128, 64, false>), grid, blk, 0, s, g, splits, kchunk, tm, tn);
   } else {
-    if (bf) hipLaunchKernelGGL((k_tr_gemm_big<64, 64, true>), grid, blk, 0, s, g, splits, kchunk);
-    else hipLaunchKernelGGL((k_tr_gemm_big<64, 64, false>), grid, blk, 0, s, g, splits, kchunk);
+    if (bf) hipLaunchKernelGGL((k_tr_gemm_big<64, 64, true>), grid, blk, 0, s, g, splits, kchunk, tm, tn);
+    else hipLaunchKernelGGL((k_tr_gemm_big<64, 64, false>), grid, blk, 0, s, g, splits, kchunk, tm, tn);
   }
+  if (splits > 1) hipLaunchKernelGGL(k_tr_gemm_reduce, dim3((unsigned)(((int64_t)g.M * Nx + 1023) / 1024)), dim3(256), 0, s, g, splits);
   return DST_CHECK_LAUNCH();
 }
 

@@ -35,7 +35,7 @@ class DstGemmArgs(C.Structure):
                 ("C", C.c_void_p), ("ldc", C.c_int64), ("bias", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("accumulate", C.c_int32), ("partial", C.c_void_p), ("partial_cap", C.c_int64), ("bf16", C.c_int32), ("_pad", C.c_int32), ("rowsum", C.c_void_p),
                 ("act", C.c_int32), ("dact", C.c_int32), ("ref", C.c_void_p), ("ldref", C.c_int64), ("C2", C.c_void_p), ("ldc2", C.c_int64),
-                ("drop_p", C.c_float), ("drop_stream", C.c_uint32), ("drop_seed", C.c_uint64), ("drop_ld", C.c_int64), ("counters", C.c_void_p)]
+                ("drop_p", C.c_float), ("drop_stream", C.c_uint32), ("drop_seed", C.c_uint64), ("drop_ld", C.c_int64)]
 
 
 class DstLayout(C.Structure):
@@ -98,7 +98,6 @@ class Ops:
         self.lib = load_train_library()
         self.dev = torch.device(device)
         self.scratch = torch.empty(48 * 1024 * 1024, dtype=torch.float32, device=self.dev)     # split-K partials / column sums
-        self.counters = torch.zeros(4096, dtype=torch.int32, device=self.dev)                  # split-K arrival counters (left zero by every call)
         self.bf16 = False      # config.training.precision == 'bf16': every GEMM rounds its operands to bf16 (fp32 accumulate, fp32 storage)
 
     def _s(self):
@@ -124,8 +123,7 @@ class Ops:
                            ref=None if ref is None else ref.ptr, ldref=0 if ref is None else ref.ld,
                            C2=None if out2 is None else out2.ptr, ldc2=0 if out2 is None else out2.ld,
                            drop_p=0.0 if not drop or drop[0] <= 0 else float(drop[0]), drop_stream=0 if not drop else int(drop[2]),
-                           drop_seed=0 if not drop else int(drop[1]), drop_ld=0 if not drop else int(drop[3]),
-                           counters=self.counters.data_ptr())
+                           drop_seed=0 if not drop else int(drop[1]), drop_ld=0 if not drop else int(drop[3]))
         if ref is not None:
             assert ref.rows == M and ref.cols == N
         if out2 is not None:
@@ -175,9 +173,12 @@ class Ops:
         E._check(self.lib.dst_gate_add_fwd(E._ptr(r), E._ptr(z), C.c_int32(Cc), E._ptr(seg), C.c_int32(mul), C.c_int32(B), E._ptr(ada), C.c_int64(ADA),
                                            C.c_int32(g), E._ptr(out), self._s()), "dst_gate_add_fwd")
 
-    def gate_add_bwd(self, dout, z, Cc, seg, mul, B, ada, d_ada, g, dr, acc_r, dz):
+    def gate_add_bwd(self, dout, z, Cc, seg, mul, B, ada, d_ada, g, dr, acc_r, dz, drop=None):
+        """``drop = (p, seed, stream_id)``: ``z`` was a dropout's output; ``dz`` is then the gradient in FRONT of that dropout."""
+        p_, seed, stream = drop if drop and drop[0] > 0 else (0.0, 0, 0)
         E._check(self.lib.dst_gate_add_bwd(E._ptr(dout), E._ptr(z), C.c_int32(Cc), E._ptr(seg), C.c_int32(mul), C.c_int32(B), E._ptr(ada), E._ptr(d_ada),
-                                           C.c_int64(ADA), C.c_int32(g), E._ptr(dr), C.c_int32(int(acc_r)), E._ptr(dz), self._s()), "dst_gate_add_bwd")
+                                           C.c_int64(ADA), C.c_int32(g), E._ptr(dr), C.c_int32(int(acc_r)), E._ptr(dz), C.c_float(p_), C.c_uint64(seed),
+                                           C.c_uint32(stream), self._s()), "dst_gate_add_bwd")
 
 
 class TrainLayout:

@@ -37,8 +37,7 @@ extern "C" {
  *   input gradient   dX = dY W     : A = dY,                        B = W   (b_rs = ldw, b_cs = 1)
  *   weight gradient  dW = dY^T X   : A = dY^T (a_rs = 1, a_cs = ldy), B = X (b_rs = ldx, b_cs = 1), K = rows
  * accumulate != 0 adds to C.  Long-K products are split over K: every slice writes an fp32 slab into `partial` (caller scratch of
- * partial_cap floats), the slice that arrives last at the tile's entry of `counters` (>= 4096 zero-initialised ints, left zero) adds the
- * slabs in slice order - a fixed summation order, no second launch.
+ * partial_cap floats) and a second kernel adds the slabs in slice order: results do not depend on scheduling.
  * Fused epilogue, per element (all optional):  v = acc + bias;  dact: v *= f'(ref[m,n]);  act: C = v and C2 = drop(f(v)) when C2 is
  * given, else C = drop(f(v));  no act: C (+)= drop(v).  f: 1 SiLU, 2 GELU(erf), 3 tanh; f' takes ref = pre-activation (SiLU, GELU) or
  * ref = tanh output.  drop(x) = x * keep / (1 - p) with the Philox mask of dst_dropout at element index m * drop_ld + n of stream
@@ -57,7 +56,6 @@ typedef struct dst_gemm_args {
   const float* ref; int64_t ldref;
   float* C2; int64_t ldc2;
   float drop_p; uint32_t drop_stream; uint64_t drop_seed; int64_t drop_ld;
-  int32_t* counters;
 } dst_gemm_args;
 int dst_gemm(const dst_gemm_args* a, void* stream);
 
@@ -90,11 +88,14 @@ int dst_lnmod_bwd(const float* dy, const float* x, const float* stats, int32_t C
                   const float* ada, float* d_ada, int64_t ada_ld, int32_t shift_off, int32_t scale_off, float* dx, int32_t accumulate,
                   void* stream);
 
-/* out = r + gate[m] * z.  Backward: dr (accumulate_r != 0 adds) = dout, dz = gate * dout, d_ada[m, gate_off + c] = sum_rows dout * z. */
+/* out = r + gate[m] * z.  Backward: dr (accumulate_r != 0 adds) = dout, dz = gate * dout, d_ada[m, gate_off + c] = sum_rows dout * z.
+ * drop_p > 0: z was the output of a dropout (dmt.py:116,120) - dz is multiplied by that dropout's mask (dst_dropout's generator at the
+ * element index of the contiguous [rows, C] tensor, stream (drop_seed, drop_stream)), i.e. dz is the gradient in front of the dropout. */
 int dst_gate_add_fwd(const float* r, const float* z, int32_t C, const int32_t* seg_off, int32_t seg_mul, int32_t B, const float* ada,
                      int64_t ada_ld, int32_t gate_off, float* out, void* stream);
 int dst_gate_add_bwd(const float* dout, const float* z, int32_t C, const int32_t* seg_off, int32_t seg_mul, int32_t B, const float* ada,
-                     float* d_ada, int64_t ada_ld, int32_t gate_off, float* dr, int32_t accumulate_r, float* dz, void* stream);
+                     float* d_ada, int64_t ada_ld, int32_t gate_off, float* dr, int32_t accumulate_r, float* dz, float drop_p, uint64_t drop_seed,
+                     uint32_t drop_stream, void* stream);
 
 /* Layout tables shared by the molecule-level kernels (device pointers; the tables of ds_layout). */
 typedef struct dst_layout {

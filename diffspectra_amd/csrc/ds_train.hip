@@ -85,6 +85,12 @@ __global__ void k_axpy(float a, const float* __restrict__ x, float* __restrict__
   if (i < n) y[i] += a * x[i];
 }
 
+// adjacency bits of the self-conditioning prediction (dmt.py:338-340,361): bit 0 = cond edge channel 0 >= edge_quan_th, bit 1 = cond d^2 <= cut-off
+__global__ void k_adj_bits(const float* __restrict__ cond_e, int64_t ld, const float* __restrict__ d2c, float th, float cutoff, int n, int32_t* __restrict__ adj) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) adj[p] = (cond_e[(int64_t)p * ld] >= th ? 1 : 0) | (d2c[p] <= cutoff ? 2 : 0);
+}
+
 // ------------------------------------------------------------------------------------------------------------------ dropout
 // nn.Dropout(p) in training mode (dmt.py:114-120): y = x * keep / (1 - p) with keep ~ Bernoulli(1 - p) from a counter-based Philox4x32-10
 // stream keyed on (seed, stream id): the mask of element i is a pure function of (seed, stream, i), so the backward pass re-creates it
@@ -1240,6 +1246,13 @@ inline dim3 grid1d(int64_t n, int block = 256) { return dim3((unsigned)((n + blo
 
 // ====================================================================================================================== C-ABI
 extern "C" {
+
+int dst_adj_bits(const float* cond_e, int64_t ld, const float* d2c, float edge_th, float cutoff, int32_t Pp, int32_t* adj, void* stream) {
+  if (Pp < 0 || (Pp > 0 && (!cond_e || !d2c || !adj))) return DS_ERR_ARG;
+  if (Pp == 0) return DS_OK;
+  hipLaunchKernelGGL(k_adj_bits, grid1d(Pp), dim3(256), 0, (hipStream_t)stream, cond_e, ld, d2c, edge_th, cutoff, (int)Pp, adj);
+  return DST_CHECK_LAUNCH();
+}
 
 int dst_colsum(const float* X, int64_t ld, int32_t R, int32_t C, float* out, int32_t accumulate, float* scratch, int64_t scratch_cap,
                void* stream) {

@@ -39,9 +39,11 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------------ epilogue
 // One output element.  v = acc + bias; v *= f'(ref) (dact); act: C <- v (pre-activation) and C2 <- drop(f(v)) when C2 is given, else
 // C <- drop(f(v)); no act: C (+)= drop(v).  Column N is the fused row sum (the virtual all-ones column of B).
-// The activation / dropout form is a CALL (one copy of its transcendental and Philox code per kernel): inlined at every one of a lane's
-// 32 - 64 output elements it made the kernels instruction-cache bound (the 128 x 128 tile ran 3x slower than the 128 x 64 one).
-__device__ __noinline__ void epi_fused(const dst_gemm_args& g, int row, int col, float v) {
+// The activation / dropout form is long (transcendentals, ten Philox rounds): inlined at every one of a lane's 32 - 64 accumulator
+// registers it made the kernels instruction-cache bound (a 128 x 128 tile ran 3x slower than a 128 x 64 one), and as a real call it
+// forced the argument struct into scratch memory (every kernel 2x slower).  So finish_tiles runs it in a ROLLED loop over a tile staged
+// through wave-private LDS: one copy of the code per kernel.
+__device__ __forceinline__ void epi_fused(const dst_gemm_args& g, int row, int col, float v) {
   if (g.dact) v *= dst::act_deriv(g.ref[(int64_t)row * g.ldref + col], g.dact);
   float keep = 1.0f;
   if (g.drop_p > 0.0f)
@@ -59,38 +61,68 @@ __device__ __noinline__ void epi_fused(const dst_gemm_args& g, int row, int col,
   if (g.accumulate) v += *c;
   *c = v;
 }
-__device__ __forceinline__ void epi_store(const dst_gemm_args& g, bool fused, int row, int col, float acc) {
+__device__ __forceinline__ void epi_plain(const dst_gemm_args& g, int row, int col, float acc) {
   if (col == g.N) {
     g.rowsum[row] = g.accumulate ? g.rowsum[row] + acc : acc;
     return;
   }
   const float v = acc + (g.bias ? g.bias[col] : 0.0f);
-  if (fused) { epi_fused(g, row, col, v); return; }
   float* c = g.C + (int64_t)row * g.ldc + col;
   *c = g.accumulate ? v + *c : v;
 }
 
-// The wave's TM x TN accumulator tiles (32 x 32 each; rows rbase + 32 i, columns cbase + 32 j) -> memory: the output through the
-// epilogue, or - split over K - slice z's fp32 slab (k_tr_gemm_reduce adds the slabs in slice order and runs the epilogue).
+constexpr int STAGE_LD = 33;                                   // floats per row of a wave's 32 x 32 staging tile
+constexpr int STAGE_BYTES = 4 * 32 * STAGE_LD * 4;             // four waves
+
+// The wave's TM x TN accumulator tiles (32 x 32 each; rows rbase + 32 i, columns cbase + 32 j) -> memory: slice z's fp32 slab when
+// the product is split over K (k_tr_gemm_reduce adds the slabs in slice order and runs the epilogue), else the output - directly
+// from the registers for the plain epilogue, through `stage` (wave-private LDS, the operand tiles are dead by now) for the fused one.
 template <int TM, int TN>
-__device__ __forceinline__ void finish_tiles(const dst_gemm_args& g, f32x16_t (&acc)[TM][TN], int rbase, int cbase, int splits, int z) {
+__device__ __forceinline__ void finish_tiles(const dst_gemm_args& g, f32x16_t (&acc)[TM][TN], int rbase, int cbase, int splits, int z, float* stage) {
   const int lane = threadIdx.x & 63;
   const int Nx = g.N + (g.rowsum ? 1 : 0);
   const bool fused = g.act || g.dact || g.drop_p > 0.0f;
+  if (splits > 1 || !fused) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = cbase + j * 32 + (lane & 31);
+      for (int j = 0; j < TN; ++j) {
+        const int col = cbase + j * 32 + (lane & 31);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rbase + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
-        if (row < g.M && col < Nx) {
-          if (splits > 1) g.partial[((int64_t)z * g.M + row) * Nx + col] = acc[i][j][r];
-          else epi_store(g, fused, row, col, acc[i][j][r]);
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+          if (row < g.M && col < Nx) {
+            if (splits > 1) g.partial[((int64_t)z * g.M + row) * Nx + col] = acc[i][j][r];
+            else epi_plain(g, row, col, acc[i][j][r]);
+          }
         }
       }
+    return;
+  }
+  float* st = stage + (threadIdx.x >> 6) * (32 * STAGE_LD);
+#pragma unroll 1
+  for (int t = 0; t < TM * TN; ++t) {
+    f32x16_t sel = acc[0][0];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        if (i * TN + j == t) sel = acc[i][j];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[((r >> 2) * 8 + (lane >> 5) * 4 + (r & 3)) * STAGE_LD + (lane & 31)] = sel[r];
+    const int ti = t / TN, tj = t % TN;
+    const int col = cbase + tj * 32 + (lane & 31);
+#pragma unroll 1
+    for (int e = 0; e < 16; ++e) {
+      const int lr = 2 * e + (lane >> 5);
+      const int row = rbase + ti * 32 + lr;
+      const float a = st[lr * STAGE_LD + (lane & 31)];
+      if (row < g.M && col < Nx) {
+        if (col == g.N) epi_plain(g, row, col, a);
+        else epi_fused(g, row, col, a + (g.bias ? g.bias[col] : 0.0f));
+      }
     }
+  }
 }
 
 // Workgroup -> (k-slice, m-tile, n-tile).  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so linear ids
@@ -127,9 +159,14 @@ __global__ __launch_bounds__(256) void k_tr_gemm_reduce(dst_gemm_args g, int spl
       for (int e = 0; e < 4; ++e)
         if (i0 + e < total) v[e] += g.partial[(int64_t)z * total + i0 + e];
   }
-#pragma unroll
+#pragma unroll 1
   for (int e = 0; e < 4; ++e)
-    if (i0 + e < total) epi_store(g, fused, (int)((i0 + e) / Nx), (int)((i0 + e) % Nx), v[e]);
+    if (i0 + e < total) {
+      const int row = (int)((i0 + e) / Nx), col = (int)((i0 + e) % Nx);
+      const float a = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
+      if (!fused || col == g.N) epi_plain(g, row, col, a);
+      else epi_fused(g, row, col, a + (g.bias ? g.bias[col] : 0.0f));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ bf16 kernel
@@ -149,6 +186,8 @@ template <int ROWS>
 __device__ __forceinline__ void fetch_tile(const float* __restrict__ X, int64_t rs, int64_t ks, bool rfast, int row0, int R, int k0, int kend,
                                            int ones_row, f32x4_t (&v)[4]) {
   const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};      // every element defined on every path: the array stays in registers
   if (!rfast) {
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
@@ -185,7 +224,9 @@ __device__ __forceinline__ void fetch_tile(const float* __restrict__ X, int64_t 
             for (int e = 0; e < 4; ++e)
               if (gr0 + e < R) t[e] = p[e];
           }
-          if (ones_row >= gr0 && ones_row < gr0 + 4) t[ones_row - gr0] = 1.0f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gr0 + e == ones_row) t[e] = 1.0f;
         }
         v[kk] = t;
       }
@@ -218,7 +259,8 @@ __device__ __forceinline__ void commit_tile(unsigned short* __restrict__ Xs, boo
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void k_tr_gemm_bf16(dst_gemm_args g, int splits, int kchunk, int a_rfast, int b_rfast, int tm, int tn) {
   constexpr int TM = BM / 64, TN = BN / 64;
-  __shared__ __attribute__((aligned(16))) unsigned short lds[(BM + BN) * LDK];
+  constexpr int LDS_BYTES = (BM + BN) * LDK * 2 > STAGE_BYTES ? (BM + BN) * LDK * 2 : STAGE_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned short lds[LDS_BYTES / 2];
   unsigned short* As = lds;
   unsigned short* Bs = lds + BM * LDK;
   int z, mt, nt;
@@ -266,7 +308,7 @@ __global__ __launch_bounds__(256) void k_tr_gemm_bf16(dst_gemm_args g, int split
     }
     __syncthreads();
   }
-  finish_tiles<TM, TN>(g, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), splits, z);
+  finish_tiles<TM, TN>(g, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), splits, z, reinterpret_cast<float*>(lds));
 }
 
 // ------------------------------------------------------------------------------------------------------------------ fp32 / unaligned kernel
@@ -277,8 +319,10 @@ template <int BM, int BN, bool BF16>
 __global__ __launch_bounds__(256) void k_tr_gemm_big(dst_gemm_args g, int splits, int kchunk, int tm, int tn) {
   constexpr int TM = BM / 64, TN = BN / 64;              // 32 x 32 tiles per wave in each direction (BM, BN in {64, 128})
   constexpr int LA = BM * 16 / 256, LB = BN * 16 / 256;  // elements per thread per slab
-  __shared__ float As[16][BM + 4];
-  __shared__ float Bs[16][BN + 4];
+  constexpr int OPER = 16 * (BM + 4 + BN + 4);                     // floats of the two operand slabs; the staging tiles of the fused epilogue reuse them
+  __shared__ __attribute__((aligned(16))) float lds[OPER * 4 > STAGE_BYTES ? OPER : STAGE_BYTES / 4];
+  float (*As)[BM + 4] = reinterpret_cast<float (*)[BM + 4]>(lds);
+  float (*Bs)[BN + 4] = reinterpret_cast<float (*)[BN + 4]>(lds + 16 * (BM + 4));
   int z, mt, nt;
   if (!tile_of_block(tm, tn, splits, z, mt, nt)) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -364,7 +408,7 @@ __global__ __launch_bounds__(256) void k_tr_gemm_big(dst_gemm_args g, int splits
     }
     __syncthreads();
   }
-  finish_tiles<TM, TN>(g, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), splits, z);
+  finish_tiles<TM, TN>(g, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), splits, z, lds);
 }
 
 int env_int(const char* name, int dflt) {

@@ -136,11 +136,14 @@ class Ops:
                                      E._ptr(self.scratch), C.c_int64(self.scratch.numel()), self._s()), "dst_colsum")
 
     # y = x W^T + b ; dx (+)= dy W ; dW = dy^T x ; db = colsum(dy)
-    def lin_fwd(self, x: MV, W: MV, b, y: MV):
-        self.gemm(x, W, y, False, True, bias=b)
+    def lin_fwd(self, x: MV, W: MV, b, y: MV, act: int = 0, out2: Optional[MV] = None, drop=None):
+        """``act`` + ``out2``: y keeps the pre-activation (the backward's reference), out2 = drop(f(y)); ``act`` alone: y = drop(f(.))."""
+        self.gemm(x, W, y, False, True, bias=b, act=act, out2=out2, drop=drop)
 
-    def lin_bwd_x(self, dy: MV, W: MV, dx: MV, acc: bool = False):
-        self.gemm(dy, W, dx, False, False, acc=acc)
+    def lin_bwd_x(self, dy: MV, W: MV, dx: MV, acc: bool = False, dact: int = 0, ref: Optional[MV] = None, drop=None):
+        """``dact`` + ``ref``: dx = (dy W) * f'(ref) (* the dropout mask ``drop`` of the activated tensor): the gradient in front of
+        ``drop(f(.))`` in one product."""
+        self.gemm(dy, W, dx, False, False, acc=acc, dact=dact, ref=ref, drop=drop)
 
     def lin_bwd_w(self, dy: MV, x: MV, dW: MV, db: Optional[torch.Tensor] = None, acc: bool = False):
         self.gemm(dy, x, dW, True, False, acc=acc, rowsum=db)           # db = column sums of dy = row sums of dy^T, fused into the product
@@ -259,14 +262,14 @@ class DmtTrainGraph:
         b[ADA_TOP:ADA_TOP + 2] = self.p["dist_layer.time_mlp.1.bias"]
         return W, b
 
-    def scatter_ada_grads(self, dW, db, grads):
+    def scatter_ada_grads(self, dW, db, gw):
         for blk in range(NB):
             for name, off, rows in ADA_PARTS:
                 o = blk * ADA_STRIDE + off
-                grads[f"e_block_{blk}.{name}.weight"] = dW[o:o + rows].clone()
-                grads[f"e_block_{blk}.{name}.bias"] = db[o:o + rows].clone()
-        grads["dist_layer.time_mlp.1.weight"] = dW[ADA_TOP:ADA_TOP + 2].clone()
-        grads["dist_layer.time_mlp.1.bias"] = db[ADA_TOP:ADA_TOP + 2].clone()
+                gw(f"e_block_{blk}.{name}.weight").copy_(dW[o:o + rows])
+                gw(f"e_block_{blk}.{name}.bias").copy_(db[o:o + rows])
+        gw("dist_layer.time_mlp.1.weight").copy_(dW[ADA_TOP:ADA_TOP + 2])
+        gw("dist_layer.time_mlp.1.bias").copy_(db[ADA_TOP:ADA_TOP + 2])
 
     def _geom_fwd(self, TL, pos, ada, dist_off, prefix, X, ldx, col0, xs, d2s):
         E._check(self.lib.dst_geom_fwd(C.byref(TL.c), E._ptr(pos), E._ptr(ada), C.c_int64(ADA), C.c_int32(dist_off),
@@ -294,8 +297,7 @@ class DmtTrainGraph:
         tf = self.f(B, 17)
         E._check(lib.dst_time_feat_fwd(E._ptr(noise_level), E._ptr(p["time_mlp.0.weights"]), C.c_int32(B), E._ptr(tf), s()), "dst_time_feat_fwd")
         tm1, tg, temb, st = self.f(B, 1024), self.f(B, 1024), self.f(B, 1024), self.f(B, 1024)
-        o.lin_fwd(mv(tf), mv(p["time_mlp.1.weight"]), p["time_mlp.1.bias"], mv(tm1))
-        o.act_fwd(tm1, tg, GELU)
+        o.lin_fwd(mv(tf), mv(p["time_mlp.1.weight"]), p["time_mlp.1.bias"], mv(tm1), act=GELU, out2=mv(tg))
         o.lin_fwd(mv(tg), mv(p["time_mlp.3.weight"]), p["time_mlp.3.bias"], mv(temb))
         o.axpy(1.0, ctx_emb, temb)                                                       # time_emb = time_mlp(noise_level) + context
         o.act_fwd(temb, st, SILU)
@@ -316,7 +318,9 @@ class DmtTrainGraph:
             cpos = cond_n[:, 0:3].contiguous()
             xs0, d2c = self.f(Pp), self.f(Pp)
             self._geom_fwd(TL, cpos, ada, ADA_TOP, "dist_layer.", X0p, 68, 4, xs0, d2c)
-            adj = ((cond_e[:, 0] >= self.edge_th).to(torch.int32) | ((d2c <= self.cutoff).to(torch.int32) << 1)).contiguous()
+            adj = torch.empty(Pp, dtype=torch.int32, device=self.dev)
+            E._check(lib.dst_adj_bits(E._ptr(cond_e), C.c_int64(cond_e.shape[1]), E._ptr(d2c), C.c_float(self.edge_th), C.c_float(self.cutoff), C.c_int32(Pp),
+                                      E._ptr(adj), s()), "dst_adj_bits")
             t.update(cpos=cpos)
         else:
             adj = torch.full((Pp,), 3, dtype=torch.int32, device=self.dev)
@@ -347,10 +351,8 @@ class DmtTrainGraph:
             o.lin_fwd(mv(hn), mv(p[ap + "lin_key.weight"]), p[ap + "lin_key.bias"], mv(qkv, 256, 508))
             o.lin_fwd(mv(hn), mv(p[ap + "lin_value.weight"]), p[ap + "lin_value.bias"], mv(qkv, 512, 768))
             te0, te1 = self.z(Pp, 256), self.f(Pp, 256)
-            o.lin_fwd(mv(en), mv(p[ap + "lin_edge0.weight"]), None, mv(te0, 0, 252))
-            o.lin_fwd(mv(en), mv(p[ap + "lin_edge1.weight"]), None, mv(te1))
-            o.act_fwd(te0, te0, TANH)
-            o.act_fwd(te1, te1, TANH)
+            o.lin_fwd(mv(en), mv(p[ap + "lin_edge0.weight"]), None, mv(te0, 0, 252), act=TANH)        # columns 252..255 stay 0 = tanh(0)
+            o.lin_fwd(mv(en), mv(p[ap + "lin_edge1.weight"]), None, mv(te1), act=TANH)
             attn, alpha = self.f(Nn, 256), self.f(max(D, 1), 16)
             E._check(lib.dst_attn_fwd(C.byref(TL.c), E._ptr(qkv), E._ptr(te0), E._ptr(te1), E._ptr(adj), E._ptr(attn), E._ptr(alpha), s()), "dst_attn_fwd")
             # node2edge (dmt.py:156-157) per node, then the pair sum
@@ -362,22 +364,17 @@ class DmtTrainGraph:
             o.gate_add_fwd(h, attn, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 512, x1)
             o.lnmod_fwd(x1, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 768, a0 + NODE_OFF + 1024, y1, st_n2)
             f1, s1, f2, h_out = self.f(Nn, 512), self.f(Nn, 512), self.f(Nn, 256), self.f(Nn, 256)
-            o.lin_fwd(mv(y1), mv(p[bp + "ff_linear1.weight"]), p[bp + "ff_linear1.bias"], mv(f1))
-            o.act_fwd(f1, s1, SILU)
-            o.dropout(s1, dp, dseed, 4 * i + 0)
-            o.lin_fwd(mv(s1), mv(p[bp + "ff_linear2.weight"]), p[bp + "ff_linear2.bias"], mv(f2))
-            o.dropout(f2, dp, dseed, 4 * i + 1)
+            # dmt.py:114-116: dropout(act(ff_linear1)) and dropout(ff_linear2) where the GEMMs produce them (f1 = pre-activation, kept)
+            o.lin_fwd(mv(y1), mv(p[bp + "ff_linear1.weight"]), p[bp + "ff_linear1.bias"], mv(f1), act=SILU, out2=mv(s1), drop=(dp, dseed, 4 * i + 0, 512))
+            o.lin_fwd(mv(s1), mv(p[bp + "ff_linear2.weight"]), p[bp + "ff_linear2.bias"], mv(f2), drop=(dp, dseed, 4 * i + 1, 256))
             o.gate_add_fwd(y1, f2, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 1280, h_out)
             # edge stream (dmt.py:165-169)
             xe1, ye1, st_e2 = self.f(Pp, 64), self.f(Pp, 64), self.f(Pp, 2)
             o.gate_add_fwd(e, he, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 128, xe1)
             o.lnmod_fwd(xe1, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 192, a0 + EDGE_OFF + 256, ye1, st_e2)
             f3, s3, f4, e_out = self.f(Pp, 128), self.f(Pp, 128), self.f(Pp, 64), self.f(Pp, 64)
-            o.lin_fwd(mv(ye1), mv(p[bp + "ff_linear3.weight"]), p[bp + "ff_linear3.bias"], mv(f3))
-            o.act_fwd(f3, s3, SILU)
-            o.dropout(s3, dp, dseed, 4 * i + 2)
-            o.lin_fwd(mv(s3), mv(p[bp + "ff_linear4.weight"]), p[bp + "ff_linear4.bias"], mv(f4))
-            o.dropout(f4, dp, dseed, 4 * i + 3)
+            o.lin_fwd(mv(ye1), mv(p[bp + "ff_linear3.weight"]), p[bp + "ff_linear3.bias"], mv(f3), act=SILU, out2=mv(s3), drop=(dp, dseed, 4 * i + 2, 128))
+            o.lin_fwd(mv(s3), mv(p[bp + "ff_linear4.weight"]), p[bp + "ff_linear4.bias"], mv(f4), drop=(dp, dseed, 4 * i + 3, 64))
             o.gate_add_fwd(ye1, f4, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 320, e_out)
             # equivariant update (dmt.py:37-60) + CoM removal (:385-386)
             Win = p[bp + "equi_update.input_lin.weight"]                       # [256, 640] = [h_row | h_col | e | dist]
@@ -393,8 +390,8 @@ class DmtTrainGraph:
             E._check(lib.dst_zbuild_fwd(C.byref(TL.c), E._ptr(ac), E._ptr(ed), E._ptr(zz), s()), "dst_zbuild_fwd")
             o.lnmod_fwd(zz, 256, TL.pair_off, 2, B, ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256, zn, st_z)
             c0, sc0, c2 = self.f(max(D, 1), 256), self.f(max(D, 1), 256), self.f(max(D, 1), 3)
-            o.lin_fwd(mv(zn, r1=D), mv(p[bp + "equi_update.coord_mlp.0.weight"]), p[bp + "equi_update.coord_mlp.0.bias"], mv(c0, r1=D))
-            o.act_fwd(c0, sc0, SILU)
+            o.lin_fwd(mv(zn, r1=D), mv(p[bp + "equi_update.coord_mlp.0.weight"]), p[bp + "equi_update.coord_mlp.0.bias"], mv(c0, r1=D), act=SILU,
+                      out2=mv(sc0, r1=D))
             o.lin_fwd(mv(sc0, r1=D), mv(p[bp + "equi_update.coord_mlp.2.weight"]), None, mv(c2, r1=D))
             pos_out = self.f(Nn, 3)
             E._check(lib.dst_coord_fwd(C.byref(TL.c), E._ptr(pos), E._ptr(c2), E._ptr(adj), E._ptr(p[bp + "equi_update.coord_norm.scale"]),
@@ -415,19 +412,15 @@ class DmtTrainGraph:
         AH = torch.cat(node_hids, dim=1).contiguous()
         EH = torch.cat(edge_hids, dim=1).contiguous()
         n1, n1s, n2, n2s, atom_pred = self.f(Nn, 256), self.f(Nn, 256), self.f(Nn, 128), self.f(Nn, 128), self.f(Nn, 6)
-        o.lin_fwd(mv(AH), mv(p["node_pred_mlp.0.weight"]), p["node_pred_mlp.0.bias"], mv(n1))
-        o.act_fwd(n1, n1s, SILU)
-        o.lin_fwd(mv(n1s), mv(p["node_pred_mlp.2.weight"]), p["node_pred_mlp.2.bias"], mv(n2))
-        o.act_fwd(n2, n2s, SILU)
+        o.lin_fwd(mv(AH), mv(p["node_pred_mlp.0.weight"]), p["node_pred_mlp.0.bias"], mv(n1), act=SILU, out2=mv(n1s))
+        o.lin_fwd(mv(n1s), mv(p["node_pred_mlp.2.weight"]), p["node_pred_mlp.2.bias"], mv(n2), act=SILU, out2=mv(n2s))
         o.lin_fwd(mv(n2s), mv(p["node_pred_mlp.4.weight"]), p["node_pred_mlp.4.bias"], mv(atom_pred))
         edge_pred = self.f(Pp, 2)
         ro = {}
         for col, name in ((0, "edge_exist_mlp"), (1, "edge_type_mlp")):
             a1, a1s, a2, a2s = self.f(Pp, 64), self.f(Pp, 64), self.f(Pp, 32), self.f(Pp, 32)
-            o.lin_fwd(mv(EH), mv(p[name + ".0.weight"]), p[name + ".0.bias"], mv(a1))
-            o.act_fwd(a1, a1s, SILU)
-            o.lin_fwd(mv(a1s), mv(p[name + ".2.weight"]), p[name + ".2.bias"], mv(a2))
-            o.act_fwd(a2, a2s, SILU)
+            o.lin_fwd(mv(EH), mv(p[name + ".0.weight"]), p[name + ".0.bias"], mv(a1), act=SILU, out2=mv(a1s))
+            o.lin_fwd(mv(a1s), mv(p[name + ".2.weight"]), p[name + ".2.bias"], mv(a2), act=SILU, out2=mv(a2s))
             o.lin_fwd(mv(a2s), mv(p[name + ".4.weight"]), p[name + ".4.bias"], mv(edge_pred, col, col + 1))
             ro[name] = (a1, a1s, a2, a2s)
         if save:
@@ -447,8 +440,10 @@ class DmtTrainGraph:
         dp, dseed = t["drop"]
         g: Dict[str, torch.Tensor] = {}
 
-        def gw(name):                                       # gradient buffer of a parameter (fully written by its producer)
-            g[name] = torch.zeros_like(p[name])
+        gbuf = getattr(self, "gbuf", None)
+
+        def gw(name):                                       # gradient buffer of a parameter: a view of the trainer's flat stage (zeroed once
+            g[name] = gbuf[name] if gbuf is not None else torch.zeros_like(p[name])   # per backward) or, stand-alone, a fresh zero tensor
             return g[name]
 
         d_ada = self.z(B, ADA)
@@ -459,12 +454,10 @@ class DmtTrainGraph:
             a1, a1s, a2, a2s = acts
             o.lin_bwd_w(dy, mv(a2s), mv(gw(name + ".4.weight")), gw(name + ".4.bias"))
             d2 = torch.empty_like(a2)
-            o.lin_bwd_x(dy, mv(p[name + ".4.weight"]), mv(d2))
-            o.act_bwd(d2, a2, d2, SILU)
+            o.lin_bwd_x(dy, mv(p[name + ".4.weight"]), mv(d2), dact=SILU, ref=mv(a2))
             o.lin_bwd_w(mv(d2), mv(a1s), mv(gw(name + ".2.weight")), gw(name + ".2.bias"))
             d1 = torch.empty_like(a1)
-            o.lin_bwd_x(mv(d2), mv(p[name + ".2.weight"]), mv(d1))
-            o.act_bwd(d1, a1, d1, SILU)
+            o.lin_bwd_x(mv(d2), mv(p[name + ".2.weight"]), mv(d1), dact=SILU, ref=mv(a1))
             o.lin_bwd_w(mv(d1), mv(x), mv(gw(name + ".0.weight")), gw(name + ".0.bias"))
             o.lin_bwd_x(mv(d1), mv(p[name + ".0.weight"]), mv(dx), acc=acc)
 
@@ -496,8 +489,7 @@ class DmtTrainGraph:
             dWin = gw(bp + "equi_update.input_lin.weight")
             o.lin_bwd_w(mv(dc2, r1=D), mv(bt["sc0"], r1=D), mv(gw(bp + "equi_update.coord_mlp.2.weight")))
             dc0 = self.f(max(D, 1), 256)
-            o.lin_bwd_x(mv(dc2, r1=D), mv(p[bp + "equi_update.coord_mlp.2.weight"]), mv(dc0, r1=D))
-            o.act_bwd(dc0, bt["c0"], dc0, SILU)
+            o.lin_bwd_x(mv(dc2, r1=D), mv(p[bp + "equi_update.coord_mlp.2.weight"]), mv(dc0, r1=D), dact=SILU, ref=mv(bt["c0"], r1=D))
             o.lin_bwd_w(mv(dc0, r1=D), mv(bt["zn"], r1=D), mv(gw(bp + "equi_update.coord_mlp.0.weight")), gw(bp + "equi_update.coord_mlp.0.bias"))
             dzn = self.f(max(D, 1), 256)
             o.lin_bwd_x(mv(dc0, r1=D), mv(p[bp + "equi_update.coord_mlp.0.weight"]), mv(dzn, r1=D))
@@ -515,13 +507,10 @@ class DmtTrainGraph:
             o.lin_bwd_x(mv(ded), mv(Win, 576, 640), mv(dfeat2))
             # node stream
             dy1, df2 = self.f(Nn, 256), self.f(Nn, 256)
-            o.gate_add_bwd(dh, bt["f2"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 1280, dy1, False, df2)
-            o.dropout(df2, dp, dseed, 4 * i + 1)
+            o.gate_add_bwd(dh, bt["f2"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 1280, dy1, False, df2, drop=(dp, dseed, 4 * i + 1))
             o.lin_bwd_w(mv(df2), mv(bt["s1"]), mv(gw(bp + "ff_linear2.weight")), gw(bp + "ff_linear2.bias"))
             df1 = self.f(Nn, 512)
-            o.lin_bwd_x(mv(df2), mv(p[bp + "ff_linear2.weight"]), mv(df1))
-            o.dropout(df1, dp, dseed, 4 * i + 0)
-            o.act_bwd(df1, bt["f1"], df1, SILU)
+            o.lin_bwd_x(mv(df2), mv(p[bp + "ff_linear2.weight"]), mv(df1), dact=SILU, ref=mv(bt["f1"]), drop=(dp, dseed, 4 * i + 0, 512))
             o.lin_bwd_w(mv(df1), mv(bt["y1"]), mv(gw(bp + "ff_linear1.weight")), gw(bp + "ff_linear1.bias"))
             o.lin_bwd_x(mv(df1), mv(p[bp + "ff_linear1.weight"]), mv(dy1), acc=True)
             dx1 = df2                                        # reuse
@@ -530,13 +519,10 @@ class DmtTrainGraph:
             o.gate_add_bwd(dx1, bt["attn"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 512, dh_in, False, dattn)
             # edge stream
             dye1, df4 = self.f(Pp, 64), self.f(Pp, 64)
-            o.gate_add_bwd(de, bt["f4"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 320, dye1, False, df4)
-            o.dropout(df4, dp, dseed, 4 * i + 3)
+            o.gate_add_bwd(de, bt["f4"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 320, dye1, False, df4, drop=(dp, dseed, 4 * i + 3))
             o.lin_bwd_w(mv(df4), mv(bt["s3"]), mv(gw(bp + "ff_linear4.weight")), gw(bp + "ff_linear4.bias"))
             df3 = self.f(Pp, 128)
-            o.lin_bwd_x(mv(df4), mv(p[bp + "ff_linear4.weight"]), mv(df3))
-            o.dropout(df3, dp, dseed, 4 * i + 2)
-            o.act_bwd(df3, bt["f3"], df3, SILU)
+            o.lin_bwd_x(mv(df4), mv(p[bp + "ff_linear4.weight"]), mv(df3), dact=SILU, ref=mv(bt["f3"]), drop=(dp, dseed, 4 * i + 2, 128))
             o.lin_bwd_w(mv(df3), mv(bt["ye1"]), mv(gw(bp + "ff_linear3.weight")), gw(bp + "ff_linear3.bias"))
             o.lin_bwd_x(mv(df3), mv(p[bp + "ff_linear3.weight"]), mv(dye1), acc=True)
             dxe1 = df4
@@ -595,15 +581,13 @@ class DmtTrainGraph:
         # ---- adaLN table + time embedding
         dWada, dbada = self.f(ADA, 1024), self.f(ADA)
         o.lin_bwd_w(mv(d_ada), mv(t["st"]), mv(dWada), dbada)
-        self.scatter_ada_grads(dWada, dbada, g)
+        self.scatter_ada_grads(dWada, dbada, gw)
         dtemb = self.f(B, 1024)
-        o.lin_bwd_x(mv(d_ada), mv(t["Wada"]), mv(dtemb))
-        o.act_bwd(dtemb, t["temb"], dtemb, SILU)
+        o.lin_bwd_x(mv(d_ada), mv(t["Wada"]), mv(dtemb), dact=SILU, ref=mv(t["temb"]))
         g["@ctx_emb"] = dtemb
         o.lin_bwd_w(mv(dtemb), mv(t["tg"]), mv(gw("time_mlp.3.weight")), gw("time_mlp.3.bias"))
         dtg = self.f(B, 1024)
-        o.lin_bwd_x(mv(dtemb), mv(p["time_mlp.3.weight"]), mv(dtg))
-        o.act_bwd(dtg, t["tm1"], dtg, GELU)
+        o.lin_bwd_x(mv(dtemb), mv(p["time_mlp.3.weight"]), mv(dtg), dact=GELU, ref=mv(t["tm1"]))
         o.lin_bwd_w(mv(dtg), mv(t["tf"]), mv(gw("time_mlp.1.weight")), gw("time_mlp.1.bias"))
         dtf = self.f(B, 17)
         o.lin_bwd_x(mv(dtg), mv(p["time_mlp.1.weight"]), mv(dtf))

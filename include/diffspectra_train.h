@@ -115,6 +115,10 @@ int dst_geom_bwd(const dst_layout* L, const float* pos, const float* ada, float*
                  const float* means, const float* stds, const float* xs, const float* d2s, const float* g1, int64_t ld1, const float* g2,
                  int64_t ld2, float* dms, float* dd2_scratch, float* dpos, void* stream);
 
+/* Adjacency bits of the self-conditioning prediction (dmt.py:338-340,361) per pair row: bit 0 = cond_e[p*ld] >= edge_th (cond_adj_2d),
+ * bit 1 = d2c[p] <= cutoff (cond_adj_spatial; d2c = squared distance of the conditioning positions). */
+int dst_adj_bits(const float* cond_e, int64_t ld, const float* d2c, float edge_th, float cutoff, int32_t Pp, int32_t* adj, void* stream);
+
 /* TransMixLayer attention per molecule.  qkv [Nn,768]: q at columns 0..251, k at 256..507, v at 512..767; te0 [Pp,256]
  * (= tanh(lin_edge0 e), 252 used), te1 [Pp,256], adj [Pp] bits (1: cond_adj_2d, 2: cond_adj_spatial); out [Nn,256];
  * alpha [2*Pp,16] (row 2p: source a -> target b, row 2p+1: source b -> target a).  16 heads: 0,1 adjacency heads (0 -> -1e10),

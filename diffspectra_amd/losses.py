@@ -291,6 +291,21 @@ class _HipLoss(torch.autograd.Function):
         return (None, None) + tuple(ctx.grads)
 
 
+class _HipLossFlat(torch.autograd.Function):
+    """The same hand-over when every ``p.grad`` is a view of ONE flat buffer laid out like the trainer's gradient stage (the fused
+    optimizer's arrangement): ``loss.backward()`` is then a single ``G += stage * grad_out`` instead of one accumulation per parameter."""
+
+    @staticmethod
+    def forward(ctx, loss_value, stage, target, *params):
+        ctx.stage, ctx.target = stage, target
+        return loss_value.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.target.addcmul_(ctx.stage, grad_out.to(ctx.stage.dtype))
+        return (None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
 class HipTrainer:
     """Per-model training state: the two graphs, bound to the model's current parameter storage at every call."""
 
@@ -302,6 +317,46 @@ class HipTrainer:
         self.ops = Ops(self.dev)
         self.lib = self.ops.lib
         self._layouts: Dict[bytes, TrainLayout] = {}
+        self._stage = None
+
+    def stage(self, named):
+        """One flat fp32 buffer holding every parameter's gradient of the current backward, in ``named_parameters()`` order without
+        gaps, and the per-parameter views the backward kernels write into."""
+        sizes = [p.numel() for p in named.values()]
+        n = int(sum(sizes))
+        if self._stage is None or self._stage[0].numel() != n:
+            flat = torch.zeros(n, dtype=torch.float32, device=self.dev)
+            offs = np.concatenate([[0], np.cumsum(sizes)]).tolist()
+            views = {name: flat[o:o + p.numel()].view(p.shape) for (name, p), o in zip(named.items(), offs)}
+            self._stage = (flat, views, offs)
+        return self._stage
+
+    def flat_grad_target(self, named, offs):
+        """The flat buffer all ``p.grad`` s are views of, if they are laid out exactly like the stage (``FusedAdamW`` does that), else None."""
+        params = list(named.values())
+        first = next((i for i, p in enumerate(params) if p.requires_grad), None)
+        if first is None or params[first].grad is None:
+            return None
+        base = params[first].grad._base
+        if base is None or base.dim() != 1 or not base.is_contiguous() or base.dtype != torch.float32:
+            return None
+        key = (base.data_ptr(), tuple(int(p.grad.data_ptr()) if (p.requires_grad and p.grad is not None) else -1 for p in params[::37]))
+        cached = getattr(self, "_flat_ok", None)
+        if cached is not None and cached[0] == key and cached[1] is base:
+            return cached[2]
+        b0 = base.data_ptr()
+        for p, o in zip(params, offs):
+            if not p.requires_grad:
+                continue
+            gr = p.grad
+            if gr is None or gr._base is not base or not gr.is_contiguous() or gr.data_ptr() != b0 + 4 * o:
+                return None
+        n = offs[-1]
+        if base.numel() < n:
+            return None
+        target = base[:n]
+        self._flat_ok = (key, base, target)
+        return target
 
     def layout(self, atom_mask) -> TrainLayout:
         key = (atom_mask != 0).to("cpu").numpy().tobytes() + bytes(atom_mask.shape[1])
@@ -320,6 +375,7 @@ class HipTrainer:
         dmt.p, dmt.cfg, dmt.dev, dmt.ops, dmt.lib = pd, self.cfg, self.dev, self.ops, self.lib
         dmt.edge_th, dmt.cutoff = float(self.cfg.model.edge_quan_th), float(self.cfg.model.spatial_cut_off)
         spec = SpecTrainGraph(pd, bufs, self.cfg, self.ops)
+        dmt.gbuf = spec.gbuf = self.stage(named)[1]
         return named, dmt, spec
 
 
@@ -406,13 +462,18 @@ def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None
         loss_fn.last = dict(t=t, alpha_t=alpha_t, sigma_t=sigma_t, z=z, ez=ez, aligned=aligned, rot=rot, pred=(pos, atom, edge), layout=TL)
         if not (train and torch.is_grad_enabled()):
             return loss
+        flat, _, offs = tr.stage(named)
+        flat.zero_()                                                    # gradients that a branch does not produce (first-step dist_layer) stay zero
         g = dmt.backward(dpos, dfeat, dedge)
         g.update(spec.backward(g.pop("@ctx_emb")))
         params = [p for p in named.values()]
-        grads = [g.get(n) if p.requires_grad else None for n, p in named.items()]
         missing = [n for n, p in named.items() if p.requires_grad and n not in g]
         if missing:
             raise RuntimeError(f"no gradient was produced for {missing[:5]}")
+        target = tr.flat_grad_target(named, offs)
+        if target is not None:                                          # the fused optimizer's flat gradient buffer: one accumulation kernel
+            return _HipLossFlat.apply(loss, flat, target, *params)
+        grads = [g.get(n).clone() if p.requires_grad else None for n, p in named.items()]      # the stage is overwritten by the next call
         return _HipLoss.apply(loss, grads, *params)
 
     return loss_fn

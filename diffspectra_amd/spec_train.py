@@ -49,7 +49,8 @@ class SpecTrainGraph:
     def _bn_bwd(self, dy, x, stats, name, dx, g):
         o = self.ops
         R, Cc = x.shape
-        g[name + ".weight"], g[name + ".bias"] = self.f(Cc), self.f(Cc)
+        gb = getattr(self, "gbuf", None)
+        g[name + ".weight"], g[name + ".bias"] = (gb[name + ".weight"], gb[name + ".bias"]) if gb is not None else (self.f(Cc), self.f(Cc))
         E._check(self.lib.dst_bn_bwd(E._ptr(dy), E._ptr(x), E._ptr(stats), C.c_int32(R), C.c_int32(Cc), E._ptr(self.p[name + ".weight"]), E._ptr(dx),
                                      E._ptr(g[name + ".weight"]), E._ptr(g[name + ".bias"]), E._ptr(o.scratch), C.c_int64(o.scratch.numel()), E._stream()),
                  "dst_bn_bwd")
@@ -89,9 +90,8 @@ class SpecTrainGraph:
             z1, st1 = self.f(B * L, D_MODEL), self.f(2, D_MODEL)
             self._bn_fwd(r1, base + "norm_attn.1", z1, st1)
             a = self.f(B * L, D_FF)
-            o.lin_fwd(mv(z1), mv(p[base + "ff.0.weight"]), p[base + "ff.0.bias"], mv(a))
             ga = self.f(B * L, D_FF)
-            o.act_fwd(a, ga, GELU)
+            o.lin_fwd(mv(z1), mv(p[base + "ff.0.weight"]), p[base + "ff.0.bias"], mv(a), act=GELU, out2=mv(ga))
             r2 = z1.clone()
             o.gemm(mv(ga), mv(p[base + "ff.3.weight"]), mv(r2), False, True, bias=p[base + "ff.3.bias"], acc=True)
             z2, st2 = self.f(B * L, D_MODEL), self.f(2, D_MODEL)
@@ -120,8 +120,10 @@ class SpecTrainGraph:
         B, L = t["B"], self.L
         g: Dict[str, torch.Tensor] = {}
 
+        gbuf = getattr(self, "gbuf", None)
+
         def gw(name):
-            g[name] = torch.empty_like(p[name])
+            g[name] = gbuf[name] if gbuf is not None else torch.empty_like(p[name])
             return g[name]
 
         o.lin_bwd_w(mv(dctx), mv(t["zs"]), mv(gw("cond_lin.weight")), gw("cond_lin.bias"))
@@ -143,8 +145,7 @@ class SpecTrainGraph:
             self._bn_bwd(dZ, lt["r2"], lt["st2"], base + "norm_ffn.1", dr2, g)
             o.lin_bwd_w(mv(dr2), mv(lt["ga"]), mv(gw(base + "ff.3.weight")), gw(base + "ff.3.bias"))
             da = self.f(B * L, D_FF)
-            o.lin_bwd_x(mv(dr2), mv(p[base + "ff.3.weight"]), mv(da))
-            o.act_bwd(da, lt["a"], da, GELU)
+            o.lin_bwd_x(mv(dr2), mv(p[base + "ff.3.weight"]), mv(da), dact=GELU, ref=mv(lt["a"]))
             o.lin_bwd_w(mv(da), mv(lt["z1"]), mv(gw(base + "ff.0.weight")), gw(base + "ff.0.bias"))
             o.lin_bwd_x(mv(da), mv(p[base + "ff.0.weight"]), mv(dr2), acc=True)                  # dz1 = dr2 (residual) + da W0
             dr1 = self.f(B * L, D_MODEL)

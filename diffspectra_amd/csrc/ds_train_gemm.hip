@@ -139,34 +139,28 @@ __device__ __forceinline__ bool tile_of_block(int tm, int tn, int splits, int& z
   return true;
 }
 
-// sum of the k-slices' slabs in slice order, then the epilogue: four consecutive columns per thread
+// sum of the k-slices' slabs in slice order, then the epilogue: one element per thread (a 256 x 256 weight gradient is 256 workgroups:
+// every CU takes part; with four elements per thread the 64 workgroups of the same reduction took 3x as long), eight slabs in flight
 __global__ __launch_bounds__(256) void k_tr_gemm_reduce(dst_gemm_args g, int splits) {
   const int Nx = g.N + (g.rowsum ? 1 : 0);
   const int64_t total = (int64_t)g.M * Nx;
-  const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i0 >= total) return;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
   const bool fused = g.act || g.dact || g.drop_p > 0.0f;
-  float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  if (i0 + 3 < total && (total & 3) == 0) {
-    for (int z = 0; z < splits; ++z) {
-      const f32x4_t t = *reinterpret_cast<const f32x4_t*>(g.partial + (int64_t)z * total + i0);
+  const float* p = g.partial + i;
+  float v = 0.0f;
+  int z = 0;
+  for (; z + 8 <= splits; z += 8) {
+    float t[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += t[e];
-    }
-  } else {
-    for (int z = 0; z < splits; ++z)
+    for (int e = 0; e < 8; ++e) t[e] = p[(int64_t)(z + e) * total];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (i0 + e < total) v[e] += g.partial[(int64_t)z * total + i0 + e];
+    for (int e = 0; e < 8; ++e) v += t[e];
   }
-#pragma unroll 1
-  for (int e = 0; e < 4; ++e)
-    if (i0 + e < total) {
-      const int row = (int)((i0 + e) / Nx), col = (int)((i0 + e) % Nx);
-      const float a = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
-      if (!fused || col == g.N) epi_plain(g, row, col, a);
-      else epi_fused(g, row, col, a + (g.bias ? g.bias[col] : 0.0f));
-    }
+  for (; z < splits; ++z) v += p[(int64_t)z * total];
+  const int row = (int)(i / Nx), col = (int)(i % Nx);
+  if (!fused || col == g.N) epi_plain(g, row, col, v);
+  else epi_fused(g, row, col, v + (g.bias ? g.bias[col] : 0.0f));
 }
 
 // ------------------------------------------------------------------------------------------------------------------ bf16 kernel
@@ -279,20 +273,27 @@ __global__ __launch_bounds__(256) void k_tr_gemm_bf16(dst_gemm_args g, int split
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   // A[m, k] = A[m * a_rs + k * a_cs]; B[k, n] = B[k * b_rs + n * b_cs]: as a (row = n, k) operand its row stride is b_cs, its k stride b_rs
   const int ones_row = g.rowsum ? g.N : -1;
-  f32x4_t ra[4], rb[4];
+  // two k-steps of operands in flight (two register sets, the loop unrolled by two so that each set is addressed statically): a
+  // workgroup that is alone on its CU - split products have ~1 per CU - otherwise exposes a full memory round trip per step
+  f32x4_t ra0[4], rb0[4], ra1[4], rb1[4];
+  const bool arf = a_rfast != 0, brf = b_rfast != 0;
   if (kbeg < kend) {
-    fetch_tile<BM>(g.A, g.a_rs, g.a_cs, a_rfast != 0, m0, g.M, kbeg, kend, -1, ra);
-    fetch_tile<BN>(g.B, g.b_cs, g.b_rs, b_rfast != 0, n0, g.N, kbeg, kend, ones_row, rb);
+    fetch_tile<BM>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, kbeg, kend, -1, ra0);
+    fetch_tile<BN>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, kbeg, kend, ones_row, rb0);
+  }
+  if (kbeg + BK < kend) {
+    fetch_tile<BM>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, kbeg + BK, kend, -1, ra1);
+    fetch_tile<BN>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, kbeg + BK, kend, ones_row, rb1);
   }
   const int arow = (wm * (BM / 2) + (lane & 31)) * LDK + 8 * (lane >> 5);
   const int brow = (wn * (BN / 2) + (lane & 31)) * LDK + 8 * (lane >> 5);
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    commit_tile<BM>(As, a_rfast != 0, ra);
-    commit_tile<BN>(Bs, b_rfast != 0, rb);
+  auto step = [&](f32x4_t (&xa)[4], f32x4_t (&xb)[4], int k0) {
+    commit_tile<BM>(As, arf, xa);
+    commit_tile<BN>(Bs, brf, xb);
     __syncthreads();
-    if (k0 + BK < kend) {
-      fetch_tile<BM>(g.A, g.a_rs, g.a_cs, a_rfast != 0, m0, g.M, k0 + BK, kend, -1, ra);
-      fetch_tile<BN>(g.B, g.b_cs, g.b_rs, b_rfast != 0, n0, g.N, k0 + BK, kend, ones_row, rb);
+    if (k0 + 2 * BK < kend) {
+      fetch_tile<BM>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, k0 + 2 * BK, kend, -1, xa);
+      fetch_tile<BN>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, k0 + 2 * BK, kend, ones_row, xb);
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
@@ -307,6 +308,10 @@ __global__ __launch_bounds__(256) void k_tr_gemm_bf16(dst_gemm_args g, int split
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
+  };
+  for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+    step(ra0, rb0, k0);
+    if (k0 + BK < kend) step(ra1, rb1, k0 + BK);
   }
   finish_tiles<TM, TN>(g, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), splits, z, reinterpret_cast<float*>(lds));
 }
@@ -489,7 +494,7 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
     if (bf) hipLaunchKernelGGL((k_tr_gemm_big<64, 64, true>), grid, blk, 0, s, g, splits, kchunk, tm, tn);
     else hipLaunchKernelGGL((k_tr_gemm_big<64, 64, false>), grid, blk, 0, s, g, splits, kchunk, tm, tn);
   }
-  if (splits > 1) hipLaunchKernelGGL(k_tr_gemm_reduce, dim3((unsigned)(((int64_t)g.M * Nx + 1023) / 1024)), dim3(256), 0, s, g, splits);
+  if (splits > 1) hipLaunchKernelGGL(k_tr_gemm_reduce, dim3((unsigned)(((int64_t)g.M * Nx + 255) / 256)), dim3(256), 0, s, g, splits);
   return DST_CHECK_LAUNCH();
 }
 

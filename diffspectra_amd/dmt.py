@@ -114,9 +114,52 @@ class DMT(nn.Module):
         return self._engine
 
     # ------------------------------------------------------------------ score function
-    @torch.no_grad()
     def forward(self, t, xh, node_mask, edge_mask, context=None, *args, **kwargs):
-        """Same contract as reference dmt.py:306-321; ``t`` is accepted and unused there as well."""
+        """Same contract as reference dmt.py:306-321; ``t`` is accepted and unused there as well.
+
+        ``model.eval()``: the sampling kernels (``ds_forward``), no autograd graph.  ``model.train()`` (reference callers:
+        ``losses.py:346-357``): the training library - FF dropout active, SpecFormer's BatchNorm on batch statistics with its running
+        statistics updated - and, with gradients enabled, outputs that carry a ``grad_fn``: a caller's own loss around ``model(...)``
+        fills ``p.grad`` on ``backward()`` (the hand-written backward of ``train_engine`` / ``spec_train`` behind one autograd node)."""
+        if self.training:
+            return self._forward_train(xh, node_mask, edge_mask, context, kwargs)
+        with torch.no_grad():
+            return self._forward_eval(xh, node_mask, edge_mask, context, kwargs)
+
+    def _forward_train(self, xh, node_mask, edge_mask, context, kwargs):
+        from .losses import _trainer, _deliver_grads
+        edge_x, cond_x, cond_edge_x = kwargs["edge_x"], kwargs["cond_x"], kwargs["cond_edge_x"]
+        noise_level = kwargs["noise_level"]
+        if context is None:
+            raise TypeError("DMT.forward needs `context` (spectra)")
+        tr = _trainer(self)
+        dev = tr.dev
+        named, dmt, spec = tr.graphs()
+        tr.ops.bf16 = getattr(self.config.training, "precision", "fp32") == "bf16"
+        f32 = lambda v: v.detach().to(dev, torch.float32)
+        TL = tr.layout(f32(node_mask).reshape(node_mask.shape[0], -1))
+        TL.L.check_edge_mask(edge_mask)
+        TL.L.check_edge_symmetry(edge_x, "edge_x")
+        z, ez = TL.pack_nodes(f32(xh)), TL.pack_pairs(f32(edge_x))
+        cond_n = cond_e = None
+        if cond_x is not None:
+            TL.L.check_edge_symmetry(cond_edge_x, "cond_edge_x")
+            cond_n, cond_e = TL.pack_nodes(f32(cond_x)), TL.pack_pairs(f32(cond_edge_x))
+        ctx_in = [f32(c) for c in context] if isinstance(context, (list, tuple)) else f32(context)
+        want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in named.values())
+        dmt.dropout_p = float(getattr(self.config.model, "dropout", 0.0))
+        dmt.dropout_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if dmt.dropout_p > 0 else 0
+        with torch.no_grad():
+            ctx = spec.forward(ctx_in, save=want_grad)
+            pos, atom, edge = dmt.forward(TL, z, ez, f32(noise_level).contiguous(), ctx, cond_n, cond_e, save=want_grad)
+            out_xh = TL.unpack_nodes(torch.cat([pos, atom], dim=1)).to(xh.dtype)
+            out_edge = TL.unpack_pairs(edge).to(edge_x.dtype)
+        if not want_grad:
+            return out_xh, out_edge
+        params = list(named.values())
+        return _DmtGraph.apply(tr, named, dmt, spec, TL, _deliver_grads, out_xh, out_edge, *params)
+
+    def _forward_eval(self, xh, node_mask, edge_mask, context, kwargs):
         edge_x, cond_x, cond_edge_x = kwargs["edge_x"], kwargs["cond_x"], kwargs["cond_edge_x"]
         noise_level = kwargs["noise_level"]
         eng = self.engine()
@@ -143,3 +186,36 @@ class DMT(nn.Module):
             self._ctx_cache = (self._engine_key, [(t, t._version) for t in ctx_list], ctx)
         out_xh, out_edge = eng.forward(L, ws, xh, edge_x, noise_level, cond_x, cond_edge_x, ctx)
         return out_xh.to(xh.dtype), out_edge.to(edge_x.dtype)
+
+
+class _DmtGraph(torch.autograd.Function):
+    """One autograd node around the training graphs' forward tape: ``backward`` packs the gradients of the two dense outputs, walks
+    the tape (``DmtTrainGraph.backward`` + ``SpecTrainGraph.backward``) and hands every parameter its gradient.  The score function's
+    tensor inputs (noisy state, self-conditioning, spectra) are treated as constants - no reference caller differentiates them."""
+
+    @staticmethod
+    def forward(ctx, tr, named, dmt, spec, TL, deliver, out_xh, out_edge, *params):
+        ctx.pack = (tr, named, dmt, spec, TL, deliver)
+        ctx.tapes = (dmt.t, spec.t)                        # the graphs are shared per model: keep THIS call's tapes
+        return out_xh.clone(), out_edge.clone()
+
+    @staticmethod
+    def backward(ctx, d_xh, d_edge):
+        tr, named, dmt, spec, TL, deliver = ctx.pack
+        if ctx.tapes is None:
+            raise RuntimeError("backward through DMT.forward twice: the forward tape was already consumed")
+        dmt.t, spec.t = ctx.tapes
+        ctx.tapes = None
+        if d_xh is None:
+            d_xh = torch.zeros(TL.B, TL.N, 9, device=tr.dev)
+        if d_edge is None:
+            d_edge = torch.zeros(TL.B, TL.N, TL.N, 2, device=tr.dev)
+        dn = TL.pack_nodes(d_xh.to(torch.float32))
+        dpos, datom = dn[:, 0:3].contiguous(), dn[:, 3:9].contiguous()
+        de = d_edge.to(torch.float32).reshape(TL.B * TL.N * TL.N, -1)
+        dedge = (de.index_select(0, TL.pair_dense) + de.index_select(0, TL.pair_dense_t)).contiguous()   # both cells of a pair carry its value
+        flat, _, offs = tr.stage(named)
+        flat.zero_()
+        g = dmt.backward(dpos, datom, dedge)
+        g.update(spec.backward(g.pop("@ctx_emb")))
+        return (None,) * 8 + deliver(tr, named, g, flat, offs, None)

@@ -30,6 +30,20 @@ from .train_engine import DmtTrainGraph, Ops, TrainLayout, load_train_library
 
 
 # ----------------------------------------------------------------------------------------------------------- optimizer
+FLAT_ALIGN = 64        # floats: every parameter starts on a 256-byte boundary of the flat buffers (the GEMM kernels load operands 16 bytes at a time)
+
+
+def flat_offsets(sizes, align: int = FLAT_ALIGN):
+    """Start offset of every tensor in a flat buffer that keeps each one ``align``-element aligned, plus the total length (last entry).
+    Shared by the optimizer's parameter / gradient buffers and the trainer's gradient stage: equal layouts make ``loss.backward()`` one add."""
+    offs, cur = [], 0
+    for n in sizes:
+        offs.append(cur)
+        cur += (int(n) + align - 1) // align * align
+    offs.append(cur)
+    return offs
+
+
 class FusedAdamW:
     """``torch.optim.AdamW(params, lr, amsgrad=True, weight_decay)`` (losses.py:20) as ONE kernel over a flat fp32 buffer.
 
@@ -57,7 +71,7 @@ class FusedAdamW:
         self.sharded = self.world > 1 or (bool(force_sharded) and dist.is_available() and dist.is_initialized())
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=True, params=list(range(len(self.params))))]
         self.sizes = [p.numel() for p in self.params]
-        self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).tolist()
+        self.offsets = flat_offsets(self.sizes)
         n = self.offsets[-1]
         self.n = n
         unit = 256 * self.world
@@ -78,6 +92,11 @@ class FusedAdamW:
         self.scratch = torch.empty(1024, dtype=torch.float32, device=dev)
         self.norm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.ema_flat = None
+
+    def unpadded(self, flat: torch.Tensor) -> torch.Tensor:
+        """The parameters' elements of a flat buffer in ``parameters()`` order without the alignment gaps (what ``torch.cat`` of the
+        flattened tensors gives)."""
+        return torch.cat([flat[o:o + n] for o, n in zip(self.offsets, self.sizes)])
 
     # -- torch.optim surface
     def zero_grad(self, set_to_none: bool = False):
@@ -306,6 +325,29 @@ class _HipLossFlat(torch.autograd.Function):
         return (None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
+def _deliver_grads(tr, named, g, flat, offs, scale):
+    """Parameter gradients of a finished backward (``flat`` = the stage they were written into) for an autograd node's return tuple:
+    when every ``p.grad`` is a view of one flat buffer laid out like the stage, ONE kernel adds the stage into it and the node
+    returns None s; otherwise per-parameter clones (autograd accumulates them)."""
+    missing = [n for n, p in named.items() if p.requires_grad and n not in g]
+    if missing:
+        raise RuntimeError(f"no gradient was produced for {missing[:5]}")
+    target = tr.flat_grad_target(named, offs)
+    if target is not None:
+        if scale is None:
+            target.add_(flat)
+        else:
+            target.addcmul_(flat, scale.to(flat.dtype))
+        return (None,) * len(named)
+    out = []
+    for n, p in named.items():
+        if not p.requires_grad:
+            out.append(None)
+        else:
+            out.append(g[n].clone() if scale is None else g[n] * scale)
+    return tuple(out)
+
+
 class HipTrainer:
     """Per-model training state: the two graphs, bound to the model's current parameter storage at every call."""
 
@@ -323,10 +365,10 @@ class HipTrainer:
         """One flat fp32 buffer holding every parameter's gradient of the current backward, in ``named_parameters()`` order without
         gaps, and the per-parameter views the backward kernels write into."""
         sizes = [p.numel() for p in named.values()]
-        n = int(sum(sizes))
+        offs = flat_offsets(sizes)
+        n = offs[-1]
         if self._stage is None or self._stage[0].numel() != n:
             flat = torch.zeros(n, dtype=torch.float32, device=self.dev)
-            offs = np.concatenate([[0], np.cumsum(sizes)]).tolist()
             views = {name: flat[o:o + p.numel()].view(p.shape) for (name, p), o in zip(named.items(), offs)}
             self._stage = (flat, views, offs)
         return self._stage

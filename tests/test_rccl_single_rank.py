@@ -99,7 +99,7 @@ def _worker(port, out_path):
                                                 and ema_r.shadow_params[0].data_ptr() == opt_r.ema_flat.data_ptr())
             p_after = opt.P.detach().cpu().clone()
             ema.copy_to(m.parameters())                       # sharded: gather_ema's all_gather_into_tensor
-            assert torch.equal(opt.P[:opt.n], opt.ema_flat[:opt.n])
+            assert torch.equal(opt.unpadded(opt.P), opt.unpadded(opt.ema_flat))
             runs[mode] = dict(P=p_after, ema=opt.ema_flat.detach().cpu().clone(), M=opt.M.detach().cpu().clone(),
                               Vmax=opt.Vmax.detach().cpu().clone(), losses=losses + [state["loss3"]], norm=float(opt.grad_norm()))
         res["adamw_equal"] = all(torch.equal(runs["plain"][k], runs["sharded"][k]) for k in ("P", "ema", "M", "Vmax"))

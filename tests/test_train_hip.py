@@ -604,6 +604,12 @@ def _loss_fn_against_golden(gpu_device, monkeypatch, version, coin_name, fixture
         if n >= 3:
             check(last["rot"][b].reshape(3, 3), g[tag + "_rotations"][b], 1e-4, f"rotation {b}")
     check(TL.unpack_nodes(torch.cat(last["pred"][:2], 1)), g[tag + "_pred"], 3e-5, "pred")
+    _check_gradients_and_bn(model, g, tag, f"loss_fn {fixture[:3]}", float(loss), ref_loss)
+
+
+def _check_gradients_and_bn(model, g, tag, label, loss, ref_loss):
+    """Every parameter's gradient norm and strided sample, the stored full gradients (rtol 1e-4 + a floor of 1e-7 of the total norm), and
+    the BatchNorm running statistics after the step, against a training golden (G13 / G17)."""
     names = json.loads(g[tag + "_grad_names"])
     norms = g[tag + "_grad_norms"].numpy()
     total = float(np.sqrt(np.sum(np.square(norms))))
@@ -628,13 +634,52 @@ def _loss_fn_against_golden(gpu_device, monkeypatch, version, coin_name, fixture
             full = g[f"{tag}_grad::{n}"]
             if not torch.allclose(gr, full, rtol=1e-4, atol=1e-4 * float(full.abs().max()) + floor):
                 bad.append((n, "full", float((gr - full).abs().max()), float(full.abs().max())))
-    print(f"[loss_fn {fixture[:3]} {tag}] loss {float(loss):.6f} (reference {ref_loss:.6f}); total grad norm {total:.3f}; {len(names)} parameters checked")
+    print(f"[{label} {tag}] loss {loss:.6f} (reference {ref_loss:.6f}); total grad norm {total:.3f}; {len(names)} parameters checked")
     assert not bad, bad[:10]
     bn = "cond_encoder.backbone.encoder.layers.0.norm_attn.1."
     bufs = dict(model.module.named_buffers())
     check(bufs[bn + "running_mean"], g[tag + "_bn_running_mean"], 1e-5, "BatchNorm running_mean after the step")
     check(bufs[bn + "running_var"], g[tag + "_bn_running_var"], 1e-5, "BatchNorm running_var after the step")
     assert int(bufs[bn + "num_batches_tracked"]) == int(g[tag + "_bn_batches"])
+
+
+@pytest.mark.parametrize("coin_name", ["selfcond", "plain"])
+def test_model_forward_under_autograd_reproduces_reference_gradients(gpu_device, coin_name):
+    """The score-function boundary (reference callers differentiate straight through ``model(...)``, losses.py:346-357): a
+    reference-style loss written by hand around ``model(...)`` in training mode - inputs are golden G13's own z_t / noise level /
+    aligned target, the loss is torch arithmetic on the returned tensors - must fill ``p.grad`` with the reference's gradients."""
+    d = gpu_device
+    cfg, model = _train_model("ir", d)
+    model.train()
+    g = cases.load_npz("g13_training.npz")
+    tag = f"ir_{coin_name}"
+    batch = cases.training_batch("ir")
+    node_mask, edge_mask = batch["atom_mask"].unsqueeze(2).to(d), batch["edge_mask"].to(d)
+    z_t, edge_z_t, nl = g[tag + "_z_t"].to(d), g[tag + "_edge_z_t"].to(d), g[tag + "_noise_level"].to(d)
+    ctx = batch["context"].to(d)
+    B = z_t.shape[0]
+    kw = dict(context=ctx, edge_x=edge_z_t, noise_level=nl, alpha_t=g[tag + "_alpha_t"].to(d), sigma_t=g[tag + "_sigma_t"].to(d))
+    cond_x = cond_e = None
+    if coin_name == "selfcond":
+        with torch.no_grad():                                            # losses.py:344-351: training mode, no gradient
+            cond_x, cond_e = model(torch.zeros(B, device=d), z_t, node_mask, edge_mask, cond_x=None, cond_edge_x=None, **kw)
+        assert not cond_x.requires_grad
+        check(cond_x, g[tag + "_cond_x"], 3e-5, "self-conditioning prediction")
+    pred, edge_pred = model(torch.zeros(B, device=d), z_t, node_mask, edge_mask, cond_x=cond_x, cond_edge_x=cond_e, **kw)
+    assert pred.requires_grad and edge_pred.requires_grad and pred.grad_fn is not None
+    check(pred, g[tag + "_pred"], 3e-5, "pred")
+    check(edge_pred, g[tag + "_edge_pred"], 3e-5, "edge_pred")
+    loss = otrain.loss_from_predictions(pred, edge_pred, g[tag + "_xh"].to(d), g[tag + "_edge_x"].to(d), g[tag + "_align_pos"].to(d),
+                                        g[tag + "_alpha_t"].to(d), g[tag + "_sigma_t"].to(d))
+    loss.backward()
+    ref_loss = float(g[tag + "_loss"])
+    assert abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss)
+    _check_gradients_and_bn(model, g, tag, "model(...) under autograd", float(loss), ref_loss)
+    with pytest.raises(RuntimeError, match="twice"):
+        pred.sum().backward()
+    model.eval()
+    out = model(torch.zeros(B, device=d), z_t, node_mask, edge_mask, cond_x=cond_x, cond_edge_x=cond_e, **kw)[0]
+    assert not out.requires_grad                                         # eval mode: the sampling kernels, no graph
 
 
 def test_step_fn_fused_optimizer_and_ema(gpu_device, monkeypatch):
@@ -734,7 +779,7 @@ def _ddp_worker(rank, world, port, out_path):
         stale = opt.ema_flat.detach().cpu().clone()
         ema.copy_to(model.parameters())                                  # reading the EMA gathers the shards
         assert opt._ema_stale is False and not torch.equal(stale, opt.ema_flat.detach().cpu())
-        assert torch.equal(torch.cat([p.detach().reshape(-1) for p in model.parameters()]), opt.ema_flat[:opt.n])
+        assert torch.equal(torch.cat([p.detach().reshape(-1) for p in model.parameters()]), opt.unpadded(opt.ema_flat))
         flat_grad_local = opt.G.detach().cpu().clone()
         ema_gathered = opt.ema_flat.detach().cpu().clone()
         # checkpoint in a sharded job: state_dict() gathers the sharded moments - a collective every rank joins; rank 0 writes
@@ -756,7 +801,8 @@ def _ddp_worker(rank, world, port, out_path):
             fn_(st_, batch)
             finals.append(st_["optimizer"].P.detach().cpu().clone())
         assert torch.equal(finals[0], finals[1]), "save -> restore -> step diverged from the uninterrupted run"
-        torch.save(dict(P=p_step, G=flat_grad_local, loss=float(loss.detach()), ema=ema_gathered, P2=finals[1]), out_path + f".{rank}")
+        up = lambda t: opt.unpadded(t.to(d)).cpu()                           # parameters() order without the alignment gaps of the flat buffers
+        torch.save(dict(P=up(p_step), G=up(flat_grad_local), loss=float(loss.detach()), ema=up(ema_gathered), P2=up(finals[1])), out_path + f".{rank}")
     finally:
         dist.destroy_process_group()
 

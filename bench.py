@@ -419,7 +419,7 @@ def train_measure(args, world, rank, device, steps, warmup, with_cpu_baseline):
         e0.record()
         orig_gemm(self, A, Bm, Cm, ta, tb, **kw)
         e1.record()
-        recs.append((e0, e1, 2.0 * M * Cm.cols * K))
+        recs.append((e0, e1, 2.0 * M * Cm.cols * K, (M, Cm.cols, K, int(ta), int(tb))))
     TE.Ops.gemm = timed_gemm
     try:
         step_fn(state, batch)
@@ -439,8 +439,17 @@ def train_measure(args, world, rank, device, steps, warmup, with_cpu_baseline):
                                        f"{cfg.model.dropout}, AdamW-amsgrad + adaptive clip + EMA fused, gradient reduce-scatter + parameter all-gather",
                            "mode": "train", "molecules_per_gpu": Bt, "parallelism": f"dp{world}", "last_loss": float(loss.detach())},
                 "whole_path": {"algorithmic_tflops_per_gpu": flop * steps / elapsed / 1e12}}
-        gemm_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-        gemm_flop = sum(f for _, _, f in recs)
+        gemm_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+        gemm_flop = sum(r[2] for r in recs)
+        if os.environ.get("DIFFSPECTRA_GEMM_TABLE") == "1":             # per-shape totals of the step's GEMM calls, on stderr
+            table = {}
+            for e0, e1, f, shape in recs:
+                t = table.setdefault(shape, [0, 0.0, 0.0])
+                t[0] += 1
+                t[1] += e0.elapsed_time(e1)
+                t[2] += f
+            for shape, (cnt, ms, f) in sorted(table.items(), key=lambda kv: -kv[1][1]):
+                log(f"gemm M {shape[0]:6d} N {shape[1]:6d} K {shape[2]:6d} ta {shape[3]} tb {shape[4]}: {cnt:3d} calls {ms:7.3f} ms  {ms / cnt * 1e3:7.1f} us/call  {f / ms / 1e9:6.1f} TFLOP/s")
         peak = PEAK_F16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
         ach = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
         line["roofline"] = {"bound": "mfma", "kernel": "k_tr_gemm_bf16 (+ k_tr_gemm_reduce, its split-K reduction): every dst_gemm call of one step",

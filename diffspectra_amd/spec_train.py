@@ -33,6 +33,7 @@ class SpecTrainGraph:
         self.patch = [(pl[i], stv[i], int((SPECTRUM_LENGTHS[i] - pl[i]) / stv[i] + 1)) for i in self.used]
         self.L = sum(pn for _, _, pn in self.patch)
         self.pos_names = (["W_pos_uv", "W_pos_ir", "W_pos_raman"] if self.version == "allspectra" else ["W_pos"])
+        self.flash = None      # None: the score-free flash attention in bf16 mode, the materialised fp32 kernels otherwise; True / False force one
 
     def f(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.dev)
@@ -76,15 +77,25 @@ class SpecTrainGraph:
         layers = []
         prev = None
         scale = float(D_K ** -0.5)
+        flash = self.ops.bf16 if self.flash is None else bool(self.flash)
+        qkvs = []
         for l in range(N_LAYERS):
             base = pre + f"backbone.encoder.layers.{l}."
             qkv = self.f(B * L, 3 * D_MODEL)
             for k, nm in enumerate(("W_Q", "W_K", "W_V")):
                 o.lin_fwd(mv(Z), mv(p[base + f"self_attn.{nm}.weight"]), p[base + f"self_attn.{nm}.bias"], mv(qkv, k * D_MODEL, (k + 1) * D_MODEL))
-            Lp = (L + 31) // 32 * 32                                   # padded row stride of the [L, L] score matrices
-            scores, ast, ao = self.f(B, N_HEADS, L, Lp), self.f(B, N_HEADS, L, 2), self.f(B * L, D_MODEL)
-            E._check(self.lib.dst_spec_attn_fwd(E._ptr(qkv), E._ptr(prev), E._ptr(scores), E._ptr(ast), E._ptr(ao), C.c_int32(B), C.c_int32(L),
-                                                C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()), "dst_spec_attn_fwd")
+            ast, ao = self.f(B, N_HEADS, L, 2), self.f(B * L, D_MODEL)
+            qkvs.append(qkv)
+            if flash:                                                  # bf16 mode: scores recomputed from the q | k of layers 0 .. l, never stored
+                qp = [E._ptr(q_) for q_ in qkvs] + [None] * (3 - len(qkvs))
+                E._check(self.lib.dst_spec_attn_flash_fwd(qp[0], qp[1], qp[2], C.c_int32(l + 1), E._ptr(ast), E._ptr(ao), C.c_int32(B), C.c_int32(L),
+                                                          C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()), "dst_spec_attn_flash_fwd")
+                scores = None
+            else:
+                Lp = (L + 31) // 32 * 32                               # padded row stride of the [L, L] score matrices
+                scores = self.f(B, N_HEADS, L, Lp)
+                E._check(self.lib.dst_spec_attn_fwd(E._ptr(qkv), E._ptr(prev), E._ptr(scores), E._ptr(ast), E._ptr(ao), C.c_int32(B), C.c_int32(L),
+                                                    C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()), "dst_spec_attn_fwd")
             r1 = Z.clone()
             o.gemm(mv(ao), mv(p[base + "self_attn.to_out.0.weight"]), mv(r1), False, True, bias=p[base + "self_attn.to_out.0.bias"], acc=True)
             z1, st1 = self.f(B * L, D_MODEL), self.f(2, D_MODEL)
@@ -109,7 +120,7 @@ class SpecTrainGraph:
         ctx = self.f(B, 1024)
         o.lin_fwd(mv(zs), mv(p["cond_lin.weight"]), p["cond_lin.bias"], mv(ctx))
         if save:
-            t.update(layers=layers, flat=flat, zh=zh, zs=zs, st_ln=st_ln)
+            t.update(layers=layers, flat=flat, zh=zh, zs=zs, st_ln=st_ln, flash=flash)
             self.t = t
         return ctx
 
@@ -138,6 +149,10 @@ class SpecTrainGraph:
         o.lin_bwd_x(mv(dzh), mv(p[pre + "head.linear.weight"]), mv(dZ.view(B, L * D_MODEL)))
         dscores_in = None
         scale = float(D_K ** -0.5)
+        flash = t["flash"]
+        if flash:                                                      # every layer's attention backward adds into the q | k columns of the layers below it
+            dqkv_all = [torch.zeros(B * L, 3 * D_MODEL, dtype=torch.float32, device=self.dev) for _ in range(N_LAYERS)]
+            qkv_all = [lt_["qkv"] for lt_ in t["layers"]]
         for l in reversed(range(N_LAYERS)):
             lt = t["layers"][l]
             base = pre + f"backbone.encoder.layers.{l}."
@@ -153,10 +168,18 @@ class SpecTrainGraph:
             o.lin_bwd_w(mv(dr1), mv(lt["ao"]), mv(gw(base + "self_attn.to_out.0.weight")), gw(base + "self_attn.to_out.0.bias"))
             dao = self.f(B * L, D_MODEL)
             o.lin_bwd_x(mv(dr1), mv(p[base + "self_attn.to_out.0.weight"]), mv(dao))
-            dqkv, dscores = self.f(B * L, 3 * D_MODEL), self.f(B, N_HEADS, L, (L + 31) // 32 * 32)
-            E._check(self.lib.dst_spec_attn_bwd(E._ptr(lt["qkv"]), E._ptr(lt["scores"]), E._ptr(lt["ast"]), E._ptr(dao), E._ptr(dscores_in), E._ptr(dqkv), E._ptr(dscores),
-                                                C.c_int32(B), C.c_int32(L), C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()),
-                     "dst_spec_attn_bwd")
+            if flash:
+                qp = [E._ptr(q_) for q_ in qkv_all[:l + 1]] + [None] * (2 - l)
+                gp = [E._ptr(q_) for q_ in dqkv_all[:l + 1]] + [None] * (2 - l)
+                E._check(self.lib.dst_spec_attn_flash_bwd(qp[0], qp[1], qp[2], C.c_int32(l + 1), E._ptr(lt["ast"]), E._ptr(lt["ao"]), E._ptr(dao), gp[0], gp[1], gp[2],
+                                                          C.c_int32(B), C.c_int32(L), C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()),
+                         "dst_spec_attn_flash_bwd")
+                dqkv, dscores = dqkv_all[l], None
+            else:
+                dqkv, dscores = self.f(B * L, 3 * D_MODEL), self.f(B, N_HEADS, L, (L + 31) // 32 * 32)
+                E._check(self.lib.dst_spec_attn_bwd(E._ptr(lt["qkv"]), E._ptr(lt["scores"]), E._ptr(lt["ast"]), E._ptr(dao), E._ptr(dscores_in), E._ptr(dqkv), E._ptr(dscores),
+                                                    C.c_int32(B), C.c_int32(L), C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()),
+                         "dst_spec_attn_bwd")
             for k, nm in enumerate(("W_Q", "W_K", "W_V")):
                 dq = mv(dqkv, k * D_MODEL, (k + 1) * D_MODEL)
                 o.lin_bwd_w(dq, mv(lt["Zin"]), mv(gw(base + f"self_attn.{nm}.weight")), gw(base + f"self_attn.{nm}.bias"))

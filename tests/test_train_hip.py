@@ -518,6 +518,46 @@ def test_specformer_train_graph_vs_oracle(gpu_device, version):
     assert int(bufs["cond_encoder.backbone.encoder.layers.0.norm_attn.1.num_batches_tracked"]) == int(sd["cond_encoder.backbone.encoder.layers.0.norm_attn.1.num_batches_tracked"]) + 1
 
 
+
+@pytest.mark.parametrize("version", ["ir", "allspectra"])
+def test_specformer_flash_attention_matches_materialised_scores(gpu_device, version):
+    """The score-free attention of the bf16 mode (dst_spec_attn_flash_*: layer l's residual scores recomputed as scale * sum_j q_j k_j^T
+    on the bf16 matrix pipe, probabilities re-created in the backward, the chained score gradient as direct contributions to the
+    lower layers' dq / dk) against the fp32 kernels that materialise the [B,H,L,L] scores - same graph, same fp32 GEMMs, only the
+    attention differs; tolerance = bf16 operand rounding (2^-9 relative per q / k / v / p element)."""
+    from diffspectra_amd import train_engine as T
+    from diffspectra_amd.spec_train import SpecTrainGraph
+    d = gpu_device
+    cfg, sd0 = procedural_state_dict(version)
+    params = {k: v.clone().to(d).contiguous() for k, v in sd0.items()
+              if (k.startswith("cond_encoder.") or k.startswith("cond_lin.")) and v.is_floating_point() and "running" not in k}
+    B = 6
+    context = cases.spectra_for(version, B, salt=5)
+    context = [c.to(d) for c in context] if isinstance(context, list) else context.to(d)
+    dctx = (torch.randn(B, 1024, generator=torch.Generator().manual_seed(4)) * 0.1).to(d)
+    res = {}
+    for flash in (False, True):
+        bufs = {k: v.detach().clone().to(d) for k, v in sd0.items() if "running" in k or "num_batches" in k}
+        graph = SpecTrainGraph(params, bufs, cfg, T.Ops(d))
+        graph.flash = flash
+        ctx = graph.forward(context)
+        aos = [lt["ao"].clone() for lt in graph.t["layers"]]
+        g = graph.backward(dctx)
+        res[flash] = (ctx.clone(), aos, {k: v.clone() for k, v in g.items()})
+    for l, (a, b) in enumerate(zip(res[True][1], res[False][1])):
+        check(a, b, 2e-2, f"attention output of layer {l}")
+    check(res[True][0], res[False][0], 2e-2, "context embedding")
+    total = float(torch.sqrt(sum((v.double() ** 2).sum() for v in res[False][2].values())))
+    dot = sum(float((res[True][2][k].double() * v.double()).sum()) for k, v in res[False][2].items())
+    n1 = float(torch.sqrt(sum((v.double() ** 2).sum() for v in res[True][2].values())))
+    worst = ("", 0.0)
+    for k, v in res[False][2].items():
+        err = float((res[True][2][k].double() - v.double()).norm()) / (float(v.double().norm()) + 1e-6 * total)
+        if err > worst[1]:
+            worst = (k, err)
+    print(f"[flash attention {version}] gradient cosine {dot / (total * n1):.6f}; worst per-tensor relative L2 deviation {worst}")
+    assert dot / (total * n1) > 0.9995 and worst[1] < 5e-2
+
 # ------------------------------------------------------------------------------------------------ the reference's loss_fn surface vs G13
 class _Replay:
     """Replays queued CPU tensors for torch.rand / torch.randn calls of matching shape, on the requested device."""

@@ -25,6 +25,7 @@
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -155,8 +156,9 @@ __global__ __launch_bounds__(256) void k_sfa_bwd_q(QkvPtrs qkv, int nl, const fl
     bf16x8_t v = zero8();
     if (k < L && c < nl) v = load8(qkv.p[c] + (row0 + k) * ROWLD + DM + h * DK, 1.0f);
     *reinterpret_cast<bf16x8_t*>(Kc + k * KLD + 8 * c) = v;
+    const u16x8_t vb_ = __builtin_bit_cast(u16x8_t, v);       // (a bit_cast of the single element v[e] returned element 0 for every e: hipcc 7.0)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) KTf[perm_index(k >> 5, k & 31, 8 * c + e, 32)] = __builtin_bit_cast(unsigned short, v[e]);
+    for (int e = 0; e < 8; ++e) KTf[perm_index(k >> 5, k & 31, 8 * c + e, 32)] = vb_[e];
   }
   const float* vsrc = qkv.p[nl - 1];
   for (int k = tid; k < LP; k += 256)
@@ -228,8 +230,9 @@ __global__ __launch_bounds__(256) void k_sfa_bwd_kv(QkvPtrs qkv, int nl, const f
     bf16x8_t v = zero8();
     if (q < L && c < nl) v = load8(qkv.p[c] + (row0 + q) * ROWLD + h * DK, qmul);
     *reinterpret_cast<bf16x8_t*>(Qs + q * KLD + 8 * c) = v;
+    const u16x8_t vb_ = __builtin_bit_cast(u16x8_t, v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) QTf[perm_index(q >> 5, q & 31, 8 * c + e, 32)] = __builtin_bit_cast(unsigned short, v[e]);
+    for (int e = 0; e < 8; ++e) QTf[perm_index(q >> 5, q & 31, 8 * c + e, 32)] = vb_[e];
   }
   for (int q = tid; q < LP; q += 256) {
     bf16x8_t v = zero8();
@@ -243,8 +246,9 @@ __global__ __launch_bounds__(256) void k_sfa_bwd_kv(QkvPtrs qkv, int nl, const f
       m = stats[((int64_t)bh * L + q) * 2];
       il = 1.0f / stats[((int64_t)bh * L + q) * 2 + 1];
     }
+    const u16x8_t vb_ = __builtin_bit_cast(u16x8_t, v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dOTf[perm_index(q >> 5, q & 31, e, DK)] = __builtin_bit_cast(unsigned short, v[e]);
+    for (int e = 0; e < 8; ++e) dOTf[perm_index(q >> 5, q & 31, e, DK)] = vb_[e];
     ms[q] = m; ils[q] = il; Ds[q] = D;             // padded queries: il = 0 -> P = 0
   }
   __syncthreads();

@@ -552,7 +552,9 @@ def test_specformer_flash_attention_matches_materialised_scores(gpu_device, vers
     n1 = float(torch.sqrt(sum((v.double() ** 2).sum() for v in res[True][2].values())))
     worst = ("", 0.0)
     for k, v in res[False][2].items():
-        err = float((res[True][2][k].double() - v.double()).norm()) / (float(v.double().norm()) + 1e-6 * total)
+        # a V / to_out bias in front of a BatchNorm has a (nearly) ZERO true gradient - a sum of cancelling terms - so the bf16 rounding
+        # noise is measured against the tensor's norm plus a small share of the total gradient norm
+        err = float((res[True][2][k].double() - v.double()).norm()) / (float(v.double().norm()) + 3e-3 * total)
         if err > worst[1]:
             worst = (k, err)
     print(f"[flash attention {version}] gradient cosine {dot / (total * n1):.6f}; worst per-tensor relative L2 deviation {worst}")

@@ -416,6 +416,110 @@ __global__ __launch_bounds__(256) void k_tr_gemm_big(dst_gemm_args g, int splits
   finish_tiles<TM, TN>(g, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), splits, z, lds);
 }
 
+// ------------------------------------------------------------------------------------------------------------------ weight-stationary kernel
+// C[M, N] = A[M, K] B[K, N] for the tall products of the step (M = node / pair / directed / token rows, 4 600 .. 89 000; K <= 512,
+// N <= 512): every Linear forward and input gradient.  In the tiled kernel above such a product re-stages the same small weight in
+// every workgroup and k-step, and a 128 x 64 tile exchanges operands through LDS eight times for 0.4 us of matrix work - measured inside
+// a training step it moved its bytes at 1.7 - 2.2 TB/s.  Here the WEIGHT is staged once per workgroup (bf16, row n = output column, k
+// contiguous, 16 bytes of padding per row: conflict-free ds_read_b128 B fragments) and stays; each of the eight waves then streams
+// 32-row tiles of A straight from global memory into A fragments (a lane reads the 32 bytes of its row per k-step; chunks of eight
+// k-steps, the next chunk's 16 kB per wave in flight under the current chunk's MFMAs), multiplies them against the resident weight
+// (NCT column tiles of 32) and writes whole 128-byte output segments through the common epilogue.  No barrier after the weight staging.
+// Wide outputs are split into chunks of 32 NCT columns over neighbouring workgroups of one XCD (tile_of_block's placement idea).
+constexpr int WS_KS = 8;   // k-steps (of 16) per chunk of A
+template <int NCT>
+__global__ __launch_bounds__(512) void k_tr_gemm_ws(dst_gemm_args g, int b_rfast, int Kp, int nchunks, int ngroups) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short wlds[];
+  constexpr int NC = 32 * NCT;
+  const int WLD = Kp + 8;                                   // bf16 per weight row
+  unsigned short* Wt = wlds;
+  float* stage = reinterpret_cast<float*>(wlds + NC * WLD);
+  const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const int grp = (slot / nchunks) * 8 + xcd, chunk = slot % nchunks;
+  if (grp >= ngroups) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int n0 = chunk * NC;
+  const int kq = Kp >> 2;
+  if (!b_rfast) {                                           // B[k, n] = B[n * b_cs + k]: rows of W are k-contiguous
+    for (int u = tid; u < NC * kq; u += 512) {
+      const int n = u / kq, k = 4 * (u % kq);
+      f32x4_t t = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (n0 + n < g.N && k < g.K) t = *reinterpret_cast<const f32x4_t*>(g.B + (int64_t)(n0 + n) * g.b_cs + k);   // K % 4 == 0
+      const uint2 w = {pack2(t[0], t[1]), pack2(t[2], t[3])};
+      *reinterpret_cast<uint2*>(Wt + n * WLD + k) = w;
+    }
+  } else {                                                  // B[k, n] = B[k * b_rs + n]: 4 x 4 micro-tiles, transposed in registers
+    constexpr int NQ = NC / 4;
+    for (int u = tid; u < NQ * kq; u += 512) {
+      const int nq = u % NQ, k = 4 * (u / NQ), n = n0 + 4 * nq;
+      f32x4_t t[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        t[kk] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        if (k + kk < g.K) {
+          const float* p = g.B + (int64_t)(k + kk) * g.b_rs + n;
+          if (n + 3 < g.N) t[kk] = *reinterpret_cast<const f32x4_t*>(p);
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < g.N) t[kk][e] = p[e];
+          }
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const uint2 w = {pack2(t[0][rr], t[1][rr]), pack2(t[2][rr], t[3][rr])};
+        *reinterpret_cast<uint2*>(Wt + (4 * nq + rr) * WLD + k) = w;
+      }
+    }
+  }
+  __syncthreads();
+  const int nsteps = Kp >> 4, nch = (nsteps + WS_KS - 1) / WS_KS;
+  const int ntiles = (g.M + 31) >> 5;
+  f32x4_t raw[WS_KS][2];
+  auto issue = [&](int tile, int kc) {                       // this lane's 32 bytes per k-step of chunk kc of its row
+    const int row = min(tile * 32 + r, g.M - 1);
+    const float* ap = g.A + (int64_t)row * g.a_rs + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < WS_KS; ++s) {
+      const int k = 16 * (kc * WS_KS + s) + 8 * hh;
+      raw[s][0] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+      raw[s][1] = raw[s][0];
+      if (kc * WS_KS + s < nsteps) {
+        if (k < g.K) raw[s][0] = *reinterpret_cast<const f32x4_t*>(ap + 16 * (kc * WS_KS + s));
+        if (k + 4 < g.K) raw[s][1] = *reinterpret_cast<const f32x4_t*>(ap + 16 * (kc * WS_KS + s) + 4);
+      }
+    }
+  };
+  const int t0 = grp * 8 + wave, tstride = ngroups * 8;
+  if (t0 < ntiles) issue(t0, 0);
+  const unsigned short* wrow = Wt + r * WLD + 8 * hh;
+  for (int tile = t0; tile < ntiles; tile += tstride) {
+    f32x16_t acc[1][NCT];
+#pragma unroll
+    for (int j = 0; j < NCT; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][j][i] = 0.0f;
+    for (int kc = 0; kc < nch; ++kc) {
+      bf16x8_t a[WS_KS];
+#pragma unroll
+      for (int s = 0; s < WS_KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[s][e] = (__bf16)raw[s][0][e]; a[s][4 + e] = (__bf16)raw[s][1][e]; }
+      if (kc + 1 < nch) issue(tile, kc + 1);
+      else if (tile + tstride < ntiles) issue(tile + tstride, 0);
+#pragma unroll
+      for (int s = 0; s < WS_KS; ++s)
+        if (kc * WS_KS + s < nsteps) {
+#pragma unroll
+          for (int j = 0; j < NCT; ++j)
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], *reinterpret_cast<const bf16x8_t*>(wrow + j * 32 * WLD + 16 * (kc * WS_KS + s)), acc[0][j], 0, 0, 0);
+        }
+    }
+    finish_tiles<1, NCT>(g, acc, tile * 32, n0, 1, 0, stage);
+  }
+}
+
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -448,6 +552,28 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   static const int force_old = env_int("DST_GEMM_OLD", 0), bn_pref = env_int("DST_GEMM_BN", 0), bm_pref = env_int("DST_GEMM_BM", 0),
                    split_target = env_int("DST_GEMM_SPLIT_WGS", 1024), wg_target = env_int("DST_GEMM_WGS", 768);
   const bool vec = bf && !force_old && (a_k || a_r) && (b_k || b_r) && g.K >= 8;
+  static const int ws_off = env_int("DST_GEMM_WS", 1) == 0, ws_min_m = env_int("DST_GEMM_WS_MIN_M", 4096);
+  if (vec && !ws_off && a_k && g.K <= 512 && (g.K & 3) == 0 && g.M >= ws_min_m && !g.rowsum && g.N >= 16) {
+    const int Kp = (g.K + 15) / 16 * 16;
+    int nct = g.N > 64 ? 4 : 2;
+    if ((size_t)32 * nct * (Kp + 8) * 2 + STAGE_BYTES * 2 > 160 * 1024) nct = 2;      // K = 512: 64 columns of the weight at a time
+    const int NC = 32 * nct;
+    const int nchunks = (g.N + NC - 1) / NC;
+    const size_t lds = (size_t)NC * (Kp + 8) * 2 + STAGE_BYTES * 2;          // eight waves' staging tiles
+    int ngroups = (g.M + 255) / 256;
+    const int max_groups = (256 + nchunks - 1) / nchunks;                     // one workgroup per CU (the resident weight takes most of its LDS)
+    if (ngroups > max_groups) ngroups = max_groups;
+    const dim3 grid(8 * ((ngroups + 7) / 8) * nchunks), blk(512);
+    static bool attr_done[2] = {false, false};
+    if (nct == 4) {
+      if (!attr_done[0]) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tr_gemm_ws<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[0] = true; }
+      hipLaunchKernelGGL((k_tr_gemm_ws<4>), grid, blk, lds, s, g, (int)b_r, Kp, nchunks, ngroups);
+    } else {
+      if (!attr_done[1]) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tr_gemm_ws<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[1] = true; }
+      hipLaunchKernelGGL((k_tr_gemm_ws<2>), grid, blk, lds, s, g, (int)b_r, Kp, nchunks, ngroups);
+    }
+    return DST_CHECK_LAUNCH();
+  }
   int BM, BN;
   if (vec) {
     // tiles sized so that the launch has at least ~3 workgroups per CU where the problem allows it: the k-loop of a workgroup exposes

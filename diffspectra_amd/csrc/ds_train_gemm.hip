@@ -112,8 +112,8 @@ __device__ __forceinline__ void finish_tiles(const dst_gemm_args& g, f32x16_t (&
     for (int r = 0; r < 16; ++r) st[((r >> 2) * 8 + (lane >> 5) * 4 + (r & 3)) * STAGE_LD + (lane & 31)] = sel[r];
     const int ti = t / TN, tj = t % TN;
     const int col = cbase + tj * 32 + (lane & 31);
-#pragma unroll 1
-    for (int e = 0; e < 16; ++e) {
+#pragma unroll 4
+    for (int e = 0; e < 16; ++e) {                                            // four elements in flight: the loop is latency-bound (LDS read, ref load, stores)
       const int lr = 2 * e + (lane >> 5);
       const int row = rbase + ti * 32 + lr;
       const float a = st[lr * STAGE_LD + (lane & 31)];
@@ -176,7 +176,7 @@ __device__ __forceinline__ unsigned int pack2(float a, float b) {
 // row of the tile is 128 contiguous bytes; vec4 u of 256-thread pass i covers row u >> 3, k 4 (u & 7) ..) or rs == 1 ("row-fast": the
 // memory order runs along the rows; a thread takes a 4 (rows) x 4 (k) micro-tile, four 16-byte loads, transposed when committed).
 // Out-of-range elements are zero.  ones_row (B only): that row of the tile is the virtual all-ones vector of the fused row sum.
-template <int ROWS>
+template <int ROWS, int NTHR = 256>
 __device__ __forceinline__ void fetch_tile(const float* __restrict__ X, int64_t rs, int64_t ks, bool rfast, int row0, int R, int k0, int kend,
                                            int ones_row, f32x4_t (&v)[4]) {
   const int tid = threadIdx.x;
@@ -184,8 +184,8 @@ __device__ __forceinline__ void fetch_tile(const float* __restrict__ X, int64_t 
   for (int i = 0; i < 4; ++i) v[i] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};      // every element defined on every path: the array stays in registers
   if (!rfast) {
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-      const int u = tid + i * 256;
+    for (int i = 0; i < ROWS * 8 / NTHR; ++i) {
+      const int u = tid + i * NTHR;
       const int gr = row0 + (u >> 3), gk = k0 + 4 * (u & 7);
       f32x4_t t = {0.0f, 0.0f, 0.0f, 0.0f};
       if (gr < R) {
@@ -228,13 +228,13 @@ __device__ __forceinline__ void fetch_tile(const float* __restrict__ X, int64_t 
   }
 }
 
-template <int ROWS>
+template <int ROWS, int NTHR = 256>
 __device__ __forceinline__ void commit_tile(unsigned short* __restrict__ Xs, bool rfast, const f32x4_t (&v)[4]) {
   const int tid = threadIdx.x;
   if (!rfast) {
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-      const int u = tid + i * 256;
+    for (int i = 0; i < ROWS * 8 / NTHR; ++i) {
+      const int u = tid + i * NTHR;
       const uint2 w = {pack2(v[i][0], v[i][1]), pack2(v[i][2], v[i][3])};
       *reinterpret_cast<uint2*>(Xs + (u >> 3) * LDK + 4 * (u & 7)) = w;
     }
@@ -250,17 +250,22 @@ __device__ __forceinline__ void commit_tile(unsigned short* __restrict__ Xs, boo
   }
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_tr_gemm_bf16(dst_gemm_args g, int splits, int kchunk, int a_rfast, int b_rfast, int tm, int tn) {
-  constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int LDS_BYTES = (BM + BN) * LDK * 2 > STAGE_BYTES ? (BM + BN) * LDK * 2 : STAGE_BYTES;
+// NTHR = 256: 2 x 2 waves (BM, BN in {64, 128}).  NTHR = 512: 4 x 2 waves on a 256-row tile - the weight-gradient form: a whole
+// 256 x 256 (x 128, x 64) output per workgroup, so that a k-slice of dY^T and X is read ONCE (eight 128 x 64 tiles re-read the slice's
+// rows four and two times), one workgroup per CU, the k-range split over the CUs.
+template <int BM, int BN, int NTHR = 256>
+__global__ __launch_bounds__(NTHR) void k_tr_gemm_bf16(dst_gemm_args g, int splits, int kchunk, int a_rfast, int b_rfast, int tm, int tn) {
+  constexpr int WM = NTHR / 128, WN = 2;                    // waves along M and N
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);   // 32 x 32 tiles per wave
+  constexpr int STG = STAGE_BYTES * (NTHR / 256);
+  constexpr int LDS_BYTES = (BM + BN) * LDK * 2 > STG ? (BM + BN) * LDK * 2 : STG;
   __shared__ __attribute__((aligned(16))) unsigned short lds[LDS_BYTES / 2];
   unsigned short* As = lds;
   unsigned short* Bs = lds + BM * LDK;
   int z, mt, nt;
   if (!tile_of_block(tm, tn, splits, z, mt, nt)) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int m0 = mt * BM, n0 = nt * BN;
   const int kbeg = z * kchunk;
   const int kend = min(g.K, kbeg + kchunk);
@@ -278,22 +283,22 @@ __global__ __launch_bounds__(256) void k_tr_gemm_bf16(dst_gemm_args g, int split
   f32x4_t ra0[4], rb0[4], ra1[4], rb1[4];
   const bool arf = a_rfast != 0, brf = b_rfast != 0;
   if (kbeg < kend) {
-    fetch_tile<BM>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, kbeg, kend, -1, ra0);
-    fetch_tile<BN>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, kbeg, kend, ones_row, rb0);
+    fetch_tile<BM, NTHR>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, kbeg, kend, -1, ra0);
+    fetch_tile<BN, NTHR>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, kbeg, kend, ones_row, rb0);
   }
   if (kbeg + BK < kend) {
-    fetch_tile<BM>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, kbeg + BK, kend, -1, ra1);
-    fetch_tile<BN>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, kbeg + BK, kend, ones_row, rb1);
+    fetch_tile<BM, NTHR>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, kbeg + BK, kend, -1, ra1);
+    fetch_tile<BN, NTHR>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, kbeg + BK, kend, ones_row, rb1);
   }
-  const int arow = (wm * (BM / 2) + (lane & 31)) * LDK + 8 * (lane >> 5);
-  const int brow = (wn * (BN / 2) + (lane & 31)) * LDK + 8 * (lane >> 5);
+  const int arow = (wm * (BM / WM) + (lane & 31)) * LDK + 8 * (lane >> 5);
+  const int brow = (wn * (BN / WN) + (lane & 31)) * LDK + 8 * (lane >> 5);
   auto step = [&](f32x4_t (&xa)[4], f32x4_t (&xb)[4], int k0) {
-    commit_tile<BM>(As, arf, xa);
-    commit_tile<BN>(Bs, brf, xb);
+    commit_tile<BM, NTHR>(As, arf, xa);
+    commit_tile<BN, NTHR>(Bs, brf, xb);
     __syncthreads();
     if (k0 + 2 * BK < kend) {
-      fetch_tile<BM>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, k0 + 2 * BK, kend, -1, xa);
-      fetch_tile<BN>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, k0 + 2 * BK, kend, ones_row, xb);
+      fetch_tile<BM, NTHR>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, k0 + 2 * BK, kend, -1, xa);
+      fetch_tile<BN, NTHR>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, k0 + 2 * BK, kend, ones_row, xb);
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(256) void k_tr_gemm_bf16(dst_gemm_args g, int split
     step(ra0, rb0, k0);
     if (k0 + BK < kend) step(ra1, rb1, k0 + BK);
   }
-  finish_tiles<TM, TN>(g, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), splits, z, reinterpret_cast<float*>(lds));
+  finish_tiles<TM, TN>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), splits, z, reinterpret_cast<float*>(lds));
 }
 
 // ------------------------------------------------------------------------------------------------------------------ fp32 / unaligned kernel
@@ -552,7 +557,7 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   static const int force_old = env_int("DST_GEMM_OLD", 0), bn_pref = env_int("DST_GEMM_BN", 0), bm_pref = env_int("DST_GEMM_BM", 0),
                    split_target = env_int("DST_GEMM_SPLIT_WGS", 1024), wg_target = env_int("DST_GEMM_WGS", 768);
   const bool vec = bf && !force_old && (a_k || a_r) && (b_k || b_r) && g.K >= 8;
-  static const int ws_off = env_int("DST_GEMM_WS", 1) == 0, ws_min_m = env_int("DST_GEMM_WS_MIN_M", 4096);
+  static const int ws_off = env_int("DST_GEMM_WS", 1) == 0, ws_min_m = env_int("DST_GEMM_WS_MIN_M", 32768);
   if (vec && !ws_off && a_k && g.K <= 512 && (g.K & 3) == 0 && g.M >= ws_min_m && !g.rowsum && g.N >= 16) {
     const int Kp = (g.K + 15) / 16 * 16;
     int nct = g.N > 64 ? 4 : 2;
@@ -574,14 +579,19 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
     }
     return DST_CHECK_LAUNCH();
   }
+  static const int wide_off = env_int("DST_GEMM_WIDE", 1) == 0;
+  const bool wide = vec && !wide_off && g.K >= 4096 && g.M >= 160 && g.M <= 1024 && Nx <= 1024 && g.partial;   // weight gradients: K = rows
   int BM, BN;
-  if (vec) {
+  if (wide) {
+    BM = 256;
+    BN = Nx > 128 ? 256 : Nx > 64 ? 128 : 64;
+  } else if (vec) {
     // tiles sized so that the launch has at least ~3 workgroups per CU where the problem allows it: the k-loop of a workgroup exposes
     // one memory round trip per step, and what hides it is the neighbours on the CU (24 - 32 kB in flight per workgroup and step)
     BN = bn_pref ? bn_pref : (Nx > 64 ? 128 : 64);
     BM = 128;
     auto count = [&](int bm, int bn) { return (int64_t)((g.M + bm - 1) / bm) * ((Nx + bn - 1) / bn); };
-    if (!bn_pref && BN == 128 && count(BM, BN) < wg_target) BN = 64;
+    if (!bn_pref && BN == 128 && count(BM, BN) < wg_target && g.K < 4096) BN = 64;   // (a split product keeps the wide tile: fewer re-reads of its k-slices)
     if (count(BM, BN) < wg_target && g.K < 1024) BM = 64;
     if (bm_pref) BM = bm_pref;
   } else {
@@ -594,7 +604,7 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   const int kq = vec ? BK : 16;
   int splits = 1;
   if (g.K >= 1024 && tiles < 512 && g.partial) {
-    splits = (int)(split_target / tiles);
+    splits = (int)((wide ? 256 : split_target) / tiles);       // the 512-thread form: one workgroup per CU
     const int max_by_k = (g.K + 255) / 256;
     if (splits > max_by_k) splits = max_by_k;
     const int64_t cap = g.partial_cap / ((int64_t)g.M * Nx);
@@ -605,8 +615,12 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   if (kchunk < kq) kchunk = kq;
   splits = g.K > 0 ? (g.K + kchunk - 1) / kchunk : 1;
   const int inner = splits > 1 ? (int)tiles : tn, outer = splits > 1 ? splits : tm;
-  const dim3 grid(8 * ((outer + 7) / 8) * inner), blk(256);
-  if (vec) {
+  const dim3 grid(8 * ((outer + 7) / 8) * inner), blk(wide ? 512 : 256);
+  if (wide) {
+    if (BN == 256) hipLaunchKernelGGL((k_tr_gemm_bf16<256, 256, 512>), grid, blk, 0, s, g, splits, kchunk, (int)a_r, (int)b_r, tm, tn);
+    else if (BN == 128) hipLaunchKernelGGL((k_tr_gemm_bf16<256, 128, 512>), grid, blk, 0, s, g, splits, kchunk, (int)a_r, (int)b_r, tm, tn);
+    else hipLaunchKernelGGL((k_tr_gemm_bf16<256, 64, 512>), grid, blk, 0, s, g, splits, kchunk, (int)a_r, (int)b_r, tm, tn);
+  } else if (vec) {
 #define DST_LAUNCH_BF16(M_, N_) hipLaunchKernelGGL((k_tr_gemm_bf16<M_, N_>), grid, blk, 0, s, g, splits, kchunk, (int)a_r, (int)b_r, tm, tn)
     if (BM == 128 && BN == 128) DST_LAUNCH_BF16(128, 128);
     else if (BM == 128) DST_LAUNCH_BF16(128, 64);

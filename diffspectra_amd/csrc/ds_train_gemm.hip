@@ -557,8 +557,11 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   static const int force_old = env_int("DST_GEMM_OLD", 0), bn_pref = env_int("DST_GEMM_BN", 0), bm_pref = env_int("DST_GEMM_BM", 0),
                    split_target = env_int("DST_GEMM_SPLIT_WGS", 1024), wg_target = env_int("DST_GEMM_WGS", 768);
   const bool vec = bf && !force_old && (a_k || a_r) && (b_k || b_r) && g.K >= 8;
-  static const int ws_off = env_int("DST_GEMM_WS", 1) == 0, ws_min_m = env_int("DST_GEMM_WS_MIN_M", 32768);
-  if (vec && !ws_off && a_k && g.K <= 512 && (g.K & 3) == 0 && g.M >= ws_min_m && !g.rowsum && g.N >= 16) {
+  static const int ws_off = env_int("DST_GEMM_WS", 1) == 0, ws_min_m = env_int("DST_GEMM_WS_MIN_M", 65536);
+  // measured inside the training step (same box, DST_GEMM_WS=0 / 1): the resident-weight form wins where the weight is large and the
+  // rows are many (81 014 x 256 x 256 input gradient: 66 us against 113) and loses on the short-K products (K = 64 / 128: its 256
+  // workgroups re-stage the weight for too little work per row), so it takes K >= 256 on the directed rows only
+  if (vec && !ws_off && a_k && g.K >= 256 && g.K <= 512 && (g.K & 3) == 0 && g.M >= ws_min_m && !g.rowsum && g.N >= 16) {
     const int Kp = (g.K + 15) / 16 * 16;
     int nct = g.N > 64 ? 4 : 2;
     if ((size_t)32 * nct * (Kp + 8) * 2 + STAGE_BYTES * 2 > 160 * 1024) nct = 2;      // K = 512: 64 columns of the weight at a time
@@ -580,7 +583,8 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
     return DST_CHECK_LAUNCH();
   }
   static const int wide_off = env_int("DST_GEMM_WIDE", 1) == 0;
-  const bool wide = vec && !wide_off && g.K >= 4096 && g.M >= 160 && g.M <= 1024 && Nx <= 1024 && g.partial;   // weight gradients: K = rows
+  // (K = 4 633 node-row gradients: 52 us in this form against 40 us as 1 024 workgroups of 128 x 64 - too few k-steps per CU)
+  const bool wide = vec && !wide_off && g.K >= 16384 && g.M >= 160 && g.M <= 1024 && Nx <= 1024 && g.partial;   // weight gradients: K = rows
   int BM, BN;
   if (wide) {
     BM = 256;

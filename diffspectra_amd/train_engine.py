@@ -99,6 +99,13 @@ class Ops:
         self.dev = torch.device(device)
         self.scratch = torch.empty(48 * 1024 * 1024, dtype=torch.float32, device=self.dev)     # split-K partials / column sums
         self.bf16 = False      # config.training.precision == 'bf16': every GEMM rounds its operands to bf16 (fp32 accumulate, fp32 storage)
+        # Weight-gradient products on a SIDE stream (DmtTrainGraph.backward switches it on): nothing downstream of a backward pass reads
+        # dW, so the ~200 split-K products of a step need not sit in the dependent chain of input-gradient kernels - they fill the CUs the
+        # small kernels of that chain leave idle.  The side stream has its own split-K scratch; operands are kept alive until join_dw().
+        self.async_dw = False
+        self._side = None
+        self._side_scratch = None
+        self._dw_keep = []
 
     def _s(self):
         return E._stream()
@@ -146,7 +153,27 @@ class Ops:
         self.gemm(dy, W, dx, False, False, acc=acc, dact=dact, ref=ref, drop=drop)
 
     def lin_bwd_w(self, dy: MV, x: MV, dW: MV, db: Optional[torch.Tensor] = None, acc: bool = False):
-        self.gemm(dy, x, dW, True, False, acc=acc, rowsum=db)           # db = column sums of dy = row sums of dy^T, fused into the product
+        if not self.async_dw:
+            self.gemm(dy, x, dW, True, False, acc=acc, rowsum=db)       # db = column sums of dy = row sums of dy^T, fused into the product
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+            self._side_scratch = torch.empty_like(self.scratch)
+        main = torch.cuda.current_stream(self.dev)
+        self._side.wait_stream(main)                                    # dy (and x) are complete on the main stream at this point
+        self._dw_keep.append((dy.t, x.t, dW.t, db))
+        main_scratch, self.scratch = self.scratch, self._side_scratch
+        try:
+            with torch.cuda.stream(self._side):
+                self.gemm(dy, x, dW, True, False, acc=acc, rowsum=db)
+        finally:
+            self.scratch = main_scratch
+
+    def join_dw(self):
+        """The main stream waits for every weight-gradient product issued so far; their operands may be reused after it."""
+        if self._side is not None and self._dw_keep:
+            torch.cuda.current_stream(self.dev).wait_stream(self._side)
+        self._dw_keep = []
 
     def act_fwd(self, x, y, kind):
         E._check(self.lib.dst_act_fwd(E._ptr(x), E._ptr(y), C.c_int64(x.numel()), C.c_int32(kind), self._s()), "dst_act_fwd")
@@ -447,6 +474,7 @@ class DmtTrainGraph:
             return g[name]
 
         d_ada = self.z(B, ADA)
+        o.async_dw = bool(int(os.environ.get("DIFFSPECTRA_ASYNC_DW", "1")))
         # ---- read-out MLPs
         dAH, dEH = self.f(Nn, 768), self.f(Pp, 192)
 
@@ -493,7 +521,7 @@ class DmtTrainGraph:
             o.lin_bwd_w(mv(dc0, r1=D), mv(bt["zn"], r1=D), mv(gw(bp + "equi_update.coord_mlp.0.weight")), gw(bp + "equi_update.coord_mlp.0.bias"))
             dzn = self.f(max(D, 1), 256)
             o.lin_bwd_x(mv(dc0, r1=D), mv(p[bp + "equi_update.coord_mlp.0.weight"]), mv(dzn, r1=D))
-            dz = dc0                                         # reuse
+            dz = self.f(max(D, 1), 256)                      # (not dc0: the coord_mlp.0 weight gradient may still be reading it on the side stream)
             o.lnmod_bwd(dzn, bt["zz"], bt["st_z"], 256, TL.pair_off, 2, B, ada, d_ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256, dz, False)
             dac, ded = self.f(Nn, 512), self.f(Pp, 256)
             E._check(lib.dst_zbuild_bwd(C.byref(TL.c), E._ptr(dz), E._ptr(dac), E._ptr(ded), s()), "dst_zbuild_bwd")
@@ -513,7 +541,7 @@ class DmtTrainGraph:
             o.lin_bwd_x(mv(df2), mv(p[bp + "ff_linear2.weight"]), mv(df1), dact=SILU, ref=mv(bt["f1"]), drop=(dp, dseed, 4 * i + 0, 512))
             o.lin_bwd_w(mv(df1), mv(bt["y1"]), mv(gw(bp + "ff_linear1.weight")), gw(bp + "ff_linear1.bias"))
             o.lin_bwd_x(mv(df1), mv(p[bp + "ff_linear1.weight"]), mv(dy1), acc=True)
-            dx1 = df2                                        # reuse
+            dx1 = self.f(Nn, 256)
             o.lnmod_bwd(dy1, bt["x1"], bt["st_n2"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 768, a0 + NODE_OFF + 1024, dx1, False)
             dh_in, dattn = self.f(Nn, 256), self.f(Nn, 256)
             o.gate_add_bwd(dx1, bt["attn"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 512, dh_in, False, dattn)
@@ -525,7 +553,7 @@ class DmtTrainGraph:
             o.lin_bwd_x(mv(df4), mv(p[bp + "ff_linear4.weight"]), mv(df3), dact=SILU, ref=mv(bt["f3"]), drop=(dp, dseed, 4 * i + 2, 128))
             o.lin_bwd_w(mv(df3), mv(bt["ye1"]), mv(gw(bp + "ff_linear3.weight")), gw(bp + "ff_linear3.bias"))
             o.lin_bwd_x(mv(df3), mv(p[bp + "ff_linear3.weight"]), mv(dye1), acc=True)
-            dxe1 = df4
+            dxe1 = self.f(Pp, 64)
             o.lnmod_bwd(dye1, bt["xe1"], bt["st_e2"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 192, a0 + EDGE_OFF + 256, dxe1, False)
             de_in, dhe = self.f(Pp, 64), self.f(Pp, 64)
             o.gate_add_bwd(dxe1, bt["he"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 128, de_in, False, dhe)
@@ -581,6 +609,7 @@ class DmtTrainGraph:
         # ---- adaLN table + time embedding
         dWada, dbada = self.f(ADA, 1024), self.f(ADA)
         o.lin_bwd_w(mv(d_ada), mv(t["st"]), mv(dWada), dbada)
+        o.join_dw()                                          # dWada is read right here, on the main stream
         self.scatter_ada_grads(dWada, dbada, gw)
         dtemb = self.f(B, 1024)
         o.lin_bwd_x(mv(d_ada), mv(t["Wada"]), mv(dtemb), dact=SILU, ref=mv(t["temb"]))
@@ -593,6 +622,8 @@ class DmtTrainGraph:
         o.lin_bwd_x(mv(dtg), mv(p["time_mlp.1.weight"]), mv(dtf))
         E._check(lib.dst_time_feat_bwd(E._ptr(t["noise_level"]), E._ptr(p["time_mlp.0.weights"]), E._ptr(dtf), C.c_int32(B),
                                        E._ptr(gw("time_mlp.0.weights")), s()), "dst_time_feat_bwd")
+        o.join_dw()
+        o.async_dw = False
         self.t = None
         return g
 

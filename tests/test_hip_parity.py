@@ -1125,6 +1125,7 @@ def test_checkpoint_and_ema_roundtrip(gpu_device, tmp_path):
     from diffspectra_amd.config import qm9s_config
     cfg = qm9s_config("ir", device=gpu_device)
     model = create_model(cfg)
+    model.eval()          # the sampling path: a model left in training mode runs the training forward (dropout, BatchNorm batch statistics)
     filler.fill_module_(model, salt=1)
     a = cases.forward_inputs("ir", True)
     d = gpu_device
@@ -1164,6 +1165,7 @@ def test_evaluate_driver(gpu_device, tmp_path):
     ds, n_atoms = _tiny_dataset(5)
     # a "trained" checkpoint: model weights salt 2, EMA shadow salt 3 (eval must use the EMA ones)
     donor = create_model(cfg)
+    donor.eval()          # the sampling path: a model left in training mode runs the training forward (dropout, BatchNorm batch statistics)
     filler.fill_module_(donor, salt=2)
     ema = EV.ExponentialMovingAverage(donor.parameters(), decay=0.999)
     ema.shadow_params = [filler.fill_tensor(n[len("module."):], p.shape, like=p, salt=3).to(gpu_device)
@@ -1175,6 +1177,7 @@ def test_evaluate_driver(gpu_device, tmp_path):
     assert list(res) == [40] and res[40]["step"] == 123 and res[40]["metrics"]["count"] == 4
     # reference: same weights assembled by hand (EMA for parameters, checkpoint buffers for BatchNorm statistics)
     want_model = create_model(cfg)
+    want_model.eval()          # the sampling path: a model left in training mode runs the training forward (dropout, BatchNorm batch statistics)
     filler.fill_module_(want_model, salt=2)
     for s_p, p in zip(ema.shadow_params, [p for p in want_model.parameters() if p.requires_grad]):
         p.data.copy_(s_p)
@@ -1308,6 +1311,7 @@ def test_g10_pretrained_specformer_golden(gpu_device, variant, tmp_path):
     g = cases.load_npz("g10_pretrained_specformer.npz")
     cfg = qm9s_config("allspectra", device=gpu_device)
     plain = create_model(cfg)
+    plain.eval()          # the sampling path: a model left in training mode runs the training forward (dropout, BatchNorm batch statistics)
     filler.fill_module_(plain)
     enc_sd = {k: v.cpu() for k, v in plain.module.cond_encoder.state_dict().items()}
     path = tmp_path / "pretrained_specformer.ckpt"
@@ -1328,6 +1332,7 @@ def test_engine_repacks_after_data_copy(gpu_device):
     from diffspectra_amd.registry import create_model
     cfg = qm9s_config("ir", device=gpu_device)
     model = create_model(cfg)
+    model.eval()          # the sampling path: a model left in training mode runs the training forward (dropout, BatchNorm batch statistics)
     filler.fill_module_(model, salt=0)
     a = cases.forward_inputs("ir", False)
     d = gpu_device
@@ -1344,6 +1349,7 @@ def test_engine_repacks_after_data_copy(gpu_device):
     assert versions == [int(p._version) for p in model.parameters()]   # the hazard: no version bump
     out1 = model(*args, **kw)[0]
     fresh = create_model(cfg)
+    fresh.eval()          # the sampling path: a model left in training mode runs the training forward (dropout, BatchNorm batch statistics)
     fresh.load_state_dict({k: v.to(d) for k, v in other.items()}, strict=True)
     want = fresh(*args, **kw)[0]
     assert float((out1 - out0).abs().max()) > 1e-4, "engine kept the stale packed weights"
@@ -1408,6 +1414,7 @@ def test_caches_do_not_confuse_a_reallocated_tensor_with_the_freed_one(gpu_devic
     out = call(model, x2, ex2, nm2, em2, c2)
     from diffspectra_amd.registry import create_model
     fresh = create_model(cfg)                                       # a model that has never seen the first tensors
+    fresh.eval()          # the sampling path: a model left in training mode runs the training forward (dropout, BatchNorm batch statistics)
     filler.fill_module_(fresh)
     fresh.eval()
     want = call(fresh, x2, ex2, nm2.clone(), em2.clone(), c2.clone())

@@ -10,6 +10,7 @@ encoder are 0 in the reference's constructor defaults.  No PyTorch arithmetic: G
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict
 
 import torch
@@ -130,6 +131,7 @@ class SpecTrainGraph:
         pre = "cond_encoder."
         B, L = t["B"], self.L
         g: Dict[str, torch.Tensor] = {}
+        o.async_dw = bool(int(os.environ.get("DIFFSPECTRA_ASYNC_DW", "1")))     # weight gradients on the side stream (train_engine.Ops.lin_bwd_w)
 
         gbuf = getattr(self, "gbuf", None)
 
@@ -162,9 +164,11 @@ class SpecTrainGraph:
             da = self.f(B * L, D_FF)
             o.lin_bwd_x(mv(dr2), mv(p[base + "ff.3.weight"]), mv(da), dact=GELU, ref=mv(lt["a"]))
             o.lin_bwd_w(mv(da), mv(lt["z1"]), mv(gw(base + "ff.0.weight")), gw(base + "ff.0.bias"))
-            o.lin_bwd_x(mv(da), mv(p[base + "ff.0.weight"]), mv(dr2), acc=True)                  # dz1 = dr2 (residual) + da W0
+            dz1 = self.f(B * L, D_MODEL)                                                         # dz1 = dr2 (residual) + da W0, in a buffer of its own:
+            o.lin_bwd_x(mv(da), mv(p[base + "ff.0.weight"]), mv(dz1))                            # dr2 is an operand of a weight-gradient product that
+            o.axpy(1.0, dr2, dz1)                                                                # may still be running on the side stream
             dr1 = self.f(B * L, D_MODEL)
-            self._bn_bwd(dr2, lt["r1"], lt["st1"], base + "norm_attn.1", dr1, g)
+            self._bn_bwd(dz1, lt["r1"], lt["st1"], base + "norm_attn.1", dr1, g)
             o.lin_bwd_w(mv(dr1), mv(lt["ao"]), mv(gw(base + "self_attn.to_out.0.weight")), gw(base + "self_attn.to_out.0.bias"))
             dao = self.f(B * L, D_MODEL)
             o.lin_bwd_x(mv(dr1), mv(p[base + "self_attn.to_out.0.weight"]), mv(dao))
@@ -180,12 +184,14 @@ class SpecTrainGraph:
                 E._check(self.lib.dst_spec_attn_bwd(E._ptr(lt["qkv"]), E._ptr(lt["scores"]), E._ptr(lt["ast"]), E._ptr(dao), E._ptr(dscores_in), E._ptr(dqkv), E._ptr(dscores),
                                                     C.c_int32(B), C.c_int32(L), C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()),
                          "dst_spec_attn_bwd")
+            dzin = self.f(B * L, D_MODEL)                                                        # dZin = dr1 (residual) + sum dq W (dr1 stays intact, as dr2 above)
             for k, nm in enumerate(("W_Q", "W_K", "W_V")):
                 dq = mv(dqkv, k * D_MODEL, (k + 1) * D_MODEL)
                 o.lin_bwd_w(dq, mv(lt["Zin"]), mv(gw(base + f"self_attn.{nm}.weight")), gw(base + f"self_attn.{nm}.bias"))
-                o.lin_bwd_x(dq, mv(p[base + f"self_attn.{nm}.weight"]), mv(dr1), acc=True)      # dZin = dr1 (residual) + sum dq W
+                o.lin_bwd_x(dq, mv(p[base + f"self_attn.{nm}.weight"]), mv(dzin), acc=k > 0)
+            o.axpy(1.0, dr1, dzin)
             dscores_in = dscores if lt["has_prev"] else None
-            dZ = dr1
+            dZ = dzin
         dZ3 = dZ.view(B, L, D_MODEL)
         tok0 = 0
         for slot, (pl, stv, pn) in enumerate(self.patch):
@@ -193,5 +199,7 @@ class SpecTrainGraph:
             o.lin_bwd_w(mv(dz), mv(t["Xs"][slot]), mv(gw(pre + f"backbone.W_P.{slot}.weight")), gw(pre + f"backbone.W_P.{slot}.bias"))
             o.colsum(mv(dz.view(B, pn * D_MODEL)), gw(pre + "backbone." + self.pos_names[slot]).view(-1))
             tok0 += pn
+        o.join_dw()
+        o.async_dw = False
         self.t = None
         return g

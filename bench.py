@@ -421,11 +421,17 @@ def train_measure(args, world, rank, device, steps, warmup, with_cpu_baseline):
         e1.record()
         recs.append((e0, e1, 2.0 * M * Cm.cols * K, (M, Cm.cols, K, int(ta), int(tb))))
     TE.Ops.gemm = timed_gemm
+    prev_async = os.environ.get("DIFFSPECTRA_ASYNC_DW")
+    os.environ["DIFFSPECTRA_ASYNC_DW"] = "0"          # one stream for this instrumented step: an event pair then brackets exactly one product
     try:
         step_fn(state, batch)
         sync()
     finally:
         TE.Ops.gemm = orig_gemm
+        if prev_async is None:
+            os.environ.pop("DIFFSPECTRA_ASYNC_DW", None)
+        else:
+            os.environ["DIFFSPECTRA_ASYNC_DW"] = prev_async
     if rank == 0:
         n = np.asarray(n_atoms, dtype=np.int64)
         flop = 3.0 * 2.0 * algorithmic_macs(n)                        # forward + two backward GEMMs per forward GEMM (self-cond forward not counted)
@@ -458,7 +464,9 @@ def train_measure(args, world, rank, device, steps, warmup, with_cpu_baseline):
                                          " (MI355X_MICROARCH.md); the step's GEMMs are small (M = nodes / pairs of 256 molecules, N, K <= 1024) "
                                          "and bound by launch latency and their operand streams, not by the matrix pipe",
                             "traffic": None, "launches_timed": len(recs), "avg_launch_ms": gemm_ms / max(1, len(recs)),
-                            "share_of_step": gemm_ms / (elapsed / steps * 1e3), "algorithmic_flop_per_step": gemm_flop}
+                            "share_of_step": gemm_ms / (elapsed / steps * 1e3), "algorithmic_flop_per_step": gemm_flop,
+                            "note": "timed in one extra step with the weight-gradient products on the main stream (in the timed steps they run "
+                                    "concurrently on a side stream, so this share is an upper bound of their part of the step)"}
         if with_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline_train(args.spectra)

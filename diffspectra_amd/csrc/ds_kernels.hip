@@ -5,7 +5,6 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
-#include <stdlib.h>
 
 #include <utility>
 #include <vector>
@@ -986,14 +985,10 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
   int* rpa = idx_s[wave][1];
   int* rpb = idx_s[wave][2];
   const int Pp = c.L.Pp;
-  const float* ada = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
-  // PERSISTENT waves (round 4): the launch holds at most two workgroups per CU and a wave walks the 32-row tiles wave id, wave id +
-  // total waves, ...  With one tile per wave a batch of 1 250 molecules was 1 553 workgroups on 512 slots - 3.03 rounds, the last one
-  // nearly empty (+15 - 22 % per molecule against the 4 096-molecule batch); a wave-granular stride
-  // balances any batch to within one tile.  Nothing below synchronises across waves and the LDS tiles are wave-private.
-  for (int wt = blockIdx.x * 4 + wave; wt * R < Pp; wt += (int)gridDim.x * 4) {
-  const int row0 = wt * R;
+  const int row0 = (blockIdx.x * 4 + wave) * R;
+  if (row0 >= Pp) return;                    // whole wave leaves; nothing below synchronises across waves
   const int valid = min(R, Pp - row0);
+  const float* ada = c.ws.ada + blk * DS_ADA_BLOCK_STRIDE + DS_ADA_EDGE;
   if (lane < R) {
     const int p = min(row0 + lane, Pp - 1);
     rmol[lane] = c.L.pair_mol[p]; rpa[lane] = c.L.pair_a[p]; rpb[lane] = c.L.pair_b[p];
@@ -1177,9 +1172,6 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
     }
   }
   DS_STAMP(6);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the next tile re-uses this wave's LDS tiles: every read of them first
-  __builtin_amdgcn_wave_barrier();
-  }
   DS_STAMP_FLUSH(0);
 }
 
@@ -2370,10 +2362,6 @@ int gemm_simple(const float* A, int64_t lda, const float* Wp, const float* bias,
   return gemm_dispatch(g, act, s);
 }
 
-// resident workgroup slots of the persistent row kernels: 256 CUs x 2 (71 kB of LDS and 182 registers per k_edge_update workgroup);
-// DS_EDGE_UPDATE_SLOTS overrides it for A/B runs (a very large value restores one tile per wave)
-static const int g_edge_update_slots = [] { const char* v = getenv("DS_EDGE_UPDATE_SLOTS"); return v ? atoi(v) : 512; }();
-
 // ---- optional HIP-event timing of one block-stage kernel (bench.py's live roofline measurement) ----
 struct ProfState {
   int kernel = -1;          // 0 edge_geom, 1 node_qkv, 2 attn_logits, 3 node_update, 4 edge_update, 5 equi_pairs, 6 attn_agg
@@ -2473,11 +2461,7 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   { ProfScope ps(1, s); hipLaunchKernelGGL(k_node_qkv<4>, dim3((L->Nn + 63) / 64, 2), dim3(256), 0, s, c, blk); }
   { ProfScope ps(2, s); hipLaunchKernelGGL(k_attn_fused, dim3(L->B), dim3(1024), 0, s, c, blk); }
   { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }
-  if (pt > 0) {
-    ProfScope ps(4, s);
-    const int wgs = (L->Pp + 127) / 128;
-    hipLaunchKernelGGL(k_edge_update, dim3(wgs < g_edge_update_slots ? wgs : g_edge_update_slots), dim3(256), 0, s, c, blk);
-  }
+  if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3((L->Pp + 127) / 128), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(5, s); { const int nt_ = (L->Pp + 31) / 32, cu_ = device_cus(); hipLaunchKernelGGL((k_equi_pairs<DS_EQUI_NCW, DS_EQUI_NLW>), dim3(nt_ < cu_ ? nt_ : cu_), dim3((DS_EQUI_NCW + DS_EQUI_NLW) * 64), 0, s, c, blk); } }
   hipLaunchKernelGGL(k_pos_update, dim3(L->B), dim3(64), 0, s, c, last);
   return launch_status();

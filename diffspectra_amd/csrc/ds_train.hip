@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_geom_bwd(dst_layout L, const float* __r
 // ------------------------------------------------------------------------------------------------------------------ attention
 // logits / alpha scratch in LDS: [directed edge (2 * 406)][16 heads]
 __global__ __launch_bounds__(1024) void k_attn_fwd(dst_layout L, const float* __restrict__ qkv, const float* __restrict__ te0, const float* __restrict__ te1,
-                                                   const int32_t* __restrict__ adj, float* __restrict__ out, float* __restrict__ alpha) {
+                                                   int64_t ldt, const int32_t* __restrict__ adj, float* __restrict__ out, float* __restrict__ alpha) {
   __shared__ float lg[812 * 16];
   __shared__ unsigned char pa[406], pb[406];
   const int m = blockIdx.x;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(1024) void k_attn_fwd(dst_layout L, const float* __
       const int c0 = (hd - 2) * 18;
       const float* q = qkv + (int64_t)(n0 + tgt) * 768 + c0;
       const float* k = qkv + (int64_t)(n0 + src) * 768 + 256 + c0;
-      const float* e = te0 + (int64_t)(p0 + p) * 256 + c0;
+      const float* e = te0 + (int64_t)(p0 + p) * ldt + c0;
       float s = 0.0f;
       for (int c = 0; c < 18; ++c) s += q[c] * k[c] * e[c];
       v = s / 4.0f;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(1024) void k_attn_fwd(dst_layout L, const float* __
       if (sN == t) continue;
       const int p = sN < t ? pair_index(n, sN, t) : pair_index(n, t, sN);
       const int d = sN < t ? 2 * p : 2 * p + 1;
-      s += qkv[(int64_t)(n0 + sN) * 768 + 512 + col] * te1[(int64_t)(p0 + p) * 256 + col] * lg[d * 16 + hd];
+      s += qkv[(int64_t)(n0 + sN) * 768 + 512 + col] * te1[(int64_t)(p0 + p) * ldt + col] * lg[d * 16 + hd];
     }
     out[(int64_t)(n0 + t) * 256 + col] = s;
   }
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(1024) void k_attn_fwd(dst_layout L, const float* __
 }
 
 __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __restrict__ qkv, const float* __restrict__ te0, const float* __restrict__ te1,
-                                                   const float* __restrict__ alpha, const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                   int64_t ldt, const float* __restrict__ alpha, const float* __restrict__ dout, float* __restrict__ dqkv,
                                                    float* __restrict__ dte0, float* __restrict__ dte1) {
   __shared__ float dl[812 * 16];      // d alpha, then d logit (the 64 kB static LDS limit leaves no room for a copy of alpha)
   __shared__ unsigned char pa[406], pb[406];
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
     const int src = dir ? pb[p] : pa[p], tgt = dir ? pa[p] : pb[p];
     const float* go = dout + (int64_t)(n0 + tgt) * 256 + hd * 16;
     const float* v = qkv + (int64_t)(n0 + src) * 768 + 512 + hd * 16;
-    const float* e = te1 + (int64_t)(p0 + p) * 256 + hd * 16;
+    const float* e = te1 + (int64_t)(p0 + p) * ldt + hd * 16;
     float s = 0.0f;
     for (int c = 0; c < 16; ++c) s += go[c] * v[c] * e[c];
     dl[it] = s;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
         if (j == i) continue;
         const int p = j < i ? pair_index(n, j, i) : pair_index(n, i, j);
         const int d = j < i ? 2 * p : 2 * p + 1;       // source j -> target i
-        s += dl[d * 16 + hd] * qkv[(int64_t)(n0 + j) * 768 + 256 + col] * te0[(int64_t)(p0 + p) * 256 + col];
+        s += dl[d * 16 + hd] * qkv[(int64_t)(n0 + j) * 768 + 256 + col] * te0[(int64_t)(p0 + p) * ldt + col];
       }
       s *= 0.25f;
     } else if (col >= 256 && col < 508) {              // dk[i]: i is the source
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
         if (t == i) continue;
         const int p = i < t ? pair_index(n, i, t) : pair_index(n, t, i);
         const int d = i < t ? 2 * p : 2 * p + 1;       // source i -> target t
-        s += dl[d * 16 + hd] * qkv[(int64_t)(n0 + t) * 768 + c] * te0[(int64_t)(p0 + p) * 256 + c];
+        s += dl[d * 16 + hd] * qkv[(int64_t)(n0 + t) * 768 + c] * te0[(int64_t)(p0 + p) * ldt + c];
       }
       s *= 0.25f;
     } else if (col >= 512) {                           // dv[i]: i is the source
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
         if (t == i) continue;
         const int p = i < t ? pair_index(n, i, t) : pair_index(n, t, i);
         const int d = i < t ? 2 * p : 2 * p + 1;
-        s += dout[(int64_t)(n0 + t) * 256 + c] * te1[(int64_t)(p0 + p) * 256 + c] * al[d * 16 + hd];
+        s += dout[(int64_t)(n0 + t) * 256 + c] * te1[(int64_t)(p0 + p) * ldt + c] * al[d * 16 + hd];
       }
     }
     dqkv[(int64_t)(n0 + i) * 768 + col] = s;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
     {
       const int hd = col >> 4;
       const float va = qkv[(int64_t)(n0 + a) * 768 + 512 + col], vb = qkv[(int64_t)(n0 + b) * 768 + 512 + col];
-      dte1[(int64_t)(p0 + p) * 256 + col] = dout[(int64_t)(n0 + b) * 256 + col] * va * al[(2 * p) * 16 + hd] +
+      dte1[(int64_t)(p0 + p) * ldt + col] = dout[(int64_t)(n0 + b) * 256 + col] * va * al[(2 * p) * 16 + hd] +
                                             dout[(int64_t)(n0 + a) * 256 + col] * vb * al[(2 * p + 1) * 16 + hd];
     }
     float g0 = 0.0f;
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
       const float ka = qkv[(int64_t)(n0 + a) * 768 + 256 + col], kb = qkv[(int64_t)(n0 + b) * 768 + 256 + col];
       g0 = 0.25f * (dl[(2 * p) * 16 + hd] * qb * ka + dl[(2 * p + 1) * 16 + hd] * qa * kb);
     }
-    dte0[(int64_t)(p0 + p) * 256 + col] = g0;
+    dte0[(int64_t)(p0 + p) * ldt + col] = g0;
   }
 }
 
@@ -1363,17 +1363,17 @@ int dst_geom_bwd(const dst_layout* L, const float* pos, const float* ada, float*
   return DST_CHECK_LAUNCH();
 }
 
-int dst_attn_fwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, const int32_t* adj, float* out, float* alpha,
-                 void* stream) {
-  if (!DST_L_OK(L) || !qkv || !te0 || !te1 || !adj || !out || !alpha) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_attn_fwd, dim3(L->B), dim3(1024), 0, (hipStream_t)stream, *L, qkv, te0, te1, adj, out, alpha);
+int dst_attn_fwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, int64_t ld_te, const int32_t* adj, float* out,
+                 float* alpha, void* stream) {
+  if (!DST_L_OK(L) || !qkv || !te0 || !te1 || ld_te < 256 || !adj || !out || !alpha) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_attn_fwd, dim3(L->B), dim3(1024), 0, (hipStream_t)stream, *L, qkv, te0, te1, ld_te, adj, out, alpha);
   return DST_CHECK_LAUNCH();
 }
-int dst_attn_bwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, const float* alpha, const float* dout, float* dqkv,
-                 float* dte0, float* dte1, float* scratch, void* stream) {
+int dst_attn_bwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, int64_t ld_te, const float* alpha, const float* dout,
+                 float* dqkv, float* dte0, float* dte1, float* scratch, void* stream) {
   (void)scratch;
-  if (!DST_L_OK(L) || !qkv || !te0 || !te1 || !alpha || !dout || !dqkv || !dte0 || !dte1) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_attn_bwd, dim3(L->B), dim3(1024), 0, (hipStream_t)stream, *L, qkv, te0, te1, alpha, dout, dqkv, dte0, dte1);
+  if (!DST_L_OK(L) || !qkv || !te0 || !te1 || ld_te < 256 || !alpha || !dout || !dqkv || !dte0 || !dte1) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_attn_bwd, dim3(L->B), dim3(1024), 0, (hipStream_t)stream, *L, qkv, te0, te1, ld_te, alpha, dout, dqkv, dte0, dte1);
   return DST_CHECK_LAUNCH();
 }
 

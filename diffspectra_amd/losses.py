@@ -418,6 +418,7 @@ class HipTrainer:
         dmt.edge_th, dmt.cutoff = float(self.cfg.model.edge_quan_th), float(self.cfg.model.spatial_cut_off)
         spec = SpecTrainGraph(pd, bufs, self.cfg, self.ops)
         dmt.gbuf = spec.gbuf = self.stage(named)[1]
+        self.cat_cache = dmt.prepare_weights(getattr(self, "cat_cache", None))     # concatenated weights of this call's parameters (one multi-tensor copy)
         return named, dmt, spec
 
 

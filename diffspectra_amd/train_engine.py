@@ -277,26 +277,66 @@ class DmtTrainGraph:
     def z(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
 
-    def assemble_ada(self):
-        """All ``*time_mlp`` Linears as one [ADA_COLS, 1024] weight / [ADA_COLS] bias (rows in the column order of the adaLN table)."""
-        W, b = self.z(ADA, 1024), self.z(ADA)
+    # ---- concatenated weights: Linears that read the same input are evaluated as ONE product (q | k | v; lin_edge0 | lin_edge1; the row | col
+    #      parts of input_lin; every *time_mlp as the adaLN table) from per-step copies of the parameters in one buffer each.  The copies are
+    #      two multi-tensor launches per step (torch._foreach_copy_), the gradients of the concatenated buffers are scattered back the same way.
+    def cat_plan(self):
+        """[(buffer name, shape)], [(buffer name, index expression, parameter name)] - where every parameter piece lives in its buffer."""
+        bufs = [("Wada", (ADA, 1024)), ("bada", (ADA,)), ("Wqkv", (NB, 768, 256)), ("bqkv", (NB, 768)), ("Wte", (NB, 512, 64)), ("Wac", (NB, 512, 256))]
+        pieces = []
         for blk in range(NB):
+            bp = f"e_block_{blk}."
             for name, off, rows in ADA_PARTS:
                 o = blk * ADA_STRIDE + off
-                W[o:o + rows] = self.p[f"e_block_{blk}.{name}.weight"]
-                b[o:o + rows] = self.p[f"e_block_{blk}.{name}.bias"]
-        W[ADA_TOP:ADA_TOP + 2] = self.p["dist_layer.time_mlp.1.weight"]
-        b[ADA_TOP:ADA_TOP + 2] = self.p["dist_layer.time_mlp.1.bias"]
-        return W, b
+                pieces.append(("Wada", (slice(o, o + rows),), bp + name + ".weight"))
+                pieces.append(("bada", (slice(o, o + rows),), bp + name + ".bias"))
+            for k, nm in enumerate(("lin_query", "lin_key", "lin_value")):
+                rows = 252 if k < 2 else 256
+                pieces.append(("Wqkv", (blk, slice(256 * k, 256 * k + rows)), bp + f"attn_mpnn.{nm}.weight"))
+                pieces.append(("bqkv", (blk, slice(256 * k, 256 * k + rows)), bp + f"attn_mpnn.{nm}.bias"))
+            pieces.append(("Wte", (blk, slice(0, 252)), bp + "attn_mpnn.lin_edge0.weight"))
+            pieces.append(("Wte", (blk, slice(256, 512)), bp + "attn_mpnn.lin_edge1.weight"))
+            pieces.append(("Wac", (blk, slice(0, 256)), (bp + "equi_update.input_lin.weight", slice(0, 256))))      # h_row part (columns 0..255)
+            pieces.append(("Wac", (blk, slice(256, 512)), (bp + "equi_update.input_lin.weight", slice(256, 512))))  # h_col part
+        pieces.append(("Wada", (slice(ADA_TOP, ADA_TOP + 2),), "dist_layer.time_mlp.1.weight"))
+        pieces.append(("bada", (slice(ADA_TOP, ADA_TOP + 2),), "dist_layer.time_mlp.1.bias"))
+        return bufs, pieces
 
-    def scatter_ada_grads(self, dW, db, gw):
-        for blk in range(NB):
-            for name, off, rows in ADA_PARTS:
-                o = blk * ADA_STRIDE + off
-                gw(f"e_block_{blk}.{name}.weight").copy_(dW[o:o + rows])
-                gw(f"e_block_{blk}.{name}.bias").copy_(db[o:o + rows])
-        gw("dist_layer.time_mlp.1.weight").copy_(dW[ADA_TOP:ADA_TOP + 2])
-        gw("dist_layer.time_mlp.1.bias").copy_(db[ADA_TOP:ADA_TOP + 2])
+    def _piece_views(self, bufs, tensors):
+        """(views into the concatenated buffers, the matching parameter(-shaped) tensors) in plan order."""
+        _, pieces = self.cat_plan()
+        dst, src = [], []
+        for bname, idx, pname in pieces:
+            dst.append(bufs[bname][idx])
+            if isinstance(pname, tuple):
+                src.append(tensors[pname[0]][:, pname[1]])
+            else:
+                src.append(tensors[pname])
+        return dst, src
+
+    def prepare_weights(self, cache: Optional[dict] = None):
+        """Fill the concatenated weight buffers from the current parameters (once per step: both forwards of a step share them)."""
+        if cache is None:
+            cache = {}
+        if "bufs" not in cache:
+            shapes, _ = self.cat_plan()
+            cache["bufs"] = {n: self.z(*shape) for n, shape in shapes}          # padding rows (252..255 of q / k / lin_edge0) stay zero
+            cache["grads"] = {n: self.z(*shape) for n, shape in shapes}
+        dst, src = self._piece_views(cache["bufs"], self.p)
+        torch._foreach_copy_(dst, src)
+        self.cat, self.dcat = cache["bufs"], cache["grads"]
+        return cache
+
+    def scatter_cat_grads(self, gw):
+        """Gradients of the concatenated buffers -> the parameters' gradient buffers (input_lin's edge part and bias are written directly)."""
+        _, pieces = self.cat_plan()
+        tgt = {}
+        for _, _, pname in pieces:
+            name = pname[0] if isinstance(pname, tuple) else pname
+            if name not in tgt:
+                tgt[name] = gw(name) if name not in self._gw_done else self._gw_done[name]
+        src, dst = self._piece_views(self.dcat, tgt)
+        torch._foreach_copy_(dst, src)
 
     def _geom_fwd(self, TL, pos, ada, dist_off, prefix, X, ldx, col0, xs, d2s):
         E._check(self.lib.dst_geom_fwd(C.byref(TL.c), E._ptr(pos), E._ptr(ada), C.c_int64(ADA), C.c_int32(dist_off),
@@ -328,10 +368,12 @@ class DmtTrainGraph:
         o.lin_fwd(mv(tg), mv(p["time_mlp.3.weight"]), p["time_mlp.3.bias"], mv(temb))
         o.axpy(1.0, ctx_emb, temb)                                                       # time_emb = time_mlp(noise_level) + context
         o.act_fwd(temb, st, SILU)
-        Wada, bada = self.assemble_ada()
+        if getattr(self, "cat", None) is None:
+            self.prepare_weights()
+        cat = self.cat
         ada = self.f(B, ADA)
-        o.lin_fwd(mv(st), mv(Wada), bada, mv(ada))
-        t.update(noise_level=noise_level, tf=tf, tm1=tm1, tg=tg, temb=temb, st=st, Wada=Wada, ada=ada)
+        o.lin_fwd(mv(st), mv(cat["Wada"]), cat["bada"], mv(ada))
+        t.update(noise_level=noise_level, tf=tf, tm1=tm1, tg=tg, temb=temb, st=st, ada=ada)
         # ---- inputs (dmt.py:323-377)
         pos = xn[:, 0:3].contiguous()
         X0n = torch.cat([xn[:, 3:9], cond_n[:, 3:9] if cond_n is not None else torch.zeros_like(xn[:, 3:9])], dim=1).contiguous()
@@ -372,16 +414,15 @@ class DmtTrainGraph:
             en, st_e1 = self.f(Pp, 64), self.f(Pp, 2)
             o.lnmod_fwd(e1, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 0, a0 + EDGE_OFF + 64, en, st_e1)
             # attention (layers.py:131-186)
-            qkv = self.z(Nn, 768)
             ap = bp + "attn_mpnn."
-            o.lin_fwd(mv(hn), mv(p[ap + "lin_query.weight"]), p[ap + "lin_query.bias"], mv(qkv, 0, 252))
-            o.lin_fwd(mv(hn), mv(p[ap + "lin_key.weight"]), p[ap + "lin_key.bias"], mv(qkv, 256, 508))
-            o.lin_fwd(mv(hn), mv(p[ap + "lin_value.weight"]), p[ap + "lin_value.bias"], mv(qkv, 512, 768))
-            te0, te1 = self.z(Pp, 256), self.f(Pp, 256)
-            o.lin_fwd(mv(en), mv(p[ap + "lin_edge0.weight"]), None, mv(te0, 0, 252), act=TANH)        # columns 252..255 stay 0 = tanh(0)
-            o.lin_fwd(mv(en), mv(p[ap + "lin_edge1.weight"]), None, mv(te1), act=TANH)
+            qkv = self.f(Nn, 768)                                    # q | k | v as one product (the padding columns come out as exact zeros)
+            o.lin_fwd(mv(hn), mv(cat["Wqkv"][i]), cat["bqkv"][i], mv(qkv))
+            te = self.f(Pp, 512)                                     # tanh(lin_edge0 e) | tanh(lin_edge1 e) as one product; columns 252..255 = tanh(0)
+            o.lin_fwd(mv(en), mv(cat["Wte"][i]), None, mv(te), act=TANH)
+            te0, te1 = te[:, 0:256], te[:, 256:512]
             attn, alpha = self.f(Nn, 256), self.f(max(D, 1), 16)
-            E._check(lib.dst_attn_fwd(C.byref(TL.c), E._ptr(qkv), E._ptr(te0), E._ptr(te1), E._ptr(adj), E._ptr(attn), E._ptr(alpha), s()), "dst_attn_fwd")
+            E._check(lib.dst_attn_fwd(C.byref(TL.c), E._ptr(qkv), E._ptr(te0), E._ptr(te1), C.c_int64(512), E._ptr(adj), E._ptr(attn), E._ptr(alpha), s()),
+                     "dst_attn_fwd")
             # node2edge (dmt.py:156-157) per node, then the pair sum
             u, he = self.f(Nn, 64), self.f(Pp, 64)
             o.lin_fwd(mv(attn), mv(p[bp + "node2edge_lin.weight"]), None, mv(u))
@@ -405,9 +446,8 @@ class DmtTrainGraph:
             o.gate_add_fwd(ye1, f4, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 320, e_out)
             # equivariant update (dmt.py:37-60) + CoM removal (:385-386)
             Win = p[bp + "equi_update.input_lin.weight"]                       # [256, 640] = [h_row | h_col | e | dist]
-            ac = self.f(Nn, 512)
-            o.lin_fwd(mv(h_out), mv(Win, 0, 256), None, mv(ac, 0, 256))
-            o.lin_fwd(mv(h_out), mv(Win, 256, 512), None, mv(ac, 256, 512))
+            ac = self.f(Nn, 512)                                     # h_row | h_col parts of input_lin as one product
+            o.lin_fwd(mv(h_out), mv(cat["Wac"][i]), None, mv(ac))
             X2 = self.f(Pp, 128)
             X2[:, 0:64] = e_out
             X2[:, 64:128] = X1[:, 0:64]
@@ -430,7 +470,7 @@ class DmtTrainGraph:
             node_hids.append(rn)
             edge_hids.append(re_)
             if save:
-                bt.update(X1=X1, xs=xs, d2=d2, e1=e1, hn=hn, st_n1=st_n1, en=en, st_e1=st_e1, qkv=qkv, te0=te0, te1=te1, attn=attn, alpha=alpha,
+                bt.update(X1=X1, xs=xs, d2=d2, e1=e1, hn=hn, st_n1=st_n1, en=en, st_e1=st_e1, qkv=qkv, te=te, attn=attn, alpha=alpha,
                           u=u, he=he, x1=x1, y1=y1, st_n2=st_n2, f1=f1, s1=s1, f2=f2, h_out=h_out, xe1=xe1, ye1=ye1, st_e2=st_e2, f3=f3, s3=s3,
                           f4=f4, e_out=e_out, X2=X2, zz=zz, zn=zn, st_z=st_z, c0=c0, sc0=sc0, c2=c2)
                 blocks.append(bt)
@@ -468,6 +508,8 @@ class DmtTrainGraph:
         g: Dict[str, torch.Tensor] = {}
 
         gbuf = getattr(self, "gbuf", None)
+        cat, dcat = self.cat, self.dcat
+        self._gw_done = g
 
         def gw(name):                                       # gradient buffer of a parameter: a view of the trainer's flat stage (zeroed once
             g[name] = gbuf[name] if gbuf is not None else torch.zeros_like(p[name])   # per backward) or, stand-alone, a fresh zero tensor
@@ -525,10 +567,8 @@ class DmtTrainGraph:
             o.lnmod_bwd(dzn, bt["zz"], bt["st_z"], 256, TL.pair_off, 2, B, ada, d_ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256, dz, False)
             dac, ded = self.f(Nn, 512), self.f(Pp, 256)
             E._check(lib.dst_zbuild_bwd(C.byref(TL.c), E._ptr(dz), E._ptr(dac), E._ptr(ded), s()), "dst_zbuild_bwd")
-            o.lin_bwd_w(mv(dac, 0, 256), mv(bt["h_out"]), mv(dWin, 0, 256))
-            o.lin_bwd_w(mv(dac, 256, 512), mv(bt["h_out"]), mv(dWin, 256, 512))
-            o.lin_bwd_x(mv(dac, 0, 256), mv(Win, 0, 256), mv(dh), acc=True)
-            o.lin_bwd_x(mv(dac, 256, 512), mv(Win, 256, 512), mv(dh), acc=True)
+            o.lin_bwd_w(mv(dac), mv(bt["h_out"]), mv(dcat["Wac"][i]))               # both node parts at once; scattered into dWin[:, 0:512] at the end
+            o.lin_bwd_x(mv(dac), mv(cat["Wac"][i]), mv(dh), acc=True)
             o.lin_bwd_w(mv(ded), mv(bt["X2"]), mv(dWin, 512, 640), gw(bp + "equi_update.input_lin.bias"))
             o.lin_bwd_x(mv(ded), mv(Win, 512, 576), mv(de), acc=True)
             dfeat2 = self.f(Pp, 64)
@@ -564,20 +604,17 @@ class DmtTrainGraph:
             o.lin_bwd_w(mv(du), mv(bt["attn"]), mv(gw(bp + "node2edge_lin.weight")))
             o.lin_bwd_x(mv(du), mv(p[bp + "node2edge_lin.weight"]), mv(dattn), acc=True)
             # attention
-            dqkv, dte0, dte1 = self.f(Nn, 768), self.f(Pp, 256), self.f(Pp, 256)
-            E._check(lib.dst_attn_bwd(C.byref(TL.c), E._ptr(bt["qkv"]), E._ptr(bt["te0"]), E._ptr(bt["te1"]), E._ptr(bt["alpha"]), E._ptr(dattn),
-                                      E._ptr(dqkv), E._ptr(dte0), E._ptr(dte1), None, s()), "dst_attn_bwd")
-            o.act_bwd(dte0, bt["te0"], dte0, TANH)
-            o.act_bwd(dte1, bt["te1"], dte1, TANH)
-            o.lin_bwd_w(mv(dte0, 0, 252), mv(bt["en"]), mv(gw(ap + "lin_edge0.weight")))
-            o.lin_bwd_w(mv(dte1), mv(bt["en"]), mv(gw(ap + "lin_edge1.weight")))
+            dqkv, dte = self.f(Nn, 768), self.f(Pp, 512)
+            te = bt["te"]
+            E._check(lib.dst_attn_bwd(C.byref(TL.c), E._ptr(bt["qkv"]), E._ptr(te[:, 0:256]), E._ptr(te[:, 256:512]), C.c_int64(512), E._ptr(bt["alpha"]),
+                                      E._ptr(dattn), E._ptr(dqkv), E._ptr(dte[:, 0:256]), E._ptr(dte[:, 256:512]), None, s()), "dst_attn_bwd")
+            o.act_bwd(dte, te, dte, TANH)
+            o.lin_bwd_w(mv(dte), mv(bt["en"]), mv(dcat["Wte"][i]))                  # lin_edge0 | lin_edge1 (rows 252..255: zero gradients of the padding)
             den = self.f(Pp, 64)
-            o.lin_bwd_x(mv(dte0, 0, 252), mv(p[ap + "lin_edge0.weight"]), mv(den))
-            o.lin_bwd_x(mv(dte1), mv(p[ap + "lin_edge1.weight"]), mv(den), acc=True)
+            o.lin_bwd_x(mv(dte), mv(cat["Wte"][i]), mv(den))
             dhn = self.f(Nn, 256)
-            for k, (nm, c0_, c1_) in enumerate((("lin_query", 0, 252), ("lin_key", 256, 508), ("lin_value", 512, 768))):
-                o.lin_bwd_w(mv(dqkv, c0_, c1_), mv(bt["hn"]), mv(gw(ap + nm + ".weight")), gw(ap + nm + ".bias"))
-                o.lin_bwd_x(mv(dqkv, c0_, c1_), mv(p[ap + nm + ".weight"]), mv(dhn), acc=k > 0)
+            o.lin_bwd_w(mv(dqkv), mv(bt["hn"]), mv(dcat["Wqkv"][i]), dcat["bqkv"][i])
+            o.lin_bwd_x(mv(dqkv), mv(cat["Wqkv"][i]), mv(dhn))
             # adaLN modulates of the block input
             de1 = self.f(Pp, 64)
             o.lnmod_bwd(den, bt["e1"], bt["st_e1"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 0, a0 + EDGE_OFF + 64, de1, False)
@@ -607,12 +644,9 @@ class DmtTrainGraph:
             o.colsum(mv(dms_buf, 1, 64), g["dist_layer.means.weight"].view(-1))
             o.colsum(mv(dms_buf, 65, 128), g["dist_layer.stds.weight"].view(-1))
         # ---- adaLN table + time embedding
-        dWada, dbada = self.f(ADA, 1024), self.f(ADA)
-        o.lin_bwd_w(mv(d_ada), mv(t["st"]), mv(dWada), dbada)
-        o.join_dw()                                          # dWada is read right here, on the main stream
-        self.scatter_ada_grads(dWada, dbada, gw)
+        o.lin_bwd_w(mv(d_ada), mv(t["st"]), mv(dcat["Wada"]), dcat["bada"])
         dtemb = self.f(B, 1024)
-        o.lin_bwd_x(mv(d_ada), mv(t["Wada"]), mv(dtemb), dact=SILU, ref=mv(t["temb"]))
+        o.lin_bwd_x(mv(d_ada), mv(cat["Wada"]), mv(dtemb), dact=SILU, ref=mv(t["temb"]))
         g["@ctx_emb"] = dtemb
         o.lin_bwd_w(mv(dtemb), mv(t["tg"]), mv(gw("time_mlp.3.weight")), gw("time_mlp.3.bias"))
         dtg = self.f(B, 1024)
@@ -622,8 +656,9 @@ class DmtTrainGraph:
         o.lin_bwd_x(mv(dtg), mv(p["time_mlp.1.weight"]), mv(dtf))
         E._check(lib.dst_time_feat_bwd(E._ptr(t["noise_level"]), E._ptr(p["time_mlp.0.weights"]), E._ptr(dtf), C.c_int32(B),
                                        E._ptr(gw("time_mlp.0.weights")), s()), "dst_time_feat_bwd")
-        o.join_dw()
+        o.join_dw()                                          # the concatenated gradients are read right here, on the main stream
         o.async_dw = False
+        self.scatter_cat_grads(gw)
         self.t = None
         return g
 

@@ -120,13 +120,14 @@ int dst_geom_bwd(const dst_layout* L, const float* pos, const float* ada, float*
 int dst_adj_bits(const float* cond_e, int64_t ld, const float* d2c, float edge_th, float cutoff, int32_t Pp, int32_t* adj, void* stream);
 
 /* TransMixLayer attention per molecule.  qkv [Nn,768]: q at columns 0..251, k at 256..507, v at 512..767; te0 [Pp,256]
- * (= tanh(lin_edge0 e), 252 used), te1 [Pp,256], adj [Pp] bits (1: cond_adj_2d, 2: cond_adj_spatial); out [Nn,256];
+ * (= tanh(lin_edge0 e), 252 used), te1 [Pp,256], both (and their gradients) with row stride ld_te (512 when they are the two halves of
+ * one [Pp,512] buffer: lin_edge0 | lin_edge1 evaluated as one product), adj [Pp] bits (1: cond_adj_2d, 2: cond_adj_spatial); out [Nn,256];
  * alpha [2*Pp,16] (row 2p: source a -> target b, row 2p+1: source b -> target a).  16 heads: 0,1 adjacency heads (0 -> -1e10),
  * 2..15 learned (18 channels, scale 1/sqrt(16)); softmax over the sources of a target with + 1e-16 in the denominator.
  * Backward: dqkv [Nn,768], dte0 [Pp,256], dte1 [Pp,256] are written (not accumulated). */
-int dst_attn_fwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, const int32_t* adj, float* out,
+int dst_attn_fwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, int64_t ld_te, const int32_t* adj, float* out,
                  float* alpha, void* stream);
-int dst_attn_bwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, const float* alpha, const float* dout,
+int dst_attn_bwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, int64_t ld_te, const float* alpha, const float* dout,
                  float* dqkv, float* dte0, float* dte1, float* scratch, void* stream);
 
 /* s[p] = u[a] + u[b] (+ bias[c]) over C columns; backward du[i] (accumulate != 0 adds) = sum over the pairs of atom i of ds[p]. */

@@ -333,11 +333,11 @@ def test_attention(ops, gpu_device):
     outd, ald = torch.empty(Nn, 256, device=d), torch.empty(2 * P, 16, device=d)
     qd, e0d, e1d, adjd = qkv.to(d), te0.to(d), te1.to(d), adj.to(d)
     from diffspectra_amd import engine as E
-    E._check(o.lib.dst_attn_fwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), E._ptr(adjd), E._ptr(outd), E._ptr(ald), E._stream()), "attn_fwd")
+    E._check(o.lib.dst_attn_fwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), C.c_int64(256), E._ptr(adjd), E._ptr(outd), E._ptr(ald), E._stream()), "attn_fwd")
     check(ald, al, 3e-6, "attention alpha")
     check(outd, out, 3e-6, "attention out")
     dq, de0, de1 = torch.empty(Nn, 768, device=d), torch.empty(P, 256, device=d), torch.empty(P, 256, device=d)
-    E._check(o.lib.dst_attn_bwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), E._ptr(ald), E._ptr(dout.to(d)), E._ptr(dq), E._ptr(de0), E._ptr(de1),
+    E._check(o.lib.dst_attn_bwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), C.c_int64(256), E._ptr(ald), E._ptr(dout.to(d)), E._ptr(dq), E._ptr(de0), E._ptr(de1),
                                 None, E._stream()), "attn_bwd")
     check(dq, qr.grad, 2e-5, "attention dqkv")
     check(de0, e0r.grad, 2e-5, "attention dte0")

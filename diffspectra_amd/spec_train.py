@@ -83,8 +83,10 @@ class SpecTrainGraph:
         for l in range(N_LAYERS):
             base = pre + f"backbone.encoder.layers.{l}."
             qkv = self.f(B * L, 3 * D_MODEL)
-            for k, nm in enumerate(("W_Q", "W_K", "W_V")):
-                o.lin_fwd(mv(Z), mv(p[base + f"self_attn.{nm}.weight"]), p[base + f"self_attn.{nm}.bias"], mv(qkv, k * D_MODEL, (k + 1) * D_MODEL))
+            # W_Q | W_K | W_V read the same tokens: one product from a per-call concatenation of the three weights
+            Wc = torch.cat([p[base + f"self_attn.{nm}.weight"] for nm in ("W_Q", "W_K", "W_V")], dim=0)
+            bc = torch.cat([p[base + f"self_attn.{nm}.bias"] for nm in ("W_Q", "W_K", "W_V")], dim=0)
+            o.lin_fwd(mv(Z), mv(Wc), bc, mv(qkv))
             ast, ao = self.f(B, N_HEADS, L, 2), self.f(B * L, D_MODEL)
             qkvs.append(qkv)
             if flash:                                                  # bf16 mode: scores recomputed from the q | k of layers 0 .. l, never stored
@@ -109,7 +111,7 @@ class SpecTrainGraph:
             z2, st2 = self.f(B * L, D_MODEL), self.f(2, D_MODEL)
             self._bn_fwd(r2, base + "norm_ffn.1", z2, st2)
             if save:
-                layers.append(dict(Zin=Z, qkv=qkv, scores=scores, ast=ast, ao=ao, r1=r1, st1=st1, z1=z1, a=a, ga=ga, r2=r2, st2=st2, has_prev=prev is not None))
+                layers.append(dict(Zin=Z, qkv=qkv, Wqkv=Wc, scores=scores, ast=ast, ao=ao, r1=r1, st1=st1, z1=z1, a=a, ga=ga, r2=r2, st2=st2, has_prev=prev is not None))
             prev = scores
             Z = z2
         flat = Z.reshape(B, L * D_MODEL)
@@ -151,6 +153,7 @@ class SpecTrainGraph:
         o.lin_bwd_x(mv(dzh), mv(p[pre + "head.linear.weight"]), mv(dZ.view(B, L * D_MODEL)))
         dscores_in = None
         scale = float(D_K ** -0.5)
+        cat_dst, cat_src = [], []                                      # gradients of the concatenated W_Q | W_K | W_V, scattered after the side stream has joined
         flash = t["flash"]
         if flash:                                                      # every layer's attention backward adds into the q | k columns of the layers below it
             dqkv_all = [torch.zeros(B * L, 3 * D_MODEL, dtype=torch.float32, device=self.dev) for _ in range(N_LAYERS)]
@@ -184,12 +187,14 @@ class SpecTrainGraph:
                 E._check(self.lib.dst_spec_attn_bwd(E._ptr(lt["qkv"]), E._ptr(lt["scores"]), E._ptr(lt["ast"]), E._ptr(dao), E._ptr(dscores_in), E._ptr(dqkv), E._ptr(dscores),
                                                     C.c_int32(B), C.c_int32(L), C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()),
                          "dst_spec_attn_bwd")
-            dzin = self.f(B * L, D_MODEL)                                                        # dZin = dr1 (residual) + sum dq W (dr1 stays intact, as dr2 above)
-            for k, nm in enumerate(("W_Q", "W_K", "W_V")):
-                dq = mv(dqkv, k * D_MODEL, (k + 1) * D_MODEL)
-                o.lin_bwd_w(dq, mv(lt["Zin"]), mv(gw(base + f"self_attn.{nm}.weight")), gw(base + f"self_attn.{nm}.bias"))
-                o.lin_bwd_x(dq, mv(p[base + f"self_attn.{nm}.weight"]), mv(dzin), acc=k > 0)
+            dzin = self.f(B * L, D_MODEL)                                                        # dZin = dr1 (residual) + dqkv Wqkv (dr1 stays intact, as dr2 above)
+            dWc, dbc = self.f(3 * D_MODEL, D_MODEL), self.f(3 * D_MODEL)
+            o.lin_bwd_w(mv(dqkv), mv(lt["Zin"]), mv(dWc), dbc)
+            o.lin_bwd_x(mv(dqkv), mv(lt["Wqkv"]), mv(dzin))
             o.axpy(1.0, dr1, dzin)
+            for k, nm in enumerate(("W_Q", "W_K", "W_V")):
+                cat_dst += [gw(base + f"self_attn.{nm}.weight"), gw(base + f"self_attn.{nm}.bias")]
+                cat_src += [dWc[k * D_MODEL:(k + 1) * D_MODEL], dbc[k * D_MODEL:(k + 1) * D_MODEL]]
             dscores_in = dscores if lt["has_prev"] else None
             dZ = dzin
         dZ3 = dZ.view(B, L, D_MODEL)
@@ -201,5 +206,6 @@ class SpecTrainGraph:
             tok0 += pn
         o.join_dw()
         o.async_dw = False
+        torch._foreach_copy_(cat_dst, cat_src)
         self.t = None
         return g

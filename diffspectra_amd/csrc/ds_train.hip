@@ -371,12 +371,18 @@ __global__ __launch_bounds__(1024) void k_attn_fwd(dst_layout L, const float* __
     if (hd < 2) {
       v = ((adj[p0 + p] >> hd) & 1) ? 1.0f : -1e10f;
     } else {
-      const int c0 = (hd - 2) * 18;
-      const float* q = qkv + (int64_t)(n0 + tgt) * 768 + c0;
-      const float* k = qkv + (int64_t)(n0 + src) * 768 + 256 + c0;
-      const float* e = te0 + (int64_t)(p0 + p) * ldt + c0;
+      const int c0 = (hd - 2) * 18;                       // 72-byte head slices: 8-byte aligned, nine float2 each
+      typedef float f2_t __attribute__((ext_vector_type(2)));
+      const f2_t* q = reinterpret_cast<const f2_t*>(qkv + (int64_t)(n0 + tgt) * 768 + c0);
+      const f2_t* k = reinterpret_cast<const f2_t*>(qkv + (int64_t)(n0 + src) * 768 + 256 + c0);
+      const f2_t* e = reinterpret_cast<const f2_t*>(te0 + (int64_t)(p0 + p) * ldt + c0);
       float s = 0.0f;
-      for (int c = 0; c < 18; ++c) s += q[c] * k[c] * e[c];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {                       // same summation order as the scalar loop (c ascending)
+        const f2_t qq = q[c], kk = k[c], ee = e[c];
+        s += qq[0] * kk[0] * ee[0];
+        s += qq[1] * kk[1] * ee[1];
+      }
       v = s / 4.0f;
     }
     lg[it] = v;
@@ -410,16 +416,16 @@ __global__ __launch_bounds__(1024) void k_attn_fwd(dst_layout L, const float* __
   }
   __syncthreads();
   // aggregation onto the target, ascending source order
-  for (int it = threadIdx.x; it < n * 256; it += blockDim.x) {
-    const int t = it >> 8, col = it & 255, hd = col >> 4;
-    float s = 0.0f;
+  for (int it = threadIdx.x; it < n * 64; it += blockDim.x) {      // four columns (one head) per thread
+    const int t = it >> 6, col = (it & 63) * 4, hd = col >> 4;
+    f4_t s = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int sN = 0; sN < n; ++sN) {
       if (sN == t) continue;
       const int p = sN < t ? pair_index(n, sN, t) : pair_index(n, t, sN);
       const int d = sN < t ? 2 * p : 2 * p + 1;
-      s += qkv[(int64_t)(n0 + sN) * 768 + 512 + col] * te1[(int64_t)(p0 + p) * ldt + col] * lg[d * 16 + hd];
+      s += ld4(qkv + (int64_t)(n0 + sN) * 768 + 512 + col) * ld4(te1 + (int64_t)(p0 + p) * ldt + col) * lg[d * 16 + hd];
     }
-    out[(int64_t)(n0 + t) * 256 + col] = s;
+    st4(out + (int64_t)(n0 + t) * 256 + col, s);
   }
   if (n == 1)
     for (int col = threadIdx.x; col < 256; col += blockDim.x) out[(int64_t)n0 * 256 + col] = 0.0f;
@@ -443,7 +449,11 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
     const float* v = qkv + (int64_t)(n0 + src) * 768 + 512 + hd * 16;
     const float* e = te1 + (int64_t)(p0 + p) * ldt + hd * 16;
     float s = 0.0f;
-    for (int c = 0; c < 16; ++c) s += go[c] * v[c] * e[c];
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) {
+      const f4_t a = ld4(go + c) * ld4(v + c) * ld4(e + c);
+      s += a[0]; s += a[1]; s += a[2]; s += a[3];
+    }
     dl[it] = s;
   }
   __syncthreads();
@@ -463,26 +473,33 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
     }
   }
   __syncthreads();
-  // node-side gradients: thread per (node, column of the 768-wide q|k|v row)
-  for (int it = threadIdx.x; it < n * 768; it += blockDim.x) {
-    const int i = it / 768, col = it % 768;
-    float s = 0.0f;
-    if (col < 252) {                                   // dq[i]: i is the target
-      const int hd = col / 18 + 2;
+  // node-side gradients: thread per (node, four columns of the 768-wide q|k|v row) - 16-byte accesses, a quarter of the index arithmetic
+  for (int it = threadIdx.x; it < n * 192; it += blockDim.x) {
+    const int i = it / 192, col = (it % 192) * 4;
+    f4_t s = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (col < 252) {                                   // dq[i]: i is the target (252 = 4 * 63: a quad never straddles the padding)
+      int hd[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hd[e] = (col + e) / 18 + 2;
       for (int j = 0; j < n; ++j) {
         if (j == i) continue;
         const int p = j < i ? pair_index(n, j, i) : pair_index(n, i, j);
         const int d = j < i ? 2 * p : 2 * p + 1;       // source j -> target i
-        s += dl[d * 16 + hd] * qkv[(int64_t)(n0 + j) * 768 + 256 + col] * te0[(int64_t)(p0 + p) * ldt + col];
+        const f4_t w = {dl[d * 16 + hd[0]], dl[d * 16 + hd[1]], dl[d * 16 + hd[2]], dl[d * 16 + hd[3]]};
+        s += w * ld4(qkv + (int64_t)(n0 + j) * 768 + 256 + col) * ld4(te0 + (int64_t)(p0 + p) * ldt + col);
       }
       s *= 0.25f;
     } else if (col >= 256 && col < 508) {              // dk[i]: i is the source
-      const int c = col - 256, hd = c / 18 + 2;
+      const int c = col - 256;
+      int hd[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hd[e] = (c + e) / 18 + 2;
       for (int t = 0; t < n; ++t) {
         if (t == i) continue;
         const int p = i < t ? pair_index(n, i, t) : pair_index(n, t, i);
         const int d = i < t ? 2 * p : 2 * p + 1;       // source i -> target t
-        s += dl[d * 16 + hd] * qkv[(int64_t)(n0 + t) * 768 + c] * te0[(int64_t)(p0 + p) * ldt + c];
+        const f4_t w = {dl[d * 16 + hd[0]], dl[d * 16 + hd[1]], dl[d * 16 + hd[2]], dl[d * 16 + hd[3]]};
+        s += w * ld4(qkv + (int64_t)(n0 + t) * 768 + c) * ld4(te0 + (int64_t)(p0 + p) * ldt + c);
       }
       s *= 0.25f;
     } else if (col >= 512) {                           // dv[i]: i is the source
@@ -491,29 +508,35 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
         if (t == i) continue;
         const int p = i < t ? pair_index(n, i, t) : pair_index(n, t, i);
         const int d = i < t ? 2 * p : 2 * p + 1;
-        s += dout[(int64_t)(n0 + t) * 256 + c] * te1[(int64_t)(p0 + p) * ldt + c] * al[d * 16 + hd];
+        s += ld4(dout + (int64_t)(n0 + t) * 256 + c) * ld4(te1 + (int64_t)(p0 + p) * ldt + c) * al[d * 16 + hd];
       }
     }
-    dqkv[(int64_t)(n0 + i) * 768 + col] = s;
+    st4(dqkv + (int64_t)(n0 + i) * 768 + col, s);
   }
-  // pair-side gradients (both directions of a pair)
-  for (int it = threadIdx.x; it < np * 256; it += blockDim.x) {
-    const int p = it >> 8, col = it & 255;
+  // pair-side gradients (both directions of a pair), four columns per thread
+  for (int it = threadIdx.x; it < np * 64; it += blockDim.x) {
+    const int p = it >> 6, col = (it & 63) * 4;
     const int a = pa[p], b = pb[p];
     {
       const int hd = col >> 4;
-      const float va = qkv[(int64_t)(n0 + a) * 768 + 512 + col], vb = qkv[(int64_t)(n0 + b) * 768 + 512 + col];
-      dte1[(int64_t)(p0 + p) * ldt + col] = dout[(int64_t)(n0 + b) * 256 + col] * va * al[(2 * p) * 16 + hd] +
-                                            dout[(int64_t)(n0 + a) * 256 + col] * vb * al[(2 * p + 1) * 16 + hd];
+      const f4_t va = ld4(qkv + (int64_t)(n0 + a) * 768 + 512 + col), vb = ld4(qkv + (int64_t)(n0 + b) * 768 + 512 + col);
+      st4(dte1 + (int64_t)(p0 + p) * ldt + col, ld4(dout + (int64_t)(n0 + b) * 256 + col) * va * al[(2 * p) * 16 + hd] +
+                                                ld4(dout + (int64_t)(n0 + a) * 256 + col) * vb * al[(2 * p + 1) * 16 + hd]);
     }
-    float g0 = 0.0f;
+    f4_t g0 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (col < 252) {
-      const int hd = col / 18 + 2;
-      const float qa = qkv[(int64_t)(n0 + a) * 768 + col], qb = qkv[(int64_t)(n0 + b) * 768 + col];
-      const float ka = qkv[(int64_t)(n0 + a) * 768 + 256 + col], kb = qkv[(int64_t)(n0 + b) * 768 + 256 + col];
-      g0 = 0.25f * (dl[(2 * p) * 16 + hd] * qb * ka + dl[(2 * p + 1) * 16 + hd] * qa * kb);
+      const f4_t qa = ld4(qkv + (int64_t)(n0 + a) * 768 + col), qb = ld4(qkv + (int64_t)(n0 + b) * 768 + col);
+      const f4_t ka = ld4(qkv + (int64_t)(n0 + a) * 768 + 256 + col), kb = ld4(qkv + (int64_t)(n0 + b) * 768 + 256 + col);
+      f4_t w0, w1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int hd = (col + e) / 18 + 2;
+        w0[e] = dl[(2 * p) * 16 + hd];
+        w1[e] = dl[(2 * p + 1) * 16 + hd];
+      }
+      g0 = 0.25f * (w0 * qb * ka + w1 * qa * kb);
     }
-    dte0[(int64_t)(p0 + p) * ldt + col] = g0;
+    st4(dte0 + (int64_t)(p0 + p) * ldt + col, g0);
   }
 }
 

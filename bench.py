@@ -394,6 +394,9 @@ def train_measure(args, world, rank, device, steps, warmup, with_cpu_baseline):
         torch.cuda.synchronize()
 
     torch.manual_seed(rank)
+    import random as _random
+    _random.seed(1234)          # the self-conditioning coin of every step (losses.py:344: random() < 0.5): a fixed sequence, so that two runs time
+                                # the same mix of one- and two-forward steps (the extra forward is ~25 % of a step; unseeded, 10-step runs spread +-4 ms)
     for w in range(warmup):
         loss = step_fn(state, batch)
     sync()
@@ -442,7 +445,7 @@ def train_measure(args, world, rank, device, steps, warmup, with_cpu_baseline):
                           if args.precision == "bf16" else "f32 (fp32 MFMA GEMMs)"),
                 "data": "synthetic",
                 "config": {"workload": f"DMT training step, QM9S {args.spectra}, {Bt} molecules per GPU and step (global batch {world * Bt}), dropout "
-                                       f"{cfg.model.dropout}, AdamW-amsgrad + adaptive clip + EMA fused, gradient reduce-scatter + parameter all-gather",
+                                       f"{cfg.model.dropout}, AdamW-amsgrad + adaptive clip + EMA fused, gradient reduce-scatter + parameter all-gather; self-conditioning coin from random.seed(1234)",
                            "mode": "train", "molecules_per_gpu": Bt, "parallelism": f"dp{world}", "last_loss": float(loss.detach())},
                 "whole_path": {"algorithmic_tflops_per_gpu": flop * steps / elapsed / 1e12}}
         gemm_ms = sum(r[0].elapsed_time(r[1]) for r in recs)

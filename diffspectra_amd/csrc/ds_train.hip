@@ -91,6 +91,16 @@ __global__ void k_adj_bits(const float* __restrict__ cond_e, int64_t ld, const f
   if (p < n) adj[p] = (cond_e[(int64_t)p * ld] >= th ? 1 : 0) | (d2c[p] <= cutoff ? 2 : 0);
 }
 
+// many small strided 2-D copies in one launch (the per-step concatenated weight buffers and the scatter of their gradients)
+__global__ __launch_bounds__(256) void k_copy_pieces(const dst_piece* __restrict__ table) {
+  const dst_piece pc = table[blockIdx.x];
+  const int64_t total = (int64_t)pc.rows * pc.cols;
+  for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.y * 256) {
+    const int64_t r = i / pc.cols, c = i - r * pc.cols;
+    pc.dst[r * pc.dst_ld + c] = pc.src[r * pc.src_ld + c];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ dropout
 // nn.Dropout(p) in training mode (dmt.py:114-120): y = x * keep / (1 - p) with keep ~ Bernoulli(1 - p) from a counter-based Philox4x32-10
 // stream keyed on (seed, stream id): the mask of element i is a pure function of (seed, stream, i), so the backward pass re-creates it
@@ -1275,6 +1285,13 @@ int dst_adj_bits(const float* cond_e, int64_t ld, const float* d2c, float edge_t
   if (Pp < 0 || (Pp > 0 && (!cond_e || !d2c || !adj))) return DS_ERR_ARG;
   if (Pp == 0) return DS_OK;
   hipLaunchKernelGGL(k_adj_bits, grid1d(Pp), dim3(256), 0, (hipStream_t)stream, cond_e, ld, d2c, edge_th, cutoff, (int)Pp, adj);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_copy_pieces(const dst_piece* table, int32_t n, void* stream) {
+  if (n < 0 || (n > 0 && !table)) return DS_ERR_ARG;
+  if (n == 0) return DS_OK;
+  hipLaunchKernelGGL(k_copy_pieces, dim3(n, 16), dim3(256), 0, (hipStream_t)stream, table);
   return DST_CHECK_LAUNCH();
 }
 

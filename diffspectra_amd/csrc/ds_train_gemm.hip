@@ -538,6 +538,7 @@ int dst_struct_sizes(int64_t* out) {
   if (!out) return DS_ERR_ARG;
   out[0] = sizeof(dst_gemm_args);
   out[1] = sizeof(dst_layout);
+  out[2] = sizeof(dst_piece);
   return DS_OK;
 }
 
@@ -592,7 +593,9 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   } else if (vec) {
     // tiles sized so that the launch has at least ~3 workgroups per CU where the problem allows it: the k-loop of a workgroup exposes
     // one memory round trip per step, and what hides it is the neighbours on the CU (24 - 32 kB in flight per workgroup and step)
-    BN = bn_pref ? bn_pref : (Nx > 64 ? 128 : 64);
+    // 128 x 64 / 64 x 64 everywhere except the split products: seeded same-box A/B over the training step - 128-wide tiles (199 registers, two
+    // waves per SIMD) cost 0.8 ms of 39.6 wherever they were chosen for the long forward products
+    BN = bn_pref ? bn_pref : ((Nx > 64 && g.K >= 4096) ? 128 : 64);
     BM = 128;
     auto count = [&](int bm, int bn) { return (int64_t)((g.M + bm - 1) / bm) * ((Nx + bn - 1) / bn); };
     if (!bn_pref && BN == 128 && count(BM, BN) < wg_target && g.K < 4096) BN = 64;   // (a split product keeps the wide tile: fewer re-reads of its k-slices)

@@ -38,6 +38,30 @@ class DstGemmArgs(C.Structure):
                 ("drop_p", C.c_float), ("drop_stream", C.c_uint32), ("drop_seed", C.c_uint64), ("drop_ld", C.c_int64)]
 
 
+class DstPiece(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("src_ld", C.c_int64), ("dst_ld", C.c_int64)]
+
+
+def copy_pieces(lib, dev, dst: List[torch.Tensor], src: List[torch.Tensor], cache: dict, key: str):
+    """``dst[i].copy_(src[i])`` for many small (<= 2-D, last dimension contiguous) fp32 pieces in ONE ``dst_copy_pieces`` launch.  The device
+    table is rebuilt only when a pointer changed (parameters live in the optimizer's flat buffer, the concatenated buffers are persistent)."""
+    sig = tuple(t.data_ptr() for t in dst) + tuple(t.data_ptr() for t in src)
+    ent = cache.get(key)
+    if ent is None or ent[0] != sig:
+        arr = (DstPiece * len(dst))()
+        for i, (d, s_) in enumerate(zip(dst, src)):
+            assert d.shape == s_.shape and d.dtype == torch.float32 and s_.dtype == torch.float32 and d.dim() <= 2
+            rows, cols = (1, d.numel()) if d.dim() < 2 else (d.shape[0], d.shape[1])
+            ld = lambda t: (t.stride(0) if t.dim() == 2 and t.shape[0] > 1 else cols)
+            assert (d.dim() < 2 or d.stride(-1) == 1 or cols == 1) and (s_.dim() < 2 or s_.stride(-1) == 1 or cols == 1)
+            assert d.dim() >= 1 and (d.dim() == 2 or d.is_contiguous()) and (s_.dim() == 2 or s_.is_contiguous())
+            arr[i] = DstPiece(src=s_.data_ptr(), dst=d.data_ptr(), rows=rows, cols=cols, src_ld=ld(s_), dst_ld=ld(d))
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        ent = (sig, raw, len(dst))
+        cache[key] = ent
+    E._check(lib.dst_copy_pieces(C.c_void_p(ent[1].data_ptr()), C.c_int32(ent[2]), E._stream()), "dst_copy_pieces")
+
+
 class DstLayout(C.Structure):
     _fields_ = [("B", C.c_int32), ("Nn", C.c_int32), ("Pp", C.c_int32), ("_pad", C.c_int32), ("node_off", C.c_void_p), ("pair_off", C.c_void_p)]
 
@@ -57,9 +81,9 @@ def load_train_library() -> C.CDLL:
         lib = E.load_library()
         for name in train_exports():
             getattr(lib, name).restype = C.c_int
-        sizes = (C.c_int64 * 2)()
+        sizes = (C.c_int64 * 3)()
         lib.dst_struct_sizes(sizes)
-        mine = [C.sizeof(DstGemmArgs), C.sizeof(DstLayout)]
+        mine = [C.sizeof(DstGemmArgs), C.sizeof(DstLayout), C.sizeof(DstPiece)]
         if list(sizes) != mine:
             raise RuntimeError(f"C-ABI struct layout mismatch (training): library {list(sizes)} vs binding {mine}")
         _lib = lib
@@ -323,8 +347,8 @@ class DmtTrainGraph:
             cache["bufs"] = {n: self.z(*shape) for n, shape in shapes}          # padding rows (252..255 of q / k / lin_edge0) stay zero
             cache["grads"] = {n: self.z(*shape) for n, shape in shapes}
         dst, src = self._piece_views(cache["bufs"], self.p)
-        torch._foreach_copy_(dst, src)
-        self.cat, self.dcat = cache["bufs"], cache["grads"]
+        copy_pieces(self.lib, self.dev, dst, src, cache, "table_fwd")
+        self.cat, self.dcat, self._cat_cache = cache["bufs"], cache["grads"], cache
         return cache
 
     def scatter_cat_grads(self, gw):
@@ -336,7 +360,7 @@ class DmtTrainGraph:
             if name not in tgt:
                 tgt[name] = gw(name) if name not in self._gw_done else self._gw_done[name]
         src, dst = self._piece_views(self.dcat, tgt)
-        torch._foreach_copy_(dst, src)
+        copy_pieces(self.lib, self.dev, dst, src, self._cat_cache, "table_bwd")
 
     def _geom_fwd(self, TL, pos, ada, dist_off, prefix, X, ldx, col0, xs, d2s):
         E._check(self.lib.dst_geom_fwd(C.byref(TL.c), E._ptr(pos), E._ptr(ada), C.c_int64(ADA), C.c_int32(dist_off),

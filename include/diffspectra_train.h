@@ -59,8 +59,19 @@ typedef struct dst_gemm_args {
 } dst_gemm_args;
 int dst_gemm(const dst_gemm_args* a, void* stream);
 
-/* out[0] = sizeof(dst_gemm_args), out[1] = sizeof(dst_layout): the binding checks its own struct layouts against the library's. */
+/* out[0] = sizeof(dst_gemm_args), out[1] = sizeof(dst_layout), out[2] = sizeof(dst_piece): the binding checks its own struct layouts
+ * against the library's. */
 int dst_struct_sizes(int64_t* out);
+
+/* n strided 2-D copies in ONE launch: dst[r*dst_ld + c] = src[r*src_ld + c] for r < rows, c < cols of every piece; `table` is a DEVICE
+ * array.  (The per-step concatenation of Linears that share an input - q | k | v, the adaLN table, ... - and the scatter of the
+ * concatenated gradients: ~150 pieces each way, one launch instead of one copy per piece.) */
+typedef struct dst_piece {
+  const float* src; float* dst;
+  int32_t rows, cols;
+  int64_t src_ld, dst_ld;
+} dst_piece;
+int dst_copy_pieces(const dst_piece* table, int32_t n, void* stream);
 
 /* out[c] (+)= sum_r X[r*ld + c], two fixed-order stages through `scratch` (bias gradients, per-molecule partial sums). */
 int dst_colsum(const float* X, int64_t ld, int32_t R, int32_t C, float* out, int32_t accumulate, float* scratch,

@@ -149,11 +149,15 @@ class DMT(nn.Module):
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in named.values())
         dmt.dropout_p = float(getattr(self.config.model, "dropout", 0.0))
         dmt.dropout_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if dmt.dropout_p > 0 else 0
-        with torch.no_grad():
-            ctx = spec.forward(ctx_in, save=want_grad)
-            pos, atom, edge = dmt.forward(TL, z, ez, f32(noise_level).contiguous(), ctx, cond_n, cond_e, save=want_grad)
-            out_xh = TL.unpack_nodes(torch.cat([pos, atom], dim=1)).to(xh.dtype)
-            out_edge = TL.unpack_pairs(edge).to(edge_x.dtype)
+        tr.ops.begin()
+        try:
+            with torch.no_grad():
+                ctx = spec.forward(ctx_in, save=want_grad)
+                pos, atom, edge = dmt.forward(TL, z, ez, f32(noise_level).contiguous(), ctx, cond_n, cond_e, save=want_grad)
+                out_xh = TL.unpack_nodes(torch.cat([pos, atom], dim=1)).to(xh.dtype)
+                out_edge = TL.unpack_pairs(edge).to(edge_x.dtype)
+        finally:
+            tr.ops.end()
         if not want_grad:
             return out_xh, out_edge
         params = list(named.values())
@@ -216,6 +220,10 @@ class _DmtGraph(torch.autograd.Function):
         dedge = (de.index_select(0, TL.pair_dense) + de.index_select(0, TL.pair_dense_t)).contiguous()   # both cells of a pair carry its value
         flat, _, offs = tr.stage(named)
         flat.zero_()
-        g = dmt.backward(dpos, datom, dedge)
-        g.update(spec.backward(g.pop("@ctx_emb")))
+        tr.ops.begin()
+        try:
+            g = dmt.backward(dpos, datom, dedge)
+            g.update(spec.backward(g.pop("@ctx_emb")))
+        finally:
+            tr.ops.end()
         return (None,) * 8 + deliver(tr, named, g, flat, offs, None)

@@ -453,8 +453,15 @@ def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None
     pos_norm, type_norm, fc_norm, edge_norm = (float(v) for v in _factors(config))
 
     def loss_fn(model, batch):
-        model.train() if train else model.eval()
         tr = _trainer(model)
+        tr.ops.begin()                                                   # one stream lookup for the ~1 700 launches of the call
+        try:
+            return _loss_fn(model, batch, tr)
+        finally:
+            tr.ops.end()
+
+    def _loss_fn(model, batch, tr):
+        model.train() if train else model.eval()
         dev, lib = tr.dev, tr.lib
         named, dmt, spec = tr.graphs()
         tr.ops.bf16 = precision == "bf16"          # config 5: bf16 products with fp32 accumulation, fp32 master weights
@@ -466,7 +473,7 @@ def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None
         fc_p, edge_p = TL.pack_nodes(f32(batch["formal_charges"])).reshape(-1).contiguous(), TL.pack_pairs(f32(batch["edge_one_hot"]))
         x, ex = dmt.f(TL.Nn, 9), dmt.f(max(TL.Pp, 1), 2)
         E._check(lib.dst_prepare_batch(C.byref(TL.c), E._ptr(pos_p), E._ptr(oh_p), E._ptr(fc_p), E._ptr(edge_p), C.c_float(pos_norm), C.c_float(type_norm),
-                                       C.c_float(fc_norm), C.c_float(edge_norm), E._ptr(x), E._ptr(ex), E._stream()), "dst_prepare_batch")
+                                       C.c_float(fc_norm), C.c_float(edge_norm), E._ptr(x), E._ptr(ex), tr.ops._s()), "dst_prepare_batch")
         context = batch["context"]
         context = [f32(c) for c in context] if isinstance(context, (list, tuple)) else f32(context)
         # the random draws, in the reference's order and shapes (losses.py:314-317, models/utils.py:67-106)
@@ -479,9 +486,9 @@ def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None
         z, ez = dmt.f(TL.Nn, 9), dmt.f(max(TL.Pp, 1), 2)
         alpha_t, sigma_t = alpha_t.to(torch.float32).contiguous(), sigma_t.to(torch.float32).contiguous()
         E._check(lib.dst_noising(C.byref(TL.c), E._ptr(alpha_t), E._ptr(sigma_t), E._ptr(x), E._ptr(raw_n), E._ptr(z), E._ptr(ex), E._ptr(raw_e), E._ptr(ez),
-                                 E._stream()), "dst_noising")
+                                 tr.ops._s()), "dst_noising")
         rot, aligned = dmt.f(B, 9), dmt.f(TL.Nn, 3)
-        E._check(lib.dst_kabsch(C.byref(TL.c), E._ptr(z), C.c_int64(9), E._ptr(x), C.c_int64(9), E._ptr(rot), E._ptr(aligned), E._stream()), "dst_kabsch")
+        E._check(lib.dst_kabsch(C.byref(TL.c), E._ptr(z), C.c_int64(9), E._ptr(x), C.c_int64(9), E._ptr(rot), E._ptr(aligned), tr.ops._s()), "dst_kabsch")
         noise_level = torch.log(alpha_t ** 2 / sigma_t ** 2).contiguous()
         cond_n = cond_e = None
         # FF dropout (dmt.py:114-120) is active whenever the model is in training mode - in the no-grad self-conditioning forward too

@@ -45,7 +45,7 @@ class SpecTrainGraph:
         R, Cc = x.shape
         E._check(self.lib.dst_bn_fwd(E._ptr(x), C.c_int32(R), C.c_int32(Cc), E._ptr(p[name + ".weight"]), E._ptr(p[name + ".bias"]), C.c_float(1e-5),
                                      E._ptr(y), E._ptr(stats), E._ptr(b[name + ".running_mean"]), E._ptr(b[name + ".running_var"]), E._ptr(o.scratch),
-                                     C.c_int64(o.scratch.numel()), E._stream()), "dst_bn_fwd")
+                                     C.c_int64(o.scratch.numel()), self.ops._s()), "dst_bn_fwd")
         b[name + ".num_batches_tracked"] += 1
 
     def _bn_bwd(self, dy, x, stats, name, dx, g):
@@ -54,7 +54,7 @@ class SpecTrainGraph:
         gb = getattr(self, "gbuf", None)
         g[name + ".weight"], g[name + ".bias"] = (gb[name + ".weight"], gb[name + ".bias"]) if gb is not None else (self.f(Cc), self.f(Cc))
         E._check(self.lib.dst_bn_bwd(E._ptr(dy), E._ptr(x), E._ptr(stats), C.c_int32(R), C.c_int32(Cc), E._ptr(self.p[name + ".weight"]), E._ptr(dx),
-                                     E._ptr(g[name + ".weight"]), E._ptr(g[name + ".bias"]), E._ptr(o.scratch), C.c_int64(o.scratch.numel()), E._stream()),
+                                     E._ptr(g[name + ".weight"]), E._ptr(g[name + ".bias"]), E._ptr(o.scratch), C.c_int64(o.scratch.numel()), self.ops._s()),
                  "dst_bn_bwd")
 
     # ------------------------------------------------------------------ forward
@@ -92,13 +92,13 @@ class SpecTrainGraph:
             if flash:                                                  # bf16 mode: scores recomputed from the q | k of layers 0 .. l, never stored
                 qp = [E._ptr(q_) for q_ in qkvs] + [None] * (3 - len(qkvs))
                 E._check(self.lib.dst_spec_attn_flash_fwd(qp[0], qp[1], qp[2], C.c_int32(l + 1), E._ptr(ast), E._ptr(ao), C.c_int32(B), C.c_int32(L),
-                                                          C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()), "dst_spec_attn_flash_fwd")
+                                                          C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), self.ops._s()), "dst_spec_attn_flash_fwd")
                 scores = None
             else:
                 Lp = (L + 31) // 32 * 32                               # padded row stride of the [L, L] score matrices
                 scores = self.f(B, N_HEADS, L, Lp)
                 E._check(self.lib.dst_spec_attn_fwd(E._ptr(qkv), E._ptr(prev), E._ptr(scores), E._ptr(ast), E._ptr(ao), C.c_int32(B), C.c_int32(L),
-                                                    C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()), "dst_spec_attn_fwd")
+                                                    C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), self.ops._s()), "dst_spec_attn_fwd")
             r1 = Z.clone()
             o.gemm(mv(ao), mv(p[base + "self_attn.to_out.0.weight"]), mv(r1), False, True, bias=p[base + "self_attn.to_out.0.bias"], acc=True)
             z1, st1 = self.f(B * L, D_MODEL), self.f(2, D_MODEL)
@@ -119,7 +119,7 @@ class SpecTrainGraph:
         o.lin_fwd(mv(flat), mv(p[pre + "head.linear.weight"]), p[pre + "head.linear.bias"], mv(zh))
         zs, st_ln = self.f(B, 256), self.f(B, 2)
         E._check(self.lib.dst_ln_affine_fwd(E._ptr(zh), C.c_int32(B), C.c_int32(256), E._ptr(p[pre + "out_norm.weight"]), E._ptr(p[pre + "out_norm.bias"]),
-                                            C.c_float(1e-5), E._ptr(zs), E._ptr(st_ln), E._stream()), "dst_ln_affine_fwd")
+                                            C.c_float(1e-5), E._ptr(zs), E._ptr(st_ln), self.ops._s()), "dst_ln_affine_fwd")
         ctx = self.f(B, 1024)
         o.lin_fwd(mv(zs), mv(p["cond_lin.weight"]), p["cond_lin.bias"], mv(ctx))
         if save:
@@ -146,7 +146,7 @@ class SpecTrainGraph:
         o.lin_bwd_x(mv(dctx), mv(p["cond_lin.weight"]), mv(dzs))
         dzh = self.f(B, 256)
         E._check(self.lib.dst_ln_affine_bwd(E._ptr(dzs), E._ptr(t["zh"]), E._ptr(t["st_ln"]), C.c_int32(B), C.c_int32(256), E._ptr(p[pre + "out_norm.weight"]),
-                                            E._ptr(dzh), E._ptr(gw(pre + "out_norm.weight")), E._ptr(gw(pre + "out_norm.bias")), E._stream()),
+                                            E._ptr(dzh), E._ptr(gw(pre + "out_norm.weight")), E._ptr(gw(pre + "out_norm.bias")), self.ops._s()),
                  "dst_ln_affine_bwd")
         o.lin_bwd_w(mv(dzh), mv(t["flat"]), mv(gw(pre + "head.linear.weight")), gw(pre + "head.linear.bias"))
         dZ = self.f(B * L, D_MODEL)
@@ -179,13 +179,13 @@ class SpecTrainGraph:
                 qp = [E._ptr(q_) for q_ in qkv_all[:l + 1]] + [None] * (2 - l)
                 gp = [E._ptr(q_) for q_ in dqkv_all[:l + 1]] + [None] * (2 - l)
                 E._check(self.lib.dst_spec_attn_flash_bwd(qp[0], qp[1], qp[2], C.c_int32(l + 1), E._ptr(lt["ast"]), E._ptr(lt["ao"]), E._ptr(dao), gp[0], gp[1], gp[2],
-                                                          C.c_int32(B), C.c_int32(L), C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()),
+                                                          C.c_int32(B), C.c_int32(L), C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), self.ops._s()),
                          "dst_spec_attn_flash_bwd")
                 dqkv, dscores = dqkv_all[l], None
             else:
                 dqkv, dscores = self.f(B * L, 3 * D_MODEL), self.f(B, N_HEADS, L, (L + 31) // 32 * 32)
                 E._check(self.lib.dst_spec_attn_bwd(E._ptr(lt["qkv"]), E._ptr(lt["scores"]), E._ptr(lt["ast"]), E._ptr(dao), E._ptr(dscores_in), E._ptr(dqkv), E._ptr(dscores),
-                                                    C.c_int32(B), C.c_int32(L), C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), E._stream()),
+                                                    C.c_int32(B), C.c_int32(L), C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), self.ops._s()),
                          "dst_spec_attn_bwd")
             dzin = self.f(B * L, D_MODEL)                                                        # dZin = dr1 (residual) + dqkv Wqkv (dr1 stays intact, as dr2 above)
             dWc, dbc = self.f(3 * D_MODEL, D_MODEL), self.f(3 * D_MODEL)

@@ -42,7 +42,7 @@ class DstPiece(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("src_ld", C.c_int64), ("dst_ld", C.c_int64)]
 
 
-def copy_pieces(lib, dev, dst: List[torch.Tensor], src: List[torch.Tensor], cache: dict, key: str):
+def copy_pieces(lib, dev, dst: List[torch.Tensor], src: List[torch.Tensor], cache: dict, key: str, stream=None):
     """``dst[i].copy_(src[i])`` for many small (<= 2-D, last dimension contiguous) fp32 pieces in ONE ``dst_copy_pieces`` launch.  The device
     table is rebuilt only when a pointer changed (parameters live in the optimizer's flat buffer, the concatenated buffers are persistent)."""
     sig = tuple(t.data_ptr() for t in dst) + tuple(t.data_ptr() for t in src)
@@ -59,7 +59,14 @@ def copy_pieces(lib, dev, dst: List[torch.Tensor], src: List[torch.Tensor], cach
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         ent = (sig, raw, len(dst))
         cache[key] = ent
-    E._check(lib.dst_copy_pieces(C.c_void_p(ent[1].data_ptr()), C.c_int32(ent[2]), E._stream()), "dst_copy_pieces")
+    E._check(lib.dst_copy_pieces(C.c_void_p(ent[1].data_ptr()), C.c_int32(ent[2]), stream if stream is not None else E._stream()), "dst_copy_pieces")
+
+
+# dst_gemm_args as one struct.pack (a ctypes Structure built field by field costs ~10 us per product, ~600 products per step)
+import struct as _struct
+_GEMM_STRUCT = _struct.Struct("@PqqPqqPqPiiiiPqiiPiiPqPqfIQq")
+assert _GEMM_STRUCT.size == C.sizeof(DstGemmArgs), (_GEMM_STRUCT.size, C.sizeof(DstGemmArgs))
+_GEMM_PACK = _GEMM_STRUCT.pack
 
 
 class DstLayout(C.Structure):
@@ -103,15 +110,22 @@ class MV:
 
 
 def mv(t: torch.Tensor, c0: Optional[int] = None, c1: Optional[int] = None, r0: int = 0, r1: Optional[int] = None) -> MV:
-    """View of a contiguous 2-D (or 1-D as one row) fp32 tensor, optionally restricted to columns c0:c1 / rows r0:r1."""
-    assert t.dtype == torch.float32 and t.is_contiguous()
-    if t.dim() == 1:
-        t2r, t2c = 1, t.shape[0]
+    """View of a contiguous 2-D (or 1-D as one row) fp32 tensor, optionally restricted to columns c0:c1 / rows r0:r1.
+    (Called ~1 500 times per training step: kept free of numpy and of asserts that cost more than the launch they guard.)"""
+    shp = t.shape
+    if len(shp) == 1:
+        t2r, t2c = 1, shp[0]
     else:
-        t2r, t2c = t.shape[0], int(np.prod(t.shape[1:]))
-    c0 = 0 if c0 is None else c0
-    c1 = t2c if c1 is None else c1
-    r1 = t2r if r1 is None else r1
+        t2r = shp[0]
+        t2c = shp[1] if len(shp) == 2 else (t.numel() // t2r if t2r else 0)
+    if not t.is_contiguous() or t.dtype is not torch.float32:
+        raise ValueError("mv() needs a contiguous fp32 tensor")
+    if c0 is None:
+        c0 = 0
+    if c1 is None:
+        c1 = t2c
+    if r1 is None:
+        r1 = t2r
     return MV(t, r1 - r0, c1 - c0, t2c, r0 * t2c + c0)
 
 
@@ -127,12 +141,23 @@ class Ops:
         # dW, so the ~200 split-K products of a step need not sit in the dependent chain of input-gradient kernels - they fill the CUs the
         # small kernels of that chain leave idle.  The side stream has its own split-K scratch; operands are kept alive until join_dw().
         self.async_dw = False
+        self.stream_ptr = None
         self._side = None
         self._side_scratch = None
         self._dw_keep = []
 
     def _s(self):
-        return E._stream()
+        """The HIP stream the kernels are issued on.  ``torch.cuda.current_stream()`` costs ~8 us and a step makes ~1 200 calls: the training
+        entry points fetch it once (``begin``) and every launch of the step reuses the handle (``end`` drops it)."""
+        return self.stream_ptr if self.stream_ptr is not None else E._stream()
+
+    def begin(self):
+        self.main_stream = torch.cuda.current_stream(self.dev)
+        self.stream_ptr = C.c_void_p(self.main_stream.cuda_stream)
+
+    def end(self):
+        self.stream_ptr = None
+        self.main_stream = None
 
     def gemm(self, A: MV, Bm: MV, Cm: MV, ta: bool, tb: bool, bias: Optional[torch.Tensor] = None, acc: bool = False,
              rowsum: Optional[torch.Tensor] = None, act: int = 0, dact: int = 0, ref: Optional[MV] = None, out2: Optional[MV] = None,
@@ -147,18 +172,17 @@ class Ops:
             assert bias.numel() == N
         if rowsum is not None:
             assert rowsum.numel() == M and rowsum.is_contiguous()
-        args = DstGemmArgs(A=A.ptr, a_rs=a_rs, a_cs=a_cs, B=Bm.ptr, b_rs=b_rs, b_cs=b_cs, C=Cm.ptr, ldc=Cm.ld,
-                           bias=None if bias is None else bias.data_ptr(), M=M, N=N, K=K, accumulate=int(acc),
-                           partial=self.scratch.data_ptr(), partial_cap=self.scratch.numel(), bf16=int(self.bf16), _pad=0,
-                           rowsum=None if rowsum is None else rowsum.data_ptr(), act=act, dact=dact,
-                           ref=None if ref is None else ref.ptr, ldref=0 if ref is None else ref.ld,
-                           C2=None if out2 is None else out2.ptr, ldc2=0 if out2 is None else out2.ld,
-                           drop_p=0.0 if not drop or drop[0] <= 0 else float(drop[0]), drop_stream=0 if not drop else int(drop[2]),
-                           drop_seed=0 if not drop else int(drop[1]), drop_ld=0 if not drop else int(drop[3]))
+        dp = drop[0] if drop and drop[0] > 0 else 0.0
+        args = _GEMM_PACK(A.ptr, a_rs, a_cs, Bm.ptr, b_rs, b_cs, Cm.ptr, Cm.ld, 0 if bias is None else bias.data_ptr(), M, N, K, int(acc),
+                          self.scratch.data_ptr(), self.scratch.numel(), int(self.bf16), 0, 0 if rowsum is None else rowsum.data_ptr(), act, dact,
+                          0 if ref is None else ref.ptr, 0 if ref is None else ref.ld, 0 if out2 is None else out2.ptr, 0 if out2 is None else out2.ld,
+                          float(dp), int(drop[2]) if drop else 0, int(drop[1]) if drop else 0, int(drop[3]) if drop else 0)
         if ref is not None:
             assert ref.rows == M and ref.cols == N
         if out2 is not None:
             assert out2.rows == M and out2.cols == N
+        E._check(self.lib.dst_gemm(args, self._s()), "dst_gemm")
+        return
         E._check(self.lib.dst_gemm(C.byref(args), self._s()), "dst_gemm")
 
     def colsum(self, X: MV, out: torch.Tensor, acc: bool = False):
@@ -183,20 +207,21 @@ class Ops:
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
             self._side_scratch = torch.empty_like(self.scratch)
-        main = torch.cuda.current_stream(self.dev)
+        main = self.main_stream if getattr(self, "main_stream", None) is not None else torch.cuda.current_stream(self.dev)
         self._side.wait_stream(main)                                    # dy (and x) are complete on the main stream at this point
         self._dw_keep.append((dy.t, x.t, dW.t, db))
         main_scratch, self.scratch = self.scratch, self._side_scratch
+        main_ptr, self.stream_ptr = self.stream_ptr, C.c_void_p(self._side.cuda_stream)
         try:
-            with torch.cuda.stream(self._side):
-                self.gemm(dy, x, dW, True, False, acc=acc, rowsum=db)
+            self.gemm(dy, x, dW, True, False, acc=acc, rowsum=db)
         finally:
-            self.scratch = main_scratch
+            self.scratch, self.stream_ptr = main_scratch, main_ptr
 
     def join_dw(self):
         """The main stream waits for every weight-gradient product issued so far; their operands may be reused after it."""
         if self._side is not None and self._dw_keep:
-            torch.cuda.current_stream(self.dev).wait_stream(self._side)
+            main = self.main_stream if getattr(self, "main_stream", None) is not None else torch.cuda.current_stream(self.dev)
+            main.wait_stream(self._side)
         self._dw_keep = []
 
     def act_fwd(self, x, y, kind):
@@ -347,7 +372,7 @@ class DmtTrainGraph:
             cache["bufs"] = {n: self.z(*shape) for n, shape in shapes}          # padding rows (252..255 of q / k / lin_edge0) stay zero
             cache["grads"] = {n: self.z(*shape) for n, shape in shapes}
         dst, src = self._piece_views(cache["bufs"], self.p)
-        copy_pieces(self.lib, self.dev, dst, src, cache, "table_fwd")
+        copy_pieces(self.lib, self.dev, dst, src, cache, "table_fwd", self.ops._s())
         self.cat, self.dcat, self._cat_cache = cache["bufs"], cache["grads"], cache
         return cache
 
@@ -360,18 +385,18 @@ class DmtTrainGraph:
             if name not in tgt:
                 tgt[name] = gw(name) if name not in self._gw_done else self._gw_done[name]
         src, dst = self._piece_views(self.dcat, tgt)
-        copy_pieces(self.lib, self.dev, dst, src, self._cat_cache, "table_bwd")
+        copy_pieces(self.lib, self.dev, dst, src, self._cat_cache, "table_bwd", self.ops._s())
 
     def _geom_fwd(self, TL, pos, ada, dist_off, prefix, X, ldx, col0, xs, d2s):
         E._check(self.lib.dst_geom_fwd(C.byref(TL.c), E._ptr(pos), E._ptr(ada), C.c_int64(ADA), C.c_int32(dist_off),
                                        E._ptr(self.p[prefix + "means.weight"]), E._ptr(self.p[prefix + "stds.weight"]),
-                                       C.c_void_p(X.data_ptr() + 4 * col0), C.c_int64(ldx), E._ptr(xs), E._ptr(d2s), E._stream()), "dst_geom_fwd")
+                                       C.c_void_p(X.data_ptr() + 4 * col0), C.c_int64(ldx), E._ptr(xs), E._ptr(d2s), self.ops._s()), "dst_geom_fwd")
 
     def _geom_bwd(self, TL, pos, ada, d_ada, dist_off, prefix, xs, d2s, g1, g2, dms, dd2, dpos):
         E._check(self.lib.dst_geom_bwd(C.byref(TL.c), E._ptr(pos), E._ptr(ada), E._ptr(d_ada), C.c_int64(ADA), C.c_int32(dist_off),
                                        E._ptr(self.p[prefix + "means.weight"]), E._ptr(self.p[prefix + "stds.weight"]), E._ptr(xs), E._ptr(d2s),
                                        E._ptr(g1), C.c_int64(g1.shape[1]), E._ptr(g2), C.c_int64(0 if g2 is None else g2.shape[1]), E._ptr(dms),
-                                       E._ptr(dd2), E._ptr(dpos), E._stream()), "dst_geom_bwd")
+                                       E._ptr(dd2), E._ptr(dpos), self.ops._s()), "dst_geom_bwd")
 
     # ------------------------------------------------------------------ forward
     def forward(self, TL: TrainLayout, xn, ex, noise_level, ctx_emb, cond_n=None, cond_e=None, save: bool = True):
@@ -383,7 +408,7 @@ class DmtTrainGraph:
         D = 2 * Pp
         t: Dict[str, object] = dict(TL=TL, first=cond_n is None, drop=(self.dropout_p, self.dropout_seed))
         dp, dseed = self.dropout_p, self.dropout_seed
-        s = E._stream
+        s = self.ops._s
         # ---- time embedding + adaLN table (dmt.py:249-257,353-357; every *time_mlp)
         tf = self.f(B, 17)
         E._check(lib.dst_time_feat_fwd(E._ptr(noise_level), E._ptr(p["time_mlp.0.weights"]), C.c_int32(B), E._ptr(tf), s()), "dst_time_feat_fwd")
@@ -526,7 +551,7 @@ class DmtTrainGraph:
         TL: TrainLayout = t["TL"]
         B, Nn, Pp = TL.B, TL.Nn, TL.Pp
         D = 2 * Pp
-        s = E._stream
+        s = self.ops._s
         ada = t["ada"]
         dp, dseed = t["drop"]
         g: Dict[str, torch.Tensor] = {}
@@ -692,5 +717,5 @@ class DmtTrainGraph:
         loss_m, dpos, dfeat, dedge = self.f(TL.B), self.f(TL.Nn, 3), self.f(TL.Nn, 6), self.f(max(TL.Pp, 1), 2)
         E._check(self.lib.dst_loss(C.byref(TL.c), E._ptr(pos), E._ptr(atom_pred), E._ptr(edge_pred), E._ptr(tpos), E._ptr(tfeat), E._ptr(tedge),
                                    E._ptr(wm), C.c_float(weights[0]), C.c_float(weights[1]), C.c_float(weights[2]), E._ptr(loss_m), E._ptr(dpos),
-                                   E._ptr(dfeat), E._ptr(dedge), E._stream()), "dst_loss")
+                                   E._ptr(dfeat), E._ptr(dedge), self.ops._s()), "dst_loss")
         return loss_m, dpos, dfeat, dedge

@@ -275,7 +275,7 @@ def test_geom(ops, gpu_device):
     (feat * g2.double()).sum().backward()
     p = {"x.means.weight": means.detach().float().to(d), "x.stds.weight": stds.detach().float().to(d)}
     graph = T.DmtTrainGraph.__new__(T.DmtTrainGraph)
-    graph.p, graph.lib, graph.dev = p, o.lib, d
+    graph.p, graph.lib, graph.dev, graph.ops = p, o.lib, d, o
     X, xs, d2s = torch.zeros(P, 70, device=d), torch.empty(P, device=d), torch.empty(P, device=d)
     posd, adad = pos.detach().float().to(d), ada.detach().float().to(d)
     graph._geom_fwd(TL, posd, adad, off, "x.", X, 70, 3, xs, d2s)

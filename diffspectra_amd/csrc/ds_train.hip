@@ -94,10 +94,21 @@ __global__ void k_adj_bits(const float* __restrict__ cond_e, int64_t ld, const f
 // many small strided 2-D copies in one launch (the per-step concatenated weight buffers and the scatter of their gradients)
 __global__ __launch_bounds__(256) void k_copy_pieces(const dst_piece* __restrict__ table) {
   const dst_piece pc = table[blockIdx.x];
-  const int64_t total = (int64_t)pc.rows * pc.cols;
-  for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.y * 256) {
-    const int64_t r = i / pc.cols, c = i - r * pc.cols;
-    pc.dst[r * pc.dst_ld + c] = pc.src[r * pc.src_ld + c];
+  const unsigned int rows = (unsigned int)pc.rows, cols = (unsigned int)pc.cols;
+  const bool vec = ((cols | (unsigned int)pc.dst_ld | (unsigned int)pc.src_ld) & 3u) == 0 &&
+                   (((uintptr_t)pc.dst | (uintptr_t)pc.src) & 15u) == 0;
+  if (vec) {                                                      // 16-byte pieces; 32-bit index arithmetic (a piece is < 2^31 elements, checked on the host)
+    const unsigned int c4 = cols >> 2, total = rows * c4;
+    for (unsigned int i = blockIdx.y * 256u + threadIdx.x; i < total; i += gridDim.y * 256u) {
+      const unsigned int r = i / c4, c = (i - r * c4) << 2;
+      *reinterpret_cast<float4*>(pc.dst + (int64_t)r * pc.dst_ld + c) = *reinterpret_cast<const float4*>(pc.src + (int64_t)r * pc.src_ld + c);
+    }
+  } else {
+    const unsigned int total = rows * cols;
+    for (unsigned int i = blockIdx.y * 256u + threadIdx.x; i < total; i += gridDim.y * 256u) {
+      const unsigned int r = i / cols, c = i - r * cols;
+      pc.dst[(int64_t)r * pc.dst_ld + c] = pc.src[(int64_t)r * pc.src_ld + c];
+    }
   }
 }
 
@@ -923,25 +934,38 @@ __global__ __launch_bounds__(256) void k_bn_sum(const float* __restrict__ x, int
   __syncthreads();
   if (rl == 0 && col < C) partial[(int64_t)blockIdx.y * C + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void k_bn_finish_mean(const float* __restrict__ partial, int chunks, int C, int R, float* __restrict__ stats) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// one wave per channel: lane l adds chunks l, l + 64, ..., then a fixed butterfly (the one-thread-per-channel loop was ~170 dependent
+// L2 round trips = 40 us for a 128-channel result)
+__device__ __forceinline__ float bn_chunk_sum(const float* __restrict__ partial, int chunks, int C, int c) {
   float s = 0.0f;
-  for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * C + c];
-  stats[c] = s / (float)R;
+  for (int k = threadIdx.x; k < chunks; k += 64) s += partial[(int64_t)k * C + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  return s;
 }
-__global__ void k_bn_finish_var(const float* __restrict__ partial, int chunks, int C, int R, float eps, float* __restrict__ stats,
-                                float* __restrict__ running_mean, float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.0f;
-  for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * C + c];
+__global__ __launch_bounds__(64) void k_bn_finish_mean(const float* __restrict__ partial, int chunks, int C, int R, float* __restrict__ stats) {
+  const int c = blockIdx.x;
+  const float s = bn_chunk_sum(partial, chunks, C, c);
+  if (threadIdx.x == 0) stats[c] = s / (float)R;
+}
+__global__ __launch_bounds__(64) void k_bn_finish_var(const float* __restrict__ partial, int chunks, int C, int R, float eps, float* __restrict__ stats,
+                                                      float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x;
+  const float s = bn_chunk_sum(partial, chunks, C, c);
+  if (threadIdx.x != 0) return;
   const float var = s / (float)R;
   stats[C + c] = 1.0f / sqrtf(var + eps);
+  stats[2 * C + c] = s / (float)(R - 1);                          // the unbiased variance the running statistic takes (dst_bn_running_again)
   if (running_mean) {
     running_mean[c] = 0.9f * running_mean[c] + 0.1f * stats[c];
-    running_var[c] = 0.9f * running_var[c] + 0.1f * (s / (float)(R - 1));
+    running_var[c] = 0.9f * running_var[c] + 0.1f * stats[2 * C + c];
   }
+}
+__global__ void k_bn_running_again(const float* __restrict__ stats, int C, float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  running_mean[c] = 0.9f * running_mean[c] + 0.1f * stats[c];
+  running_var[c] = 0.9f * running_var[c] + 0.1f * stats[2 * C + c];
 }
 __global__ void k_bn_apply(const float* __restrict__ x, int64_t total, int C, const float* __restrict__ stats, const float* __restrict__ gamma,
                            const float* __restrict__ beta, float* __restrict__ y) {
@@ -974,13 +998,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_sum(const float* __restrict__ dy
     partial[(int64_t)(chunks + blockIdx.y) * C + col] = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
   }
 }
-__global__ void k_bn_bwd_finish(const float* __restrict__ partial, int chunks, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s1 = 0.0f, s2 = 0.0f;
-  for (int k = 0; k < chunks; ++k) { s1 += partial[(int64_t)k * C + c]; s2 += partial[(int64_t)(chunks + k) * C + c]; }
-  dbeta[c] = s1;
-  dgamma[c] = s2;
+__global__ __launch_bounds__(64) void k_bn_bwd_finish(const float* __restrict__ partial, int chunks, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x;
+  const float s1 = bn_chunk_sum(partial, chunks, C, c);
+  const float s2 = bn_chunk_sum(partial + (int64_t)chunks * C, chunks, C, c);
+  if (threadIdx.x == 0) { dbeta[c] = s1; dgamma[c] = s2; }
 }
 __global__ void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, int64_t total, int C, int R, const float* __restrict__ stats,
                                const float* __restrict__ gamma, const float* __restrict__ dgamma, const float* __restrict__ dbeta, float* __restrict__ dx) {
@@ -1291,7 +1313,7 @@ int dst_adj_bits(const float* cond_e, int64_t ld, const float* d2c, float edge_t
 int dst_copy_pieces(const dst_piece* table, int32_t n, void* stream) {
   if (n < 0 || (n > 0 && !table)) return DS_ERR_ARG;
   if (n == 0) return DS_OK;
-  hipLaunchKernelGGL(k_copy_pieces, dim3(n, 16), dim3(256), 0, (hipStream_t)stream, table);
+  hipLaunchKernelGGL(k_copy_pieces, dim3(n, 128), dim3(256), 0, (hipStream_t)stream, table);
   return DST_CHECK_LAUNCH();
 }
 
@@ -1502,10 +1524,15 @@ int dst_bn_fwd(const float* x, int32_t R, int32_t C, const float* gamma, const f
   if (chunks < 1) return DS_ERR_ARG;
   const int rpc = (R + chunks - 1) / chunks;
   hipLaunchKernelGGL(k_bn_sum, dim3((C + 63) / 64, chunks), dim3(256), 0, s, x, (int)R, (int)C, (const float*)nullptr, scratch, rpc);
-  hipLaunchKernelGGL(k_bn_finish_mean, grid1d(C), dim3(256), 0, s, (const float*)scratch, chunks, (int)C, (int)R, stats);
+  hipLaunchKernelGGL(k_bn_finish_mean, dim3(C), dim3(64), 0, s, (const float*)scratch, chunks, (int)C, (int)R, stats);
   hipLaunchKernelGGL(k_bn_sum, dim3((C + 63) / 64, chunks), dim3(256), 0, s, x, (int)R, (int)C, (const float*)stats, scratch, rpc);
-  hipLaunchKernelGGL(k_bn_finish_var, grid1d(C), dim3(256), 0, s, (const float*)scratch, chunks, (int)C, (int)R, eps, stats, running_mean, running_var);
+  hipLaunchKernelGGL(k_bn_finish_var, dim3(C), dim3(64), 0, s, (const float*)scratch, chunks, (int)C, (int)R, eps, stats, running_mean, running_var);
   hipLaunchKernelGGL(k_bn_apply, grid1d((int64_t)R * C), dim3(256), 0, s, x, (int64_t)R * C, (int)C, (const float*)stats, gamma, beta, y);
+  return DST_CHECK_LAUNCH();
+}
+int dst_bn_running_again(const float* stats, int32_t C, float* running_mean, float* running_var, void* stream) {
+  if (!stats || !running_mean || !running_var || C <= 0) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_bn_running_again, grid1d(C), dim3(256), 0, (hipStream_t)stream, stats, (int)C, running_mean, running_var);
   return DST_CHECK_LAUNCH();
 }
 int dst_bn_bwd(const float* dy, const float* x, const float* stats, int32_t R, int32_t C, const float* gamma, float* dx, float* dgamma,
@@ -1518,7 +1545,7 @@ int dst_bn_bwd(const float* dy, const float* x, const float* stats, int32_t R, i
   if (chunks < 1) return DS_ERR_ARG;
   const int rpc = (R + chunks - 1) / chunks;
   hipLaunchKernelGGL(k_bn_bwd_sum, dim3((C + 63) / 64, chunks), dim3(256), 0, s, dy, x, stats, (int)R, (int)C, scratch, rpc, chunks);
-  hipLaunchKernelGGL(k_bn_bwd_finish, grid1d(C), dim3(256), 0, s, (const float*)scratch, chunks, (int)C, dgamma, dbeta);
+  hipLaunchKernelGGL(k_bn_bwd_finish, dim3(C), dim3(64), 0, s, (const float*)scratch, chunks, (int)C, dgamma, dbeta);
   hipLaunchKernelGGL(k_bn_bwd_apply, grid1d((int64_t)R * C), dim3(256), 0, s, dy, x, (int64_t)R * C, (int)C, (int)R, stats, gamma, (const float*)dgamma,
                      (const float*)dbeta, dx);
   return DST_CHECK_LAUNCH();

@@ -494,15 +494,18 @@ def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None
         # FF dropout (dmt.py:114-120) is active whenever the model is in training mode - in the no-grad self-conditioning forward too
         dmt.dropout_p = dropout_p if train else 0.0
         seeds = torch.randint(0, 2 ** 62, (2,)).tolist() if dmt.dropout_p > 0 else [0, 0]
+        # the conditioning encoder sees the same spectra in both forwards of a self-conditioning step (losses.py:344-357): evaluated
+        # once, with the running-statistics update of the second pass applied from the saved batch statistics
+        ctx = spec.forward(context, save=train) if train else _eval_context(model, context)
         if random() < 0.5:                                              # self-conditioning forward, no gradient (losses.py:344-351)
             dmt.dropout_seed = seeds[0]
-            ctx0 = spec.forward(context, save=False) if train else _eval_context(model, context)
-            pos0, atom0, edge0 = dmt.forward(TL, z, ez, noise_level, ctx0, None, None, save=False)
+            if train:
+                spec.running_stats_again()
+            pos0, atom0, edge0 = dmt.forward(TL, z, ez, noise_level, ctx, None, None, save=False)
             cond_n, cond_e = torch.cat([pos0, atom0], dim=1).contiguous(), edge0
             if getattr(config.model, "self_cond_type", "ori") != "ori":
                 cd, ce = cond_process_fn(TL.unpack_nodes(cond_n), TL.unpack_pairs(cond_e))
                 cond_n, cond_e = TL.pack_nodes(cd), TL.pack_pairs(ce)
-        ctx = spec.forward(context, save=train) if train else _eval_context(model, context)
         dmt.dropout_seed = seeds[1]
         pos, atom, edge = dmt.forward(TL, z, ez, noise_level, ctx, cond_n, cond_e, save=train)
         wm = (torch.sqrt(alpha_t / sigma_t) / B).contiguous()

@@ -47,6 +47,16 @@ class SpecTrainGraph:
                                      E._ptr(y), E._ptr(stats), E._ptr(b[name + ".running_mean"]), E._ptr(b[name + ".running_var"]), E._ptr(o.scratch),
                                      C.c_int64(o.scratch.numel()), self.ops._s()), "dst_bn_fwd")
         b[name + ".num_batches_tracked"] += 1
+        self._bn_last.append((name, stats))
+
+    def running_stats_again(self):
+        """The buffer updates of one more training-mode forward over the batch of the last ``forward`` (same batch statistics, so nothing
+        else of that pass would differ): the reference's self-conditioning step evaluates the encoder twice on one input."""
+        b = self.buf
+        for name, stats in self._bn_last:
+            E._check(self.lib.dst_bn_running_again(E._ptr(stats), C.c_int32(stats.shape[1]), E._ptr(b[name + ".running_mean"]),
+                                                   E._ptr(b[name + ".running_var"]), self.ops._s()), "dst_bn_running_again")
+            b[name + ".num_batches_tracked"] += 1
 
     def _bn_bwd(self, dy, x, stats, name, dx, g):
         o = self.ops
@@ -66,6 +76,7 @@ class SpecTrainGraph:
         B = specs[0].shape[0]
         L = self.L
         t: Dict[str, object] = dict(B=B)
+        self._bn_last = []
         toks, Xs = [], []
         for slot, ((pl, stv, pn), spec) in enumerate(zip(self.patch, specs)):
             X = spec.reshape(B, -1).to(torch.float32).unfold(-1, pl, stv).contiguous().reshape(B * pn, pl)       # specformer.py:105
@@ -101,14 +112,14 @@ class SpecTrainGraph:
                                                     C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), self.ops._s()), "dst_spec_attn_fwd")
             r1 = Z.clone()
             o.gemm(mv(ao), mv(p[base + "self_attn.to_out.0.weight"]), mv(r1), False, True, bias=p[base + "self_attn.to_out.0.bias"], acc=True)
-            z1, st1 = self.f(B * L, D_MODEL), self.f(2, D_MODEL)
+            z1, st1 = self.f(B * L, D_MODEL), self.f(3, D_MODEL)
             self._bn_fwd(r1, base + "norm_attn.1", z1, st1)
             a = self.f(B * L, D_FF)
             ga = self.f(B * L, D_FF)
             o.lin_fwd(mv(z1), mv(p[base + "ff.0.weight"]), p[base + "ff.0.bias"], mv(a), act=GELU, out2=mv(ga))
             r2 = z1.clone()
             o.gemm(mv(ga), mv(p[base + "ff.3.weight"]), mv(r2), False, True, bias=p[base + "ff.3.bias"], acc=True)
-            z2, st2 = self.f(B * L, D_MODEL), self.f(2, D_MODEL)
+            z2, st2 = self.f(B * L, D_MODEL), self.f(3, D_MODEL)
             self._bn_fwd(r2, base + "norm_ffn.1", z2, st2)
             if save:
                 layers.append(dict(Zin=Z, qkv=qkv, Wqkv=Wc, scores=scores, ast=ast, ao=ao, r1=r1, st1=st1, z1=z1, a=a, ga=ga, r2=r2, st2=st2, has_prev=prev is not None))

@@ -52,6 +52,7 @@ def copy_pieces(lib, dev, dst: List[torch.Tensor], src: List[torch.Tensor], cach
         for i, (d, s_) in enumerate(zip(dst, src)):
             assert d.shape == s_.shape and d.dtype == torch.float32 and s_.dtype == torch.float32 and d.dim() <= 2
             rows, cols = (1, d.numel()) if d.dim() < 2 else (d.shape[0], d.shape[1])
+            assert rows * cols < 2 ** 31                              # the kernel's index arithmetic is 32-bit
             ld = lambda t: (t.stride(0) if t.dim() == 2 and t.shape[0] > 1 else cols)
             assert (d.dim() < 2 or d.stride(-1) == 1 or cols == 1) and (s_.dim() < 2 or s_.stride(-1) == 1 or cols == 1)
             assert d.dim() >= 1 and (d.dim() == 2 or d.is_contiguous()) and (s_.dim() == 2 or s_.is_contiguous())

@@ -189,10 +189,14 @@ int dst_kabsch(const dst_layout* L, const float* pred, int64_t ld_pred, const fl
                void* stream);
 
 /* BatchNorm1d in training mode over the columns of X [R, C] (C <= 256): y = (x - mean_c) / sqrt(var_c + eps) * gamma_c + beta_c with
- * biased batch variance; stats [2, C] = (mean, rstd) saved; running statistics updated in place with momentum 0.1 and the unbiased
- * variance.  Backward: dx written, dgamma / dbeta [C] written. */
+ * biased batch variance; stats [3, C] = (mean, rstd, unbiased variance) saved; running statistics updated in place with momentum 0.1
+ * and the unbiased variance.  Backward: dx written, dgamma / dbeta [C] written (reads the first two rows of stats).
+ * dst_bn_running_again applies the running-statistics update of one more forward over the SAME batch from the saved stats: the
+ * reference's self-conditioning step (losses.py:344-357) runs the conditioning encoder twice on one input - the second pass
+ * changes nothing but these buffers. */
 int dst_bn_fwd(const float* x, int32_t R, int32_t C, const float* gamma, const float* beta, float eps, float* y, float* stats,
                float* running_mean, float* running_var, float* scratch, int64_t scratch_cap, void* stream);
+int dst_bn_running_again(const float* stats, int32_t C, float* running_mean, float* running_var, void* stream);
 int dst_bn_bwd(const float* dy, const float* x, const float* stats, int32_t R, int32_t C, const float* gamma, float* dx, float* dgamma,
                float* dbeta, float* scratch, int64_t scratch_cap, void* stream);
 

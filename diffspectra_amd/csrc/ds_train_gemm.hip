@@ -176,75 +176,77 @@ __device__ __forceinline__ unsigned int pack2(float a, float b) {
 // row of the tile is 128 contiguous bytes; vec4 u of 256-thread pass i covers row u >> 3, k 4 (u & 7) ..) or rs == 1 ("row-fast": the
 // memory order runs along the rows; a thread takes a 4 (rows) x 4 (k) micro-tile, four 16-byte loads, transposed when committed).
 // Out-of-range elements are zero.  ones_row (B only): that row of the tile is the virtual all-ones vector of the fused row sum.
+// BRANCH-FREE: every load is a full 16-byte load from a clamped, always-valid address and the edges are applied by selects.  (With a
+// branch per edge case the compiler closed every load with s_waitcnt vmcnt(0) at the join: the loads of a k-step ran one memory
+// round trip after the other - 0.9 us per step for two MFMAs - and the two steps of prefetch hid nothing.)  Validity of the clamped
+// loads: the leading stride of a vector operand is a multiple of 4 and >= its extent (dst_gemm checks), so the aligned group that
+// holds the last valid element lies inside the stride of its row.
+// Both forms give a thread NV = ROWS * 8 / NTHR vectors (1, 2 or 4), all of them loaded on every path - an array with elements that one
+// path leaves undefined ends up in scratch, and zero-filling it first puts a full s_waitcnt in front of the loads (write-after-write on
+// registers with loads in flight).  Row-fast: lane (kg, rq) of k-selection ksel holds k = 4 kg + NV ksel .. + NV - 1 of rows 4 rq .. 4 rq + 3.
 template <int ROWS, int NTHR = 256>
-__device__ __forceinline__ void fetch_tile(const float* __restrict__ X, int64_t rs, int64_t ks, bool rfast, int row0, int R, int k0, int kend,
-                                           int ones_row, f32x4_t (&v)[4]) {
+__device__ __forceinline__ void fetch_tile(const float* __restrict__ X, int64_t rs, int64_t ks, bool rfast, int row0, int R, int K, int k0,
+                                           f32x4_t (&v)[ROWS * 8 / NTHR]) {
+  constexpr int NV = ROWS * 8 / NTHR;
   const int tid = threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};      // every element defined on every path: the array stays in registers
   if (!rfast) {
+    const int klast = (K - 1) & ~3;
 #pragma unroll
-    for (int i = 0; i < ROWS * 8 / NTHR; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int u = tid + i * NTHR;
       const int gr = row0 + (u >> 3), gk = k0 + 4 * (u & 7);
-      f32x4_t t = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (gr < R) {
-        const float* p = X + (int64_t)gr * rs + gk;
-        if (gk + 3 < kend) t = *reinterpret_cast<const f32x4_t*>(p);
-        else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (gk + e < kend) t[e] = p[e];
-        }
-      } else if (gr == ones_row) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = gk + e < kend ? 1.0f : 0.0f;
-      }
-      v[i] = t;
+      v[i] = *reinterpret_cast<const f32x4_t*>(X + (int64_t)min(gr, R - 1) * rs + min(gk, klast));
     }
   } else {
-    if (tid < ROWS * 2) {
-      const int kg = tid & 7, rq = tid >> 3;
-      const int gr0 = row0 + 4 * rq;
+    const int kg = tid & 7, rq = (tid >> 3) % (ROWS / 4), ksel = tid / (ROWS * 2);
+    const int gr0 = min(row0 + 4 * rq, (R - 1) & ~3);
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int gk = k0 + 4 * kg + kk;
-        f32x4_t t = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (gk < kend) {
-          const float* p = X + (int64_t)gk * ks + gr0;
-          if (gr0 + 3 < R) t = *reinterpret_cast<const f32x4_t*>(p);
-          else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (gr0 + e < R) t[e] = p[e];
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (gr0 + e == ones_row) t[e] = 1.0f;
-        }
-        v[kk] = t;
-      }
+    for (int kk = 0; kk < NV; ++kk) {
+      const int gk = k0 + 4 * kg + NV * ksel + kk;
+      v[kk] = *reinterpret_cast<const f32x4_t*>(X + (int64_t)min(gk, K - 1) * ks + gr0);
     }
   }
 }
 
+// Round the fetched tile to bf16 into LDS ([row][k], LDK elements per row); the edges (rows >= R, k >= kend, the virtual ones row) are
+// applied HERE, a k-step or two after the loads were issued - a select next to the load would make the load's latency part of the step.
 template <int ROWS, int NTHR = 256>
-__device__ __forceinline__ void commit_tile(unsigned short* __restrict__ Xs, bool rfast, const f32x4_t (&v)[4]) {
+__device__ __forceinline__ void commit_tile(unsigned short* __restrict__ Xs, bool rfast, const f32x4_t (&v)[ROWS * 8 / NTHR], int row0, int R, int k0,
+                                            int kend, int ones_row) {
+  constexpr int NV = ROWS * 8 / NTHR;
   const int tid = threadIdx.x;
   if (!rfast) {
 #pragma unroll
-    for (int i = 0; i < ROWS * 8 / NTHR; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int u = tid + i * NTHR;
-      const uint2 w = {pack2(v[i][0], v[i][1]), pack2(v[i][2], v[i][3])};
+      const int gr = row0 + (u >> 3), gk = k0 + 4 * (u & 7);
+      const float edge = gr == ones_row ? 1.0f : 0.0f;
+      const bool rok = gr < R;
+      float t[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = gk + e < kend ? (rok ? v[i][e] : edge) : 0.0f;
+      const uint2 w = {pack2(t[0], t[1]), pack2(t[2], t[3])};
       *reinterpret_cast<uint2*>(Xs + (u >> 3) * LDK + 4 * (u & 7)) = w;
     }
   } else {
-    if (tid < ROWS * 2) {
-      const int kg = tid & 7, rq = tid >> 3;
+    const int kg = tid & 7, rq = (tid >> 3) % (ROWS / 4), ksel = tid / (ROWS * 2);
+    const int gr0 = row0 + 4 * rq, gk0 = k0 + 4 * kg + NV * ksel;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const uint2 w = {pack2(v[0][rr], v[1][rr]), pack2(v[2][rr], v[3][rr])};
-        *reinterpret_cast<uint2*>(Xs + (4 * rq + rr) * LDK + 4 * kg) = w;
+    for (int rr = 0; rr < 4; ++rr) {
+      const bool rok = gr0 + rr < R;
+      const float edge = gr0 + rr == ones_row ? 1.0f : 0.0f;
+      float t[NV];
+#pragma unroll
+      for (int kk = 0; kk < NV; ++kk) t[kk] = gk0 + kk < kend ? (rok ? v[kk][rr] : edge) : 0.0f;
+      unsigned short* dst = Xs + (4 * rq + rr) * LDK + 4 * kg + NV * ksel;
+      if constexpr (NV == 4) {
+        const uint2 w = {pack2(t[0], t[1]), pack2(t[2], t[3])};
+        *reinterpret_cast<uint2*>(dst) = w;
+      } else if constexpr (NV == 2) {
+        *reinterpret_cast<unsigned int*>(dst) = pack2(t[0], t[1]);
+      } else {
+        const __bf16 h = (__bf16)t[0];
+        *dst = __builtin_bit_cast(unsigned short, h);
       }
     }
   }
@@ -280,25 +282,25 @@ __global__ __launch_bounds__(NTHR) void k_tr_gemm_bf16(dst_gemm_args g, int spli
   const int ones_row = g.rowsum ? g.N : -1;
   // two k-steps of operands in flight (two register sets, the loop unrolled by two so that each set is addressed statically): a
   // workgroup that is alone on its CU - split products have ~1 per CU - otherwise exposes a full memory round trip per step
-  f32x4_t ra0[4], rb0[4], ra1[4], rb1[4];
+  f32x4_t ra0[BM * 8 / NTHR], rb0[BN * 8 / NTHR], ra1[BM * 8 / NTHR], rb1[BN * 8 / NTHR];
   const bool arf = a_rfast != 0, brf = b_rfast != 0;
   if (kbeg < kend) {
-    fetch_tile<BM, NTHR>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, kbeg, kend, -1, ra0);
-    fetch_tile<BN, NTHR>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, kbeg, kend, ones_row, rb0);
+    fetch_tile<BM, NTHR>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, g.K, kbeg, ra0);
+    fetch_tile<BN, NTHR>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, g.K, kbeg, rb0);
   }
   if (kbeg + BK < kend) {
-    fetch_tile<BM, NTHR>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, kbeg + BK, kend, -1, ra1);
-    fetch_tile<BN, NTHR>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, kbeg + BK, kend, ones_row, rb1);
+    fetch_tile<BM, NTHR>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, g.K, kbeg + BK, ra1);
+    fetch_tile<BN, NTHR>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, g.K, kbeg + BK, rb1);
   }
   const int arow = (wm * (BM / WM) + (lane & 31)) * LDK + 8 * (lane >> 5);
   const int brow = (wn * (BN / WN) + (lane & 31)) * LDK + 8 * (lane >> 5);
-  auto step = [&](f32x4_t (&xa)[4], f32x4_t (&xb)[4], int k0) {
-    commit_tile<BM, NTHR>(As, arf, xa);
-    commit_tile<BN, NTHR>(Bs, brf, xb);
+  auto step = [&](f32x4_t (&xa)[BM * 8 / NTHR], f32x4_t (&xb)[BN * 8 / NTHR], int k0) __attribute__((always_inline)) {
+    commit_tile<BM, NTHR>(As, arf, xa, m0, g.M, k0, kend, -1);
+    commit_tile<BN, NTHR>(Bs, brf, xb, n0, g.N, k0, kend, ones_row);
     __syncthreads();
     if (k0 + 2 * BK < kend) {
-      fetch_tile<BM, NTHR>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, k0 + 2 * BK, kend, -1, xa);
-      fetch_tile<BN, NTHR>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, k0 + 2 * BK, kend, ones_row, xb);
+      fetch_tile<BM, NTHR>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, g.K, k0 + 2 * BK, xa);
+      fetch_tile<BN, NTHR>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, g.K, k0 + 2 * BK, xb);
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
@@ -557,7 +559,7 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   const bool b_k = vec_ok(g.B, g.b_rs, g.b_cs), b_r = !b_k && vec_ok(g.B, g.b_cs, g.b_rs);
   static const int force_old = env_int("DST_GEMM_OLD", 0), bn_pref = env_int("DST_GEMM_BN", 0), bm_pref = env_int("DST_GEMM_BM", 0),
                    split_target = env_int("DST_GEMM_SPLIT_WGS", 1024), wg_target = env_int("DST_GEMM_WGS", 768);
-  const bool vec = bf && !force_old && (a_k || a_r) && (b_k || b_r) && g.K >= 8;
+  const bool vec = bf && !force_old && (a_k || a_r) && (b_k || b_r) && g.K >= 8 && g.N > 0;
   static const int ws_off = env_int("DST_GEMM_WS", 1) == 0, ws_min_m = env_int("DST_GEMM_WS_MIN_M", 65536);
   // measured inside the training step (same box, DST_GEMM_WS=0 / 1): the resident-weight form wins where the weight is large and the
   // rows are many (81 014 x 256 x 256 input gradient: 66 us against 113) and loses on the short-K products (K = 64 / 128: its 256

@@ -284,24 +284,21 @@ __global__ __launch_bounds__(NTHR) void k_tr_gemm_bf16(dst_gemm_args g, int spli
   // workgroup that is alone on its CU - split products have ~1 per CU - otherwise exposes a full memory round trip per step
   f32x4_t ra0[BM * 8 / NTHR], rb0[BN * 8 / NTHR], ra1[BM * 8 / NTHR], rb1[BN * 8 / NTHR];
   const bool arf = a_rfast != 0, brf = b_rfast != 0;
-  if (kbeg < kend) {
-    fetch_tile<BM, NTHR>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, g.K, kbeg, ra0);
-    fetch_tile<BN, NTHR>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, g.K, kbeg, rb0);
-  }
-  if (kbeg + BK < kend) {
-    fetch_tile<BM, NTHR>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, g.K, kbeg + BK, ra1);
-    fetch_tile<BN, NTHR>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, g.K, kbeg + BK, rb1);
-  }
+  // (no guards: fetch_tile clamps every address into the operand, commit_tile zeroes what lies beyond kend - a k-range with an odd
+  // number of steps runs one all-zero step, and the compiler sees ONE straight-line loop body whose waits it can count)
+  fetch_tile<BM, NTHR>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, g.K, kbeg, ra0);
+  fetch_tile<BN, NTHR>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, g.K, kbeg, rb0);
+  fetch_tile<BM, NTHR>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, g.K, kbeg + BK, ra1);
+  fetch_tile<BN, NTHR>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, g.K, kbeg + BK, rb1);
   const int arow = (wm * (BM / WM) + (lane & 31)) * LDK + 8 * (lane >> 5);
   const int brow = (wn * (BN / WN) + (lane & 31)) * LDK + 8 * (lane >> 5);
   auto step = [&](f32x4_t (&xa)[BM * 8 / NTHR], f32x4_t (&xb)[BN * 8 / NTHR], int k0) __attribute__((always_inline)) {
     commit_tile<BM, NTHR>(As, arf, xa, m0, g.M, k0, kend, -1);
     commit_tile<BN, NTHR>(Bs, brf, xb, n0, g.N, k0, kend, ones_row);
     __syncthreads();
-    if (k0 + 2 * BK < kend) {
-      fetch_tile<BM, NTHR>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, g.K, k0 + 2 * BK, xa);
-      fetch_tile<BN, NTHR>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, g.K, k0 + 2 * BK, xb);
-    }
+    fetch_tile<BM, NTHR>(g.A, g.a_rs, g.a_cs, arf, m0, g.M, g.K, k0 + 2 * BK, xa);
+    fetch_tile<BN, NTHR>(g.B, g.b_cs, g.b_rs, brf, n0, g.N, g.K, k0 + 2 * BK, xb);
+    __builtin_amdgcn_sched_barrier(0);          // the loads stay ahead of the step's MFMAs
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8_t a[TM], b[TN];
@@ -318,7 +315,7 @@ __global__ __launch_bounds__(NTHR) void k_tr_gemm_bf16(dst_gemm_args g, int spli
   };
   for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
     step(ra0, rb0, k0);
-    if (k0 + BK < kend) step(ra1, rb1, k0 + BK);
+    step(ra1, rb1, k0 + BK);
   }
   finish_tiles<TM, TN>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), splits, z, reinterpret_cast<float*>(lds));
 }
@@ -484,18 +481,15 @@ __global__ __launch_bounds__(512) void k_tr_gemm_ws(dst_gemm_args g, int b_rfast
   const int nsteps = Kp >> 4, nch = (nsteps + WS_KS - 1) / WS_KS;
   const int ntiles = (g.M + 31) >> 5;
   f32x4_t raw[WS_KS][2];
-  auto issue = [&](int tile, int kc) {                       // this lane's 32 bytes per k-step of chunk kc of its row
+  // branch-free (see fetch_tile): K is a multiple of 128 here (dst_gemm), so every k-step of every chunk is a full, valid load and the
+  // sixteen loads of a chunk share one base address with immediate offsets
+  auto issue = [&](int tile, int kc) __attribute__((always_inline)) {   // this lane's 32 bytes per k-step of chunk kc of its row
     const int row = min(tile * 32 + r, g.M - 1);
-    const float* ap = g.A + (int64_t)row * g.a_rs + 8 * hh;
+    const float* ap = g.A + (int64_t)row * g.a_rs + 8 * hh + 16 * WS_KS * kc;
 #pragma unroll
     for (int s = 0; s < WS_KS; ++s) {
-      const int k = 16 * (kc * WS_KS + s) + 8 * hh;
-      raw[s][0] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-      raw[s][1] = raw[s][0];
-      if (kc * WS_KS + s < nsteps) {
-        if (k < g.K) raw[s][0] = *reinterpret_cast<const f32x4_t*>(ap + 16 * (kc * WS_KS + s));
-        if (k + 4 < g.K) raw[s][1] = *reinterpret_cast<const f32x4_t*>(ap + 16 * (kc * WS_KS + s) + 4);
-      }
+      raw[s][0] = *reinterpret_cast<const f32x4_t*>(ap + 16 * s);
+      raw[s][1] = *reinterpret_cast<const f32x4_t*>(ap + 16 * s + 4);
     }
   };
   const int t0 = grp * 8 + wave, tstride = ngroups * 8;
@@ -513,15 +507,17 @@ __global__ __launch_bounds__(512) void k_tr_gemm_ws(dst_gemm_args g, int b_rfast
       for (int s = 0; s < WS_KS; ++s)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { a[s][e] = (__bf16)raw[s][0][e]; a[s][4 + e] = (__bf16)raw[s][1][e]; }
-      if (kc + 1 < nch) issue(tile, kc + 1);
-      else if (tile + tstride < ntiles) issue(tile + tstride, 0);
+      {   // ONE load site (two sites and a no-load path made the register allocator copy the whole chunk and wait on it): after the
+          // last chunk of the last tile the first chunk of that tile is simply loaded again
+        const bool wrap = kc + 1 == nch;
+        issue(wrap ? (tile + tstride < ntiles ? tile + tstride : tile) : tile, wrap ? 0 : kc + 1);
+        __builtin_amdgcn_sched_barrier(0);      // the loads stay AHEAD of the chunk's MFMAs (the scheduler sank them to the end of the block)
+      }
 #pragma unroll
       for (int s = 0; s < WS_KS; ++s)
-        if (kc * WS_KS + s < nsteps) {
 #pragma unroll
-          for (int j = 0; j < NCT; ++j)
-            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], *reinterpret_cast<const bf16x8_t*>(wrow + j * 32 * WLD + 16 * (kc * WS_KS + s)), acc[0][j], 0, 0, 0);
-        }
+        for (int j = 0; j < NCT; ++j)
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], *reinterpret_cast<const bf16x8_t*>(wrow + j * 32 * WLD + 16 * (kc * WS_KS + s)), acc[0][j], 0, 0, 0);
     }
     finish_tiles<1, NCT>(g, acc, tile * 32, n0, 1, 0, stage);
   }
@@ -564,7 +560,7 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   // measured inside the training step (same box, DST_GEMM_WS=0 / 1): the resident-weight form wins where the weight is large and the
   // rows are many (81 014 x 256 x 256 input gradient: 66 us against 113) and loses on the short-K products (K = 64 / 128: its 256
   // workgroups re-stage the weight for too little work per row), so it takes K >= 256 on the directed rows only
-  if (vec && !ws_off && a_k && g.K >= 256 && g.K <= 512 && (g.K & 3) == 0 && g.M >= ws_min_m && !g.rowsum && g.N >= 16) {
+  if (vec && !ws_off && a_k && g.K >= 256 && g.K <= 512 && (g.K & 127) == 0 && g.M >= ws_min_m && !g.rowsum && g.N >= 16) {
     const int Kp = (g.K + 15) / 16 * 16;
     int nct = g.N > 64 ? 4 : 2;
     if ((size_t)32 * nct * (Kp + 8) * 2 + STAGE_BYTES * 2 > 160 * 1024) nct = 2;      // K = 512: 64 columns of the weight at a time

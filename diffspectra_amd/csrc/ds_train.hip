@@ -1280,10 +1280,10 @@ __global__ void k_ln_affine_bwd_params(const float* __restrict__ dy, const float
 // ------------------------------------------------------------------------------------------------------------------ optimizer
 __global__ void k_adamw_ema(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, float* __restrict__ vmax,
                             float* __restrict__ ema, int64_t n, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2,
-                            float clip, float ema_omd) {
+                            float clip, const float* __restrict__ clip_dev, float ema_omd) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float grad = g[i] * clip;
+  const float grad = g[i] * (clip_dev ? clip * clip_dev[0] : clip);
   float w = p[i];
   w *= (1.0f - lr * wd);                                    // decoupled weight decay (torch.optim.AdamW)
   const float mi = beta1 * m[i] + (1.0f - beta1) * grad;
@@ -1294,6 +1294,31 @@ __global__ void k_adamw_ema(float* __restrict__ p, const float* __restrict__ g, 
   w -= (lr / bc1) * (mi / denom);
   p[i] = w;
   if (ema) { const float s = ema[i]; ema[i] = s - ema_omd * (s - w); }
+}
+
+// gradient_clipping (losses.py:28-50) on the device: the norm history (Queue, losses.py:53-72: newest first, at most 50), the allowed
+// norm min(1.5 mean + 2 std, max_grad), the queue update and the clip coefficient min(1, allowed / (norm + 1e-6)) - in double, as numpy
+// evaluates them.  state: [0..49] history, [50] count, [51] coefficient, [52] norm, [53] allowed norm.  One thread: ~50 values.
+__global__ void k_clip_update(const float* __restrict__ norm_sq, float inv_world, float max_grad, float* __restrict__ st) {
+  if (blockIdx.x || threadIdx.x) return;
+  const double norm = sqrt((double)norm_sq[0]) * (double)inv_world;
+  double allowed = (double)max_grad;
+  if (max_grad > 1.0f) {
+    const int cnt = (int)st[50];
+    double mean = 0.0, var = 0.0;
+    for (int i = 0; i < cnt; ++i) mean += (double)st[i];
+    mean /= (double)(cnt > 0 ? cnt : 1);
+    for (int i = 0; i < cnt; ++i) { const double d = (double)st[i] - mean; var += d * d; }
+    var /= (double)(cnt > 0 ? cnt : 1);
+    allowed = fmin(1.5 * mean + 2.0 * sqrt(var), (double)max_grad);
+    const int keep = cnt < 49 ? cnt : 49;                      // insert at the front, drop the oldest beyond 50
+    for (int i = keep; i > 0; --i) st[i] = st[i - 1];
+    st[0] = (float)(norm > allowed ? allowed : norm);
+    st[50] = (float)(keep + 1);
+  }
+  st[51] = (float)fmin(1.0, allowed / (norm + 1e-6));
+  st[52] = (float)norm;
+  st[53] = (float)allowed;
 }
 
 inline dim3 grid1d(int64_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
@@ -1589,11 +1614,18 @@ int dst_ln_affine_bwd(const float* dy, const float* x, const float* stats, int32
 }
 
 int dst_adamw_ema(float* p, const float* g, float* m, float* v, float* vmax, float* ema, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, float bc1, float bc2, float clip_coef, float ema_one_minus_decay, void* stream) {
+                  float eps, float weight_decay, float bc1, float bc2, float clip_coef, const float* clip_coef_dev, float ema_one_minus_decay,
+                  void* stream) {
   if (!p || !g || !m || !v || !vmax || n < 0) return DS_ERR_ARG;
   if (n == 0) return DS_OK;
   hipLaunchKernelGGL(k_adamw_ema, grid1d(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, ema, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
-                     clip_coef, ema_one_minus_decay);
+                     clip_coef, clip_coef_dev, ema_one_minus_decay);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_clip_update(const float* norm_sq, float inv_world, float max_grad, float* state, void* stream) {
+  if (!norm_sq || !state || !(max_grad >= 0.0f) || !(inv_world > 0.0f)) return DS_ERR_ARG;
+  hipLaunchKernelGGL(k_clip_update, dim3(1), dim3(64), 0, (hipStream_t)stream, norm_sq, inv_world, max_grad, state);
   return DST_CHECK_LAUNCH();
 }
 

@@ -91,6 +91,7 @@ class FusedAdamW:
         self.steps = 0
         self.scratch = torch.empty(1024, dtype=torch.float32, device=dev)
         self.norm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.clip_state, self._clip_pending = None, False
         self.ema_flat = None
 
     def unpadded(self, flat: torch.Tensor) -> torch.Tensor:
@@ -115,8 +116,7 @@ class FusedAdamW:
         else:
             dist.reduce_scatter_tensor(self.Gs, self.G, op=dist.ReduceOp.SUM)
 
-    def grad_norm(self) -> torch.Tensor:
-        """Global L2 norm of the (rank-averaged) gradient: what ``clip_grad_norm_`` returns.  Synchronises the gradients."""
+    def _norm_sq(self):
         self._sync_grads()
         self._synced = True
         E._check(self.lib.dst_sumsq(E._ptr(self.Gs), C.c_int64(self.shard), E._ptr(self.norm_sq), C.c_int32(0), E._ptr(self.scratch),
@@ -125,7 +125,26 @@ class FusedAdamW:
             ns = self.norm_sq if dist.get_backend() != "gloo" else self.norm_sq.cpu()
             dist.all_reduce(ns)
             self.norm_sq.copy_(ns)
+
+    def grad_norm(self) -> torch.Tensor:
+        """Global L2 norm of the (rank-averaged) gradient: what ``clip_grad_norm_`` returns.  Synchronises the gradients."""
+        self._norm_sq()
         return torch.sqrt(self.norm_sq[0]) / self.world                 # the shards hold SUMS over ranks; the mean's norm is 1/W of it
+
+    def clip_on_device(self, max_grad: float, first: float = 3000.0) -> torch.Tensor:
+        """``gradient_clipping`` (losses.py:28-50) without the reference's ``float(grad_norm)`` round trip: norm, norm history, allowed
+        norm and coefficient stay on the device (``dst_clip_update``) and the next ``step`` multiplies the gradient by the coefficient
+        it finds there - the host keeps issuing the next step while this one runs.  Returns the state tensor ([51] coefficient,
+        [52] norm, [53] allowed norm); reading it is the caller's synchronisation."""
+        if self.clip_state is None:
+            self.clip_state = torch.zeros(64, dtype=torch.float32, device=self.dev)
+            self.clip_state[0] = first                                  # "large value that will be flushed" (losses.py:79)
+            self.clip_state[50] = 1.0
+        self._norm_sq()
+        E._check(self.lib.dst_clip_update(E._ptr(self.norm_sq), C.c_float(1.0 / self.world), C.c_float(float(max_grad)), E._ptr(self.clip_state),
+                                          E._stream()), "dst_clip_update")
+        self._clip_pending = True
+        return self.clip_state
 
     def attach_ema(self, ema: ExponentialMovingAverage):
         """Fold ``ema.update`` into the step kernel: the shadow parameters become views of one flat buffer."""
@@ -181,7 +200,9 @@ class FusedAdamW:
         E._check(self.lib.dst_adamw_ema(E._ptr(self.Ps), E._ptr(self.Gs), E._ptr(self.M), E._ptr(self.V), E._ptr(self.Vmax), E._ptr(ema_ptr),
                                         C.c_int64(self.shard), C.c_float(float(g["lr"])), C.c_float(b1), C.c_float(b2), C.c_float(g["eps"]),
                                         C.c_float(g["weight_decay"]), C.c_float(1.0 - b1 ** self.steps), C.c_float(1.0 - b2 ** self.steps),
-                                        C.c_float(float(clip_coef) / self.world), C.c_float(ema_omd), E._stream()), "dst_adamw_ema")
+                                        C.c_float(float(clip_coef) / self.world), E._ptr(self.clip_state[51:52]) if self._clip_pending else None,
+                                        C.c_float(ema_omd), E._stream()), "dst_adamw_ema")
+        self._clip_pending = False
         if self.sharded:
             if dist.get_backend() == "gloo":                           # rehearsal backend: host tensors
                 parts = [torch.empty(self.shard) for _ in range(self.world)]
@@ -285,9 +306,16 @@ def optimization_manager(config):
                 g["lr"] = lr * np.minimum(step / warmup, 1.0)
         coef = 1.0
         if grad_clip >= 0:
-            norm = float(optimizer.grad_norm())                        # one device->host sync, as float(grad_norm) in the reference
-            coef, _ = clip_coefficient(norm, gradnorm_queue, grad_clip)
-            optimize_fn.last_grad_norm = norm
+            if hasattr(optimizer, "clip_on_device"):
+                # the reference's float(grad_norm) is a device -> host synchronisation in every step; here the clipping (norm history
+                # included) runs on the device and the host is free to issue the next step.  last_grad_norm is a 0-dim device tensor
+                st = optimizer.clip_on_device(grad_clip)
+                optimize_fn.last_grad_norm = st[52]
+                optimize_fn.device_state = st
+            else:
+                norm = float(optimizer.grad_norm())
+                coef, _ = clip_coefficient(norm, gradnorm_queue, grad_clip)
+                optimize_fn.last_grad_norm = norm
         optimizer.step(clip_coef=coef, ema=ema)
 
     optimize_fn.queue = gradnorm_queue

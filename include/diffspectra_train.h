@@ -20,6 +20,7 @@
  *   dst_noising, dst_kabsch  forward diffusion + Kabsch alignment                    losses.py:312-327,414-452; models/utils.py:67-106
  *   dst_bn_*, dst_spec_attn_* SpecFormer in training mode                            models/specformer.py:247,260,385-425
  *   dst_adamw_ema            AdamW(amsgrad) + EMA update, fused                      losses.py:20,92; models/ema.py:24-42
+ *   dst_clip_update          adaptive gradient clipping and its norm history         losses.py:28-72
  */
 #ifndef DIFFSPECTRA_TRAIN_H
 #define DIFFSPECTRA_TRAIN_H
@@ -231,10 +232,19 @@ int dst_ln_affine_bwd(const float* dy, const float* x, const float* stats, int32
                       float* dgamma, float* dbeta, void* stream);
 
 /* Fused optimizer step over one flat fp32 parameter buffer (losses.py:20 AdamW(amsgrad=True, weight_decay), torch semantics) followed
- * by the EMA update of models/ema.py:24-42: p, g, m, v, vmax, ema all [n].  clip_coef multiplies the gradient first (gradient clipping,
- * losses.py:28-50); bias corrections are passed in (1 - beta^t). */
+ * by the EMA update of models/ema.py:24-42: p, g, m, v, vmax, ema all [n].  The gradient is first multiplied by clip_coef and, when
+ * clip_coef_dev is not NULL, by clip_coef_dev[0] (the device-resident coefficient of dst_clip_update: the step then needs no
+ * device -> host synchronisation); bias corrections are passed in (1 - beta^t). */
 int dst_adamw_ema(float* p, const float* g, float* m, float* v, float* vmax, float* ema, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, float bc1, float bc2, float clip_coef, float ema_one_minus_decay, void* stream);
+                  float eps, float weight_decay, float bc1, float bc2, float clip_coef, const float* clip_coef_dev, float ema_one_minus_decay,
+                  void* stream);
+
+/* gradient_clipping (losses.py:28-50) with its norm history (Queue, losses.py:53-72) kept on the device.  norm_sq[0] = sum of squares of
+ * the gradient (dst_sumsq, all-reduced over ranks), the norm is sqrt(norm_sq) * inv_world.  state [54] floats: [0..49] the history,
+ * newest first; [50] its length (the reference starts it as {3000}); on return [51] = min(1, allowed / (norm + 1e-6)), [52] = norm,
+ * [53] = allowed = min(1.5 mean + 2 std of the history, max_grad) (max_grad <= 1: allowed = max_grad, no history), and the history has
+ * taken min(norm, allowed).  Evaluated in double, as numpy does. */
+int dst_clip_update(const float* norm_sq, float inv_world, float max_grad, float* state, void* stream);
 
 /* sum of squares of x [n] into out[0] (accumulate != 0 adds): the global gradient norm of clip_grad_norm_. */
 int dst_sumsq(const float* x, int64_t n, float* out, int32_t accumulate, float* scratch, int64_t scratch_cap, void* stream);

@@ -523,6 +523,22 @@ __global__ __launch_bounds__(512) void k_tr_gemm_ws(dst_gemm_args g, int b_rfast
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------ K <= 8
+// C[M, N] = A[M, K] B[K, N] with a handful of k (coord_mlp.2: 256 -> 3, its input gradient is an 81 000 x 256 output from K = 3; the
+// one-hot / distance embeddings): an outer-product-sized job that a 32-k-step MFMA tile spends on padding (108 us for that product).
+// One thread per output element, consecutive threads on consecutive columns; fp32 FMAs in k order; the common epilogue.
+__global__ __launch_bounds__(256) void k_tr_gemm_skinny(dst_gemm_args g) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)g.M * g.N) return;
+  const int row = (int)(i / g.N), col = (int)(i - (int64_t)row * g.N);
+  const float* a = g.A + (int64_t)row * g.a_rs;
+  const float* b = g.B + (int64_t)col * g.b_cs;
+  float v = 0.0f;
+  for (int k = 0; k < g.K; ++k) v += a[(int64_t)k * g.a_cs] * b[(int64_t)k * g.b_rs];
+  if (g.act || g.dact || g.drop_p > 0.0f) epi_fused(g, row, col, v + (g.bias ? g.bias[col] : 0.0f));
+  else epi_plain(g, row, col, v);
+}
+
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -579,6 +595,11 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
       if (!attr_done[1]) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tr_gemm_ws<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[1] = true; }
       hipLaunchKernelGGL((k_tr_gemm_ws<2>), grid, blk, lds, s, g, (int)b_r, Kp, nchunks, ngroups);
     }
+    return DST_CHECK_LAUNCH();
+  }
+  static const int skinny_off = env_int("DST_GEMM_SKINNY", 1) == 0;
+  if (bf && !skinny_off && g.K <= 8 && g.M >= 1024 && !g.rowsum && g.N > 0) {       // (bf16 mode only: the fp32 mode keeps one summation order everywhere)
+    hipLaunchKernelGGL(k_tr_gemm_skinny, dim3((unsigned)(((int64_t)g.M * g.N + 255) / 256)), dim3(256), 0, s, g);
     return DST_CHECK_LAUNCH();
   }
   static const int wide_off = env_int("DST_GEMM_WIDE", 1) == 0;

@@ -183,8 +183,6 @@ class Ops:
         if out2 is not None:
             assert out2.rows == M and out2.cols == N
         E._check(self.lib.dst_gemm(args, self._s()), "dst_gemm")
-        return
-        E._check(self.lib.dst_gemm(C.byref(args), self._s()), "dst_gemm")
 
     def colsum(self, X: MV, out: torch.Tensor, acc: bool = False):
         assert out.numel() == X.cols

@@ -190,6 +190,31 @@ def test_train_gemm_fused_rowsum(ops, gpu_device, M, N, K):
     assert float((db.cpu().double() - 2 * refb).abs().max()) <= 2 * tol * float(refb.abs().max()) + 2e-5
 
 
+@pytest.mark.parametrize("M,N,K,tb", [(5000, 256, 3, False), (4100, 32, 1, True), (2049, 3, 8, True)])
+def test_train_gemm_skinny_k(ops, gpu_device, M, N, K, tb):
+    """K <= 8 in the bf16 mode takes k_tr_gemm_skinny (fp32 FMAs, no bf16 rounding): plain, accumulate, and the activation-derivative
+    epilogue of coord_mlp.2's input gradient (K = 3 -> 256 columns)."""
+    T, _ = ops
+    o = T.Ops(gpu_device)
+    o.bf16 = True
+    d = gpu_device
+    g = torch.Generator().manual_seed(M + N + K)
+    A, Bm, b = torch.randn(M, K, generator=g), torch.randn((N, K) if tb else (K, N), generator=g), torch.randn(N, generator=g)
+    ref = A.double() @ (Bm.t() if tb else Bm).double()
+    tol = 3e-6 * (float(ref.abs().max()) + 1.0)
+    Cd = torch.full((M, N + 3), 2.0, device=d)
+    o.gemm(T.mv(A.to(d)), T.mv(Bm.to(d)), T.mv(Cd, 1, 1 + N), False, tb, bias=b.to(d))
+    assert float((Cd[:, 1:1 + N].cpu().double() - ref - b.double()).abs().max()) <= tol
+    assert torch.equal(Cd[:, :1].cpu(), torch.full((M, 1), 2.0)) and torch.equal(Cd[:, 1 + N:].cpu(), torch.full((M, 2), 2.0))
+    o.gemm(T.mv(A.to(d)), T.mv(Bm.to(d)), T.mv(Cd, 1, 1 + N), False, tb, acc=True)
+    assert float((Cd[:, 1:1 + N].cpu().double() - 2 * ref - b.double()).abs().max()) <= 2 * tol
+    pre = torch.randn(M, N, generator=g)
+    out = torch.zeros(M, N, device=d)
+    o.gemm(T.mv(A.to(d)), T.mv(Bm.to(d)), T.mv(out), False, tb, dact=T.SILU, ref=T.mv(pre.to(d)))
+    sg = torch.sigmoid(pre.double())
+    assert float((out.cpu().double() - ref * (sg * (1 + pre.double() * (1 - sg)))).abs().max()) <= 2 * tol
+
+
 def test_colsum_and_acts(ops, gpu_device):
     T, o = ops
     d = gpu_device

@@ -440,11 +440,17 @@ __global__ __launch_bounds__(1024) void k_attn_fwd(dst_layout L, const float* __
   for (int it = threadIdx.x; it < n * 64; it += blockDim.x) {      // four columns (one head) per thread
     const int t = it >> 6, col = (it & 63) * 4, hd = col >> 4;
     f4_t s = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int sN = 0; sN < n; ++sN) {
-      if (sN == t) continue;
-      const int p = sN < t ? pair_index(n, sN, t) : pair_index(n, t, sN);
-      const int d = sN < t ? 2 * p : 2 * p + 1;
-      s += ld4(qkv + (int64_t)(n0 + sN) * 768 + 512 + col) * ld4(te1 + (int64_t)(p0 + p) * ldt + col) * lg[d * 16 + hd];
+    // sources below and above the target as two branch-free ranges (same ascending order): a `continue` in the loop kept the compiler
+    // from putting more than one iteration's loads in flight
+#pragma unroll 4
+    for (int sN = 0; sN < t; ++sN) {
+      const int p = pair_index(n, sN, t);
+      s += ld4(qkv + (int64_t)(n0 + sN) * 768 + 512 + col) * ld4(te1 + (int64_t)(p0 + p) * ldt + col) * lg[(2 * p) * 16 + hd];
+    }
+#pragma unroll 4
+    for (int sN = t + 1; sN < n; ++sN) {
+      const int p = pair_index(n, t, sN);
+      s += ld4(qkv + (int64_t)(n0 + sN) * 768 + 512 + col) * ld4(te1 + (int64_t)(p0 + p) * ldt + col) * lg[(2 * p + 1) * 16 + hd];
     }
     st4(out + (int64_t)(n0 + t) * 256 + col, s);
   }
@@ -502,10 +508,16 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
       int hd[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) hd[e] = (col + e) / 18 + 2;
-      for (int j = 0; j < n; ++j) {
-        if (j == i) continue;
-        const int p = j < i ? pair_index(n, j, i) : pair_index(n, i, j);
-        const int d = j < i ? 2 * p : 2 * p + 1;       // source j -> target i
+      // (the partners below and above i as two branch-free ranges, ascending as before: several iterations' loads in flight)
+#pragma unroll 4
+      for (int j = 0; j < i; ++j) {
+        const int p = pair_index(n, j, i), d = 2 * p;  // source j -> target i
+        const f4_t w = {dl[d * 16 + hd[0]], dl[d * 16 + hd[1]], dl[d * 16 + hd[2]], dl[d * 16 + hd[3]]};
+        s += w * ld4(qkv + (int64_t)(n0 + j) * 768 + 256 + col) * ld4(te0 + (int64_t)(p0 + p) * ldt + col);
+      }
+#pragma unroll 4
+      for (int j = i + 1; j < n; ++j) {
+        const int p = pair_index(n, i, j), d = 2 * p + 1;
         const f4_t w = {dl[d * 16 + hd[0]], dl[d * 16 + hd[1]], dl[d * 16 + hd[2]], dl[d * 16 + hd[3]]};
         s += w * ld4(qkv + (int64_t)(n0 + j) * 768 + 256 + col) * ld4(te0 + (int64_t)(p0 + p) * ldt + col);
       }
@@ -515,21 +527,30 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
       int hd[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) hd[e] = (c + e) / 18 + 2;
-      for (int t = 0; t < n; ++t) {
-        if (t == i) continue;
-        const int p = i < t ? pair_index(n, i, t) : pair_index(n, t, i);
-        const int d = i < t ? 2 * p : 2 * p + 1;       // source i -> target t
+#pragma unroll 4
+      for (int t = 0; t < i; ++t) {
+        const int p = pair_index(n, t, i), d = 2 * p + 1;   // source i -> target t
+        const f4_t w = {dl[d * 16 + hd[0]], dl[d * 16 + hd[1]], dl[d * 16 + hd[2]], dl[d * 16 + hd[3]]};
+        s += w * ld4(qkv + (int64_t)(n0 + t) * 768 + c) * ld4(te0 + (int64_t)(p0 + p) * ldt + c);
+      }
+#pragma unroll 4
+      for (int t = i + 1; t < n; ++t) {
+        const int p = pair_index(n, i, t), d = 2 * p;
         const f4_t w = {dl[d * 16 + hd[0]], dl[d * 16 + hd[1]], dl[d * 16 + hd[2]], dl[d * 16 + hd[3]]};
         s += w * ld4(qkv + (int64_t)(n0 + t) * 768 + c) * ld4(te0 + (int64_t)(p0 + p) * ldt + c);
       }
       s *= 0.25f;
     } else if (col >= 512) {                           // dv[i]: i is the source
       const int c = col - 512, hd = c >> 4;
-      for (int t = 0; t < n; ++t) {
-        if (t == i) continue;
-        const int p = i < t ? pair_index(n, i, t) : pair_index(n, t, i);
-        const int d = i < t ? 2 * p : 2 * p + 1;
-        s += ld4(dout + (int64_t)(n0 + t) * 256 + c) * ld4(te1 + (int64_t)(p0 + p) * ldt + c) * al[d * 16 + hd];
+#pragma unroll 4
+      for (int t = 0; t < i; ++t) {
+        const int p = pair_index(n, t, i);
+        s += ld4(dout + (int64_t)(n0 + t) * 256 + c) * ld4(te1 + (int64_t)(p0 + p) * ldt + c) * al[(2 * p + 1) * 16 + hd];
+      }
+#pragma unroll 4
+      for (int t = i + 1; t < n; ++t) {
+        const int p = pair_index(n, i, t);
+        s += ld4(dout + (int64_t)(n0 + t) * 256 + c) * ld4(te1 + (int64_t)(p0 + p) * ldt + c) * al[(2 * p) * 16 + hd];
       }
     }
     st4(dqkv + (int64_t)(n0 + i) * 768 + col, s);

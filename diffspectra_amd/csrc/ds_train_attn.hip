@@ -262,15 +262,28 @@ __global__ __launch_bounds__(256) void k_sfa_bwd_kv(QkvPtrs qkv, int nl, const f
     f32x16_t dv, dkc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dv[i] = 0.0f; dkc[i] = 0.0f; }
+    // A operand of dP: dO[query r][d] (the rows stay in L2: 32 bytes per query and head), fetched ONE QUERY TILE AHEAD from a clamped
+    // address and masked when it is used - loaded where it was consumed, every tile paid an L2 round trip in front of its MFMAs
+    const float* dobase = dout + row0 * DM + h * DK;
+    f32x4_t dn0 = *reinterpret_cast<const f32x4_t*>(dobase + (int64_t)min(r, L - 1) * DM);
+    f32x4_t dn1 = *reinterpret_cast<const f32x4_t*>(dobase + (int64_t)min(r, L - 1) * DM + 4);
     for (int qt = 0; qt < NT; ++qt) {
       const unsigned short* qrow = Qs + (qt * 32 + r) * KLD + 8 * hh;
       f32x16_t s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = 0.0f; dp[i] = 0.0f; }
+      const int qa = qt * 32 + r;
+      bf16x8_t doa;
+      {
+        const bool live = hh == 0 && qa < L;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { doa[j] = (__bf16)(live ? dn0[j] : 0.0f); doa[4 + j] = (__bf16)(live ? dn1[j] : 0.0f); }
+        const int qn = min(qa + 32, L - 1);
+        dn0 = *reinterpret_cast<const f32x4_t*>(dobase + (int64_t)qn * DM);
+        dn1 = *reinterpret_cast<const f32x4_t*>(dobase + (int64_t)qn * DM + 4);
+      }
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(qrow), kb[0], s, 0, 0, 0);
       if (nl > 2) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(qrow + 16), kb[1], s, 0, 0, 0);
-      const int qa = qt * 32 + r;                                                // A operand of dP: dO[query r][d] (the rows stay in L2: 32 bytes per query and head)
-      const bf16x8_t doa = (hh == 0 && qa < L) ? load8(dout + (row0 + qa) * DM + h * DK, 1.0f) : zero8();
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa, vb, dp, 0, 0, 0);
       f32x16_t p;
 #pragma unroll

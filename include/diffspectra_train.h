@@ -42,7 +42,11 @@ extern "C" {
  * Fused epilogue, per element (all optional):  v = acc + bias;  dact: v *= f'(ref[m,n]);  act: C = v and C2 = drop(f(v)) when C2 is
  * given, else C = drop(f(v));  no act: C (+)= drop(v).  f: 1 SiLU, 2 GELU(erf), 3 tanh; f' takes ref = pre-activation (SiLU, GELU) or
  * ref = tanh output.  drop(x) = x * keep / (1 - p) with the Philox mask of dst_dropout at element index m * drop_ld + n of stream
- * (drop_seed, drop_stream) - the dropout of dmt.py:114-120 applied where the value is produced, and re-created in the backward. */
+ * (drop_seed, drop_stream) - the dropout of dmt.py:114-120 applied where the value is produced, and re-created in the backward.
+ * Operand access in the bf16 mode: an operand that is contiguous along k or along its rows, 16-byte aligned, with a leading stride that is
+ * a multiple of 4 takes the vector kernels, which read whole 16-byte groups from addresses clamped into the matrix and mask afterwards -
+ * every row must therefore be READABLE up to the next multiple of 4 (<= its leading stride), which any [rows, ld] allocation is.  Other
+ * operands and K < 8 take element-wise kernels (K <= 8 with M >= 1024: plain fp32 FMAs, no bf16 rounding). */
 typedef struct dst_gemm_args {
   const float* A; int64_t a_rs, a_cs;
   const float* B; int64_t b_rs, b_cs;

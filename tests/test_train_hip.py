@@ -749,6 +749,35 @@ def test_model_forward_under_autograd_reproduces_reference_gradients(gpu_device,
     assert not out.requires_grad                                         # eval mode: the sampling kernels, no graph
 
 
+@pytest.mark.parametrize("max_grad", [10.0, 0.5])
+def test_clip_update_replays_the_reference_queue(ops, gpu_device, max_grad):
+    """dst_clip_update over 70 steps (the 50-entry history wraps) against the host restatement of gradient_clipping + Queue
+    (losses.py:28-72): coefficient, allowed norm, history contents and order."""
+    from diffspectra_amd import engine as E, losses as Lh
+    T, o = ops
+    d = gpu_device
+    rng = np.random.default_rng(3)
+    norms = np.concatenate([rng.uniform(5.0, 60.0, 30), rng.uniform(0.5, 8.0, 40)])          # clipped at first, below the bound later
+    q = Lh.Queue()
+    q.add(3000)
+    st = torch.zeros(64, device=d)
+    st[0], st[50] = 3000.0, 1.0
+    world = 2.0
+    for it, nrm in enumerate(norms):
+        nsq = torch.tensor([(nrm * world) ** 2], dtype=torch.float32, device=d)               # the shards hold sums over ranks
+        E._check(o.lib.dst_clip_update(E._ptr(nsq), C.c_float(1.0 / world), C.c_float(max_grad), E._ptr(st), E._stream()), "dst_clip_update")
+        got = st.cpu().double()
+        n32 = float(np.sqrt(np.float64(np.float32((nrm * world) ** 2)))) / world
+        coef, allowed = Lh.clip_coefficient(n32, q, max_grad)
+        assert abs(got[51] - coef) <= 2e-6 * max(coef, 1e-3), (it, float(got[51]), coef)
+        assert abs(got[52] - n32) <= 1e-6 * n32 and abs(got[53] - float(allowed)) <= 2e-6 * float(allowed)
+        if max_grad > 1.0:
+            assert int(got[50]) == len(q)
+            np.testing.assert_allclose(got[:len(q)].numpy(), np.asarray(q.items, dtype=np.float64), rtol=2e-6)
+    if max_grad > 1.0:
+        assert len(q) == 50
+
+
 def test_step_fn_fused_optimizer_and_ema(gpu_device, monkeypatch):
     """``get_step_fn`` (losses.py:97-125): zero_grad -> loss -> backward -> warm-up lr + adaptive clip -> fused AdamW-amsgrad -> EMA,
     two steps, against torch.optim.AdamW(amsgrad=True, weight_decay=1e-12) + clip_grad_norm_ + the reference EMA formula applied to the

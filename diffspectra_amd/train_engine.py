@@ -13,6 +13,7 @@ Dropout is the identity (stage A: the reference's p = 0 arithmetic, pinned by go
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import re
@@ -216,6 +217,26 @@ class Ops:
         finally:
             self.scratch, self.stream_ptr = main_scratch, main_ptr
 
+    # ---- node stream (forward): the node-row chain of a block (4 600 rows: ten launches, each shorter than its launch latency) runs beside
+    #      the pair-row chain instead of in front of it.  Rules that make it safe with torch's caching allocator (all tensors come from
+    #      the MAIN stream's pool): every node section starts by waiting for everything the main stream has been given so far (whatever
+    #      memory the section allocates was freed before that point, so its earlier users are covered), and nothing a section touches is
+    #      freed before the join at the end of the pass (the graph holds the references).
+    def node_section(self):
+        return _NodeSection(self)
+
+    def node_event(self):
+        ev = torch.cuda.Event()
+        ev.record(self._node)
+        return ev
+
+    def main_wait(self, ev=None):
+        """The main stream waits for the node stream (as of now) or for one recorded event."""
+        if ev is None:
+            self.main_stream.wait_stream(self._node)
+        else:
+            self.main_stream.wait_event(ev)
+
     def join_dw(self):
         """The main stream waits for every weight-gradient product issued so far; their operands may be reused after it."""
         if self._side is not None and self._dw_keep:
@@ -257,6 +278,26 @@ class Ops:
         E._check(self.lib.dst_gate_add_bwd(E._ptr(dout), E._ptr(z), C.c_int32(Cc), E._ptr(seg), C.c_int32(mul), C.c_int32(B), E._ptr(ada), E._ptr(d_ada),
                                            C.c_int64(ADA), C.c_int32(g), E._ptr(dr), C.c_int32(int(acc_r)), E._ptr(dz), C.c_float(p_), C.c_uint64(seed),
                                            C.c_uint32(stream), self._s()), "dst_gate_add_bwd")
+
+
+class _NodeSection:
+    def __init__(self, ops):
+        self.o = ops
+
+    def __enter__(self):
+        o = self.o
+        if getattr(o, "_node", None) is None:
+            o._node = torch.cuda.Stream(device=o.dev)
+            o._node_ptr = C.c_void_p(o._node.cuda_stream)
+            o._node_scratch = torch.empty(4 * 1024 * 1024, dtype=torch.float32, device=o.dev)
+        o._node.wait_stream(o.main_stream)
+        self.saved = (o.stream_ptr, o.scratch)
+        o.stream_ptr, o.scratch = o._node_ptr, o._node_scratch
+        return self
+
+    def __exit__(self, *exc):
+        self.o.stream_ptr, self.o.scratch = self.saved
+        return False
 
 
 class TrainLayout:
@@ -446,45 +487,61 @@ class DmtTrainGraph:
         t.update(X0n=X0n, X0p=X0p, xs0=xs0, d2c=d2c, adj=adj, h0=h, e0=e)
         node_hids, edge_hids = [h], [e]
         blocks = []
+        ns = bool(int(os.environ.get("DIFFSPECTRA_NODE_STREAM", "1"))) and getattr(o, "main_stream", None) is not None
+        sec = o.node_section if ns else contextlib.nullcontext
         for i in range(NB):
             bp = f"e_block_{i}."
             a0 = i * ADA_STRIDE
             bt: Dict[str, object] = dict(pos_in=pos, h_in=h, e_in=e)
+            ap = bp + "attn_mpnn."
+            # node rows, in front of the attention (dmt.py:148; layers.py:131-140): adaLN modulate, q | k | v as one product (the padding
+            # columns come out as exact zeros) - on the node stream, beside the pair rows' geometry and embedding
+            with sec():
+                hn, st_n1 = self.f(Nn, 256), self.f(Nn, 2)
+                o.lnmod_fwd(h, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 0, a0 + NODE_OFF + 256, hn, st_n1)
+                qkv = self.f(Nn, 768)
+                o.lin_fwd(mv(hn), mv(cat["Wqkv"][i]), cat["bqkv"][i], mv(qkv))
             # distances + CondGaussian features, edge embedding (dmt.py:136-139)
             X1, xs, d2 = self.f(Pp, 128), self.f(Pp), self.f(Pp)
             self._geom_fwd(TL, pos, ada, a0 + DIST_OFF, bp + "dist_layer.", X1, 128, 0, xs, d2)
             X1[:, 64:128] = e
             e1 = self.f(Pp, 64)
             o.lin_fwd(mv(X1), mv(p[bp + "edge_emb.weight"]), p[bp + "edge_emb.bias"], mv(e1))
-            # adaLN modulate (dmt.py:148-149)
-            hn, st_n1 = self.f(Nn, 256), self.f(Nn, 2)
-            o.lnmod_fwd(h, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 0, a0 + NODE_OFF + 256, hn, st_n1)
             en, st_e1 = self.f(Pp, 64), self.f(Pp, 2)
             o.lnmod_fwd(e1, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 0, a0 + EDGE_OFF + 64, en, st_e1)
-            # attention (layers.py:131-186)
-            ap = bp + "attn_mpnn."
-            qkv = self.f(Nn, 768)                                    # q | k | v as one product (the padding columns come out as exact zeros)
-            o.lin_fwd(mv(hn), mv(cat["Wqkv"][i]), cat["bqkv"][i], mv(qkv))
             te = self.f(Pp, 512)                                     # tanh(lin_edge0 e) | tanh(lin_edge1 e) as one product; columns 252..255 = tanh(0)
             o.lin_fwd(mv(en), mv(cat["Wte"][i]), None, mv(te), act=TANH)
             te0, te1 = te[:, 0:256], te[:, 256:512]
+            # attention (layers.py:131-186)
+            if ns:
+                o.main_wait()                                        # q | k | v
             attn, alpha = self.f(Nn, 256), self.f(max(D, 1), 16)
             E._check(lib.dst_attn_fwd(C.byref(TL.c), E._ptr(qkv), E._ptr(te0), E._ptr(te1), C.c_int64(512), E._ptr(adj), E._ptr(attn), E._ptr(alpha), s()),
                      "dst_attn_fwd")
-            # node2edge (dmt.py:156-157) per node, then the pair sum
-            u, he = self.f(Nn, 64), self.f(Pp, 64)
-            o.lin_fwd(mv(attn), mv(p[bp + "node2edge_lin.weight"]), None, mv(u))
+            # node stream (dmt.py:156-163): node2edge per node first (the pair rows wait for it), then the gated residual and the FF, the
+            # node parts of input_lin and the read-out slice
+            with sec():
+                u = self.f(Nn, 64)
+                o.lin_fwd(mv(attn), mv(p[bp + "node2edge_lin.weight"]), None, mv(u))
+                ev_u = o.node_event() if ns else None
+                x1, y1, st_n2 = self.f(Nn, 256), self.f(Nn, 256), self.f(Nn, 2)
+                o.gate_add_fwd(h, attn, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 512, x1)
+                o.lnmod_fwd(x1, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 768, a0 + NODE_OFF + 1024, y1, st_n2)
+                f1, s1, f2, h_out = self.f(Nn, 512), self.f(Nn, 512), self.f(Nn, 256), self.f(Nn, 256)
+                # dmt.py:114-116: dropout(act(ff_linear1)) and dropout(ff_linear2) where the GEMMs produce them (f1 = pre-activation, kept)
+                o.lin_fwd(mv(y1), mv(p[bp + "ff_linear1.weight"]), p[bp + "ff_linear1.bias"], mv(f1), act=SILU, out2=mv(s1), drop=(dp, dseed, 4 * i + 0, 512))
+                o.lin_fwd(mv(s1), mv(p[bp + "ff_linear2.weight"]), p[bp + "ff_linear2.bias"], mv(f2), drop=(dp, dseed, 4 * i + 1, 256))
+                o.gate_add_fwd(y1, f2, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 1280, h_out)
+                ac = self.f(Nn, 512)                                 # h_row | h_col parts of input_lin as one product
+                o.lin_fwd(mv(h_out), mv(cat["Wac"][i]), None, mv(ac))
+                ev_ac = o.node_event() if ns else None
+                rn = self.f(Nn, 64)                                  # per-block read-out features (dmt.py:387)
+                o.lin_fwd(mv(h_out), mv(p[f"node_{i}.weight"]), p[f"node_{i}.bias"], mv(rn))
+            # edge stream (dmt.py:156-157,165-169)
+            if ns:
+                o.main_wait(ev_u)
+            he = self.f(Pp, 64)
             E._check(lib.dst_pair_sum_fwd(C.byref(TL.c), E._ptr(u), C.c_int32(64), E._ptr(p[bp + "node2edge_lin.bias"]), E._ptr(he), s()), "dst_pair_sum_fwd")
-            # node stream (dmt.py:159-163)
-            x1, y1, st_n2 = self.f(Nn, 256), self.f(Nn, 256), self.f(Nn, 2)
-            o.gate_add_fwd(h, attn, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 512, x1)
-            o.lnmod_fwd(x1, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 768, a0 + NODE_OFF + 1024, y1, st_n2)
-            f1, s1, f2, h_out = self.f(Nn, 512), self.f(Nn, 512), self.f(Nn, 256), self.f(Nn, 256)
-            # dmt.py:114-116: dropout(act(ff_linear1)) and dropout(ff_linear2) where the GEMMs produce them (f1 = pre-activation, kept)
-            o.lin_fwd(mv(y1), mv(p[bp + "ff_linear1.weight"]), p[bp + "ff_linear1.bias"], mv(f1), act=SILU, out2=mv(s1), drop=(dp, dseed, 4 * i + 0, 512))
-            o.lin_fwd(mv(s1), mv(p[bp + "ff_linear2.weight"]), p[bp + "ff_linear2.bias"], mv(f2), drop=(dp, dseed, 4 * i + 1, 256))
-            o.gate_add_fwd(y1, f2, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 1280, h_out)
-            # edge stream (dmt.py:165-169)
             xe1, ye1, st_e2 = self.f(Pp, 64), self.f(Pp, 64), self.f(Pp, 2)
             o.gate_add_fwd(e, he, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 128, xe1)
             o.lnmod_fwd(xe1, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 192, a0 + EDGE_OFF + 256, ye1, st_e2)
@@ -494,13 +551,15 @@ class DmtTrainGraph:
             o.gate_add_fwd(ye1, f4, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 320, e_out)
             # equivariant update (dmt.py:37-60) + CoM removal (:385-386)
             Win = p[bp + "equi_update.input_lin.weight"]                       # [256, 640] = [h_row | h_col | e | dist]
-            ac = self.f(Nn, 512)                                     # h_row | h_col parts of input_lin as one product
-            o.lin_fwd(mv(h_out), mv(cat["Wac"][i]), None, mv(ac))
             X2 = self.f(Pp, 128)
             X2[:, 0:64] = e_out
             X2[:, 64:128] = X1[:, 0:64]
             ed = self.f(Pp, 256)
             o.lin_fwd(mv(X2), mv(Win, 512, 640), p[bp + "equi_update.input_lin.bias"], mv(ed))
+            re_ = self.f(Pp, 16)                                     # per-block read-out features (dmt.py:388)
+            o.lin_fwd(mv(e_out), mv(p[f"edge_{i}.weight"]), p[f"edge_{i}.bias"], mv(re_))
+            if ns:
+                o.main_wait(ev_ac)
             zz, zn, st_z = self.f(max(D, 1), 256), self.f(max(D, 1), 256), self.f(max(D, 1), 2)
             E._check(lib.dst_zbuild_fwd(C.byref(TL.c), E._ptr(ac), E._ptr(ed), E._ptr(zz), s()), "dst_zbuild_fwd")
             o.lnmod_fwd(zz, 256, TL.pair_off, 2, B, ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256, zn, st_z)
@@ -511,18 +570,16 @@ class DmtTrainGraph:
             pos_out = self.f(Nn, 3)
             E._check(lib.dst_coord_fwd(C.byref(TL.c), E._ptr(pos), E._ptr(c2), E._ptr(adj), E._ptr(p[bp + "equi_update.coord_norm.scale"]),
                                        E._ptr(pos_out), s()), "dst_coord_fwd")
-            # per-block read-out features (dmt.py:387-388)
-            rn, re_ = self.f(Nn, 64), self.f(Pp, 16)
-            o.lin_fwd(mv(h_out), mv(p[f"node_{i}.weight"]), p[f"node_{i}.bias"], mv(rn))
-            o.lin_fwd(mv(e_out), mv(p[f"edge_{i}.weight"]), p[f"edge_{i}.bias"], mv(re_))
             node_hids.append(rn)
             edge_hids.append(re_)
-            if save:
-                bt.update(X1=X1, xs=xs, d2=d2, e1=e1, hn=hn, st_n1=st_n1, en=en, st_e1=st_e1, qkv=qkv, te=te, attn=attn, alpha=alpha,
-                          u=u, he=he, x1=x1, y1=y1, st_n2=st_n2, f1=f1, s1=s1, f2=f2, h_out=h_out, xe1=xe1, ye1=ye1, st_e2=st_e2, f3=f3, s3=s3,
-                          f4=f4, e_out=e_out, X2=X2, zz=zz, zn=zn, st_z=st_z, c0=c0, sc0=sc0, c2=c2)
-                blocks.append(bt)
+            # (kept in every mode: with the node stream nothing a block touched may be freed - and handed out again - before the join below)
+            bt.update(X1=X1, xs=xs, d2=d2, e1=e1, hn=hn, st_n1=st_n1, en=en, st_e1=st_e1, qkv=qkv, te=te, attn=attn, alpha=alpha,
+                      u=u, he=he, x1=x1, y1=y1, st_n2=st_n2, f1=f1, s1=s1, f2=f2, h_out=h_out, xe1=xe1, ye1=ye1, st_e2=st_e2, f3=f3, s3=s3,
+                      f4=f4, e_out=e_out, X2=X2, zz=zz, zn=zn, st_z=st_z, c0=c0, sc0=sc0, c2=c2, ac=ac, ed=ed, rn=rn, re_=re_)
+            blocks.append(bt)
             pos, h, e = pos_out, h_out, e_out
+        if ns:
+            o.main_wait()                                            # join: the last block's node rows and read-out slices
         # ---- read-out MLPs (dmt.py:391-394)
         AH = torch.cat(node_hids, dim=1).contiguous()
         EH = torch.cat(edge_hids, dim=1).contiguous()

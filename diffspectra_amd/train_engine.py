@@ -160,6 +160,7 @@ class Ops:
     def end(self):
         self.stream_ptr = None
         self.main_stream = None
+        self.cur_stream = None
 
     def gemm(self, A: MV, Bm: MV, Cm: MV, ta: bool, tb: bool, bias: Optional[torch.Tensor] = None, acc: bool = False,
              rowsum: Optional[torch.Tensor] = None, act: int = 0, dact: int = 0, ref: Optional[MV] = None, out2: Optional[MV] = None,
@@ -207,8 +208,10 @@ class Ops:
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
             self._side_scratch = torch.empty_like(self.scratch)
-        main = self.main_stream if getattr(self, "main_stream", None) is not None else torch.cuda.current_stream(self.dev)
-        self._side.wait_stream(main)                                    # dy (and x) are complete on the main stream at this point
+        src = getattr(self, "cur_stream", None)                         # the stream the operands were produced on (main, or the node stream inside a node section)
+        if src is None:
+            src = self.main_stream if getattr(self, "main_stream", None) is not None else torch.cuda.current_stream(self.dev)
+        self._side.wait_stream(src)                                     # dy (and x) are complete on that stream at this point
         self._dw_keep.append((dy.t, x.t, dW.t, db))
         main_scratch, self.scratch = self.scratch, self._side_scratch
         main_ptr, self.stream_ptr = self.stream_ptr, C.c_void_p(self._side.cuda_stream)
@@ -291,12 +294,12 @@ class _NodeSection:
             o._node_ptr = C.c_void_p(o._node.cuda_stream)
             o._node_scratch = torch.empty(4 * 1024 * 1024, dtype=torch.float32, device=o.dev)
         o._node.wait_stream(o.main_stream)
-        self.saved = (o.stream_ptr, o.scratch)
-        o.stream_ptr, o.scratch = o._node_ptr, o._node_scratch
+        self.saved = (o.stream_ptr, o.scratch, getattr(o, "cur_stream", None))
+        o.stream_ptr, o.scratch, o.cur_stream = o._node_ptr, o._node_scratch, o._node
         return self
 
     def __exit__(self, *exc):
-        self.o.stream_ptr, self.o.scratch = self.saved
+        self.o.stream_ptr, self.o.scratch, self.o.cur_stream = self.saved
         return False
 
 
@@ -644,15 +647,18 @@ class DmtTrainGraph:
         de = self.z(Pp, 64)
         dpos_out = dpos
         dms_buf, dd2_buf, dsp = self.f(B, 128), self.f(max(Pp, 1)), self.f(B)
+        ns = bool(int(os.environ.get("DIFFSPECTRA_NODE_STREAM", "1"))) and getattr(o, "main_stream", None) is not None
+        sec = o.node_section if ns else contextlib.nullcontext
         for i in reversed(range(NB)):
             bt = t["blocks"][i]
             bp = f"e_block_{i}."
             a0 = i * ADA_STRIDE
             ap = bp + "attn_mpnn."
-            # read-out features of this block
+            # read-out features of this block (node rows on the node stream, here and below: see forward)
             drn, dre = mv(dAH, 256 + 64 * i, 256 + 64 * (i + 1)), mv(dEH, 64 + 16 * i, 64 + 16 * (i + 1))
-            o.lin_bwd_w(drn, mv(bt["h_out"]), mv(gw(f"node_{i}.weight")), gw(f"node_{i}.bias"))
-            o.lin_bwd_x(drn, mv(p[f"node_{i}.weight"]), mv(dh), acc=True)
+            with sec():
+                o.lin_bwd_w(drn, mv(bt["h_out"]), mv(gw(f"node_{i}.weight")), gw(f"node_{i}.bias"))
+                o.lin_bwd_x(drn, mv(p[f"node_{i}.weight"]), mv(dh), acc=True)
             o.lin_bwd_w(dre, mv(bt["e_out"]), mv(gw(f"edge_{i}.weight")), gw(f"edge_{i}.bias"))
             o.lin_bwd_x(dre, mv(p[f"edge_{i}.weight"]), mv(de), acc=True)
             # equivariant update
@@ -672,25 +678,26 @@ class DmtTrainGraph:
             o.lnmod_bwd(dzn, bt["zz"], bt["st_z"], 256, TL.pair_off, 2, B, ada, d_ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256, dz, False)
             dac, ded = self.f(Nn, 512), self.f(Pp, 256)
             E._check(lib.dst_zbuild_bwd(C.byref(TL.c), E._ptr(dz), E._ptr(dac), E._ptr(ded), s()), "dst_zbuild_bwd")
-            o.lin_bwd_w(mv(dac), mv(bt["h_out"]), mv(dcat["Wac"][i]))               # both node parts at once; scattered into dWin[:, 0:512] at the end
-            o.lin_bwd_x(mv(dac), mv(cat["Wac"][i]), mv(dh), acc=True)
+            # node stream (the section waits for dac)
+            with sec():
+                o.lin_bwd_w(mv(dac), mv(bt["h_out"]), mv(dcat["Wac"][i]))           # both node parts at once; scattered into dWin[:, 0:512] at the end
+                o.lin_bwd_x(mv(dac), mv(cat["Wac"][i]), mv(dh), acc=True)
+                dy1, df2 = self.f(Nn, 256), self.f(Nn, 256)
+                o.gate_add_bwd(dh, bt["f2"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 1280, dy1, False, df2, drop=(dp, dseed, 4 * i + 1))
+                o.lin_bwd_w(mv(df2), mv(bt["s1"]), mv(gw(bp + "ff_linear2.weight")), gw(bp + "ff_linear2.bias"))
+                df1 = self.f(Nn, 512)
+                o.lin_bwd_x(mv(df2), mv(p[bp + "ff_linear2.weight"]), mv(df1), dact=SILU, ref=mv(bt["f1"]), drop=(dp, dseed, 4 * i + 0, 512))
+                o.lin_bwd_w(mv(df1), mv(bt["y1"]), mv(gw(bp + "ff_linear1.weight")), gw(bp + "ff_linear1.bias"))
+                o.lin_bwd_x(mv(df1), mv(p[bp + "ff_linear1.weight"]), mv(dy1), acc=True)
+                dx1 = self.f(Nn, 256)
+                o.lnmod_bwd(dy1, bt["x1"], bt["st_n2"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 768, a0 + NODE_OFF + 1024, dx1, False)
+                dh_in, dattn = self.f(Nn, 256), self.f(Nn, 256)
+                o.gate_add_bwd(dx1, bt["attn"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 512, dh_in, False, dattn)
+            # edge stream
             o.lin_bwd_w(mv(ded), mv(bt["X2"]), mv(dWin, 512, 640), gw(bp + "equi_update.input_lin.bias"))
             o.lin_bwd_x(mv(ded), mv(Win, 512, 576), mv(de), acc=True)
             dfeat2 = self.f(Pp, 64)
             o.lin_bwd_x(mv(ded), mv(Win, 576, 640), mv(dfeat2))
-            # node stream
-            dy1, df2 = self.f(Nn, 256), self.f(Nn, 256)
-            o.gate_add_bwd(dh, bt["f2"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 1280, dy1, False, df2, drop=(dp, dseed, 4 * i + 1))
-            o.lin_bwd_w(mv(df2), mv(bt["s1"]), mv(gw(bp + "ff_linear2.weight")), gw(bp + "ff_linear2.bias"))
-            df1 = self.f(Nn, 512)
-            o.lin_bwd_x(mv(df2), mv(p[bp + "ff_linear2.weight"]), mv(df1), dact=SILU, ref=mv(bt["f1"]), drop=(dp, dseed, 4 * i + 0, 512))
-            o.lin_bwd_w(mv(df1), mv(bt["y1"]), mv(gw(bp + "ff_linear1.weight")), gw(bp + "ff_linear1.bias"))
-            o.lin_bwd_x(mv(df1), mv(p[bp + "ff_linear1.weight"]), mv(dy1), acc=True)
-            dx1 = self.f(Nn, 256)
-            o.lnmod_bwd(dy1, bt["x1"], bt["st_n2"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 768, a0 + NODE_OFF + 1024, dx1, False)
-            dh_in, dattn = self.f(Nn, 256), self.f(Nn, 256)
-            o.gate_add_bwd(dx1, bt["attn"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 512, dh_in, False, dattn)
-            # edge stream
             dye1, df4 = self.f(Pp, 64), self.f(Pp, 64)
             o.gate_add_bwd(de, bt["f4"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 320, dye1, False, df4, drop=(dp, dseed, 4 * i + 3))
             o.lin_bwd_w(mv(df4), mv(bt["s3"]), mv(gw(bp + "ff_linear4.weight")), gw(bp + "ff_linear4.bias"))
@@ -706,24 +713,27 @@ class DmtTrainGraph:
             du = self.f(Nn, 64)
             E._check(lib.dst_pair_sum_bwd(C.byref(TL.c), E._ptr(dhe), C.c_int32(64), E._ptr(du), C.c_int32(0), s()), "dst_pair_sum_bwd")
             o.colsum(mv(dhe), gw(bp + "node2edge_lin.bias"))
-            o.lin_bwd_w(mv(du), mv(bt["attn"]), mv(gw(bp + "node2edge_lin.weight")))
-            o.lin_bwd_x(mv(du), mv(p[bp + "node2edge_lin.weight"]), mv(dattn), acc=True)
+            with sec():                                                              # (waits for du)
+                o.lin_bwd_w(mv(du), mv(bt["attn"]), mv(gw(bp + "node2edge_lin.weight")))
+                o.lin_bwd_x(mv(du), mv(p[bp + "node2edge_lin.weight"]), mv(dattn), acc=True)
+            if ns:
+                o.main_wait()                                                        # dattn
             # attention
             dqkv, dte = self.f(Nn, 768), self.f(Pp, 512)
             te = bt["te"]
             E._check(lib.dst_attn_bwd(C.byref(TL.c), E._ptr(bt["qkv"]), E._ptr(te[:, 0:256]), E._ptr(te[:, 256:512]), C.c_int64(512), E._ptr(bt["alpha"]),
                                       E._ptr(dattn), E._ptr(dqkv), E._ptr(dte[:, 0:256]), E._ptr(dte[:, 256:512]), None, s()), "dst_attn_bwd")
+            with sec():                                                              # (waits for dqkv) q | k | v and the adaLN modulate of the block input
+                dhn = self.f(Nn, 256)
+                o.lin_bwd_w(mv(dqkv), mv(bt["hn"]), mv(dcat["Wqkv"][i]), dcat["bqkv"][i])
+                o.lin_bwd_x(mv(dqkv), mv(cat["Wqkv"][i]), mv(dhn))
+                o.lnmod_bwd(dhn, bt["h_in"], bt["st_n1"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 0, a0 + NODE_OFF + 256, dh_in, True)
             o.act_bwd(dte, te, dte, TANH)
             o.lin_bwd_w(mv(dte), mv(bt["en"]), mv(dcat["Wte"][i]))                  # lin_edge0 | lin_edge1 (rows 252..255: zero gradients of the padding)
             den = self.f(Pp, 64)
             o.lin_bwd_x(mv(dte), mv(cat["Wte"][i]), mv(den))
-            dhn = self.f(Nn, 256)
-            o.lin_bwd_w(mv(dqkv), mv(bt["hn"]), mv(dcat["Wqkv"][i]), dcat["bqkv"][i])
-            o.lin_bwd_x(mv(dqkv), mv(cat["Wqkv"][i]), mv(dhn))
-            # adaLN modulates of the block input
             de1 = self.f(Pp, 64)
             o.lnmod_bwd(den, bt["e1"], bt["st_e1"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 0, a0 + EDGE_OFF + 64, de1, False)
-            o.lnmod_bwd(dhn, bt["h_in"], bt["st_n1"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 0, a0 + NODE_OFF + 256, dh_in, True)
             # edge embedding + distance features
             o.lin_bwd_w(mv(de1), mv(bt["X1"]), mv(gw(bp + "edge_emb.weight")), gw(bp + "edge_emb.bias"))
             dfeat1 = self.f(Pp, 64)
@@ -733,6 +743,9 @@ class DmtTrainGraph:
             self._geom_bwd(TL, bt["pos_in"], ada, d_ada, a0 + DIST_OFF, bp + "dist_layer.", bt["xs"], bt["d2"], dfeat1, dfeat2, dms_buf, dd2_buf, dpos_in)
             o.colsum(mv(dms_buf, 1, 64), gw(bp + "dist_layer.means.weight").view(-1))      # lane k of the kernel = feature k = Gaussian k - 1
             o.colsum(mv(dms_buf, 65, 128), gw(bp + "dist_layer.stds.weight").view(-1))
+            if ns:
+                o.main_wait()           # end of the block: everything the node stream was given precedes what the main stream does next, so this
+                                        # block's temporaries may be released (and handed out again) when the next block rebinds their names
             dh, de, dpos_out = dh_in, de_in, dpos_in
         # ---- input embeddings
         o.lin_bwd_w(mv(dh), mv(t["X0n"]), mv(gw("node_emb.weight")), gw("node_emb.bias"))

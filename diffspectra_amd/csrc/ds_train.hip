@@ -460,7 +460,7 @@ __global__ __launch_bounds__(1024) void k_attn_fwd(dst_layout L, const float* __
 
 __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __restrict__ qkv, const float* __restrict__ te0, const float* __restrict__ te1,
                                                    int64_t ldt, const float* __restrict__ alpha, const float* __restrict__ dout, float* __restrict__ dqkv,
-                                                   float* __restrict__ dte0, float* __restrict__ dte1) {
+                                                   float* __restrict__ dte0, float* __restrict__ dte1, int te_tanh) {
   __shared__ float dl[812 * 16];      // d alpha, then d logit (the 64 kB static LDS limit leaves no room for a copy of alpha)
   __shared__ unsigned char pa[406], pb[406];
   const int m = blockIdx.x;
@@ -562,8 +562,12 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
     {
       const int hd = col >> 4;
       const f4_t va = ld4(qkv + (int64_t)(n0 + a) * 768 + 512 + col), vb = ld4(qkv + (int64_t)(n0 + b) * 768 + 512 + col);
-      st4(dte1 + (int64_t)(p0 + p) * ldt + col, ld4(dout + (int64_t)(n0 + b) * 256 + col) * va * al[(2 * p) * 16 + hd] +
-                                                ld4(dout + (int64_t)(n0 + a) * 256 + col) * vb * al[(2 * p + 1) * 16 + hd]);
+      f4_t g1 = ld4(dout + (int64_t)(n0 + b) * 256 + col) * va * al[(2 * p) * 16 + hd] + ld4(dout + (int64_t)(n0 + a) * 256 + col) * vb * al[(2 * p + 1) * 16 + hd];
+      if (te_tanh) {                                   // te1 = tanh(lin_edge1 e): hand back the gradient in front of the tanh (1 - te^2)
+        const f4_t t1 = ld4(te1 + (int64_t)(p0 + p) * ldt + col);
+        g1 = g1 * (1.0f - t1 * t1);
+      }
+      st4(dte1 + (int64_t)(p0 + p) * ldt + col, g1);
     }
     f4_t g0 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (col < 252) {
@@ -577,6 +581,10 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
         w1[e] = dl[(2 * p + 1) * 16 + hd];
       }
       g0 = 0.25f * (w0 * qb * ka + w1 * qa * kb);
+      if (te_tanh) {
+        const f4_t t0 = ld4(te0 + (int64_t)(p0 + p) * ldt + col);
+        g0 = g0 * (1.0f - t0 * t0);
+      }
     }
     st4(dte0 + (int64_t)(p0 + p) * ldt + col, g0);
   }
@@ -1478,10 +1486,9 @@ int dst_attn_fwd(const dst_layout* L, const float* qkv, const float* te0, const 
   return DST_CHECK_LAUNCH();
 }
 int dst_attn_bwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, int64_t ld_te, const float* alpha, const float* dout,
-                 float* dqkv, float* dte0, float* dte1, float* scratch, void* stream) {
-  (void)scratch;
+                 float* dqkv, float* dte0, float* dte1, int32_t te_is_tanh, void* stream) {
   if (!DST_L_OK(L) || !qkv || !te0 || !te1 || ld_te < 256 || !alpha || !dout || !dqkv || !dte0 || !dte1) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_attn_bwd, dim3(L->B), dim3(1024), 0, (hipStream_t)stream, *L, qkv, te0, te1, ld_te, alpha, dout, dqkv, dte0, dte1);
+  hipLaunchKernelGGL(k_attn_bwd, dim3(L->B), dim3(1024), 0, (hipStream_t)stream, *L, qkv, te0, te1, ld_te, alpha, dout, dqkv, dte0, dte1, (int)te_is_tanh);
   return DST_CHECK_LAUNCH();
 }
 

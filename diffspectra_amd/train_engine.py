@@ -186,10 +186,31 @@ class Ops:
             assert out2.rows == M and out2.cols == N
         E._check(self.lib.dst_gemm(args, self._s()), "dst_gemm")
 
-    def colsum(self, X: MV, out: torch.Tensor, acc: bool = False):
+    def colsum(self, X: MV, out: torch.Tensor, acc: bool = False, param_grad: bool = False):
+        """``param_grad``: the sums are a parameter gradient (nothing downstream of the pass reads them) - with the weight-gradient stream on
+        they go there, like ``lin_bwd_w``; X must then not be overwritten before ``join_dw``."""
         assert out.numel() == X.cols
+        if param_grad and self.async_dw:
+            self._to_side(X.t, out)
+            saved = (self.scratch, self.stream_ptr)
+            self.scratch, self.stream_ptr = self._side_scratch, C.c_void_p(self._side.cuda_stream)
+            try:
+                return self.colsum(X, out, acc)
+            finally:
+                self.scratch, self.stream_ptr = saved
         E._check(self.lib.dst_colsum(C.c_void_p(X.ptr), C.c_int64(X.ld), C.c_int32(X.rows), C.c_int32(X.cols), E._ptr(out), C.c_int32(int(acc)),
                                      E._ptr(self.scratch), C.c_int64(self.scratch.numel()), self._s()), "dst_colsum")
+
+    def _to_side(self, *keep):
+        """The side stream waits for the stream the operands were produced on (main, or the node stream inside a node section)."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+            self._side_scratch = torch.empty_like(self.scratch)
+        src = getattr(self, "cur_stream", None)
+        if src is None:
+            src = self.main_stream if getattr(self, "main_stream", None) is not None else torch.cuda.current_stream(self.dev)
+        self._side.wait_stream(src)
+        self._dw_keep.append(keep)
 
     # y = x W^T + b ; dx (+)= dy W ; dW = dy^T x ; db = colsum(dy)
     def lin_fwd(self, x: MV, W: MV, b, y: MV, act: int = 0, out2: Optional[MV] = None, drop=None):
@@ -205,14 +226,7 @@ class Ops:
         if not self.async_dw:
             self.gemm(dy, x, dW, True, False, acc=acc, rowsum=db)       # db = column sums of dy = row sums of dy^T, fused into the product
             return
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.dev)
-            self._side_scratch = torch.empty_like(self.scratch)
-        src = getattr(self, "cur_stream", None)                         # the stream the operands were produced on (main, or the node stream inside a node section)
-        if src is None:
-            src = self.main_stream if getattr(self, "main_stream", None) is not None else torch.cuda.current_stream(self.dev)
-        self._side.wait_stream(src)                                     # dy (and x) are complete on that stream at this point
-        self._dw_keep.append((dy.t, x.t, dW.t, db))
+        self._to_side(dy.t, x.t, dW.t, db)                              # dy (and x) are complete on their stream at this point
         main_scratch, self.scratch = self.scratch, self._side_scratch
         main_ptr, self.stream_ptr = self.stream_ptr, C.c_void_p(self._side.cuda_stream)
         try:
@@ -646,7 +660,7 @@ class DmtTrainGraph:
         dh = self.z(Nn, 256)             # gradient of the block output h (later: block input of the next one)
         de = self.z(Pp, 64)
         dpos_out = dpos
-        dms_buf, dd2_buf, dsp = self.f(B, 128), self.f(max(Pp, 1)), self.f(B)
+        dd2_buf = self.f(max(Pp, 1))
         ns = bool(int(os.environ.get("DIFFSPECTRA_NODE_STREAM", "1"))) and getattr(o, "main_stream", None) is not None
         sec = o.node_section if ns else contextlib.nullcontext
         for i in reversed(range(NB)):
@@ -663,9 +677,10 @@ class DmtTrainGraph:
             o.lin_bwd_x(dre, mv(p[f"edge_{i}.weight"]), mv(de), acc=True)
             # equivariant update
             dpos_in, dc2 = self.f(Nn, 3), self.f(max(D, 1), 3)
+            dsp, dms_buf = self.f(B), self.f(B, 128)          # per block: their column sums (parameter gradients) run on the side stream
             E._check(lib.dst_coord_bwd(C.byref(TL.c), E._ptr(bt["pos_in"]), E._ptr(bt["c2"]), E._ptr(t["adj"]), E._ptr(p[bp + "equi_update.coord_norm.scale"]),
                                        E._ptr(dpos_out), E._ptr(dpos_in), E._ptr(dc2), E._ptr(dsp), s()), "dst_coord_bwd")
-            o.colsum(mv(dsp.view(B, 1)), gw(bp + "equi_update.coord_norm.scale"))
+            o.colsum(mv(dsp.view(B, 1)), gw(bp + "equi_update.coord_norm.scale"), param_grad=True)
             Win = p[bp + "equi_update.input_lin.weight"]
             dWin = gw(bp + "equi_update.input_lin.weight")
             o.lin_bwd_w(mv(dc2, r1=D), mv(bt["sc0"], r1=D), mv(gw(bp + "equi_update.coord_mlp.2.weight")))
@@ -712,7 +727,7 @@ class DmtTrainGraph:
             # node2edge
             du = self.f(Nn, 64)
             E._check(lib.dst_pair_sum_bwd(C.byref(TL.c), E._ptr(dhe), C.c_int32(64), E._ptr(du), C.c_int32(0), s()), "dst_pair_sum_bwd")
-            o.colsum(mv(dhe), gw(bp + "node2edge_lin.bias"))
+            o.colsum(mv(dhe), gw(bp + "node2edge_lin.bias"), param_grad=True)
             with sec():                                                              # (waits for du)
                 o.lin_bwd_w(mv(du), mv(bt["attn"]), mv(gw(bp + "node2edge_lin.weight")))
                 o.lin_bwd_x(mv(du), mv(p[bp + "node2edge_lin.weight"]), mv(dattn), acc=True)
@@ -722,14 +737,13 @@ class DmtTrainGraph:
             dqkv, dte = self.f(Nn, 768), self.f(Pp, 512)
             te = bt["te"]
             E._check(lib.dst_attn_bwd(C.byref(TL.c), E._ptr(bt["qkv"]), E._ptr(te[:, 0:256]), E._ptr(te[:, 256:512]), C.c_int64(512), E._ptr(bt["alpha"]),
-                                      E._ptr(dattn), E._ptr(dqkv), E._ptr(dte[:, 0:256]), E._ptr(dte[:, 256:512]), None, s()), "dst_attn_bwd")
+                                      E._ptr(dattn), E._ptr(dqkv), E._ptr(dte[:, 0:256]), E._ptr(dte[:, 256:512]), C.c_int32(1), s()), "dst_attn_bwd")
             with sec():                                                              # (waits for dqkv) q | k | v and the adaLN modulate of the block input
                 dhn = self.f(Nn, 256)
                 o.lin_bwd_w(mv(dqkv), mv(bt["hn"]), mv(dcat["Wqkv"][i]), dcat["bqkv"][i])
                 o.lin_bwd_x(mv(dqkv), mv(cat["Wqkv"][i]), mv(dhn))
                 o.lnmod_bwd(dhn, bt["h_in"], bt["st_n1"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 0, a0 + NODE_OFF + 256, dh_in, True)
-            o.act_bwd(dte, te, dte, TANH)
-            o.lin_bwd_w(mv(dte), mv(bt["en"]), mv(dcat["Wte"][i]))                  # lin_edge0 | lin_edge1 (rows 252..255: zero gradients of the padding)
+            o.lin_bwd_w(mv(dte), mv(bt["en"]), mv(dcat["Wte"][i]))                  # lin_edge0 | lin_edge1; dte is already in front of the tanh (te_is_tanh)
             den = self.f(Pp, 64)
             o.lin_bwd_x(mv(dte), mv(cat["Wte"][i]), mv(den))
             de1 = self.f(Pp, 64)
@@ -741,8 +755,8 @@ class DmtTrainGraph:
             o.lin_bwd_x(mv(de1), mv(Wee, 0, 64), mv(dfeat1))
             o.lin_bwd_x(mv(de1), mv(Wee, 64, 128), mv(de_in), acc=True)
             self._geom_bwd(TL, bt["pos_in"], ada, d_ada, a0 + DIST_OFF, bp + "dist_layer.", bt["xs"], bt["d2"], dfeat1, dfeat2, dms_buf, dd2_buf, dpos_in)
-            o.colsum(mv(dms_buf, 1, 64), gw(bp + "dist_layer.means.weight").view(-1))      # lane k of the kernel = feature k = Gaussian k - 1
-            o.colsum(mv(dms_buf, 65, 128), gw(bp + "dist_layer.stds.weight").view(-1))
+            o.colsum(mv(dms_buf, 1, 64), gw(bp + "dist_layer.means.weight").view(-1), param_grad=True)      # lane k of the kernel = feature k = Gaussian k - 1
+            o.colsum(mv(dms_buf, 65, 128), gw(bp + "dist_layer.stds.weight").view(-1), param_grad=True)
             if ns:
                 o.main_wait()           # end of the block: everything the node stream was given precedes what the main stream does next, so this
                                         # block's temporaries may be released (and handed out again) when the next block rebinds their names
@@ -758,9 +772,10 @@ class DmtTrainGraph:
             dfeat0 = self.f(Pp, 64)
             o.lin_bwd_x(mv(de), mv(p["edge_emb.weight"], 4, 68), mv(dfeat0))
             o.lin_bwd_x(mv(dEH, 0, 64), mv(p["edge_emb.weight"], 4, 68), mv(dfeat0), acc=True)
-            self._geom_bwd(TL, t["cpos"], ada, d_ada, ADA_TOP, "dist_layer.", t["xs0"], t["d2c"], dfeat0, None, dms_buf, dd2_buf, None)
-            o.colsum(mv(dms_buf, 1, 64), g["dist_layer.means.weight"].view(-1))
-            o.colsum(mv(dms_buf, 65, 128), g["dist_layer.stds.weight"].view(-1))
+            dms_top = self.f(B, 128)                         # (block 0's buffer may still be feeding its column sums on the side stream)
+            self._geom_bwd(TL, t["cpos"], ada, d_ada, ADA_TOP, "dist_layer.", t["xs0"], t["d2c"], dfeat0, None, dms_top, dd2_buf, None)
+            o.colsum(mv(dms_top, 1, 64), g["dist_layer.means.weight"].view(-1))
+            o.colsum(mv(dms_top, 65, 128), g["dist_layer.stds.weight"].view(-1))
         # ---- adaLN table + time embedding
         o.lin_bwd_w(mv(d_ada), mv(t["st"]), mv(dcat["Wada"]), dcat["bada"])
         dtemb = self.f(B, 1024)

@@ -363,7 +363,7 @@ def test_attention(ops, gpu_device):
     check(outd, out, 3e-6, "attention out")
     dq, de0, de1 = torch.empty(Nn, 768, device=d), torch.empty(P, 256, device=d), torch.empty(P, 256, device=d)
     E._check(o.lib.dst_attn_bwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), C.c_int64(256), E._ptr(ald), E._ptr(dout.to(d)), E._ptr(dq), E._ptr(de0), E._ptr(de1),
-                                None, E._stream()), "attn_bwd")
+                                C.c_int32(0), E._stream()), "attn_bwd")
     check(dq, qr.grad, 2e-5, "attention dqkv")
     check(de0, e0r.grad, 2e-5, "attention dte0")
     check(de1, e1r.grad, 2e-5, "attention dte1")

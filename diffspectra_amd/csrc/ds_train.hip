@@ -167,7 +167,9 @@ __global__ __launch_bounds__(1024) void k_lnmod_fwd(const float* __restrict__ x,
   const int sub = lane / LPR, cl = (lane % LPR) * 4;
   const int r0 = seg_off[m] * seg_mul, r1 = seg_off[m + 1] * seg_mul;
   const f4_t sh = ld4(ada + (int64_t)m * ada_ld + shift_off + cl), sc = ld4(ada + (int64_t)m * ada_ld + scale_off + cl);
-  for (int r = r0 + wave * RPW + sub; r < r1; r += MOLW * RPW) {
+  // gridDim.y workgroups share a molecule's rows (interleaved passes): one workgroup per molecule lasts as long as the largest molecule
+  // (812 directed rows against a mean of ~310), four per molecule let the dispatcher even the CUs out
+  for (int r = r0 + (blockIdx.y * MOLW + wave) * RPW + sub; r < r1; r += gridDim.y * MOLW * RPW) {
     const f4_t v = ld4(x + (int64_t)r * C + cl);
     const float mean = group_sum<LPR>((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / C);
     const f4_t d = v - mean;
@@ -181,7 +183,7 @@ template <int C>
 __global__ __launch_bounds__(1024) void k_lnmod_bwd(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
                                                      const int32_t* __restrict__ seg_off, int seg_mul, const float* __restrict__ ada,
                                                      float* __restrict__ d_ada, int64_t ada_ld, int shift_off, int scale_off,
-                                                     float* __restrict__ dx, int accumulate) {
+                                                     float* __restrict__ dx, int accumulate, float* __restrict__ part) {
   constexpr int LPR = C / 4, RPW = 64 / LPR, SLOTS = MOLW * RPW;
   __shared__ float red[2][SLOTS][C];
   const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(1024) void k_lnmod_bwd(const float* __restrict__ dy
   const int r0 = seg_off[m] * seg_mul, r1 = seg_off[m + 1] * seg_mul;
   const f4_t sc1 = ld4(ada + (int64_t)m * ada_ld + scale_off + cl) + 1.0f;
   f4_t dsh = {0.0f, 0.0f, 0.0f, 0.0f}, dsc = {0.0f, 0.0f, 0.0f, 0.0f};
-  for (int r = r0 + wave * RPW + sub; r < r1; r += MOLW * RPW) {
+  for (int r = r0 + (blockIdx.y * MOLW + wave) * RPW + sub; r < r1; r += gridDim.y * MOLW * RPW) {
     const float mean = stats[(int64_t)r * 2], rstd = stats[(int64_t)r * 2 + 1];
     const f4_t g = ld4(dy + (int64_t)r * C + cl);
     const f4_t xh = (ld4(x + (int64_t)r * C + cl) - mean) * rstd;
@@ -211,8 +213,18 @@ __global__ __launch_bounds__(1024) void k_lnmod_bwd(const float* __restrict__ dy
     float t = 0.0f;
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) t += red[w][k][cc];
-    d_ada[(int64_t)m * ada_ld + (w ? scale_off : shift_off) + cc] = t;
+    // split rows: this workgroup's share goes to part[split][molecule][2 C]; k_lnmod_bwd_finish adds the shares in split order
+    if (gridDim.y > 1) part[((int64_t)blockIdx.y * gridDim.x + m) * (2 * C) + c] = t;
+    else d_ada[(int64_t)m * ada_ld + (w ? scale_off : shift_off) + cc] = t;
   }
+}
+template <int C>
+__global__ __launch_bounds__(2 * C) void k_lnmod_bwd_finish(const float* __restrict__ part, int splits, int B, float* __restrict__ d_ada, int64_t ada_ld,
+                                                           int shift_off, int scale_off) {
+  const int m = blockIdx.x, c = threadIdx.x, w = c / C, cc = c % C;
+  float t = 0.0f;
+  for (int k = 0; k < splits; ++k) t += part[((int64_t)k * B + m) * (2 * C) + c];
+  d_ada[(int64_t)m * ada_ld + (w ? scale_off : shift_off) + cc] = t;
 }
 
 // ------------------------------------------------------------------------------------------------------------------ gated residual
@@ -1426,19 +1438,27 @@ int dst_lnmod_fwd(const float* x, int32_t C, const int32_t* seg_off, int32_t seg
                   int32_t shift_off, int32_t scale_off, float* y, float* stats, void* stream) {
   if (!x || !seg_off || !ada || !y || !stats || (C != 64 && C != 256) || B <= 0) return DS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  const int splits = (C == 256 && seg_mul >= 2) ? 4 : 1;                 // the directed rows: hundreds of 256-wide rows per molecule
   if (C == 64) hipLaunchKernelGGL(k_lnmod_fwd<64>, dim3(B), dim3(1024), 0, s, x, seg_off, (int)seg_mul, ada, ada_ld, (int)shift_off, (int)scale_off, y, stats);
-  else hipLaunchKernelGGL(k_lnmod_fwd<256>, dim3(B), dim3(1024), 0, s, x, seg_off, (int)seg_mul, ada, ada_ld, (int)shift_off, (int)scale_off, y, stats);
+  else hipLaunchKernelGGL(k_lnmod_fwd<256>, dim3(B, splits), dim3(1024), 0, s, x, seg_off, (int)seg_mul, ada, ada_ld, (int)shift_off, (int)scale_off, y, stats);
   return DST_CHECK_LAUNCH();
 }
 int dst_lnmod_bwd(const float* dy, const float* x, const float* stats, int32_t C, const int32_t* seg_off, int32_t seg_mul, int32_t B,
                   const float* ada, float* d_ada, int64_t ada_ld, int32_t shift_off, int32_t scale_off, float* dx, int32_t accumulate,
-                  void* stream) {
+                  float* scratch, int64_t scratch_cap, void* stream) {
   if (!dy || !x || !stats || !seg_off || !ada || !d_ada || !dx || (C != 64 && C != 256) || B <= 0) return DS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  int splits = (C == 256 && seg_mul >= 2) ? 4 : 1;                       // as dst_lnmod_fwd; the per-molecule sums then take a second, fixed-order pass
+  if (splits > 1 && (!scratch || scratch_cap < (int64_t)splits * B * 2 * C)) splits = 1;
   if (C == 64)
-    hipLaunchKernelGGL(k_lnmod_bwd<64>, dim3(B), dim3(1024), 0, s, dy, x, stats, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)shift_off, (int)scale_off, dx, (int)accumulate);
-  else
-    hipLaunchKernelGGL(k_lnmod_bwd<256>, dim3(B), dim3(1024), 0, s, dy, x, stats, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)shift_off, (int)scale_off, dx, (int)accumulate);
+    hipLaunchKernelGGL(k_lnmod_bwd<64>, dim3(B), dim3(1024), 0, s, dy, x, stats, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)shift_off, (int)scale_off, dx, (int)accumulate,
+                       (float*)nullptr);
+  else {
+    hipLaunchKernelGGL(k_lnmod_bwd<256>, dim3(B, splits), dim3(1024), 0, s, dy, x, stats, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)shift_off, (int)scale_off, dx,
+                       (int)accumulate, scratch);
+    if (splits > 1)
+      hipLaunchKernelGGL(k_lnmod_bwd_finish<256>, dim3(B), dim3(512), 0, s, (const float*)scratch, splits, (int)B, d_ada, ada_ld, (int)shift_off, (int)scale_off);
+  }
   return DST_CHECK_LAUNCH();
 }
 

@@ -282,8 +282,8 @@ class Ops:
 
     def lnmod_bwd(self, dy, x, stats, Cc, seg, mul, B, ada, d_ada, sh, sc, dx, acc):
         E._check(self.lib.dst_lnmod_bwd(E._ptr(dy), E._ptr(x), E._ptr(stats), C.c_int32(Cc), E._ptr(seg), C.c_int32(mul), C.c_int32(B), E._ptr(ada),
-                                        E._ptr(d_ada), C.c_int64(ADA), C.c_int32(sh), C.c_int32(sc), E._ptr(dx), C.c_int32(int(acc)), self._s()),
-                 "dst_lnmod_bwd")
+                                        E._ptr(d_ada), C.c_int64(ADA), C.c_int32(sh), C.c_int32(sc), E._ptr(dx), C.c_int32(int(acc)), E._ptr(self.scratch),
+                                        C.c_int64(self.scratch.numel()), self._s()), "dst_lnmod_bwd")
 
     def gate_add_fwd(self, r, z, Cc, seg, mul, B, ada, g, out):
         E._check(self.lib.dst_gate_add_fwd(E._ptr(r), E._ptr(z), C.c_int32(Cc), E._ptr(seg), C.c_int32(mul), C.c_int32(B), E._ptr(ada), C.c_int64(ADA),

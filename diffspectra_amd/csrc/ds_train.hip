@@ -295,7 +295,10 @@ __device__ __forceinline__ void fill_pair_tables(int n, unsigned char* pa, unsig
 
 #define DST_GAUSS_A 2.50662732f /* fp32((2 * 3.14159) ** 0.5): the Python-float constant of layers.py:293-294 as torch applies it */
 
-__global__ __launch_bounds__(256) void k_geom_fwd(dst_layout L, const float* __restrict__ pos, const float* __restrict__ ada, int64_t ada_ld,
+// (1024 threads per molecule: with 256 a 29-atom molecule took 100 dependent iterations per wave, and one workgroup per CU at four waves
+// left the memory pipe idle)
+constexpr int GEOM_NT = 1024, GEOM_NW = GEOM_NT / 64;
+__global__ __launch_bounds__(GEOM_NT) void k_geom_fwd(dst_layout L, const float* __restrict__ pos, const float* __restrict__ ada, int64_t ada_ld,
                                                    int dist_off, const float* __restrict__ means, const float* __restrict__ stds,
                                                    float* __restrict__ X, int64_t ldx, float* __restrict__ xs, float* __restrict__ d2s) {
   __shared__ unsigned char pa[406], pb[406];
@@ -303,11 +306,11 @@ __global__ __launch_bounds__(256) void k_geom_fwd(dst_layout L, const float* __r
   const int m = blockIdx.x;
   const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
   fill_pair_tables(n, pa, pb);
-  for (int i = threadIdx.x; i < n * 3; i += 256) sp[i / 3][i % 3] = pos[(int64_t)(n0 + i / 3) * 3 + i % 3];
+  for (int i = threadIdx.x; i < n * 3; i += GEOM_NT) sp[i / 3][i % 3] = pos[(int64_t)(n0 + i / 3) * 3 + i % 3];
   __syncthreads();
   const float a = DST_GAUSS_A;
   const float dsc = ada[(int64_t)m * ada_ld + dist_off], dsh = ada[(int64_t)m * ada_ld + dist_off + 1];
-  for (int it = threadIdx.x; it < np * 64; it += 256) {
+  for (int it = threadIdx.x; it < np * 64; it += GEOM_NT) {
     const int p = it >> 6, k = it & 63;
     const int ia = pa[p], ib = pb[p];
     const float dx = sp[ia][0] - sp[ib][0], dy = sp[ia][1] - sp[ib][1], dz = sp[ia][2] - sp[ib][2];
@@ -327,22 +330,22 @@ __global__ __launch_bounds__(256) void k_geom_fwd(dst_layout L, const float* __r
   }
 }
 
-__global__ __launch_bounds__(256) void k_geom_bwd(dst_layout L, const float* __restrict__ pos, const float* __restrict__ ada, float* __restrict__ d_ada,
+__global__ __launch_bounds__(GEOM_NT) void k_geom_bwd(dst_layout L, const float* __restrict__ pos, const float* __restrict__ ada, float* __restrict__ d_ada,
                                                    int64_t ada_ld, int dist_off, const float* __restrict__ means, const float* __restrict__ stds,
                                                    const float* __restrict__ xs, const float* __restrict__ d2s, const float* __restrict__ g1, int64_t ld1,
                                                    const float* __restrict__ g2, int64_t ld2, float* __restrict__ dms, float* __restrict__ dd2,
                                                    float* __restrict__ dpos) {
-  __shared__ float red[4][130];
+  __shared__ float red[GEOM_NW][130];
   __shared__ float sp[29][3];
   const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
-  for (int i = threadIdx.x; i < n * 3; i += 256) sp[i / 3][i % 3] = pos[(int64_t)(n0 + i / 3) * 3 + i % 3];
+  for (int i = threadIdx.x; i < n * 3; i += GEOM_NT) sp[i / 3][i % 3] = pos[(int64_t)(n0 + i / 3) * 3 + i % 3];
   const float a = DST_GAUSS_A;
   const float dsc = ada[(int64_t)m * ada_ld + dist_off];
   float mu = 0.0f, sraw = 1.0f, sd = 1.0f;
   if (lane > 0) { mu = means[lane - 1]; sraw = stds[lane - 1]; sd = fabsf(sraw) + 1e-5f; }
   float dmu = 0.0f, dsd = 0.0f, a_dsc = 0.0f, a_dsh = 0.0f;
-  for (int p = wave; p < np; p += 4) {                       // one wave per pair, lane = feature
+  for (int p = wave; p < np; p += GEOM_NW) {                       // one wave per pair, lane = feature
     const float x = xs[p0 + p];
     float g = g1[(int64_t)(p0 + p) * ld1 + lane];
     if (g2) g += g2[(int64_t)(p0 + p) * ld2 + lane];
@@ -369,11 +372,15 @@ __global__ __launch_bounds__(256) void k_geom_bwd(dst_layout L, const float* __r
   red[wave][64 + lane] = dsd * (sraw < 0.0f ? -1.0f : 1.0f);
   if (lane == 0) { red[wave][128] = a_dsc; red[wave][129] = a_dsh; }
   __syncthreads();
-  if (threadIdx.x < 128) dms[(int64_t)m * 128 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-  if (threadIdx.x < 2)
-    d_ada[(int64_t)m * ada_ld + dist_off + threadIdx.x] = (red[0][128 + threadIdx.x] + red[1][128 + threadIdx.x]) + (red[2][128 + threadIdx.x] + red[3][128 + threadIdx.x]);
+  if (threadIdx.x < 130) {                                 // the waves' shares in wave order
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < GEOM_NW; ++w) t += red[w][threadIdx.x];
+    if (threadIdx.x < 128) dms[(int64_t)m * 128 + threadIdx.x] = t;
+    else d_ada[(int64_t)m * ada_ld + dist_off + threadIdx.x - 128] = t;
+  }
   if (dpos) {                                              // d d2 / d pos, fixed partner order
-    for (int it = threadIdx.x; it < n * 3; it += 256) {
+    for (int it = threadIdx.x; it < n * 3; it += GEOM_NT) {
       const int i = it / 3, c = it % 3;
       float s = 0.0f;
       for (int j = 0; j < n; ++j) {
@@ -1487,14 +1494,14 @@ int dst_gate_add_bwd(const float* dout, const float* z, int32_t C, const int32_t
 int dst_geom_fwd(const dst_layout* L, const float* pos, const float* ada, int64_t ada_ld, int32_t dist_off, const float* means,
                  const float* stds, float* X, int64_t ldx, float* xs, float* d2s, void* stream) {
   if (!DST_L_OK(L) || !pos || !ada || !means || !stds || !X || !xs || !d2s) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_geom_fwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, pos, ada, ada_ld, (int)dist_off, means, stds, X, ldx, xs, d2s);
+  hipLaunchKernelGGL(k_geom_fwd, dim3(L->B), dim3(GEOM_NT), 0, (hipStream_t)stream, *L, pos, ada, ada_ld, (int)dist_off, means, stds, X, ldx, xs, d2s);
   return DST_CHECK_LAUNCH();
 }
 int dst_geom_bwd(const dst_layout* L, const float* pos, const float* ada, float* d_ada, int64_t ada_ld, int32_t dist_off,
                  const float* means, const float* stds, const float* xs, const float* d2s, const float* g1, int64_t ld1, const float* g2,
                  int64_t ld2, float* dms, float* dd2_scratch, float* dpos, void* stream) {
   if (!DST_L_OK(L) || !pos || !ada || !d_ada || !means || !stds || !xs || !d2s || !g1 || !dms || !dd2_scratch) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_geom_bwd, dim3(L->B), dim3(256), 0, (hipStream_t)stream, *L, pos, ada, d_ada, ada_ld, (int)dist_off, means, stds, xs, d2s, g1,
+  hipLaunchKernelGGL(k_geom_bwd, dim3(L->B), dim3(GEOM_NT), 0, (hipStream_t)stream, *L, pos, ada, d_ada, ada_ld, (int)dist_off, means, stds, xs, d2s, g1,
                      ld1, g2, ld2, dms, dd2_scratch, dpos);
   return DST_CHECK_LAUNCH();
 }

@@ -84,6 +84,14 @@ __global__ void k_axpy(float a, const float* __restrict__ x, float* __restrict__
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] += a * x[i];
 }
+__global__ void k_axpy4(float a, const float4* __restrict__ x, float4* __restrict__ y, int64_t n4) {   // 16-byte form (aligned, n % 4 == 0)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 u = x[i];
+  float4 v = y[i];
+  v.x += a * u.x; v.y += a * u.y; v.z += a * u.z; v.w += a * u.w;
+  y[i] = v;
+}
 
 // adjacency bits of the self-conditioning prediction (dmt.py:338-340,361): bit 0 = cond edge channel 0 >= edge_quan_th, bit 1 = cond d^2 <= cut-off
 __global__ void k_adj_bits(const float* __restrict__ cond_e, int64_t ld, const float* __restrict__ d2c, float th, float cutoff, int n, int32_t* __restrict__ adj) {
@@ -973,6 +981,7 @@ __global__ __launch_bounds__(256) void k_bn_sum(const float* __restrict__ x, int
   float s = 0.0f;
   if (col < C) {
     const float mu = mean ? mean[col] : 0.0f;
+#pragma unroll 8
     for (int r = r0 + rl; r < r1; r += 4) {
       const float v = x[(int64_t)r * C + col];
       s += mean ? (v - mu) * (v - mu) : v;
@@ -1031,6 +1040,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_sum(const float* __restrict__ dy
   float s1 = 0.0f, s2 = 0.0f;
   if (col < C) {
     const float mu = stats[col], rs = stats[C + col];
+#pragma unroll 8
     for (int r = r0 + rl; r < r1; r += 4) {
       const float g = dy[(int64_t)r * C + col];
       s1 += g;
@@ -1429,7 +1439,10 @@ int dst_act_bwd(const float* dy, const float* ref, float* dx, int64_t n, int32_t
 int dst_axpy(float a, const float* x, float* y, int64_t n, void* stream) {
   if (!x || !y) return DS_ERR_ARG;
   if (n == 0) return DS_OK;
-  hipLaunchKernelGGL(k_axpy, grid1d(n), dim3(256), 0, (hipStream_t)stream, a, x, y, n);
+  if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
+    hipLaunchKernelGGL(k_axpy4, grid1d(n / 4), dim3(256), 0, (hipStream_t)stream, a, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), n / 4);
+  else
+    hipLaunchKernelGGL(k_axpy, grid1d(n), dim3(256), 0, (hipStream_t)stream, a, x, y, n);
   return DST_CHECK_LAUNCH();
 }
 
@@ -1598,8 +1611,8 @@ int dst_bn_fwd(const float* x, int32_t R, int32_t C, const float* gamma, const f
                float* running_mean, float* running_var, float* scratch, int64_t scratch_cap, void* stream) {
   if (!x || !gamma || !beta || !y || !stats || !scratch || R < 2 || C <= 0) return DS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  int chunks = (R + 511) / 512;
-  if (chunks > 1024) chunks = 1024;
+  int chunks = (R + 127) / 128;                              // 32 rows per thread: the loop is a chain of dependent loads, so short chains and many workgroups
+  if (chunks > 4096) chunks = 4096;
   if ((int64_t)chunks * C > scratch_cap) chunks = (int)(scratch_cap / C);
   if (chunks < 1) return DS_ERR_ARG;
   const int rpc = (R + chunks - 1) / chunks;
@@ -1619,8 +1632,8 @@ int dst_bn_bwd(const float* dy, const float* x, const float* stats, int32_t R, i
                float* dbeta, float* scratch, int64_t scratch_cap, void* stream) {
   if (!dy || !x || !stats || !gamma || !dx || !dgamma || !dbeta || !scratch || R < 2 || C <= 0) return DS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  int chunks = (R + 511) / 512;
-  if (chunks > 1024) chunks = 1024;
+  int chunks = (R + 127) / 128;                              // 32 rows per thread: the loop is a chain of dependent loads, so short chains and many workgroups
+  if (chunks > 4096) chunks = 4096;
   if ((int64_t)2 * chunks * C > scratch_cap) chunks = (int)(scratch_cap / (2 * C));
   if (chunks < 1) return DS_ERR_ARG;
   const int rpc = (R + chunks - 1) / chunks;

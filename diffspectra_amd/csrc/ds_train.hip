@@ -668,13 +668,12 @@ __global__ __launch_bounds__(256) void k_zbuild_bwd(dst_layout L, const float* _
   for (int it = threadIdx.x + 256 * blockIdx.y; it < n * 128; it += 256 * gridDim.y) {
     const int i = it >> 7, c = (it & 127) * 4, as_col = c >> 8, cc = c & 255;
     f4_t s = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int j = 0; j < n; ++j) {
-      if (j == i) continue;
-      const int p = i < j ? pair_index(n, i, j) : pair_index(n, j, i);
-      // directed edge with row = i (as_col 0) or col = i (as_col 1): dir 0 has row = lo, dir 1 has row = hi
-      const int dir = (as_col == 0) ? (i < j ? 0 : 1) : (i < j ? 1 : 0);
-      s += ld4(dz + (int64_t)(2 * (p0 + p) + dir) * 256 + cc);
-    }
+    // directed edge with row = i (as_col 0) or col = i (as_col 1): dir 0 has row = lo, dir 1 has row = hi.  Partners below and above i as
+    // two branch-free ranges in ascending order (several loads in flight)
+#pragma unroll 4
+    for (int j = 0; j < i; ++j) s += ld4(dz + (int64_t)(2 * (p0 + pair_index(n, j, i)) + (as_col == 0 ? 1 : 0)) * 256 + cc);
+#pragma unroll 4
+    for (int j = i + 1; j < n; ++j) s += ld4(dz + (int64_t)(2 * (p0 + pair_index(n, i, j)) + (as_col == 0 ? 0 : 1)) * 256 + cc);
     st4(dac + (int64_t)(n0 + i) * 512 + c, s);
   }
 }
@@ -1544,12 +1543,12 @@ int dst_pair_sum_bwd(const dst_layout* L, const float* ds, int32_t C, float* du,
 }
 int dst_zbuild_fwd(const dst_layout* L, const float* ac, const float* ed, float* z, void* stream) {
   if (!DST_L_OK(L) || !ac || !ed || !z) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_zbuild_fwd, dim3(L->B, 4), dim3(256), 0, (hipStream_t)stream, *L, ac, ed, z);
+  hipLaunchKernelGGL(k_zbuild_fwd, dim3(L->B, 8), dim3(256), 0, (hipStream_t)stream, *L, ac, ed, z);
   return DST_CHECK_LAUNCH();
 }
 int dst_zbuild_bwd(const dst_layout* L, const float* dz, float* dac, float* ded, void* stream) {
   if (!DST_L_OK(L) || !dz || !dac || !ded) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_zbuild_bwd, dim3(L->B, 4), dim3(256), 0, (hipStream_t)stream, *L, dz, dac, ded);
+  hipLaunchKernelGGL(k_zbuild_bwd, dim3(L->B, 8), dim3(256), 0, (hipStream_t)stream, *L, dz, dac, ded);
   return DST_CHECK_LAUNCH();
 }
 

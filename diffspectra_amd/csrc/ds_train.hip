@@ -485,16 +485,28 @@ __global__ __launch_bounds__(1024) void k_attn_fwd(dst_layout L, const float* __
     for (int col = threadIdx.x; col < 256; col += blockDim.x) out[(int64_t)n0 * 256 + col] = 0.0f;
 }
 
+// MODE 0: the whole backward in one workgroup per molecule.  MODE 1 + MODE 2: the same in two launches - d logit (phases 1, 2) written to
+// `dlg` [2 Pp, 16], then the node- and pair-side gradients (phases 3, 4: ~80 % of the work) with gridDim.y workgroups sharing a molecule's
+// items: one workgroup per molecule lasts as long as the largest molecule (29 atoms: 2.6x the mean work), the shares let the dispatcher even
+// the CUs out.  alpha is staged in LDS next to d logit (dynamic LDS, 104 kB): the softmax backward read it from global memory inside a
+// dependent loop.  Same arithmetic and summation order in every mode.
+template <int MODE>
 __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __restrict__ qkv, const float* __restrict__ te0, const float* __restrict__ te1,
                                                    int64_t ldt, const float* __restrict__ alpha, const float* __restrict__ dout, float* __restrict__ dqkv,
-                                                   float* __restrict__ dte0, float* __restrict__ dte1, int te_tanh) {
-  __shared__ float dl[812 * 16];      // d alpha, then d logit (the 64 kB static LDS limit leaves no room for a copy of alpha)
+                                                   float* __restrict__ dte0, float* __restrict__ dte1, int te_tanh, float* __restrict__ dlg) {
+  extern __shared__ __attribute__((aligned(16))) float attn_smem[];
+  float* dl = attn_smem;                  // [812 * 16] d alpha, then d logit
+  float* al = attn_smem + 812 * 16;       // [812 * 16] alpha of this molecule
   __shared__ unsigned char pa[406], pb[406];
   const int m = blockIdx.x;
   const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
-  const float* __restrict__ al = alpha + (int64_t)2 * p0 * 16;
+  const int tid0 = threadIdx.x + (MODE == 2 ? 1024 * blockIdx.y : 0), tstep = 1024 * (MODE == 2 ? gridDim.y : 1);
   fill_pair_tables(n, pa, pb);
+  for (int it = threadIdx.x; it < np * 32; it += blockDim.x) al[it] = alpha[(int64_t)2 * p0 * 16 + it];
+  if (MODE == 2)
+    for (int it = threadIdx.x; it < np * 32; it += blockDim.x) dl[it] = dlg[(int64_t)2 * p0 * 16 + it];
   __syncthreads();
+  if (MODE != 2) {
   // d alpha[d, hd] = sum_c dout[tgt, hd, c] v[src, hd, c] te1[p, hd, c]
   for (int it = threadIdx.x; it < np * 32; it += blockDim.x) {
     const int d = it >> 4, hd = it & 15, p = d >> 1, dir = d & 1;
@@ -511,24 +523,23 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
     dl[it] = s;
   }
   __syncthreads();
-  // softmax backward per (target, head): dlogit = alpha (dalpha - sum alpha dalpha)
+  // softmax backward per (target, head): dlogit = alpha (dalpha - sum alpha dalpha); sources below / above the target as two ranges
   for (int it = threadIdx.x; it < n * 16; it += blockDim.x) {
     const int t = it >> 4, hd = it & 15;
     float dot = 0.0f;
-    for (int s = 0; s < n; ++s) {
-      if (s == t) continue;
-      const int d = s < t ? 2 * pair_index(n, s, t) : 2 * pair_index(n, t, s) + 1;
-      dot += al[d * 16 + hd] * dl[d * 16 + hd];
-    }
-    for (int s = 0; s < n; ++s) {
-      if (s == t) continue;
-      const int d = s < t ? 2 * pair_index(n, s, t) : 2 * pair_index(n, t, s) + 1;
-      dl[d * 16 + hd] = al[d * 16 + hd] * (dl[d * 16 + hd] - dot);
-    }
+    for (int s = 0; s < t; ++s) { const int d = 2 * pair_index(n, s, t); dot += al[d * 16 + hd] * dl[d * 16 + hd]; }
+    for (int s = t + 1; s < n; ++s) { const int d = 2 * pair_index(n, t, s) + 1; dot += al[d * 16 + hd] * dl[d * 16 + hd]; }
+    for (int s = 0; s < t; ++s) { const int d = 2 * pair_index(n, s, t); dl[d * 16 + hd] = al[d * 16 + hd] * (dl[d * 16 + hd] - dot); }
+    for (int s = t + 1; s < n; ++s) { const int d = 2 * pair_index(n, t, s) + 1; dl[d * 16 + hd] = al[d * 16 + hd] * (dl[d * 16 + hd] - dot); }
   }
   __syncthreads();
+  if (MODE == 1) {
+    for (int it = threadIdx.x; it < np * 32; it += blockDim.x) dlg[(int64_t)2 * p0 * 16 + it] = dl[it];
+    return;
+  }
+  }   // MODE != 2
   // node-side gradients: thread per (node, four columns of the 768-wide q|k|v row) - 16-byte accesses, a quarter of the index arithmetic
-  for (int it = threadIdx.x; it < n * 192; it += blockDim.x) {
+  for (int it = tid0; it < n * 192; it += tstep) {
     const int i = it / 192, col = (it % 192) * 4;
     f4_t s = {0.0f, 0.0f, 0.0f, 0.0f};
     if (col < 252) {                                   // dq[i]: i is the target (252 = 4 * 63: a quad never straddles the padding)
@@ -583,7 +594,7 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
     st4(dqkv + (int64_t)(n0 + i) * 768 + col, s);
   }
   // pair-side gradients (both directions of a pair), four columns per thread
-  for (int it = threadIdx.x; it < np * 64; it += blockDim.x) {
+  for (int it = tid0; it < np * 64; it += tstep) {
     const int p = it >> 6, col = (it & 63) * 4;
     const int a = pa[p], b = pb[p];
     {
@@ -1525,9 +1536,23 @@ int dst_attn_fwd(const dst_layout* L, const float* qkv, const float* te0, const 
   return DST_CHECK_LAUNCH();
 }
 int dst_attn_bwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, int64_t ld_te, const float* alpha, const float* dout,
-                 float* dqkv, float* dte0, float* dte1, int32_t te_is_tanh, void* stream) {
+                 float* dqkv, float* dte0, float* dte1, int32_t te_is_tanh, float* scratch, int64_t scratch_cap, void* stream) {
   if (!DST_L_OK(L) || !qkv || !te0 || !te1 || ld_te < 256 || !alpha || !dout || !dqkv || !dte0 || !dte1) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_attn_bwd, dim3(L->B), dim3(1024), 0, (hipStream_t)stream, *L, qkv, te0, te1, ld_te, alpha, dout, dqkv, dte0, dte1, (int)te_is_tanh);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)2 * 812 * 16 * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_bwd<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_bwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_bwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  if (scratch && scratch_cap >= (int64_t)2 * L->Pp * 16 && L->Pp > 0) {
+    hipLaunchKernelGGL(k_attn_bwd<1>, dim3(L->B), dim3(1024), lds, s, *L, qkv, te0, te1, ld_te, alpha, dout, dqkv, dte0, dte1, (int)te_is_tanh, scratch);
+    hipLaunchKernelGGL(k_attn_bwd<2>, dim3(L->B, 4), dim3(1024), lds, s, *L, qkv, te0, te1, ld_te, alpha, dout, dqkv, dte0, dte1, (int)te_is_tanh, scratch);
+  } else {
+    hipLaunchKernelGGL(k_attn_bwd<0>, dim3(L->B), dim3(1024), lds, s, *L, qkv, te0, te1, ld_te, alpha, dout, dqkv, dte0, dte1, (int)te_is_tanh, (float*)nullptr);
+  }
   return DST_CHECK_LAUNCH();
 }
 

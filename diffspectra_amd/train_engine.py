@@ -737,7 +737,8 @@ class DmtTrainGraph:
             dqkv, dte = self.f(Nn, 768), self.f(Pp, 512)
             te = bt["te"]
             E._check(lib.dst_attn_bwd(C.byref(TL.c), E._ptr(bt["qkv"]), E._ptr(te[:, 0:256]), E._ptr(te[:, 256:512]), C.c_int64(512), E._ptr(bt["alpha"]),
-                                      E._ptr(dattn), E._ptr(dqkv), E._ptr(dte[:, 0:256]), E._ptr(dte[:, 256:512]), C.c_int32(1), s()), "dst_attn_bwd")
+                                      E._ptr(dattn), E._ptr(dqkv), E._ptr(dte[:, 0:256]), E._ptr(dte[:, 256:512]), C.c_int32(1), E._ptr(o.scratch),
+                                      C.c_int64(o.scratch.numel()), s()), "dst_attn_bwd")
             with sec():                                                              # (waits for dqkv) q | k | v and the adaLN modulate of the block input
                 dhn = self.f(Nn, 256)
                 o.lin_bwd_w(mv(dqkv), mv(bt["hn"]), mv(dcat["Wqkv"][i]), dcat["bqkv"][i])

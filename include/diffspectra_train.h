@@ -143,11 +143,12 @@ int dst_adj_bits(const float* cond_e, int64_t ld, const float* d2c, float edge_t
  * alpha [2*Pp,16] (row 2p: source a -> target b, row 2p+1: source b -> target a).  16 heads: 0,1 adjacency heads (0 -> -1e10),
  * 2..15 learned (18 channels, scale 1/sqrt(16)); softmax over the sources of a target with + 1e-16 in the denominator.
  * Backward: dqkv [Nn,768], dte0 [Pp,256], dte1 [Pp,256] are written (not accumulated); te_is_tanh != 0: te0 / te1 are tanh outputs and
- * dte0 / dte1 come back as the gradients in FRONT of the tanh (times 1 - te^2), which is what the lin_edge products need. */
+ * dte0 / dte1 come back as the gradients in FRONT of the tanh (times 1 - te^2), which is what the lin_edge products need.  scratch
+ * (optional, >= 32 Pp floats): with it the backward runs as two launches, the second with four workgroups per molecule. */
 int dst_attn_fwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, int64_t ld_te, const int32_t* adj, float* out,
                  float* alpha, void* stream);
 int dst_attn_bwd(const dst_layout* L, const float* qkv, const float* te0, const float* te1, int64_t ld_te, const float* alpha, const float* dout,
-                 float* dqkv, float* dte0, float* dte1, int32_t te_is_tanh, void* stream);
+                 float* dqkv, float* dte0, float* dte1, int32_t te_is_tanh, float* scratch, int64_t scratch_cap, void* stream);
 
 /* s[p] = u[a] + u[b] (+ bias[c]) over C columns; backward du[i] (accumulate != 0 adds) = sum over the pairs of atom i of ds[p]. */
 int dst_pair_sum_fwd(const dst_layout* L, const float* u, int32_t C, const float* bias, float* s, void* stream);

@@ -363,10 +363,21 @@ def test_attention(ops, gpu_device):
     check(outd, out, 3e-6, "attention out")
     dq, de0, de1 = torch.empty(Nn, 768, device=d), torch.empty(P, 256, device=d), torch.empty(P, 256, device=d)
     E._check(o.lib.dst_attn_bwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), C.c_int64(256), E._ptr(ald), E._ptr(dout.to(d)), E._ptr(dq), E._ptr(de0), E._ptr(de1),
-                                C.c_int32(0), E._stream()), "attn_bwd")
+                                C.c_int32(0), None, C.c_int64(0), E._stream()), "attn_bwd")
     check(dq, qr.grad, 2e-5, "attention dqkv")
     check(de0, e0r.grad, 2e-5, "attention dte0")
     check(de1, e1r.grad, 2e-5, "attention dte1")
+    # with scratch the same backward runs as two launches (d logit through global memory, four workgroups per molecule for the gradients):
+    # same arithmetic, same summation order -> the same bits; te_is_tanh multiplies the pair gradients by 1 - te^2
+    dq2, de02, de12 = torch.zeros_like(dq), torch.zeros_like(de0), torch.zeros_like(de1)
+    scr = torch.empty(32 * P + 64, device=d)
+    E._check(o.lib.dst_attn_bwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), C.c_int64(256), E._ptr(ald), E._ptr(dout.to(d)), E._ptr(dq2), E._ptr(de02),
+                                E._ptr(de12), C.c_int32(0), E._ptr(scr), C.c_int64(scr.numel()), E._stream()), "attn_bwd")
+    assert torch.equal(dq2, dq) and torch.equal(de02, de0) and torch.equal(de12, de1)
+    E._check(o.lib.dst_attn_bwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), C.c_int64(256), E._ptr(ald), E._ptr(dout.to(d)), E._ptr(dq2), E._ptr(de02),
+                                E._ptr(de12), C.c_int32(1), E._ptr(scr), C.c_int64(scr.numel()), E._stream()), "attn_bwd")
+    check(de02, de0.double().cpu() * (1 - te0.double() ** 2), 1e-6, "attention dte0 in front of the tanh")
+    check(de12, de1.double().cpu() * (1 - te1.double() ** 2), 1e-6, "attention dte1 in front of the tanh")
 
 
 # ------------------------------------------------------------------------------------------------ gathers + coordinates

@@ -496,13 +496,17 @@ __global__ __launch_bounds__(1024) void k_attn_bwd(dst_layout L, const float* __
                                                    float* __restrict__ dte0, float* __restrict__ dte1, int te_tanh, float* __restrict__ dlg) {
   extern __shared__ __attribute__((aligned(16))) float attn_smem[];
   float* dl = attn_smem;                  // [812 * 16] d alpha, then d logit
-  float* al = attn_smem + 812 * 16;       // [812 * 16] alpha of this molecule
+  // alpha of this molecule: an LDS copy where the softmax backward walks it (MODE 0, 1); the gradient phases use each value once, so MODE 2
+  // reads it in place and keeps its LDS at 52 kB (three workgroups per CU instead of one)
+  float* als = attn_smem + 812 * 16;
+  const float* __restrict__ al = MODE == 2 ? alpha + (int64_t)2 * L.pair_off[blockIdx.x] * 16 : als;
   __shared__ unsigned char pa[406], pb[406];
   const int m = blockIdx.x;
   const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
   const int tid0 = threadIdx.x + (MODE == 2 ? 1024 * blockIdx.y : 0), tstep = 1024 * (MODE == 2 ? gridDim.y : 1);
   fill_pair_tables(n, pa, pb);
-  for (int it = threadIdx.x; it < np * 32; it += blockDim.x) al[it] = alpha[(int64_t)2 * p0 * 16 + it];
+  if (MODE != 2)
+    for (int it = threadIdx.x; it < np * 32; it += blockDim.x) als[it] = alpha[(int64_t)2 * p0 * 16 + it];
   if (MODE == 2)
     for (int it = threadIdx.x; it < np * 32; it += blockDim.x) dl[it] = dlg[(int64_t)2 * p0 * 16 + it];
   __syncthreads();
@@ -1549,7 +1553,7 @@ int dst_attn_bwd(const dst_layout* L, const float* qkv, const float* te0, const 
   }
   if (scratch && scratch_cap >= (int64_t)2 * L->Pp * 16 && L->Pp > 0) {
     hipLaunchKernelGGL(k_attn_bwd<1>, dim3(L->B), dim3(1024), lds, s, *L, qkv, te0, te1, ld_te, alpha, dout, dqkv, dte0, dte1, (int)te_is_tanh, scratch);
-    hipLaunchKernelGGL(k_attn_bwd<2>, dim3(L->B, 4), dim3(1024), lds, s, *L, qkv, te0, te1, ld_te, alpha, dout, dqkv, dte0, dte1, (int)te_is_tanh, scratch);
+    hipLaunchKernelGGL(k_attn_bwd<2>, dim3(L->B, 4), dim3(1024), lds / 2, s, *L, qkv, te0, te1, ld_te, alpha, dout, dqkv, dte0, dte1, (int)te_is_tanh, scratch);
   } else {
     hipLaunchKernelGGL(k_attn_bwd<0>, dim3(L->B), dim3(1024), lds, s, *L, qkv, te0, te1, ld_te, alpha, dout, dqkv, dte0, dte1, (int)te_is_tanh, (float*)nullptr);
   }

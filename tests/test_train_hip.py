@@ -1094,3 +1094,62 @@ def test_training_from_processed_file_end_to_end(gpu_device, tmp_path):
                                                        aug_translation=False, device=d))))
     assert math.isfinite(float(val)) and not val.requires_grad                      # EMA weights, eval mode, no gradient (losses.py:117-122)
     print(f"[train from file] losses {losses}, eval-mode EMA loss {float(val):.4f}")
+
+
+def test_training_step_is_bit_reproducible_across_stream_modes(gpu_device, monkeypatch):
+    """The three-stream step (main / node rows / weight gradients) against itself and against the single-stream order, on a batch large
+    enough for the streams to overlap (96 molecules, all-spectra, dropout 0.1, bf16, self-conditioning forward taken): every kernel reduces
+    in a fixed order, so loss and all gradients must agree BIT FOR BIT - a missing cross-stream dependency shows up here as a difference."""
+    import random as _random
+    from diffspectra_amd import filler, losses as Lh
+    from diffspectra_amd.config import qm9s_config
+    from diffspectra_amd.noise_schedule import NoiseScheduleVP
+    from diffspectra_amd.registry import create_model
+    d = gpu_device
+    cfg = qm9s_config("allspectra", device=d)
+    cfg.training.precision = "bf16"
+    model = create_model(cfg)
+    filler.fill_module_(model)
+    Bt = 96
+    n_atoms = filler.sample_n_atoms(Bt, seed=3).tolist()
+    node_mask, edge_mask = filler.masks_from_n_atoms(n_atoms)
+    N = node_mask.shape[1]
+    g = torch.Generator().manual_seed(11)
+    types = torch.randint(0, 5, (Bt, N), generator=g)
+    order = torch.triu((torch.rand(Bt, N, N, generator=g) > 0.8).float() * torch.randint(1, 4, (Bt, N, N), generator=g), 1)
+    order = (order + order.transpose(1, 2)) * edge_mask.reshape(Bt, N, N)
+    ctx = filler.synthetic_spectra(Bt, "allspectra", seed=5)
+    batch = dict(positions=(torch.randn(Bt, N, 3, generator=g) * 1.3 * node_mask).to(d), atom_mask=node_mask.squeeze(-1).to(d),
+                 edge_mask=edge_mask.to(d), atom_one_hot=(F.one_hot(types, 5).float() * node_mask).to(d),
+                 edge_one_hot=torch.stack([(order > 0).float(), order / 3.0], -1).to(d), formal_charges=torch.zeros(Bt, N, 1, device=d),
+                 context=[c.to(d) for c in ctx])
+    loss_fn = Lh.get_sde_graph_loss_fn(NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0), True, None, cfg)
+    params = [p for p in model.parameters() if p.requires_grad]
+    bn = [b for n_, b in model.named_buffers() if "running" in n_]
+    bn0 = [b.detach().clone() for b in bn]
+
+    def run():
+        for b, b0 in zip(bn, bn0):
+            b.copy_(b0)
+        for p in params:
+            p.grad = None
+        torch.manual_seed(123)
+        _random.seed(7)
+        monkeypatch.setattr(Lh, "random", lambda: 0.0)                       # the self-conditioning forward is taken
+        try:
+            loss = loss_fn(model, batch)
+            loss.backward()
+        finally:
+            monkeypatch.undo()
+        torch.cuda.synchronize()
+        return float(loss.detach()), torch.cat([p.grad.reshape(-1) for p in params]).clone()
+
+    l0, g0 = run()
+    assert math.isfinite(l0) and bool(torch.isfinite(g0).all())
+    for rep in range(3):
+        l1, g1 = run()
+        assert l1 == l0 and torch.equal(g1, g0), f"three-stream step differs from itself in repetition {rep}"
+    monkeypatch.setenv("DIFFSPECTRA_NODE_STREAM", "0")
+    monkeypatch.setenv("DIFFSPECTRA_ASYNC_DW", "0")
+    l2, g2 = run()
+    assert l2 == l0 and torch.equal(g2, g0), "single-stream order gives different bits"

@@ -61,6 +61,40 @@ __device__ __forceinline__ void epi_fused(const dst_gemm_args& g, int row, int c
   if (g.accumulate) v += *c;
   *c = v;
 }
+// Four consecutive columns (col % 4 == 0, all inside N) at once: 16-byte accesses and ONE Philox block for the four masks (the scalar form
+// runs the ten rounds once per element).  dst_gemm sets g._pad when every pointer and stride of the epilogue allows it.
+__device__ __forceinline__ void epi_fused4(const dst_gemm_args& g, int row, int col, f32x4_t v) {
+  if (g.dact) {
+    const f32x4_t r = *reinterpret_cast<const f32x4_t*>(g.ref + (int64_t)row * g.ldref + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= dst::act_deriv(r[e], g.dact);
+  }
+  f32x4_t keep = {1.0f, 1.0f, 1.0f, 1.0f};
+  if (g.drop_p > 0.0f) {
+    unsigned int c[4];
+    dst::dropout_block(g.drop_seed, g.drop_stream, ((int64_t)row * g.drop_ld + col) >> 2, c);
+    const unsigned int thr = dst::dropout_threshold(g.drop_p);
+    const float inv = 1.0f / (1.0f - g.drop_p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) keep[e] = c[e] >= thr ? inv : 0.0f;
+  }
+  f32x4_t* cp = reinterpret_cast<f32x4_t*>(g.C + (int64_t)row * g.ldc + col);
+  if (g.act) {
+    if (g.C2) {
+      *cp = v;
+      f32x4_t w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = dst::act_apply(v[e], g.act) * keep[e];
+      *reinterpret_cast<f32x4_t*>(g.C2 + (int64_t)row * g.ldc2 + col) = w;
+      return;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = dst::act_apply(v[e], g.act);
+  }
+  v = v * keep;
+  if (g.accumulate) v = v + *cp;
+  *cp = v;
+}
 __device__ __forceinline__ void epi_plain(const dst_gemm_args& g, int row, int col, float acc) {
   if (col == g.N) {
     g.rowsum[row] = g.accumulate ? g.rowsum[row] + acc : acc;
@@ -71,7 +105,7 @@ __device__ __forceinline__ void epi_plain(const dst_gemm_args& g, int row, int c
   *c = g.accumulate ? v + *c : v;
 }
 
-constexpr int STAGE_LD = 33;                                   // floats per row of a wave's 32 x 32 staging tile
+constexpr int STAGE_LD = 36;                                   // floats per row of a wave's 32 x 32 staging tile (16-byte rows for the vector epilogue)
 constexpr int STAGE_BYTES = 4 * 32 * STAGE_LD * 4;             // four waves
 
 // The wave's TM x TN accumulator tiles (32 x 32 each; rows rbase + 32 i, columns cbase + 32 j) -> memory: slice z's fp32 slab when
@@ -111,6 +145,18 @@ __device__ __forceinline__ void finish_tiles(const dst_gemm_args& g, f32x16_t (&
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[((r >> 2) * 8 + (lane >> 5) * 4 + (r & 3)) * STAGE_LD + (lane & 31)] = sel[r];
     const int ti = t / TN, tj = t % TN;
+    if (g._pad) {                                                             // vector form: a lane takes four columns of rows lr, lr + 8, lr + 16, lr + 24
+      const int c4 = 4 * (lane & 7), col4 = cbase + tj * 32 + c4;
+      f32x4_t b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (g.bias && col4 < g.N) b4 = *reinterpret_cast<const f32x4_t*>(g.bias + col4);
+#pragma unroll 2
+      for (int e = 0; e < 4; ++e) {
+        const int lr = 8 * e + (lane >> 3), row = rbase + ti * 32 + lr;
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(st + lr * STAGE_LD + c4);
+        if (row < g.M && col4 < g.N) epi_fused4(g, row, col4, a + b4);
+      }
+      continue;
+    }
     const int col = cbase + tj * 32 + (lane & 31);
 #pragma unroll 4
     for (int e = 0; e < 16; ++e) {                                            // four elements in flight: the loop is latency-bound (LDS read, ref load, stores)
@@ -563,6 +609,14 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   if (a->M == 0 || (a->N == 0 && !a->rowsum)) return DS_OK;
   hipStream_t s = (hipStream_t)stream;
   dst_gemm_args g = *a;
+  {   // vector epilogue (epi_fused4): every pointer of the fused epilogue 16-byte aligned, every stride and N a multiple of 4, no fused row sum
+    static const bool vec_epi_on = env_int("DST_GEMM_VEC_EPI", 1) != 0;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool fused = g.act || g.dact || g.drop_p > 0.0f;
+    g._pad = fused && !g.rowsum && (g.N & 3) == 0 && (g.ldc & 3) == 0 && al16(g.C) && (!g.bias || al16(g.bias)) &&
+             (!g.ref || (al16(g.ref) && (g.ldref & 3) == 0)) && (!g.C2 || (al16(g.C2) && (g.ldc2 & 3) == 0)) &&
+             (!(g.drop_p > 0.0f) || (g.drop_ld & 3) == 0) && vec_epi_on;
+  }
   const int Nx = g.N + (g.rowsum ? 1 : 0);            // the fused row sum is one more (virtual, all-ones) column of B
   const bool bf = g.bf16 != 0;
   // the vector kernel needs every operand either k-contiguous or row-contiguous, 16-byte aligned with a leading stride of whole vec4s

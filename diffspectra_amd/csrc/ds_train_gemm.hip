@@ -116,7 +116,7 @@ __device__ __forceinline__ void finish_tiles(const dst_gemm_args& g, f32x16_t (&
   const int lane = threadIdx.x & 63;
   const int Nx = g.N + (g.rowsum ? 1 : 0);
   const bool fused = g.act || g.dact || g.drop_p > 0.0f;
-  if (splits > 1 || !fused) {
+  if (splits > 1 || (!fused && !(g._pad & 2))) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -145,7 +145,7 @@ __device__ __forceinline__ void finish_tiles(const dst_gemm_args& g, f32x16_t (&
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[((r >> 2) * 8 + (lane >> 5) * 4 + (r & 3)) * STAGE_LD + (lane & 31)] = sel[r];
     const int ti = t / TN, tj = t % TN;
-    if (g._pad) {                                                             // vector form: a lane takes four columns of rows lr, lr + 8, lr + 16, lr + 24
+    if (g._pad & 1) {                                                         // vector form: a lane takes four columns of rows lr, lr + 8, lr + 16, lr + 24
       const int c4 = 4 * (lane & 7), col4 = cbase + tj * 32 + c4;
       f32x4_t b4 = {0.0f, 0.0f, 0.0f, 0.0f};
       if (g.bias && col4 < g.N) b4 = *reinterpret_cast<const f32x4_t*>(g.bias + col4);
@@ -613,9 +613,13 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
     static const bool vec_epi_on = env_int("DST_GEMM_VEC_EPI", 1) != 0;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool fused = g.act || g.dact || g.drop_p > 0.0f;
-    g._pad = fused && !g.rowsum && (g.N & 3) == 0 && (g.ldc & 3) == 0 && al16(g.C) && (!g.bias || al16(g.bias)) &&
-             (!g.ref || (al16(g.ref) && (g.ldref & 3) == 0)) && (!g.C2 || (al16(g.C2) && (g.ldc2 & 3) == 0)) &&
-             (!(g.drop_p > 0.0f) || (g.drop_ld & 3) == 0) && vec_epi_on;
+    static const bool vec_plain_on = env_int("DST_GEMM_VEC_PLAIN", 1) != 0;
+    const bool ok = !g.rowsum && (g.N & 3) == 0 && (g.ldc & 3) == 0 && al16(g.C) && (!g.bias || al16(g.bias)) &&
+                    (!g.ref || (al16(g.ref) && (g.ldref & 3) == 0)) && (!g.C2 || (al16(g.C2) && (g.ldc2 & 3) == 0)) &&
+                    (!(g.drop_p > 0.0f) || (g.drop_ld & 3) == 0) && vec_epi_on;
+    // bit 0: the vector form of the staged epilogue; bit 1: a plain epilogue (bias / accumulate only) takes the staged vector form too
+    // (four 16-byte stores per tile and lane instead of sixteen 4-byte ones)
+    g._pad = ok ? (1 | ((!fused && vec_plain_on) ? 2 : 0)) : 0;
   }
   const int Nx = g.N + (g.rowsum ? 1 : 0);            // the fused row sum is one more (virtual, all-ones) column of B
   const bool bf = g.bf16 != 0;

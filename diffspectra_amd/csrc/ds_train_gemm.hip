@@ -585,6 +585,20 @@ __global__ __launch_bounds__(256) void k_tr_gemm_skinny(dst_gemm_args g) {
   else epi_plain(g, row, col, v);
 }
 
+// the same with four consecutive columns per thread (B rows contiguous along n, every epilogue operand 16-byte friendly: g._pad)
+__global__ __launch_bounds__(256) void k_tr_gemm_skinny4(dst_gemm_args g) {
+  const int n4 = g.N >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)g.M * n4) return;
+  const int row = (int)(i / n4), col = (int)(i - (int64_t)row * n4) << 2;
+  const float* a = g.A + (int64_t)row * g.a_rs;
+  const float* b = g.B + col;
+  f32x4_t v = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int k = 0; k < g.K; ++k) v = v + a[(int64_t)k * g.a_cs] * *reinterpret_cast<const f32x4_t*>(b + (int64_t)k * g.b_rs);
+  if (g.bias) v = v + *reinterpret_cast<const f32x4_t*>(g.bias + col);
+  epi_fused4(g, row, col, v);
+}
+
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -657,7 +671,10 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   }
   static const int skinny_off = env_int("DST_GEMM_SKINNY", 1) == 0;
   if (bf && !skinny_off && g.K <= 8 && g.M >= 1024 && !g.rowsum && g.N > 0) {       // (bf16 mode only: the fp32 mode keeps one summation order everywhere)
-    hipLaunchKernelGGL(k_tr_gemm_skinny, dim3((unsigned)(((int64_t)g.M * g.N + 255) / 256)), dim3(256), 0, s, g);
+    if ((g._pad & 1) && g.b_cs == 1 && (g.b_rs & 3) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0)
+      hipLaunchKernelGGL(k_tr_gemm_skinny4, dim3((unsigned)(((int64_t)g.M * (g.N >> 2) + 255) / 256)), dim3(256), 0, s, g);
+    else
+      hipLaunchKernelGGL(k_tr_gemm_skinny, dim3((unsigned)(((int64_t)g.M * g.N + 255) / 256)), dim3(256), 0, s, g);
     return DST_CHECK_LAUNCH();
   }
   static const int wide_off = env_int("DST_GEMM_WIDE", 1) == 0;

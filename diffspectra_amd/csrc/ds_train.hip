@@ -51,7 +51,18 @@ __global__ void k_colsum_final(const float* __restrict__ partial, int chunks, in
 __global__ __launch_bounds__(256) void k_sumsq_partial(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
   __shared__ float red[4];
   float s = 0.0f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+  if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {        // 16-byte loads, four independent partial sums per thread (the scalar grid-stride loop
+    const int64_t n4 = n >> 2;                             // was a chain of ~140 dependent 4-byte loads: 180 us for 37 MB)
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      s0 += v.x * v.x; s1 += v.y * v.y; s2 += v.z * v.z; s3 += v.w * v.w;
+    }
+    s = (s0 + s1) + (s2 + s3);
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) { const float t = x[(n4 << 2) + threadIdx.x]; s += t * t; }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -1393,6 +1404,35 @@ __global__ void k_clip_update(const float* __restrict__ norm_sq, float inv_world
   st[53] = (float)allowed;
 }
 
+// four parameters per thread, 16-byte accesses (same arithmetic per element)
+__global__ void k_adamw_ema4(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m, float4* __restrict__ v, float4* __restrict__ vmax,
+                             float4* __restrict__ ema, int64_t n4, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2,
+                             float clip, const float* __restrict__ clip_dev, float ema_omd) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float cl = clip_dev ? clip * clip_dev[0] : clip;
+  const float4 G = g[i];
+  float4 W = p[i], M = m[i], V = v[i], X = vmax[i], S = ema ? ema[i] : W;
+  float* w = &W.x; float* mm = &M.x; float* vv = &V.x; float* xx = &X.x; float* ss = &S.x;
+  const float* gg = &G.x;
+  const float sq2 = sqrtf(bc2);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float grad = gg[e] * cl;
+    float wv = w[e] * (1.0f - lr * wd);
+    const float mi = beta1 * mm[e] + (1.0f - beta1) * grad;
+    const float vi = beta2 * vv[e] + (1.0f - beta2) * grad * grad;
+    const float vm = fmaxf(xx[e], vi);
+    mm[e] = mi; vv[e] = vi; xx[e] = vm;
+    const float denom = sqrtf(vm) / sq2 + eps;
+    wv -= (lr / bc1) * (mi / denom);
+    w[e] = wv;
+    ss[e] = ss[e] - ema_omd * (ss[e] - wv);
+  }
+  p[i] = W; m[i] = M; v[i] = V; vmax[i] = X;
+  if (ema) ema[i] = S;
+}
+
 inline dim3 grid1d(int64_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -1714,8 +1754,14 @@ int dst_adamw_ema(float* p, const float* g, float* m, float* v, float* vmax, flo
                   void* stream) {
   if (!p || !g || !m || !v || !vmax || n < 0) return DS_ERR_ARG;
   if (n == 0) return DS_OK;
-  hipLaunchKernelGGL(k_adamw_ema, grid1d(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, ema, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
-                     clip_coef, clip_coef_dev, ema_one_minus_decay);
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if ((n & 3) == 0 && al16(p) && al16(g) && al16(m) && al16(v) && al16(vmax) && (!ema || al16(ema)))
+    hipLaunchKernelGGL(k_adamw_ema4, grid1d(n >> 2), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(p), reinterpret_cast<const float4*>(g),
+                       reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v), reinterpret_cast<float4*>(vmax), reinterpret_cast<float4*>(ema), n >> 2, lr,
+                       beta1, beta2, eps, weight_decay, bc1, bc2, clip_coef, clip_coef_dev, ema_one_minus_decay);
+  else
+    hipLaunchKernelGGL(k_adamw_ema, grid1d(n), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, ema, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+                       clip_coef, clip_coef_dev, ema_one_minus_decay);
   return DST_CHECK_LAUNCH();
 }
 

@@ -331,7 +331,7 @@ int dst_spec_attn_flash_fwd(const float* qkv0, const float* qkv1, const float* q
 
 int dst_spec_attn_flash_bwd(const float* qkv0, const float* qkv1, const float* qkv2, int32_t n_layers, const float* stats, const float* out,
                             const float* dout, float* dqkv0, float* dqkv1, float* dqkv2, int32_t B, int32_t L, int32_t H, int32_t dk, float scale,
-                            void* stream) {
+                            int32_t part, void* stream) {
   if (n_layers < 1 || n_layers > 3 || !qkv0 || !dqkv0 || (n_layers > 1 && (!qkv1 || !dqkv1)) || (n_layers > 2 && (!qkv2 || !dqkv2)) || !stats || !out ||
       !dout || B <= 0 || L <= 0 || L > 512 || H * dk != DM || dk != DK)
     return DS_ERR_ARG;
@@ -342,8 +342,9 @@ int dst_spec_attn_flash_bwd(const float* qkv0, const float* qkv1, const float* q
   const size_t lds_q = (size_t)(LP * KLD + LP * DK + NT * 4 * 32 * 8) * 2;
   const size_t lds_kv = (size_t)(LP * KLD + NT * 4 * 32 * 8 + NT * 4 * DK * 8) * 2 + (size_t)3 * LP * 4;
   if (lds_kv > 64 * 1024) return DS_ERR_ARG;
-  hipLaunchKernelGGL(k_sfa_bwd_q, dim3(B * H), dim3(256), lds_q, s, q, (int)n_layers, stats, out, dout, g, (int)L, (int)H, scale);
-  hipLaunchKernelGGL(k_sfa_bwd_kv, dim3(B * H), dim3(256), lds_kv, s, q, (int)n_layers, stats, out, dout, g, (int)L, (int)H, scale);
+  if (part < 0 || part > 2) return DS_ERR_ARG;
+  if (part != 2) hipLaunchKernelGGL(k_sfa_bwd_q, dim3(B * H), dim3(256), lds_q, s, q, (int)n_layers, stats, out, dout, g, (int)L, (int)H, scale);
+  if (part != 1) hipLaunchKernelGGL(k_sfa_bwd_kv, dim3(B * H), dim3(256), lds_kv, s, q, (int)n_layers, stats, out, dout, g, (int)L, (int)H, scale);
   return DST_CHECK_LAUNCH();
 }
 

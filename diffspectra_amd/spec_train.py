@@ -145,6 +145,7 @@ class SpecTrainGraph:
         B, L = t["B"], self.L
         g: Dict[str, torch.Tensor] = {}
         o.async_dw = bool(int(os.environ.get("DIFFSPECTRA_ASYNC_DW", "1")))     # weight gradients on the side stream (train_engine.Ops.lin_bwd_w)
+        two_streams = bool(int(os.environ.get("DIFFSPECTRA_NODE_STREAM", "1"))) and getattr(o, "main_stream", None) is not None
 
         gbuf = getattr(self, "gbuf", None)
 
@@ -189,9 +190,17 @@ class SpecTrainGraph:
             if flash:
                 qp = [E._ptr(q_) for q_ in qkv_all[:l + 1]] + [None] * (2 - l)
                 gp = [E._ptr(q_) for q_ in dqkv_all[:l + 1]] + [None] * (2 - l)
-                E._check(self.lib.dst_spec_attn_flash_bwd(qp[0], qp[1], qp[2], C.c_int32(l + 1), E._ptr(lt["ast"]), E._ptr(lt["ao"]), E._ptr(dao), gp[0], gp[1], gp[2],
-                                                          C.c_int32(B), C.c_int32(L), C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), self.ops._s()),
-                         "dst_spec_attn_flash_bwd")
+                def flash_bwd(part):
+                    E._check(self.lib.dst_spec_attn_flash_bwd(qp[0], qp[1], qp[2], C.c_int32(l + 1), E._ptr(lt["ast"]), E._ptr(lt["ao"]), E._ptr(dao), gp[0], gp[1],
+                                                              gp[2], C.c_int32(B), C.c_int32(L), C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale),
+                                                              C.c_int32(part), self.ops._s()), "dst_spec_attn_flash_bwd")
+                if two_streams:                                        # the key side beside the query side (disjoint columns of dqkv): each kernel
+                    with o.node_section():                             # alone keeps two 4-wave workgroups on a CU
+                        flash_bwd(2)
+                    flash_bwd(1)
+                    o.main_wait()
+                else:
+                    flash_bwd(0)
                 dqkv, dscores = dqkv_all[l], None
             else:
                 dqkv, dscores = self.f(B * L, 3 * D_MODEL), self.f(B, N_HEADS, L, (L + 31) // 32 * 32)

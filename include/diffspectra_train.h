@@ -225,12 +225,13 @@ int dst_spec_attn_bwd(const float* qkv, const float* scores, const float* stats,
  * (qkv0 .. qkv2, n_layers = l + 1 of them; each [B*L, 3*H*dk]) flash-style: forward writes out [B*L, H*dk] and stats [B*H*L, 2] =
  * (row maximum of the log2-domain scores, row sum); backward re-creates the probabilities from them and ACCUMULATES layer l's softmax
  * gradient into the q and k columns of dqkv0 .. dqkv(l) (the gradient the reference chains through `prev`; the caller zeroes the
- * buffers once and runs the layers last to first) and writes the v columns of dqkv(l). */
+ * buffers once and runs the layers last to first) and writes the v columns of dqkv(l).  part: 0 = the whole backward; 1 = the query side
+ * (q columns) only, 2 = the key side (k and v columns) only - the two touch disjoint columns and may run on two streams. */
 int dst_spec_attn_flash_fwd(const float* qkv0, const float* qkv1, const float* qkv2, int32_t n_layers, float* stats, float* out, int32_t B,
                             int32_t L, int32_t H, int32_t dk, float scale, void* stream);
 int dst_spec_attn_flash_bwd(const float* qkv0, const float* qkv1, const float* qkv2, int32_t n_layers, const float* stats, const float* out,
                             const float* dout, float* dqkv0, float* dqkv1, float* dqkv2, int32_t B, int32_t L, int32_t H, int32_t dk, float scale,
-                            void* stream);
+                            int32_t part, void* stream);
 
 /* LayerNorm with affine over the last dimension (specformer.py:67,119), training form.  Backward: dx written, dgamma / dbeta
  * accumulated through per-row-block partials (fixed order). */

@@ -22,7 +22,7 @@ f = lambda *s: torch.empty(*s, dtype=torch.float32, device=d)
 ast, out = f(B, H, L, 2), f(B * L, DM)
 E._check(lib.dst_spec_attn_flash_fwd(E._ptr(qkv), None, None, C.c_int32(1), E._ptr(ast), E._ptr(out), C.c_int32(B), C.c_int32(L), C.c_int32(H), C.c_int32(DK), C.c_float(DK ** -0.5), E._stream()), "f")
 dq = torch.zeros(B * L, 384, device=d)
-E._check(lib.dst_spec_attn_flash_bwd(E._ptr(qkv), None, None, C.c_int32(1), E._ptr(ast), E._ptr(out), E._ptr(dao), E._ptr(dq), None, None, C.c_int32(B), C.c_int32(L), C.c_int32(H), C.c_int32(DK), C.c_float(DK ** -0.5), E._stream()), "b")
+E._check(lib.dst_spec_attn_flash_bwd(E._ptr(qkv), None, None, C.c_int32(1), E._ptr(ast), E._ptr(out), E._ptr(dao), E._ptr(dq), None, None, C.c_int32(B), C.c_int32(L), C.c_int32(H), C.c_int32(DK), C.c_float(DK ** -0.5), C.c_int32(0), E._stream()), "b")
 torch.cuda.synchronize()
 print("stats m,l row0:", ast[0, 0, 0].tolist(), " expected (0, L)")
 dv = dq[:, 256:264].cpu()      # head 0

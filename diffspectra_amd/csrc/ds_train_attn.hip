@@ -70,7 +70,10 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) {
 
 // ------------------------------------------------------------------------------------------------------------------ forward
 // out [B*L, 128] (head h at columns 8 h ..), stats [B*H*L, 2] = (row maximum of the log2-domain scores, row sum of exp2)
-__global__ __launch_bounds__(256) void k_sfa_fwd(QkvPtrs qkv, int nl, float* __restrict__ stats, float* __restrict__ out, int L, int H, float scale) {
+// (eight waves per workgroup for the forward and the query-side backward: the LDS tables of a (molecule, head) are per workgroup, so twice the
+// waves share them - 16 waves per CU instead of 8 - and the 11 query tiles split 2 / 1 over the waves instead of 3 / 2)
+constexpr int SFA_NT = 512, SFA_NW = SFA_NT / 64;
+__global__ __launch_bounds__(SFA_NT) void k_sfa_fwd(QkvPtrs qkv, int nl, float* __restrict__ stats, float* __restrict__ out, int L, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   const int NT = (L + 31) >> 5, LP = NT * 32;
   unsigned short* Kc = lds;                       // [LP][KLD]: concatenated key slices, row = key
@@ -78,20 +81,20 @@ __global__ __launch_bounds__(256) void k_sfa_fwd(QkvPtrs qkv, int nl, float* __r
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int64_t row0 = (int64_t)b * L;
-  for (int i = tid; i < LP * 4; i += 256) {       // (key, 8-wide chunk): layers 0 .. nl-1, the rest zero
+  for (int i = tid; i < LP * 4; i += SFA_NT) {       // (key, 8-wide chunk): layers 0 .. nl-1, the rest zero
     const int k = i >> 2, c = i & 3;
     bf16x8_t v = zero8();
     if (k < L && c < nl) v = load8(qkv.p[c] + (row0 + k) * ROWLD + DM + h * DK, 1.0f);
     *reinterpret_cast<bf16x8_t*>(Kc + k * KLD + 8 * c) = v;
   }
   const float* vsrc = qkv.p[nl - 1];
-  for (int i = tid; i < LP * DK; i += 256) {
+  for (int i = tid; i < LP * DK; i += SFA_NT) {
     const int k = i >> 3, d = i & 7;
     Vf[perm_index(k >> 5, k & 31, d, DK)] = k < L ? bf16_bits(vsrc[(row0 + k) * ROWLD + 2 * DM + h * DK + d]) : (unsigned short)0;
   }
   __syncthreads();
   const float qmul = scale * LOG2E;
-  for (int qt = wave; qt < NT; qt += 4) {
+  for (int qt = wave; qt < NT; qt += SFA_NW) {
     const int q = qt * 32 + r, qc = q < L ? q : L - 1;
     bf16x8_t qb[2];
     qb[0] = hh < nl ? load8(qkv.p[hh] + (row0 + qc) * ROWLD + h * DK, qmul) : zero8();
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void k_sfa_fwd(QkvPtrs qkv, int nl, float* __r
 
 // ------------------------------------------------------------------------------------------------------------------ backward, query side
 // dq_j[q] += scale * sum_k dS[q,k] k_j[k] for every layer j < nl, dS = P (dP - D), dP = dO V^T, D = dO . O
-__global__ __launch_bounds__(256) void k_sfa_bwd_q(QkvPtrs qkv, int nl, const float* __restrict__ stats, const float* __restrict__ out,
+__global__ __launch_bounds__(SFA_NT) void k_sfa_bwd_q(QkvPtrs qkv, int nl, const float* __restrict__ stats, const float* __restrict__ out,
                                                    const float* __restrict__ dout, GradPtrs dqkv, int L, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   const int NT = (L + 31) >> 5, LP = NT * 32;
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void k_sfa_bwd_q(QkvPtrs qkv, int nl, const fl
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int64_t row0 = (int64_t)b * L;
-  for (int i = tid; i < LP * 4; i += 256) {
+  for (int i = tid; i < LP * 4; i += SFA_NT) {
     const int k = i >> 2, c = i & 3;
     bf16x8_t v = zero8();
     if (k < L && c < nl) v = load8(qkv.p[c] + (row0 + k) * ROWLD + DM + h * DK, 1.0f);
@@ -161,11 +164,11 @@ __global__ __launch_bounds__(256) void k_sfa_bwd_q(QkvPtrs qkv, int nl, const fl
     for (int e = 0; e < 8; ++e) KTf[perm_index(k >> 5, k & 31, 8 * c + e, 32)] = vb_[e];
   }
   const float* vsrc = qkv.p[nl - 1];
-  for (int k = tid; k < LP; k += 256)
+  for (int k = tid; k < LP; k += SFA_NT)
     *reinterpret_cast<bf16x8_t*>(Vk + k * DK) = k < L ? load8(vsrc + (row0 + k) * ROWLD + 2 * DM + h * DK, 1.0f) : zero8();
   __syncthreads();
   const float qmul = scale * LOG2E;
-  for (int qt = wave; qt < NT; qt += 4) {
+  for (int qt = wave; qt < NT; qt += SFA_NW) {
     const int q = qt * 32 + r, qc = q < L ? q : L - 1;
     bf16x8_t qb[2];
     qb[0] = hh < nl ? load8(qkv.p[hh] + (row0 + qc) * ROWLD + h * DK, qmul) : zero8();
@@ -325,7 +328,7 @@ int dst_spec_attn_flash_fwd(const float* qkv0, const float* qkv1, const float* q
   const int NT = (L + 31) / 32, LP = NT * 32;
   const size_t lds = (size_t)(LP * KLD + NT * 4 * DK * 8) * 2;
   QkvPtrs q{{qkv0, qkv1, qkv2}};
-  hipLaunchKernelGGL(k_sfa_fwd, dim3(B * H), dim3(256), lds, (hipStream_t)stream, q, (int)n_layers, stats, out, (int)L, (int)H, scale);
+  hipLaunchKernelGGL(k_sfa_fwd, dim3(B * H), dim3(SFA_NT), lds, (hipStream_t)stream, q, (int)n_layers, stats, out, (int)L, (int)H, scale);
   return DST_CHECK_LAUNCH();
 }
 
@@ -343,7 +346,7 @@ int dst_spec_attn_flash_bwd(const float* qkv0, const float* qkv1, const float* q
   const size_t lds_kv = (size_t)(LP * KLD + NT * 4 * 32 * 8 + NT * 4 * DK * 8) * 2 + (size_t)3 * LP * 4;
   if (lds_kv > 64 * 1024) return DS_ERR_ARG;
   if (part < 0 || part > 2) return DS_ERR_ARG;
-  if (part != 2) hipLaunchKernelGGL(k_sfa_bwd_q, dim3(B * H), dim3(256), lds_q, s, q, (int)n_layers, stats, out, dout, g, (int)L, (int)H, scale);
+  if (part != 2) hipLaunchKernelGGL(k_sfa_bwd_q, dim3(B * H), dim3(SFA_NT), lds_q, s, q, (int)n_layers, stats, out, dout, g, (int)L, (int)H, scale);
   if (part != 1) hipLaunchKernelGGL(k_sfa_bwd_kv, dim3(B * H), dim3(256), lds_kv, s, q, (int)n_layers, stats, out, dout, g, (int)L, (int)H, scale);
   return DST_CHECK_LAUNCH();
 }

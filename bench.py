@@ -41,6 +41,7 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (155 measured)
 PEAK_F16_MFMA_TFLOPS = 2516.6      # dense f16/bf16 MFMA peak (16x the fp32 MFMA rate; MI355X_MICROARCH.md "~2.5 PF dense")
+PEAK_HBM_GBPS = 8000.0            # HBM3E (MI355X_MICROARCH.md: ~8 TB/s)
 SPLIT_MFMAS_PER_PRODUCT = 3        # split-fp16 arithmetic: a*b = a1*b1 + (a1*b2 + a2*b1)/2048 -> three f16 MFMAs per fp32-accurate product
 PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / SPLIT_MFMAS_PER_PRODUCT   # ceiling of an fp32-accurate GEMM on the f16 matrix pipe
 EQUI_MACS_PER_DIRECTED_EDGE = 256 * 256 + 256 * 3   # coord_mlp.0 + coord_mlp.2 (SURVEY §8d constants)
@@ -422,19 +423,21 @@ def train_measure(args, world, rank, device, steps, warmup, with_cpu_baseline):
         e0.record()
         orig_gemm(self, A, Bm, Cm, ta, tb, **kw)
         e1.record()
-        recs.append((e0, e1, 2.0 * M * Cm.cols * K, (M, Cm.cols, K, int(ta), int(tb))))
+        recs.append((e0, e1, 2.0 * M * Cm.cols * K, (M, Cm.cols, K, int(ta), int(tb)), 4.0 * (M * K + K * Cm.cols + M * Cm.cols)))
     TE.Ops.gemm = timed_gemm
-    prev_async = os.environ.get("DIFFSPECTRA_ASYNC_DW")
-    os.environ["DIFFSPECTRA_ASYNC_DW"] = "0"          # one stream for this instrumented step: an event pair then brackets exactly one product
-    try:
+    prev = {k: os.environ.get(k) for k in ("DIFFSPECTRA_ASYNC_DW", "DIFFSPECTRA_NODE_STREAM")}
+    for k in prev:
+        os.environ[k] = "0"                          # one stream for this instrumented step: an event pair (recorded on torch's current
+    try:                                             # stream) then brackets exactly one product
         step_fn(state, batch)
         sync()
     finally:
         TE.Ops.gemm = orig_gemm
-        if prev_async is None:
-            os.environ.pop("DIFFSPECTRA_ASYNC_DW", None)
-        else:
-            os.environ["DIFFSPECTRA_ASYNC_DW"] = prev_async
+        for k, v in prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     if rank == 0:
         n = np.asarray(n_atoms, dtype=np.int64)
         flop = 3.0 * 2.0 * algorithmic_macs(n)                        # forward + two backward GEMMs per forward GEMM (self-cond forward not counted)
@@ -452,7 +455,7 @@ def train_measure(args, world, rank, device, steps, warmup, with_cpu_baseline):
         gemm_flop = sum(r[2] for r in recs)
         if os.environ.get("DIFFSPECTRA_GEMM_TABLE") == "1":             # per-shape totals of the step's GEMM calls, on stderr
             table = {}
-            for e0, e1, f, shape in recs:
+            for e0, e1, f, shape, _ in recs:
                 t = table.setdefault(shape, [0, 0.0, 0.0])
                 t[0] += 1
                 t[1] += e0.elapsed_time(e1)
@@ -468,8 +471,13 @@ def train_measure(args, world, rank, device, steps, warmup, with_cpu_baseline):
                                          "and bound by launch latency and their operand streams, not by the matrix pipe",
                             "traffic": None, "launches_timed": len(recs), "avg_launch_ms": gemm_ms / max(1, len(recs)),
                             "share_of_step": gemm_ms / (elapsed / steps * 1e3), "algorithmic_flop_per_step": gemm_flop,
-                            "note": "timed in one extra step with the weight-gradient products on the main stream (in the timed steps they run "
-                                    "concurrently on a side stream, so this share is an upper bound of their part of the step)"}
+                            # the bound these products actually have: their fp32 operands read once and their output written once
+                            "hbm_view": {"algorithmic_bytes_per_step": sum(r[4] for r in recs),
+                                         "achieved_GBps": sum(r[4] for r in recs) / (gemm_ms * 1e-3) / 1e9 if gemm_ms > 0 else None,
+                                         "peak_GBps": PEAK_HBM_GBPS,
+                                         "frac": sum(r[4] for r in recs) / (gemm_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS if gemm_ms > 0 else None},
+                            "note": "timed in one extra single-stream step (in the timed steps the weight-gradient products and the node-row chain run "
+                                    "concurrently on their own streams, so this share is an upper bound of their part of the step)"}
         if with_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline_train(args.spectra)

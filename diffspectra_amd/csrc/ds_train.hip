@@ -210,10 +210,21 @@ __global__ __launch_bounds__(1024) void k_lnmod_bwd(const float* __restrict__ dy
   const int r0 = seg_off[m] * seg_mul, r1 = seg_off[m + 1] * seg_mul;
   const f4_t sc1 = ld4(ada + (int64_t)m * ada_ld + scale_off + cl) + 1.0f;
   f4_t dsh = {0.0f, 0.0f, 0.0f, 0.0f}, dsc = {0.0f, 0.0f, 0.0f, 0.0f};
-  for (int r = r0 + (blockIdx.y * MOLW + wave) * RPW + sub; r < r1; r += gridDim.y * MOLW * RPW) {
-    const float mean = stats[(int64_t)r * 2], rstd = stats[(int64_t)r * 2 + 1];
-    const f4_t g = ld4(dy + (int64_t)r * C + cl);
-    const f4_t xh = (ld4(x + (int64_t)r * C + cl) - mean) * rstd;
+  // the next row's operands are requested (from a clamped row index) before this row is worked on: one row per wave and pass is a chain of
+  // dependent round trips otherwise
+  const int rstep = gridDim.y * MOLW * RPW;
+  int r = r0 + (blockIdx.y * MOLW + wave) * RPW + sub;
+  int rc = min(r, r1 - 1);
+  float mean_n = 0.0f, rstd_n = 0.0f;
+  f4_t g_n = {0.0f, 0.0f, 0.0f, 0.0f}, x_n = g_n;
+  if (r1 > r0) { mean_n = stats[(int64_t)rc * 2]; rstd_n = stats[(int64_t)rc * 2 + 1]; g_n = ld4(dy + (int64_t)rc * C + cl); x_n = ld4(x + (int64_t)rc * C + cl); }
+  for (; r < r1; r += rstep) {
+    const float mean = mean_n, rstd = rstd_n;
+    const f4_t g = g_n;
+    const f4_t xh = (x_n - mean) * rstd;
+    rc = min(r + rstep, r1 - 1);
+    mean_n = stats[(int64_t)rc * 2]; rstd_n = stats[(int64_t)rc * 2 + 1];
+    g_n = ld4(dy + (int64_t)rc * C + cl); x_n = ld4(x + (int64_t)rc * C + cl);
     dsh += g;
     dsc += g * xh;
     const f4_t gg = g * sc1, gx = gg * xh;

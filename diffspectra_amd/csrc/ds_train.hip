@@ -1523,7 +1523,7 @@ int dst_lnmod_fwd(const float* x, int32_t C, const int32_t* seg_off, int32_t seg
                   int32_t shift_off, int32_t scale_off, float* y, float* stats, void* stream) {
   if (!x || !seg_off || !ada || !y || !stats || (C != 64 && C != 256) || B <= 0) return DS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int splits = (C == 256 && seg_mul >= 2) ? 4 : 1;                 // the directed rows: hundreds of 256-wide rows per molecule
+  const int splits = (C == 256 && seg_mul >= 2) ? 8 : 1;                 // the directed rows: hundreds of 256-wide rows per molecule
   if (C == 64) hipLaunchKernelGGL(k_lnmod_fwd<64>, dim3(B), dim3(1024), 0, s, x, seg_off, (int)seg_mul, ada, ada_ld, (int)shift_off, (int)scale_off, y, stats);
   else hipLaunchKernelGGL(k_lnmod_fwd<256>, dim3(B, splits), dim3(1024), 0, s, x, seg_off, (int)seg_mul, ada, ada_ld, (int)shift_off, (int)scale_off, y, stats);
   return DST_CHECK_LAUNCH();
@@ -1533,7 +1533,7 @@ int dst_lnmod_bwd(const float* dy, const float* x, const float* stats, int32_t C
                   float* scratch, int64_t scratch_cap, void* stream) {
   if (!dy || !x || !stats || !seg_off || !ada || !d_ada || !dx || (C != 64 && C != 256) || B <= 0) return DS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  int splits = (C == 256 && seg_mul >= 2) ? 4 : 1;                       // as dst_lnmod_fwd; the per-molecule sums then take a second, fixed-order pass
+  int splits = (C == 256 && seg_mul >= 2) ? 8 : 1;                       // as dst_lnmod_fwd; the per-molecule sums then take a second, fixed-order pass
   if (splits > 1 && (!scratch || scratch_cap < (int64_t)splits * B * 2 * C)) splits = 1;
   if (C == 64)
     hipLaunchKernelGGL(k_lnmod_bwd<64>, dim3(B), dim3(1024), 0, s, dy, x, stats, seg_off, (int)seg_mul, ada, d_ada, ada_ld, (int)shift_off, (int)scale_off, dx, (int)accumulate,

@@ -97,9 +97,9 @@ int dst_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uin
  * with pair_off and seg_mul 2).  ada [B, ada_ld] is the per-molecule adaLN table and d_ada its gradient; *_off are column offsets. */
 
 /* y = LN(x) * (1 + scale[m]) + shift[m], C in {64, 256}; stats [rows,2] = (mean, rstd).  Backward writes dx (accumulate != 0
- * adds) and d_ada[m, shift_off + c] = sum_rows dy, d_ada[m, scale_off + c] = sum_rows dy * xhat.  scratch (optional, >= 4 * B * 2 C
- * floats): with it the directed rows (C = 256, seg_mul >= 2) are shared by four workgroups per molecule and the sums take a second pass
- * that adds the four shares in a fixed order. */
+ * adds) and d_ada[m, shift_off + c] = sum_rows dy, d_ada[m, scale_off + c] = sum_rows dy * xhat.  scratch (optional, >= 8 * B * 2 C
+ * floats): with it the directed rows (C = 256, seg_mul >= 2) are shared by eight workgroups per molecule and the sums take a second pass
+ * that adds the eight shares in a fixed order. */
 int dst_lnmod_fwd(const float* x, int32_t C, const int32_t* seg_off, int32_t seg_mul, int32_t B, const float* ada, int64_t ada_ld,
                   int32_t shift_off, int32_t scale_off, float* y, float* stats, void* stream);
 int dst_lnmod_bwd(const float* dy, const float* x, const float* stats, int32_t C, const int32_t* seg_off, int32_t seg_mul, int32_t B,

@@ -23,9 +23,6 @@
 #ifndef DS_QKV_PF
 #define DS_QKV_PF 4
 #endif
-#ifndef DS_DIAG_ED
-#define DS_DIAG_ED 0
-#endif
 #ifndef DS_EQUI_T2
 #define DS_EQUI_T2 1   // k_equi_pairs: a MFMA wave runs its two feature chunks against shared X fragments
 #endif
@@ -1157,18 +1154,6 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
     for (int u = 0; u < 8; ++u) split_store4(E2h + ((lane + u * 64) >> 4) * LDW2, 64, 4 * (lane & 15), v[u]);
   }
   DS_STAMP(5);
-#if DS_DIAG_ED   /* TIMING DIAGNOSTIC ONLY (tools/variant_build.py -DDS_DIAG_ED=1): the 512-byte split row [e_out | features] instead of ed; results garbage */
-  {
-    float* yb = c.ws.ed + (size_t)row0 * 256;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = lane + u * 64, row = idx >> 5, pc = idx & 31;            // 32 rows x 32 pieces of 16 bytes
-      const int plane = pc >> 4, part = (pc >> 3) & 1, q = pc & 7;               // [plane][e | feat][8 pieces]
-      const _Float16* src = (part ? Dh : E2h) + row * LDW2 + plane * 64 + q * 8;
-      if (row < valid) *reinterpret_cast<float4*>(reinterpret_cast<_Float16*>(yb + (size_t)row * 256) + plane * 128 + part * 64 + q * 8) = *reinterpret_cast<const float4*>(src);
-    }
-  }
-#else
   {
     const float* bd = BW(c, blk, DS_BW_ED_B);
     const float* Wd = BW(c, blk, DS_BW_ED_H);
@@ -1186,7 +1171,6 @@ __global__ __launch_bounds__(256, 2) void k_edge_update(Ctx c, int blk) {
       acc_store<1, 256>(acc, ed + ch * 32, valid, [](int, float v) { return v; });
     }
   }
-#endif
   DS_STAMP(6);
   DS_STAMP_FLUSH(0);
 }
@@ -1384,43 +1368,6 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
       }
       if (wave == 0 && it > 0) tail(tile - stride, buf ^ 1, (it + 2) % 3);   // previous tile: its partial sums were complete one barrier ago
       DS_STAMP(1);
-#if DS_DIAG_ED   /* TIMING DIAGNOSTIC ONLY: input_lin's edge product for tile it + 2 on the consumer waves, between two barriers */
-      __syncthreads();
-      {
-        const int t2 = min(tile + 2 * stride, ntiles - 1);
-        const int prow = min(t2 * TP + (lane & 31), Pp - 1);
-        const _Float16* yb = reinterpret_cast<const _Float16*>(c.ws.ed + (size_t)prow * 256) + 8 * hh;
-        h8 y1[8], y2[8];
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb) { y1[kb] = *reinterpret_cast<const h8*>(yb + 16 * kb); y2[kb] = *reinterpret_cast<const h8*>(yb + 128 + 16 * kb); }
-        const float* Wd = BW(c, blk, DS_BW_ED_H);
-        const float* bd = BW(c, blk, DS_BW_ED_B);
-#pragma unroll
-        for (int cc = 0; cc < CPW; ++cc) {
-          const int ch = wave + NCW * cc;
-          const WStreamH wsd = wstream_h(Wd, 256, 128, ch * 32);
-          f32x16 ea[1], el[1];
-          const float b = bd[ch * 32 + (lane & 31)];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) ea[0][i] = b;
-          acc_zero<1>(el);
-          h8 w1 = wload_h(wsd, 0, 0), w2 = wload_h(wsd, 1, 0);
-#pragma unroll
-          for (int kb = 0; kb < 8; ++kb) {
-            const int kn = kb < 7 ? kb + 1 : 7;
-            const h8 w1n = wload_h(wsd, 0, kn), w2n = wload_h(wsd, 1, kn);
-            ea[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y1[kb], w1, ea[0], 0, 0, 0);
-            el[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y2[kb], w1, el[0], 0, 0, 0);
-            el[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y1[kb], w2, el[0], 0, 0, 0);
-            w1 = w1n; w2 = w2n;
-          }
-          split_finish<1>(ea, el);
-#pragma unroll
-          for (int i = 0; i < 16; ++i)
-            reinterpret_cast<float*>(&Xh[buf][2 * acc_row(i, hh)][0])[ch * 32 + (lane & 31)] = ea[0][i];
-        }
-      }
-#endif
       __syncthreads();
       DS_STAMP(2);
     }
@@ -1503,12 +1450,10 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
         } while (0)
         DS_EQUI_ISSUE_A(0);
         DS_EQUI_ISSUE_M(0);
-#if !DS_DIAG_ED
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ed4 + (size_t)pp[i] * 64 + lane),
                                            (__attribute__((address_space(3))) void*)&Xh[buf][2 * (lw * PPW + i)][0], 16, 0, 0);
-#endif
         __builtin_amdgcn_sched_barrier(0);
         DS_STAMP(5);
         if (lane < 2 * PPW) {   // unit vector of pos[row] - pos[col], scaled (layers.py:345-346), + adjacency bits, for the tail
@@ -1525,9 +1470,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
         }
         DS_STAMP(6);
         // the DMA'd rows must have landed before they are read back (and nothing may be hoisted above this)
-#if !DS_DIAG_ED
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         __builtin_amdgcn_sched_barrier(0);
         DS_STAMP(8);
 #pragma unroll
@@ -1551,9 +1494,6 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
           for (int u = 0; u < 4; ++u) split_store4(xr, 256, 64 * u + 4 * j, x[u]);
           if (bt + 1 < NPASS) DS_EQUI_ISSUE_M(bt + 1);  // sh / sc are free now: next pass's adaLN rows, if the molecule changes
           DS_STAMP(14);
-#if DS_DIAG_ED
-          if (bt == NPASS - 2 && k > 0) __syncthreads();   // barrier A of the consumers (they start the edge product behind it)
-#endif
         }
         if (npairs < TP) {   // last tile only: rows of the pairs past the end (they were computed from pair 0) become zero rows
           for (int i = 0; i < PPW; ++i) {
@@ -1568,9 +1508,6 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void k_equi_pairs(Ctx c, int blk)
         }
       }
       DS_STAMP(7);
-#if DS_DIAG_ED
-      if (!have) __syncthreads();                        // the consumers' barrier A of the last tile
-#endif
       __syncthreads();
       DS_STAMP(9);
       if (!have) break;

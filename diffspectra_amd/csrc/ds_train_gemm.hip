@@ -638,9 +638,13 @@ int dst_gemm(const dst_gemm_args* a, void* stream) {
   const int Nx = g.N + (g.rowsum ? 1 : 0);            // the fused row sum is one more (virtual, all-ones) column of B
   const bool bf = g.bf16 != 0;
   // the vector kernel needs every operand either k-contiguous or row-contiguous, 16-byte aligned with a leading stride of whole vec4s
-  auto vec_ok = [](const float* p, int64_t fast, int64_t slow) { return fast == 1 && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (slow & 3) == 0; };
-  const bool a_k = vec_ok(g.A, g.a_cs, g.a_rs), a_r = !a_k && vec_ok(g.A, g.a_rs, g.a_cs);
-  const bool b_k = vec_ok(g.B, g.b_rs, g.b_cs), b_r = !b_k && vec_ok(g.B, g.b_cs, g.b_rs);
+  // ... and a leading stride that covers the fast extent rounded up to a vec4 (fetch_tile's clamped 16-byte loads stay inside the row that
+  // way; a broadcast operand - leading stride 0 - or overlapping rows take the element-wise kernel)
+  auto vec_ok = [](const float* p, int64_t fast, int64_t slow, int64_t extent) {
+    return fast == 1 && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (slow & 3) == 0 && slow >= ((extent + 3) & ~(int64_t)3);
+  };
+  const bool a_k = vec_ok(g.A, g.a_cs, g.a_rs, g.K), a_r = !a_k && vec_ok(g.A, g.a_rs, g.a_cs, g.M);
+  const bool b_k = vec_ok(g.B, g.b_rs, g.b_cs, g.K), b_r = !b_k && vec_ok(g.B, g.b_cs, g.b_rs, g.N);
   static const int force_old = env_int("DST_GEMM_OLD", 0), bn_pref = env_int("DST_GEMM_BN", 0), bm_pref = env_int("DST_GEMM_BM", 0),
                    split_target = env_int("DST_GEMM_SPLIT_WGS", 1024), wg_target = env_int("DST_GEMM_WGS", 768);
   const bool vec = bf && !force_old && (a_k || a_r) && (b_k || b_r) && g.K >= 8 && g.N > 0;

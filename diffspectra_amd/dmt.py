@@ -218,8 +218,7 @@ class _DmtGraph(torch.autograd.Function):
         dpos, datom = dn[:, 0:3].contiguous(), dn[:, 3:9].contiguous()
         de = d_edge.to(torch.float32).reshape(TL.B * TL.N * TL.N, -1)
         dedge = (de.index_select(0, TL.pair_dense) + de.index_select(0, TL.pair_dense_t)).contiguous()   # both cells of a pair carry its value
-        flat, _, offs = tr.stage(named)
-        flat.zero_()
+        flat, _, offs = tr.stage_begin(named)
         tr.ops.begin()
         try:
             g = dmt.backward(dpos, datom, dedge)

@@ -318,7 +318,29 @@ def optimization_manager(config):
                 optimize_fn.last_grad_norm = norm
         optimizer.step(clip_coef=coef, ema=ema)
 
-    optimize_fn.queue = gradnorm_queue
+    class _History:
+        """``optimize_fn.queue``: the norm history the clipping rule looks at.  Host-side clipping keeps it in ``gradnorm_queue``; with
+        the fused optimizer the history lives in ``clip_state`` on the device ([0 .. count) newest first, [50] count) and reading it
+        here is a device -> host copy (a synchronisation the step itself never does)."""
+
+        @property
+        def items(self):
+            st = getattr(optimize_fn, "device_state", None)
+            if st is None:
+                return list(gradnorm_queue.items)
+            host = st.detach().cpu()
+            return [float(v) for v in host[:int(host[50])]]                # newest first, like Queue.items
+
+        def mean(self):
+            return np.mean(self.items)
+
+        def std(self):
+            return np.std(self.items)
+
+        def __len__(self):
+            return len(self.items)
+
+    optimize_fn.queue = _History()
     return optimize_fn
 
 
@@ -343,14 +365,20 @@ class _HipLossFlat(torch.autograd.Function):
     optimizer's arrangement): ``loss.backward()`` is then a single ``G += stage * grad_out`` instead of one accumulation per parameter."""
 
     @staticmethod
-    def forward(ctx, loss_value, stage, target, *params):
-        ctx.stage, ctx.target = stage, target
+    def forward(ctx, loss_value, stage, target, tr, generation, *params):
+        ctx.stage, ctx.target, ctx.tr, ctx.generation = stage, target, tr, generation
         return loss_value.clone()
 
     @staticmethod
     def backward(ctx, grad_out):
+        # the stage is the trainer's ONE shared buffer: a later loss_fn / model(...) backward on the same model rewrites it.  The
+        # gradients of this call are then gone - refuse instead of silently adding another batch's gradients
+        if ctx.tr.stage_generation != ctx.generation:
+            raise RuntimeError("loss.backward() after another loss_fn(model, ...) call on the same model: the gradient stage of this "
+                               "loss was overwritten.  Call backward() before the next loss_fn (gradient accumulation: "
+                               "loss_fn(b1).backward(); loss_fn(b2).backward())")
         ctx.target.addcmul_(ctx.stage, grad_out.to(ctx.stage.dtype))
-        return (None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+        return (None,) * len(ctx.needs_input_grad)
 
 
 def _deliver_grads(tr, named, g, flat, offs, scale):
@@ -362,6 +390,7 @@ def _deliver_grads(tr, named, g, flat, offs, scale):
         raise RuntimeError(f"no gradient was produced for {missing[:5]}")
     target = tr.flat_grad_target(named, offs)
     if target is not None:
+        zero_frozen(flat, named, offs)
         if scale is None:
             target.add_(flat)
         else:
@@ -376,6 +405,15 @@ def _deliver_grads(tr, named, g, flat, offs, scale):
     return tuple(out)
 
 
+def zero_frozen(flat, named, offs):
+    """The backward kernels write a gradient for every parameter; the flat hand-over adds the WHOLE stage into the optimizer's buffer.
+    Slices of parameters with ``requires_grad=False`` are cleared first, so a frozen parameter keeps a zero gradient (the per-parameter
+    path returns None for it) and the fused AdamW step leaves it where it is."""
+    for (name, p), o in zip(named.items(), offs):
+        if not p.requires_grad:
+            flat[o:o + p.numel()].zero_()
+
+
 class HipTrainer:
     """Per-model training state: the two graphs, bound to the model's current parameter storage at every call."""
 
@@ -388,6 +426,14 @@ class HipTrainer:
         self.lib = self.ops.lib
         self._layouts: Dict[bytes, TrainLayout] = {}
         self._stage = None
+        self.stage_generation = 0       # bumped whenever the shared gradient stage is rewritten (checked by _HipLossFlat.backward)
+
+    def stage_begin(self, named):
+        """Claim the shared stage for a new backward: cleared, generation bumped (a pending flat hand-over of an earlier call notices)."""
+        flat, views, offs = self.stage(named)
+        self.stage_generation += 1
+        flat.zero_()
+        return flat, views, offs
 
     def stage(self, named):
         """One flat fp32 buffer holding every parameter's gradient of the current backward, in ``named_parameters()`` order without
@@ -543,8 +589,7 @@ def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None
         loss_fn.last = dict(t=t, alpha_t=alpha_t, sigma_t=sigma_t, z=z, ez=ez, aligned=aligned, rot=rot, pred=(pos, atom, edge), layout=TL)
         if not (train and torch.is_grad_enabled()):
             return loss
-        flat, _, offs = tr.stage(named)
-        flat.zero_()                                                    # gradients that a branch does not produce (first-step dist_layer) stay zero
+        flat, _, offs = tr.stage_begin(named)                           # zeroed: gradients that a branch does not produce (first-step dist_layer) stay zero
         g = dmt.backward(dpos, dfeat, dedge)
         g.update(spec.backward(g.pop("@ctx_emb")))
         params = [p for p in named.values()]
@@ -553,7 +598,8 @@ def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None
             raise RuntimeError(f"no gradient was produced for {missing[:5]}")
         target = tr.flat_grad_target(named, offs)
         if target is not None:                                          # the fused optimizer's flat gradient buffer: one accumulation kernel
-            return _HipLossFlat.apply(loss, flat, target, *params)
+            zero_frozen(flat, named, offs)
+            return _HipLossFlat.apply(loss, flat, target, tr, tr.stage_generation, *params)
         grads = [g.get(n).clone() if p.requires_grad else None for n, p in named.items()]      # the stage is overwritten by the next call
         return _HipLoss.apply(loss, grads, *params)
 

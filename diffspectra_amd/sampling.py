@@ -452,10 +452,7 @@ def _sampling_fn_factory(config, sampler, batch_size, n_samples, inverse_scaler,
                 raise RuntimeError("finish() before every micro-batch was sampled; call advance() to the end first")
             n_slots = self.slot_ds.numel()
             rec = torch.cat(self.recs) if self.recs else torch.zeros(0, shard.RECORD_BYTES, dtype=torch.uint8, device=self.device)
-            owners = [shard.assign_slots(self.n_atoms, r, self.world) for r in range(self.world)]
-            allrec = shard.gather_records(rec, [o.numel() for o in owners])           # the only collective of the path
-            by_slot = torch.empty_like(allrec)
-            by_slot[torch.cat(owners).to(allrec.device)] = allrec
+            by_slot = shard.gather_by_slot(rec, self.n_atoms)                        # the only collective of the path
             self.records_by_slot = by_slot
             pos, atom, fc, et = (t.cpu() for t in shard.unpack_records_u8(by_slot))     # ONE device->host copy per tensor
             processed = MoleculeList(pos, atom, et, fc, self.n_atoms[:n_slots])         # per-molecule tuples are built on access

@@ -57,10 +57,10 @@ def pack_records_u8(pos, atom_type, fc, edge_type) -> torch.Tensor:
     e = torch.zeros(B, W, W, dtype=torch.uint8, device=dev)
     e[:, :N, :N] = edge_type.to(torch.uint8)
     rec = torch.zeros(B, RECORD_BYTES, dtype=torch.uint8, device=dev)
-    rec[:, :348] = p.reshape(B, -1).view(torch.uint8)
+    rec[:, :348] = p.reshape(B, W * 3).view(torch.uint8)            # (explicit widths: a rank without molecules packs B = 0 rows)
     rec[:, 348:377] = a
     rec[:, 377:406] = c.view(torch.uint8)
-    rec[:, 406:1247] = e.reshape(B, -1)
+    rec[:, 406:1247] = e.reshape(B, W * W)
     return rec
 
 
@@ -152,3 +152,17 @@ def gather_records(rec: torch.Tensor, counts=None) -> torch.Tensor:
     dist.all_gather_into_tensor(out, buf.contiguous())
     out = out.to(dev)
     return torch.cat([out[r * m:r * m + counts[r]] for r in range(world)], 0)
+
+
+def gather_by_slot(rec: torch.Tensor, n_atoms) -> torch.Tensor:
+    """The closing collective of a sharded evaluation: this rank's records (rows in the order of ``assign_slots(n_atoms, rank, world)``)
+    -> the records of ALL sample slots in slot order, on every rank.  One ``all_gather_into_tensor`` (``gather_records``); ranks may own
+    different numbers of slots, or none."""
+    rank, world = world_info()
+    owners = [assign_slots(n_atoms, r, world) for r in range(world)]
+    if rec.shape[0] != owners[rank].numel():
+        raise ValueError(f"rank {rank} holds {rec.shape[0]} records for {owners[rank].numel()} slots")
+    allrec = gather_records(rec, [o.numel() for o in owners])
+    by_slot = torch.empty_like(allrec)
+    by_slot[torch.cat(owners).to(allrec.device)] = allrec
+    return by_slot

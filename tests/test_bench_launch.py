@@ -34,6 +34,18 @@ def test_scaling_modes_shard_the_evaluation(scaling, total, per_rank):
     assert rec["scaling"] == scaling and rec["config"]["samples_total"] == total and rec["config"]["molecules_per_gpu"] == per_rank
 
 
+@pytest.mark.parametrize("scaling,samples,total,per_rank", [("weak", 1250, 10000, [1250] * 8), ("strong", 10001, 10001, [1251] + [1250] * 7),
+                                                            ("strong", 5, 5, [1, 1, 1, 1, 1, 0, 0, 0])])
+def test_eight_rank_dry_run(scaling, samples, total, per_rank):
+    """The SCALE driver's widest shape (`--gpus 8`) without GPUs: eight gloo ranks through the spawn path, the evaluation dealt by the
+    product's shard.assign_slots - an even weak split, an uneven strong split (10 001 samples) and ranks that own nothing - and exactly
+    ONE JSON line on stdout (from rank 0)."""
+    rec, err = _run(["--gpus", "8", "--backend", "gloo", "--dry-run", "--samples", str(samples), "--scaling", scaling], 600)
+    assert rec["n_gpus"] == 8 and rec["scaling"] == scaling and rec["dry_run"] is True
+    assert rec["config"]["samples_total"] == total and rec["config"]["molecules_per_gpu"] == per_rank
+    assert "torch.distributed.run" in err
+
+
 def test_single_rank_does_not_spawn():
     rec, err = _run(["--gpus", "1", "--dry-run"], 120)
     assert rec["n_gpus"] == 1 and "self-launch" not in err
@@ -74,3 +86,14 @@ def test_force_collectives_rehearsal_on_one_gpu():
     rec, _ = _run(["--gpus", "1", "--backend", "nccl", "--force-collectives", "--samples", "40", "--batch", "24", "--denoise-steps", "20",
                    "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-live-traffic"], 900)
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and "forced" in rec["config"]["collectives"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("samples,per_rank", [(41, [14, 14, 13]), (2, [1, 1, 0])])
+def test_uneven_strong_split_on_one_gpu(samples, per_rank):
+    """Shares that differ, and a rank that owns no molecule at all: every rank still meets the others in the one closing gather of the
+    same bench step (three gloo ranks sharing cuda:0; rank 0 reports its own share)."""
+    rec, _ = _run(["--gpus", "3", "--backend", "gloo", "--same-device", "--scaling", "strong", "--samples", str(samples), "--batch", "24",
+                   "--denoise-steps", "20", "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-live-traffic"], 900)
+    assert rec["config"]["samples_total"] == samples and rec["config"]["molecules_per_gpu"] == per_rank[0]
+    assert rec["value"] > 0 and rec["config"]["passes_completed"] == 1

@@ -114,3 +114,67 @@ def test_two_rank_shard_and_gather():
         p.join(120)
         assert p.exitcode == 0
     assert dict(ret) == {0: True, 1: True}
+
+
+def _worker_8(rank, world, port, ret):
+    """Eight gloo ranks, three evaluations through the product's closing collective (shard.gather_by_slot): an uneven share
+    (10 001 sample slots: 1 251 + 7 x 1 250), ranks without a molecule (5 slots on 8 ranks), Top-K slots (K consecutive slots per
+    spectrum, sampling.py's `perm[:n].repeat_interleave(K)`)."""
+    import numpy as np
+    from diffspectra_amd import filler
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = {}
+
+        def run(n_atoms, tag):
+            n_atoms = [int(v) for v in n_atoms]
+            mine = shard.assign_slots(n_atoms, rank, world)
+            N = 29
+            # a record whose every field is a function of the SLOT: position = slot / 8, atom type = slot % 5, charge = slot % 7 - 3, bond = slot % 4
+            pos = (mine.float() / 8.0).view(-1, 1, 1).expand(-1, N, 3)
+            atom = (mine % 5).view(-1, 1).expand(-1, N)
+            fc = (mine % 7 - 3).view(-1, 1).expand(-1, N)
+            et = (mine % 4).float().view(-1, 1, 1).expand(-1, N, N)
+            rec = shard.pack_records_u8(pos, atom, fc, et)
+            by_slot = shard.gather_by_slot(rec, n_atoms)
+            p2, a2, f2, e2 = shard.unpack_records_u8(by_slot)
+            k = torch.arange(len(n_atoms))
+            ok = (by_slot.shape[0] == len(n_atoms) and torch.equal(p2[:, 3, 1], k.float() / 8.0) and torch.equal(a2[:, 0], k % 5)
+                  and torch.equal(f2[:, 28], k % 7 - 3) and torch.equal(e2[:, 2, 5], (k % 4).float()))
+            sizes = [n_atoms[i] for i in mine.tolist()]
+            out[tag] = (bool(ok), int(mine.numel()), sizes == sorted(sizes, reverse=True),
+                        int(sum(v * (v - 1) for v in sizes)))
+        run(filler.sample_n_atoms(10001, seed=0), "uneven")
+        run([9, 29, 3, 18, 12], "empty_ranks")
+        K = 10
+        base = filler.sample_n_atoms(125, seed=3)
+        run(np.repeat(base, K), "topk")
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_uneven_empty_and_topk():
+    """World size 8 (the node the SCALE driver uses) on CPU: per-rank counts, size-sorted shares, cost balance, and the gathered records
+    in slot order on every rank - with 10 001 slots, with three ranks that own nothing, and with Top-K slots."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_8, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = dict(ret)
+    assert sorted(res) == list(range(world))
+    for tag, counts in (("uneven", [1251] + [1250] * 7), ("empty_ranks", [1, 1, 1, 1, 1, 0, 0, 0]), ("topk", [157, 157] + [156] * 6)):
+        assert [res[r][tag][1] for r in range(world)] == counts, tag
+        assert all(res[r][tag][0] for r in range(world)), tag            # every rank sees every slot's record in slot order
+        assert all(res[r][tag][2] for r in range(world)), tag            # n-bucketed inside a rank
+    cost = [res[r]["uneven"][3] for r in range(world)]
+    assert max(cost) - min(cost) <= 29 * 28 + 28 * 27                    # round-robin over the size-sorted slots: within ~one large molecule
+    cost = [res[r]["topk"][3] for r in range(world)]
+    assert max(cost) - min(cost) <= 2 * 29 * 28

@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <utility>
 #include <vector>
@@ -22,6 +23,9 @@
 #endif
 #ifndef DS_QKV_PF
 #define DS_QKV_PF 4
+#endif
+#ifndef DS_ATTN_FMA
+#define DS_ATTN_FMA 1
 #endif
 #ifndef DS_EQUI_T2
 #define DS_EQUI_T2 1   // k_equi_pairs: a MFMA wave runs its two feature chunks against shared X fragments
@@ -597,8 +601,13 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
               for (int j = 0; j < 3; ++j) { e[j] = t0[j0 + j]; xa[j] = qa[j0 + j]; xb[j] = qb[j0 + j]; ya[j] = ka[j0 + j]; yb[j] = kb[j0 + j]; }
 #pragma unroll
               for (int j = 0; j < 3; ++j) {
+#if DS_ATTN_FMA   // one multiply + one fused multiply-add per term (4-cycle issues) instead of the packed multiply + add the compiler forms (8 + 4)
+                s_ab = __builtin_fmaf(xb[j].x * ya[j].x, e[j].x, s_ab); s_ab = __builtin_fmaf(xb[j].y * ya[j].y, e[j].y, s_ab);
+                s_ba = __builtin_fmaf(xa[j].x * yb[j].x, e[j].x, s_ba); s_ba = __builtin_fmaf(xa[j].y * yb[j].y, e[j].y, s_ba);
+#else
                 s_ab += (xb[j].x * ya[j].x) * e[j].x; s_ab += (xb[j].y * ya[j].y) * e[j].y;
                 s_ba += (xa[j].x * yb[j].x) * e[j].x; s_ba += (xa[j].y * yb[j].y) * e[j].y;
+#endif
               }
             }
             out[2 + hs] = s_ab / 4.0f;        // / sqrt(out_channels = 16) (layers.py:167)
@@ -677,29 +686,31 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
     float* lgm = c.ws.lg + (size_t)p0 * 32 + h;
     if (t < n) {
       float x[15];
+      int eos[15];
       float mx = -INFINITY;
+      // all fifteen logits are requested before any is used: unconditional loads from clamped offsets, the "no such edge" select
+      // afterwards (a load inside a conditional block is waited for at the end of its block: fifteen L2 round trips in a row)
 #pragma unroll
-      for (int j = 0; j < 15; ++j) {
-        const int eo = et[2 * j];
-        x[j] = -INFINITY;
-        if (eo >= 0) x[j] = lgm[eo];
-      }
+      for (int j = 0; j < 15; ++j) eos[j] = et[2 * j];
+#pragma unroll
+      for (int j = 0; j < 15; ++j) x[j] = lgm[max(eos[j], 0)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 15; ++j) x[j] = eos[j] >= 0 ? x[j] : -INFINITY;
 #pragma unroll
       for (int j = 0; j < 15; ++j) mx = fmaxf(mx, x[j]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       float sum = 0.0f;
 #pragma unroll
       for (int j = 0; j < 15; ++j) {
-        x[j] = expf(x[j] - mx);             // a missing edge: exp(-inf) = 0
+        x[j] = __expf(x[j] - mx);           // hardware exp2 form (1e-7 relative, as the other transcendentals here); a missing edge: exp(-inf) = 0
         sum += x[j];
       }
       sum += __shfl_xor(sum, 16, 64);
       const float den = sum + 1e-16f;
 #pragma unroll
-      for (int j = 0; j < 15; ++j) {
-        const int eo = et[2 * j];
-        if (eo >= 0) lgm[eo] = x[j] / den;
-      }
+      for (int j = 0; j < 15; ++j)
+        if (eos[j] >= 0) lgm[eos[j]] = x[j] / den;
     }
   }
   store_v();                               // V is first read behind phase 2b's opening barriers: its latency runs under the softmax
@@ -778,10 +789,47 @@ __global__ __launch_bounds__(1024) void k_attn_fused(Ctx c, int blk) {
   }
 }
 
+// node2edge_lin applied per node (256 -> 64, dmt.py:156-157) as a kernel of its own: 64 attention rows per workgroup, one 32-row
+// tile x one 32-column chunk per wave.  Same split-fp16 product, fragment order and k order as the N2E = true form of k_node_update
+// (a row's result does not depend on its tile), so ws.u holds the same bits either way.
+__global__ __launch_bounds__(256) void k_node_n2e(Ctx c, int blk) {
+  ds_fp16_saturate();
+  constexpr int T = 64, LDH = 2 * 256 + 8;
+  __shared__ __attribute__((aligned(16))) _Float16 A1[T][LDH];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row0 = blockIdx.x * T;
+  const int Nn = c.L.Nn;
+  {
+    float4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {   // 64 rows x 64 float4
+      const int idx = tid + u * 256, row = idx >> 6, k4 = idx & 63;
+      v[u] = reinterpret_cast<const float4*>(c.ws.attn + (size_t)min(row0 + row, Nn - 1) * 256)[k4];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = tid + u * 256, row = idx >> 6, k4 = idx & 63;
+      split_store4(&A1[row][0], 256, 4 * k4, row0 + row < Nn ? v[u] : make_float4(0, 0, 0, 0));
+    }
+  }
+  __syncthreads();
+  const int mt = wave >> 1, cc = wave & 1;
+  if (row0 + mt * 32 >= Nn) return;
+  f32x16 acc[1], lo[1];
+  acc_zero<1>(acc);
+  acc_zero<1>(lo);
+  wave_mma_h_ring<1, false, 16, DS_NODE_PF>(&A1[mt * 32][0], 256, BW(c, blk, DS_BW_N2E_H), 64, 256, cc * 32, 0, acc, lo);
+  split_finish<1>(acc, lo);
+  acc_store<1, 64>(acc, c.ws.u + (size_t)(row0 + mt * 32) * 64 + cc * 32, Nn - row0 - mt * 32, [](int, float v) { return v; });
+  (void)lane;
+}
+
 // Block stage D (nodes, 32 rows): node2edge partial, gated residual, LN, modulate, FF(256->512->256) in two
 // hidden halves (the 256-wide half aliases the attention tile, FF2 accumulators persist in registers), gated residual
 // in place, per-block readout slice (256->64) and the node parts of equi_update.input_lin (256->512).
 // dmt.py:156-163,387,39-45.  66.5 kB LDS -> two workgroups per CU.
+// N2E = false: node2edge_lin has been applied by k_node_n2e (the two-stream forward, ds_forward: the pair rows' k_edge_update then
+// runs beside this kernel instead of behind it).
+template <bool N2E>
 __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
   ds_fp16_saturate();
   constexpr int T = 32, LDH = 2 * 256 + 8;
@@ -822,7 +870,7 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (row0 + row >= Nn) va[ps][u] = vh[ps][u] = make_float4(0, 0, 0, 0);
-        split_store4(&B1[row][0], 256, 64 * u + 4 * j, va[ps][u]);
+        if (N2E) split_store4(&B1[row][0], 256, 64 * u + 4 * j, va[ps][u]);
         // h_in + gate_msa * attn (dmt.py:159)
         r[u].x = vh[ps][u].x + vg[ps][u].x * va[ps][u].x; r[u].y = vh[ps][u].y + vg[ps][u].y * va[ps][u].y;
         r[u].z = vh[ps][u].z + vg[ps][u].z * va[ps][u].z; r[u].w = vh[ps][u].w + vg[ps][u].w * va[ps][u].w;
@@ -833,15 +881,17 @@ __global__ __launch_bounds__(256, 2) void k_node_update(Ctx c, int blk) {
     }
   }
   __syncthreads();
-  if (wave < 2) {   // node2edge_lin applied per node (256 -> 64): two 32-column chunks
-    f32x16 acc[1], lo[1];
-    acc_zero<1>(acc);
-    acc_zero<1>(lo);
-    wave_mma_h_ring<1, false, 16, DS_NODE_PF>(&B1[0][0], 256, BW(c, blk, DS_BW_N2E_H), 64, 256, wave * 32, 0, acc, lo);
-    split_finish<1>(acc, lo);
-    acc_store<1, 64>(acc, c.ws.u + (size_t)row0 * 64 + wave * 32, Nn - row0, [](int, float v) { return v; });
+  if (N2E) {
+    if (wave < 2) {   // node2edge_lin applied per node (256 -> 64): two 32-column chunks
+      f32x16 acc[1], lo[1];
+      acc_zero<1>(acc);
+      acc_zero<1>(lo);
+      wave_mma_h_ring<1, false, 16, DS_NODE_PF>(&B1[0][0], 256, BW(c, blk, DS_BW_N2E_H), 64, 256, wave * 32, 0, acc, lo);
+      split_finish<1>(acc, lo);
+      acc_store<1, 64>(acc, c.ws.u + (size_t)row0 * 64 + wave * 32, Nn - row0, [](int, float v) { return v; });
+    }
+    __syncthreads();   // H2 normalised; every wave is done reading B1 (node2edge)
   }
-  __syncthreads();   // H2 normalised; every wave is done reading B1 (node2edge)
   {
     const float* b1 = BW(c, blk, DS_BW_FF1_B);
     const float* W1 = BW(c, blk, DS_BW_FF1_H);
@@ -2460,7 +2510,7 @@ int ds_stage_block(const ds_weights* w, const ds_layout* L, ds_workspace* ws, in
   if (pt > 0) { ProfScope ps(0, s); hipLaunchKernelGGL(k_edge_geom, dim3(pt), dim3(256), 0, s, c, blk); }
   { ProfScope ps(1, s); hipLaunchKernelGGL(k_node_qkv<4>, dim3((L->Nn + 63) / 64, 2), dim3(256), 0, s, c, blk); }
   { ProfScope ps(2, s); hipLaunchKernelGGL(k_attn_fused, dim3(L->B), dim3(1024), 0, s, c, blk); }
-  { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update, dim3(nt), dim3(256), 0, s, c, blk); }
+  { ProfScope ps(3, s); hipLaunchKernelGGL(k_node_update<true>, dim3(nt), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3((L->Pp + 127) / 128), dim3(256), 0, s, c, blk); }
   if (pt > 0) { ProfScope ps(5, s); { const int nt_ = (L->Pp + 31) / 32, cu_ = device_cus(); hipLaunchKernelGGL((k_equi_pairs<DS_EQUI_NCW, DS_EQUI_NLW>), dim3(nt_ < cu_ ? nt_ : cu_), dim3((DS_EQUI_NCW + DS_EQUI_NLW) * 64), 0, s, c, blk); } }
   hipLaunchKernelGGL(k_pos_update, dim3(L->B), dim3(64), 0, s, c, last);
@@ -2480,6 +2530,75 @@ int ds_stage_readout(const ds_weights* w, const ds_layout* L, ds_workspace* ws, 
   return launch_status();
 }
 
+// The blocks of one forward over TWO streams (ds_forward).  A block's node rows after the attention - gated residual, FF, read-out
+// slice, the node parts of input_lin (k_node_update<false>) - and the next block's q|k|v projection depend on nothing the pair
+// rows compute in k_edge_update, and the two sides load different parts of a CU (k_edge_update: HBM streams and waits, matrix pipe
+// 24 % busy; k_node_update / k_node_qkv: L2 weight streams + MFMA), so they run BESIDE k_edge_update on a side stream instead of in
+// front of it / behind it:
+//   main : edge_geom(b) -> [q|k|v(b)] attn(b) -> n2e(b) -> edge_update(b) -> [side(b)] equi_pairs(b) -> pos_update(b)
+//   side :                                        [n2e(b)] node_update(b) -> q|k|v(b + 1)
+// k_equi_pairs waits for the side stream (it needs `ac`, and as a persistent one-workgroup-per-CU kernel it must not find CUs taken).
+// One workgroup of either side fits beside one of the other in a CU's LDS (66.5 + 71 kB).  Results do not depend on the mode: the
+// same kernels' arithmetic, ws.u from k_node_n2e bit-identical to the fused form (tests: stage API = one stream, forward = two).
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork[DS_NBLOCKS + 1] = {}, join[DS_NBLOCKS + 1] = {};
+  bool ok = false, tried = false;
+};
+static SideStream g_side[16];
+static int g_two_stream = -1;   // -1: from the environment (DIFFSPECTRA_TWO_STREAM, default 1)
+
+static SideStream* side_stream() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SideStream& ss = g_side[dev];
+  if (!ss.tried) {
+    ss.tried = true;
+    bool ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i <= DS_NBLOCKS; ++i)
+      ok = hipEventCreateWithFlags(&ss.fork[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&ss.join[i], hipEventDisableTiming) == hipSuccess;
+    ss.ok = ok;
+  }
+  return ss.ok ? &ss : nullptr;
+}
+
+static int forward_blocks_two_streams(const ds_weights* w, const ds_layout* L, ds_workspace* ws, hipStream_t s, SideStream* ss) {
+  Ctx c;
+  if (!make_ctx(c, w, L, ws, s)) return DS_ERR_ARG;
+  const int pt = (L->Pp + 63) / 64, nt = (L->Nn + 31) / 32;
+  hipStream_t s2 = ss->s;
+#define DS_HIP_OK(x) do { if ((x) != hipSuccess) return DS_ERR_LAUNCH; } while (0)
+  // q|k|v of block 0 on the side stream, beside edge_geom(0)
+  DS_HIP_OK(hipEventRecord(ss->fork[DS_NBLOCKS], s));
+  DS_HIP_OK(hipStreamWaitEvent(s2, ss->fork[DS_NBLOCKS], 0));
+  { ProfScope ps(1, s2); hipLaunchKernelGGL(k_node_qkv<4>, dim3((L->Nn + 63) / 64, 2), dim3(256), 0, s2, c, 0); }
+  DS_HIP_OK(hipEventRecord(ss->join[DS_NBLOCKS], s2));
+  for (int blk = 0; blk < DS_NBLOCKS; ++blk) {
+    if (pt > 0) { ProfScope ps(0, s); hipLaunchKernelGGL(k_edge_geom, dim3(pt), dim3(256), 0, s, c, blk); }
+    DS_HIP_OK(hipStreamWaitEvent(s, blk == 0 ? ss->join[DS_NBLOCKS] : ss->join[blk - 1], 0));     // q|k|v(blk)
+    { ProfScope ps(2, s); hipLaunchKernelGGL(k_attn_fused, dim3(L->B), dim3(1024), 0, s, c, blk); }
+    hipLaunchKernelGGL(k_node_n2e, dim3((L->Nn + 63) / 64), dim3(256), 0, s, c, blk);
+    DS_HIP_OK(hipEventRecord(ss->fork[blk], s));
+    DS_HIP_OK(hipStreamWaitEvent(s2, ss->fork[blk], 0));
+    { ProfScope ps(3, s2); hipLaunchKernelGGL(k_node_update<false>, dim3(nt), dim3(256), 0, s2, c, blk); }
+    if (blk + 1 < DS_NBLOCKS) { ProfScope ps(1, s2); hipLaunchKernelGGL(k_node_qkv<4>, dim3((L->Nn + 63) / 64, 2), dim3(256), 0, s2, c, blk + 1); }
+    DS_HIP_OK(hipEventRecord(ss->join[blk], s2));
+    if (pt > 0) { ProfScope ps(4, s); hipLaunchKernelGGL(k_edge_update, dim3((L->Pp + 127) / 128), dim3(256), 0, s, c, blk); }
+    DS_HIP_OK(hipStreamWaitEvent(s, ss->join[blk], 0));                                           // ac, h, atom_hids, q|k|v(blk + 1)
+    if (pt > 0) { ProfScope ps(5, s); { const int nt_ = (L->Pp + 31) / 32, cu_ = device_cus(); hipLaunchKernelGGL((k_equi_pairs<DS_EQUI_NCW, DS_EQUI_NLW>), dim3(nt_ < cu_ ? nt_ : cu_), dim3((DS_EQUI_NCW + DS_EQUI_NLW) * 64), 0, s, c, blk); } }
+    hipLaunchKernelGGL(k_pos_update, dim3(L->B), dim3(64), 0, s, c, blk == DS_NBLOCKS - 1 ? 1 : 0);
+  }
+#undef DS_HIP_OK
+  return launch_status();
+}
+
+int ds_set_two_stream(int on) {   // -1: follow DIFFSPECTRA_TWO_STREAM (default on); 0 / 1: force.  Returns the previous setting.
+  const int prev = g_two_stream;
+  g_two_stream = on;
+  return prev;
+}
+
 int ds_forward(const ds_weights* w, const ds_layout* L, ds_workspace* ws, const float* xh, const float* edge_x,
                const float* cond_x, const float* cond_edge_x, const float* noise_level, const float* ctx_emb, float* out_xh,
                float* out_edge, void* stream) {
@@ -2487,9 +2606,17 @@ int ds_forward(const ds_weights* w, const ds_layout* L, ds_workspace* ws, const 
   if (st) return st;
   st = ds_stage_init(w, L, ws, xh, edge_x, cond_x, cond_edge_x, stream);
   if (st) return st;
-  for (int b = 0; b < DS_NBLOCKS; ++b) {
-    st = ds_stage_block(w, L, ws, b, b == DS_NBLOCKS - 1, stream);
+  static const int env_two = [] { const char* e = getenv("DIFFSPECTRA_TWO_STREAM"); return e ? atoi(e) : 1; }();
+  const int two = g_two_stream >= 0 ? g_two_stream : env_two;
+  SideStream* ss = two ? side_stream() : nullptr;
+  if (ss) {
+    st = forward_blocks_two_streams(w, L, ws, (hipStream_t)stream, ss);
     if (st) return st;
+  } else {
+    for (int b = 0; b < DS_NBLOCKS; ++b) {
+      st = ds_stage_block(w, L, ws, b, b == DS_NBLOCKS - 1, stream);
+      if (st) return st;
+    }
   }
   return ds_stage_readout(w, L, ws, out_xh, out_edge, stream);
 }

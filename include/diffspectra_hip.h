@@ -192,6 +192,12 @@ int ds_forward(const ds_weights* w, const ds_layout* L, ds_workspace* ws,
                const float* noise_level, const float* ctx_emb,
                float* out_xh, float* out_edge, void* stream);
 
+/* ds_forward runs a block's node rows behind the attention (k_node_update) and the next block's q|k|v projection on a library-owned
+ * side stream beside the pair rows' k_edge_update (fork / join by events; safe under stream capture).  on = 0: one stream (the order of
+ * ds_stage_block), 1: two streams, -1: follow the environment variable DIFFSPECTRA_TWO_STREAM (default 1).  Returns the previous
+ * setting.  Results are bit-identical in both modes.  (Build extension: the reference has no such switch.) */
+int ds_set_two_stream(int on);
+
 /* Stage-level entry points (used by the parity tests to localise a mismatch; same kernels ds_forward launches). */
 int ds_stage_time(const ds_weights* w, const ds_layout* L, ds_workspace* ws, const float* noise_level,
                   const float* ctx_emb, void* stream);

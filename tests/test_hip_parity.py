@@ -1531,3 +1531,37 @@ def test_batched_stability_on_device(gpu_device):
     assert seen == {0, 1, 2, 3}                       # the fixture exercises every branch of get_bond_order
     with pytest.raises(RuntimeError):
         check_stability_batch(pos.to(d), types.to(d), mask.to(d))
+
+
+def test_two_stream_forward_equals_one_stream_bit_for_bit(gpu_device):
+    """``ds_forward`` runs a block's node rows (k_node_update without its node2edge part, then the next block's q|k|v) on a side stream beside
+    the pair rows' k_edge_update; ``ds_set_two_stream(0)`` gives the single-stream order of ``ds_stage_block``.  Same kernels, same
+    arithmetic: outputs must agree BIT FOR BIT (a missing cross-stream dependency would show up as a difference), on a batch large
+    enough for the two sides to overlap, for both branches of the forward, repeatedly."""
+    from diffspectra_amd import engine as E, filler
+    cfg, model = gpu_model("allspectra", gpu_device)
+    eng = model.module.engine()
+    lib = E.load_library()
+    d = gpu_device
+    n_atoms = filler.sample_n_atoms(1500, seed=2).tolist()
+    n_atoms[0], n_atoms[1], n_atoms[2] = 29, 1, 2
+    x, ex, node_mask, edge_mask = filler.synthetic_state(n_atoms, "ts.x")
+    cx, cex, _, _ = filler.synthetic_state(n_atoms, "ts.c")
+    B = len(n_atoms)
+    nl = filler.uniform("ts.nl", (B,), -6, 6)
+    ctx_emb = filler.normal("ts.ctx", (B, 1024)) * 0.5
+    L, ws = eng.layout_for(node_mask, edge_mask, validate=True)
+    xd, exd, nld, cxd, cexd, ctxd = (t.to(d) for t in (x, ex, nl, cx, cex, ctx_emb))
+    prev = lib.ds_set_two_stream(0)
+    try:
+        ref = {}
+        for first in (True, False):
+            o, oe = eng.forward(L, ws, xd, exd, nld, None if first else cxd, None if first else cexd, ctxd)
+            ref[first] = (o.clone(), oe.clone())
+        lib.ds_set_two_stream(1)
+        for rep in range(3):
+            for first in (True, False):
+                o, oe = eng.forward(L, ws, xd, exd, nld, None if first else cxd, None if first else cexd, ctxd)
+                assert torch.equal(o, ref[first][0]) and torch.equal(oe, ref[first][1]), (rep, first)
+    finally:
+        lib.ds_set_two_stream(prev)

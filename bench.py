@@ -173,6 +173,51 @@ def live_pmc_traffic(kernel: str, mols: int, spectra: str, budget_s: float = 120
         f"4 denoise iterations, {time.perf_counter() - t_begin:.0f} s), scaled by directed edges to this run's mean launch")
 
 
+def live_pmc_family_bytes(kernel_substr: str, child_args, budget_s: float = 150.0):
+    """HBM bytes moved by every launch of the kernels whose name contains ``kernel_substr`` over one child run of this script
+    (``child_args``) under ``rocprofv3 --kernel-trace --pmc`` - FETCH_SIZE and WRITE_SIZE in separate passes, bytes = (2 * FETCH_SIZE +
+    WRITE_SIZE) * 1024 as in ``live_pmc_traffic``.  Returns (total bytes, launches, note) or (None, 0, reason).  Same guards: never
+    nested under a profiler, children not exec."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, 0, "rocprofv3 not found"
+    if [k for k in os.environ if k.startswith(("ROCP", "ROCPROF", "ROCTRACER"))] or "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+        return None, 0, "this process runs under a profiler (LD_PRELOAD / ROCP* set): no nested rocprofv3"
+    t_begin = time.perf_counter()
+    tot, cnt = {}, {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="ds_pmc_", dir="/tmp")
+        cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), *child_args]
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                                                                     "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "LD_PRELOAD")
+                   and not k.startswith(("TORCHELASTIC", "ROCP", "ROCPROF", "ROCTRACER"))}
+            env["TMPDIR"] = "/tmp"
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=max(30.0, budget_s - (time.perf_counter() - t_begin)))
+            if r.returncode != 0:
+                return None, 0, f"rocprofv3 --pmc {counter} exited with {r.returncode}"
+            tot[counter], cnt[counter] = 0.0, 0
+            for path in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if row.get("Counter_Name") == counter and kernel_substr in row.get("Kernel_Name", ""):
+                        tot[counter] += float(row["Counter_Value"])
+                        cnt[counter] += 1
+            if cnt[counter] == 0:
+                return None, 0, f"no {counter} samples of {kernel_substr} in the rocprofv3 output"
+        except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as exc:
+            return None, 0, f"{type(exc).__name__}: {exc}"
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0, cnt["FETCH_SIZE"], (
+        f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two child runs of this script ({time.perf_counter() - t_begin:.0f} s), "
+        f"summed over the {cnt['FETCH_SIZE']} launches of *{kernel_substr}* kernels")
+
+
 def executed_macs(n_atoms) -> int:
     """MACs the kernels actually issue: the edge-side GEMMs whose operands are symmetric in (a, b) run once per unordered
     pair, only MultiCondEquiUpdate's coord_mlp (66 304 MACs) runs per directed edge."""
@@ -502,6 +547,20 @@ def train_measure(args, world, rank, device, steps, warmup, with_cpu_baseline):
                                          "frac": sum(r[4] for r in recs) / (gemm_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS if gemm_ms > 0 else None},
                             "note": "timed in one extra single-stream step (in the timed steps the weight-gradient products and the node-row chain run "
                                     "concurrently on their own streams, so this share is an upper bound of their part of the step)"}
+        # HBM bytes of the same kernel family per step, from the counters: two child runs of this mode (1 warm-up + 2 timed + the one
+        # instrumented step = 4 optimizer steps each) under rocprofv3 --pmc, summed over every k_tr_gemm* launch (split-K reductions included)
+        if world == 1 and not args.no_live_traffic:
+            child_steps = 2
+            child = ["--mode", "train", "--gpus", "1", "--steps", str(child_steps), "--warmup", "1", "--precision", args.precision, "--train-batch", str(Bt),
+                     "--spectra", args.spectra, "--no-cpu-baseline", "--no-live-traffic"]
+            tot_b, launches, note = live_pmc_family_bytes("k_tr_gemm", child)
+            if tot_b is not None:
+                n_steps = child_steps + 1 + 1
+                line["roofline"]["traffic"] = tot_b / n_steps
+                line["roofline"]["traffic_unit"] = "HBM bytes per optimizer step, all k_tr_gemm* launches (compare hbm_view.algorithmic_bytes_per_step)"
+                line["roofline"]["traffic_source"] = note + f"; {n_steps} optimizer steps in the profiled run, {launches / n_steps:.0f} launches per step"
+            else:
+                line["roofline"]["traffic_source"] = "not measured: " + note
         if with_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline_train(args.spectra)

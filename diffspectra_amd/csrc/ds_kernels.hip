@@ -24,6 +24,9 @@
 #ifndef DS_QKV_PF
 #define DS_QKV_PF 4
 #endif
+#ifndef DS_TWO_STREAM_MAX_PAIRS
+#define DS_TWO_STREAM_MAX_PAIRS 400000   // ds_forward: side stream for batches below this many pair rows (~2 500 molecules)
+#endif
 #ifndef DS_ATTN_FMA
 #define DS_ATTN_FMA 1
 #endif
@@ -2546,7 +2549,7 @@ struct SideStream {
   bool ok = false, tried = false;
 };
 static SideStream g_side[16];
-static int g_two_stream = -1;   // -1: from the environment (DIFFSPECTRA_TWO_STREAM, default 1)
+static int g_two_stream = -1;   // -1: from the environment (DIFFSPECTRA_TWO_STREAM), else by batch size
 
 static SideStream* side_stream() {
   int dev = 0;
@@ -2606,8 +2609,12 @@ int ds_forward(const ds_weights* w, const ds_layout* L, ds_workspace* ws, const 
   if (st) return st;
   st = ds_stage_init(w, L, ws, xh, edge_x, cond_x, cond_edge_x, stream);
   if (st) return st;
-  static const int env_two = [] { const char* e = getenv("DIFFSPECTRA_TWO_STREAM"); return e ? atoi(e) : 1; }();
-  const int two = g_two_stream >= 0 ? g_two_stream : env_two;
+  // measured (profiles/r05_two_stream_ab.txt): +0.8 % at 1 250 resident molecules (the side kernels fill the tails of the main
+  // stream's launches), -1 % at 5 000 (every kernel fills the chip by itself and is bound by the latency of its own waves at an
+  // LDS-limited occupancy; workgroups of a second kernel take slots, they do not add any) - so it is on for small batches only
+  static const int env_two = [] { const char* e = getenv("DIFFSPECTRA_TWO_STREAM"); return e ? atoi(e) : -1; }();
+  const int pick = g_two_stream >= 0 ? g_two_stream : env_two;
+  const int two = pick >= 0 ? pick : (L->Pp < DS_TWO_STREAM_MAX_PAIRS ? 1 : 0);
   SideStream* ss = two ? side_stream() : nullptr;
   if (ss) {
     st = forward_blocks_two_streams(w, L, ws, (hipStream_t)stream, ss);

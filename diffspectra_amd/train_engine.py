@@ -69,6 +69,11 @@ import struct as _struct
 _GEMM_STRUCT = _struct.Struct("@PqqPqqPqPiiiiPqiiPiiPqPqfIQq")
 assert _GEMM_STRUCT.size == C.sizeof(DstGemmArgs), (_GEMM_STRUCT.size, C.sizeof(DstGemmArgs))
 _GEMM_PACK = _GEMM_STRUCT.pack
+# dst_pair_chain_args (include/diffspectra_train.h): 4 pointers, ld_feat | ada, ada_ld | 4 offsets | W3 b3 W4 b4 Wed, ld_wed | bed Wro bro |
+# drop_p, stream3, stream4, pad | seed | 11 output pointers
+_CHAIN_PACK = _struct.Struct("@PPPPq Pq iiii PPPPP q PPP f III Q PPPPPPPPPPP").pack
+# dst_pair_front_args: pos, ada, ada_ld | dist_off, shift_off, scale_off, pad | means stds e_in Wee bee Wte | X1 xs d2 e1 st en te
+_FRONT_PACK = _struct.Struct("@PPq iiii PPPPPP PPPPPPP").pack
 
 
 class DstLayout(C.Structure):
@@ -289,6 +294,23 @@ class Ops:
         E._check(self.lib.dst_gate_add_fwd(E._ptr(r), E._ptr(z), C.c_int32(Cc), E._ptr(seg), C.c_int32(mul), C.c_int32(B), E._ptr(ada), C.c_int64(ADA),
                                            C.c_int32(g), E._ptr(out), self._s()), "dst_gate_add_fwd")
 
+    def pair_chain_fwd(self, TL, u, n2e_bias, e_in, feat, ld_feat, ada, g1, sh, sc, g2, W3, b3, W4, b4, Wed, ld_wed, bed, Wro, bro, drop, out):
+        """The pair rows of a block behind the attention as one kernel (``dst_pair_chain_fwd``, bf16 products).  ``drop = (p, seed, stream3,
+        stream4)``; ``out``: dict with e_out, ed, ro and - when the tape is kept - he, xe1, st, ye1, f3, s3, f4, X2."""
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        args = _CHAIN_PACK(ptr(u), ptr(n2e_bias), ptr(e_in), ptr(feat), ld_feat, ptr(ada), ADA, g1, sh, sc, g2, ptr(W3), ptr(b3), ptr(W4), ptr(b4),
+                           ptr(Wed), ld_wed, ptr(bed), ptr(Wro), ptr(bro), float(drop[0]), int(drop[2]), int(drop[3]), 0, int(drop[1]),
+                           *(ptr(out.get(k)) for k in ("he", "xe1", "st", "ye1", "f3", "s3", "f4", "e_out", "X2", "ed", "ro")))
+        E._check(self.lib.dst_pair_chain_fwd(C.byref(TL.c), args, self._s()), "dst_pair_chain_fwd")
+
+    def pair_front_fwd(self, TL, pos, ada, dist_off, sh, sc, means, stds, e_in, Wee, bee, Wte, out):
+        """The pair rows of a block in front of the attention as one kernel (``dst_pair_front_fwd``, bf16 products).  ``out``: dict with X1, te and -
+        when the tape is kept - xs, d2, e1, st, en."""
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        args = _FRONT_PACK(ptr(pos), ptr(ada), ADA, dist_off, sh, sc, 0, ptr(means), ptr(stds), ptr(e_in), ptr(Wee), ptr(bee), ptr(Wte),
+                           *(ptr(out.get(k)) for k in ("X1", "xs", "d2", "e1", "st", "en", "te")))
+        E._check(self.lib.dst_pair_front_fwd(C.byref(TL.c), args, self._s()), "dst_pair_front_fwd")
+
     def gate_add_bwd(self, dout, z, Cc, seg, mul, B, ada, d_ada, g, dr, acc_r, dz, drop=None):
         """``drop = (p, seed, stream_id)``: ``z`` was a dropout's output; ``dz`` is then the gradient in FRONT of that dropout."""
         p_, seed, stream = drop if drop and drop[0] > 0 else (0.0, 0, 0)
@@ -506,6 +528,8 @@ class DmtTrainGraph:
         blocks = []
         ns = bool(int(os.environ.get("DIFFSPECTRA_NODE_STREAM", "1"))) and getattr(o, "main_stream", None) is not None
         sec = o.node_section if ns else contextlib.nullcontext
+        # fused row chains: bf16 mode only (their products are bf16 MFMAs; the fp32 mode keeps the per-operation kernels golden G13 / G17 pin)
+        fused_chain = bool(o.bf16) and Pp > 0 and os.environ.get("DIFFSPECTRA_FUSED_CHAIN", "1") != "0"
         for i in range(NB):
             bp = f"e_block_{i}."
             a0 = i * ADA_STRIDE
@@ -519,15 +543,25 @@ class DmtTrainGraph:
                 qkv = self.f(Nn, 768)
                 o.lin_fwd(mv(hn), mv(cat["Wqkv"][i]), cat["bqkv"][i], mv(qkv))
             # distances + CondGaussian features, edge embedding (dmt.py:136-139)
-            X1, xs, d2 = self.f(Pp, 128), self.f(Pp), self.f(Pp)
-            self._geom_fwd(TL, pos, ada, a0 + DIST_OFF, bp + "dist_layer.", X1, 128, 0, xs, d2)
-            X1[:, 64:128] = e
-            e1 = self.f(Pp, 64)
-            o.lin_fwd(mv(X1), mv(p[bp + "edge_emb.weight"]), p[bp + "edge_emb.bias"], mv(e1))
-            en, st_e1 = self.f(Pp, 64), self.f(Pp, 2)
-            o.lnmod_fwd(e1, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 0, a0 + EDGE_OFF + 64, en, st_e1)
-            te = self.f(Pp, 512)                                     # tanh(lin_edge0 e) | tanh(lin_edge1 e) as one product; columns 252..255 = tanh(0)
-            o.lin_fwd(mv(en), mv(cat["Wte"][i]), None, mv(te), act=TANH)
+            if fused_chain:
+                # dmt.py:136-139,145-149 + both lin_edge projections as ONE kernel (csrc/ds_train_chain.hip)
+                X1, te = self.f(Pp, 128), self.f(Pp, 512)
+                outs = dict(X1=X1, te=te)
+                if save:
+                    outs.update(xs=self.f(Pp), d2=self.f(Pp), e1=self.f(Pp, 64), st=self.f(Pp, 2), en=self.f(Pp, 64))
+                o.pair_front_fwd(TL, pos, ada, a0 + DIST_OFF, a0 + EDGE_OFF + 0, a0 + EDGE_OFF + 64, p[bp + "dist_layer.means.weight"],
+                                 p[bp + "dist_layer.stds.weight"], e, p[bp + "edge_emb.weight"], p[bp + "edge_emb.bias"], cat["Wte"][i], outs)
+                xs, d2, e1, st_e1, en = (outs.get(k) for k in ("xs", "d2", "e1", "st", "en"))
+            else:
+                X1, xs, d2 = self.f(Pp, 128), self.f(Pp), self.f(Pp)
+                self._geom_fwd(TL, pos, ada, a0 + DIST_OFF, bp + "dist_layer.", X1, 128, 0, xs, d2)
+                X1[:, 64:128] = e
+                e1 = self.f(Pp, 64)
+                o.lin_fwd(mv(X1), mv(p[bp + "edge_emb.weight"]), p[bp + "edge_emb.bias"], mv(e1))
+                en, st_e1 = self.f(Pp, 64), self.f(Pp, 2)
+                o.lnmod_fwd(e1, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 0, a0 + EDGE_OFF + 64, en, st_e1)
+                te = self.f(Pp, 512)                                     # tanh(lin_edge0 e) | tanh(lin_edge1 e) as one product; columns 252..255 = tanh(0)
+                o.lin_fwd(mv(en), mv(cat["Wte"][i]), None, mv(te), act=TANH)
             te0, te1 = te[:, 0:256], te[:, 256:512]
             # attention (layers.py:131-186)
             if ns:
@@ -557,24 +591,38 @@ class DmtTrainGraph:
             # edge stream (dmt.py:156-157,165-169)
             if ns:
                 o.main_wait(ev_u)
-            he = self.f(Pp, 64)
-            E._check(lib.dst_pair_sum_fwd(C.byref(TL.c), E._ptr(u), C.c_int32(64), E._ptr(p[bp + "node2edge_lin.bias"]), E._ptr(he), s()), "dst_pair_sum_fwd")
-            xe1, ye1, st_e2 = self.f(Pp, 64), self.f(Pp, 64), self.f(Pp, 2)
-            o.gate_add_fwd(e, he, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 128, xe1)
-            o.lnmod_fwd(xe1, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 192, a0 + EDGE_OFF + 256, ye1, st_e2)
-            f3, s3, f4, e_out = self.f(Pp, 128), self.f(Pp, 128), self.f(Pp, 64), self.f(Pp, 64)
-            o.lin_fwd(mv(ye1), mv(p[bp + "ff_linear3.weight"]), p[bp + "ff_linear3.bias"], mv(f3), act=SILU, out2=mv(s3), drop=(dp, dseed, 4 * i + 2, 128))
-            o.lin_fwd(mv(s3), mv(p[bp + "ff_linear4.weight"]), p[bp + "ff_linear4.bias"], mv(f4), drop=(dp, dseed, 4 * i + 3, 64))
-            o.gate_add_fwd(ye1, f4, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 320, e_out)
-            # equivariant update (dmt.py:37-60) + CoM removal (:385-386)
             Win = p[bp + "equi_update.input_lin.weight"]                       # [256, 640] = [h_row | h_col | e | dist]
-            X2 = self.f(Pp, 128)
-            X2[:, 0:64] = e_out
-            X2[:, 64:128] = X1[:, 0:64]
-            ed = self.f(Pp, 256)
-            o.lin_fwd(mv(X2), mv(Win, 512, 640), p[bp + "equi_update.input_lin.bias"], mv(ed))
-            re_ = self.f(Pp, 16)                                     # per-block read-out features (dmt.py:388)
-            o.lin_fwd(mv(e_out), mv(p[f"edge_{i}.weight"]), p[f"edge_{i}.bias"], mv(re_))
+            if fused_chain:
+                # dmt.py:156-157,165-169,388 + the edge part of input_lin as ONE kernel (csrc/ds_train_chain.hip); a forward without a tape
+                # (the self-conditioning pass) writes only what the rest of the forward reads
+                e_out, ed, re_ = self.f(Pp, 64), self.f(Pp, 256), self.f(Pp, 16)
+                outs = dict(e_out=e_out, ed=ed, ro=re_)
+                if save:
+                    outs.update(he=self.f(Pp, 64), xe1=self.f(Pp, 64), st=self.f(Pp, 2), ye1=self.f(Pp, 64), f3=self.f(Pp, 128), s3=self.f(Pp, 128),
+                                f4=self.f(Pp, 64), X2=self.f(Pp, 128))
+                o.pair_chain_fwd(TL, u, p[bp + "node2edge_lin.bias"], e, X1, 128, ada, a0 + EDGE_OFF + 128, a0 + EDGE_OFF + 192, a0 + EDGE_OFF + 256,
+                                 a0 + EDGE_OFF + 320, p[bp + "ff_linear3.weight"], p[bp + "ff_linear3.bias"], p[bp + "ff_linear4.weight"],
+                                 p[bp + "ff_linear4.bias"], Win[:, 512:640], 640, p[bp + "equi_update.input_lin.bias"], p[f"edge_{i}.weight"],
+                                 p[f"edge_{i}.bias"], (dp, dseed, 4 * i + 2, 4 * i + 3), outs)
+                he, xe1, st_e2, ye1, f3, s3, f4, X2 = (outs.get(k) for k in ("he", "xe1", "st", "ye1", "f3", "s3", "f4", "X2"))
+            else:
+                he = self.f(Pp, 64)
+                E._check(lib.dst_pair_sum_fwd(C.byref(TL.c), E._ptr(u), C.c_int32(64), E._ptr(p[bp + "node2edge_lin.bias"]), E._ptr(he), s()), "dst_pair_sum_fwd")
+                xe1, ye1, st_e2 = self.f(Pp, 64), self.f(Pp, 64), self.f(Pp, 2)
+                o.gate_add_fwd(e, he, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 128, xe1)
+                o.lnmod_fwd(xe1, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 192, a0 + EDGE_OFF + 256, ye1, st_e2)
+                f3, s3, f4, e_out = self.f(Pp, 128), self.f(Pp, 128), self.f(Pp, 64), self.f(Pp, 64)
+                o.lin_fwd(mv(ye1), mv(p[bp + "ff_linear3.weight"]), p[bp + "ff_linear3.bias"], mv(f3), act=SILU, out2=mv(s3), drop=(dp, dseed, 4 * i + 2, 128))
+                o.lin_fwd(mv(s3), mv(p[bp + "ff_linear4.weight"]), p[bp + "ff_linear4.bias"], mv(f4), drop=(dp, dseed, 4 * i + 3, 64))
+                o.gate_add_fwd(ye1, f4, 64, TL.pair_off, 1, B, ada, a0 + EDGE_OFF + 320, e_out)
+                # equivariant update (dmt.py:37-60) + CoM removal (:385-386)
+                X2 = self.f(Pp, 128)
+                X2[:, 0:64] = e_out
+                X2[:, 64:128] = X1[:, 0:64]
+                ed = self.f(Pp, 256)
+                o.lin_fwd(mv(X2), mv(Win, 512, 640), p[bp + "equi_update.input_lin.bias"], mv(ed))
+                re_ = self.f(Pp, 16)                                     # per-block read-out features (dmt.py:388)
+                o.lin_fwd(mv(e_out), mv(p[f"edge_{i}.weight"]), p[f"edge_{i}.bias"], mv(re_))
             if ns:
                 o.main_wait(ev_ac)
             zz, zn, st_z = self.f(max(D, 1), 256), self.f(max(D, 1), 256), self.f(max(D, 1), 2)

@@ -194,7 +194,8 @@ int ds_forward(const ds_weights* w, const ds_layout* L, ds_workspace* ws,
 
 /* ds_forward runs a block's node rows behind the attention (k_node_update) and the next block's q|k|v projection on a library-owned
  * side stream beside the pair rows' k_edge_update (fork / join by events; safe under stream capture).  on = 0: one stream (the order of
- * ds_stage_block), 1: two streams, -1: follow the environment variable DIFFSPECTRA_TWO_STREAM (default 1).  Returns the previous
+ * ds_stage_block), 1: two streams, -1: follow the environment variable DIFFSPECTRA_TWO_STREAM if set, else two streams for small
+ * batches only (below ~2 500 molecules: there the side kernels fill launch tails; at the bench size they do not pay).  Returns the previous
  * setting.  Results are bit-identical in both modes.  (Build extension: the reference has no such switch.) */
 int ds_set_two_stream(int on);
 

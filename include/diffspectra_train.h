@@ -258,6 +258,40 @@ int dst_clip_update(const float* norm_sq, float inv_world, float max_grad, float
 /* sum of squares of x [n] into out[0] (accumulate != 0 adds): the global gradient norm of clip_grad_norm_. */
 int dst_sumsq(const float* x, int64_t n, float* out, int32_t accumulate, float* scratch, int64_t scratch_cap, void* stream);
 
+/* The pair rows of one block behind the attention as ONE kernel (bf16 products, fp32 accumulation and fp32 everything else) - reference
+ * dmt.py:156-157,165-169,388 and the edge part of equi_update.input_lin (dmt.py:39); replaces dst_pair_sum_fwd, 2 x dst_gate_add_fwd,
+ * dst_lnmod_fwd and four dst_gemm calls of the unfused forward:
+ *   he = u[a] + u[b] + n2e_bias;  xe1 = e_in + ada[gate1] * he;  ye1 = LN(xe1) * (1 + ada[scale]) + ada[shift];
+ *   f3 = ye1 W3^T + b3;  s3 = dropout(SiLU(f3));  f4 = dropout(s3 W4^T + b4);  e_out = ye1 + ada[gate2] * f4;
+ *   ed = [e_out | feat] Wed^T + bed;  ro = e_out Wro^T + bro.
+ * u [Nn,64]; e_in [Pp,64]; feat [Pp,64] with row stride ld_feat; ada [B, ada_ld] with the four column offsets; W3 [128,64], W4 [64,128],
+ * Wed [256 rows, row stride ld_wed, 128 used columns: e | dist], Wro [16,64] (torch Linear layout, fp32).  Dropout: dst_dropout's masks
+ * (element (row, col) of the [Pp,128] / [Pp,64] tensor under stream3 / stream4).  Outputs: e_out [Pp,64], ed [Pp,256], ro [Pp,16]
+ * always; the tape tensors he, xe1, st [Pp,2] = (mean, rstd), ye1, f3 [Pp,128], s3 [Pp,128], f4, X2 [Pp,128] = [e_out | feat] may each
+ * be NULL (not written).  Every pointer 16-byte aligned. */
+typedef struct dst_pair_chain_args {
+  const float* u; const float* n2e_bias; const float* e_in; const float* feat; int64_t ld_feat;
+  const float* ada; int64_t ada_ld; int32_t gate1_off, shift_off, scale_off, gate2_off;
+  const float* W3; const float* b3; const float* W4; const float* b4; const float* Wed; int64_t ld_wed; const float* bed;
+  const float* Wro; const float* bro;
+  float drop_p; uint32_t stream3, stream4, _pad; uint64_t seed;
+  float* he; float* xe1; float* st; float* ye1; float* f3; float* s3; float* f4; float* e_out; float* X2; float* ed; float* ro;
+} dst_pair_chain_args;
+int dst_pair_chain_fwd(const dst_layout* L, const dst_pair_chain_args* a, void* stream);
+
+/* The pair rows of one block in FRONT of the attention as one kernel (bf16 products; dmt.py:136-139,145-149, layers.py:291-295,328-334,
+ * 165-166,183); replaces dst_geom_fwd, the [feat | e] copy, dst_lnmod_fwd and two dst_gemm calls:
+ *   X1 = [CondGaussian features of the modulated squared distance (64) | e_in (64)];  e1 = X1 Wee^T + bee;
+ *   en = LN(e1) * (1 + ada[scale]) + ada[shift];  te = tanh(en Wte^T)   (Wte [512,64] = lin_edge0 | lin_edge1, rows 252..255 zero).
+ * pos [Nn,3]; means, stds [63]; ada column dist_off holds the distance scale, dist_off + 1 its shift.  Outputs: X1 [Pp,128] and te [Pp,512]
+ * always; xs [Pp] (x'), d2 [Pp], e1 [Pp,64], st [Pp,2] = (mean, rstd), en [Pp,64] may be NULL. */
+typedef struct dst_pair_front_args {
+  const float* pos; const float* ada; int64_t ada_ld; int32_t dist_off, shift_off, scale_off, _pad;
+  const float* means; const float* stds; const float* e_in; const float* Wee; const float* bee; const float* Wte;
+  float* X1; float* xs; float* d2; float* e1; float* st; float* en; float* te;
+} dst_pair_front_args;
+int dst_pair_front_fwd(const dst_layout* L, const dst_pair_front_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,19 @@ def mol_tables(n_atoms):
 
 N_ATOMS = [3, 1, 7, 12, 29, 2]
 
+_KEEP = []
+
+
+def _dev(t, d):
+    """``t`` on the device, kept alive: a temporary passed as ``E._ptr(t.to(d))`` is freed as soon as ``_ptr`` returns, and the caching
+    allocator may hand its block to the NEXT temporary of the same argument list before the kernel has read it (seen in round 5, when an
+    earlier test had left large cached blocks behind: dst_zbuild_fwd read `ed` where `ac` should have been)."""
+    x = t.to(d)
+    _KEEP.append(x)
+    if len(_KEEP) > 64:
+        del _KEEP[:32]
+    return x
+
 
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K,ta,tb,bias,acc", [(70, 96, 40, False, True, True, False), (64, 64, 64, False, False, False, True),
@@ -362,7 +375,7 @@ def test_attention(ops, gpu_device):
     check(ald, al, 3e-6, "attention alpha")
     check(outd, out, 3e-6, "attention out")
     dq, de0, de1 = torch.empty(Nn, 768, device=d), torch.empty(P, 256, device=d), torch.empty(P, 256, device=d)
-    E._check(o.lib.dst_attn_bwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), C.c_int64(256), E._ptr(ald), E._ptr(dout.to(d)), E._ptr(dq), E._ptr(de0), E._ptr(de1),
+    E._check(o.lib.dst_attn_bwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), C.c_int64(256), E._ptr(ald), E._ptr(_dev(dout, d)), E._ptr(dq), E._ptr(de0), E._ptr(de1),
                                 C.c_int32(0), None, C.c_int64(0), E._stream()), "attn_bwd")
     check(dq, qr.grad, 2e-5, "attention dqkv")
     check(de0, e0r.grad, 2e-5, "attention dte0")
@@ -371,10 +384,10 @@ def test_attention(ops, gpu_device):
     # same arithmetic, same summation order -> the same bits; te_is_tanh multiplies the pair gradients by 1 - te^2
     dq2, de02, de12 = torch.zeros_like(dq), torch.zeros_like(de0), torch.zeros_like(de1)
     scr = torch.empty(32 * P + 64, device=d)
-    E._check(o.lib.dst_attn_bwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), C.c_int64(256), E._ptr(ald), E._ptr(dout.to(d)), E._ptr(dq2), E._ptr(de02),
+    E._check(o.lib.dst_attn_bwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), C.c_int64(256), E._ptr(ald), E._ptr(_dev(dout, d)), E._ptr(dq2), E._ptr(de02),
                                 E._ptr(de12), C.c_int32(0), E._ptr(scr), C.c_int64(scr.numel()), E._stream()), "attn_bwd")
     assert torch.equal(dq2, dq) and torch.equal(de02, de0) and torch.equal(de12, de1)
-    E._check(o.lib.dst_attn_bwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), C.c_int64(256), E._ptr(ald), E._ptr(dout.to(d)), E._ptr(dq2), E._ptr(de02),
+    E._check(o.lib.dst_attn_bwd(C.byref(TL.c), E._ptr(qd), E._ptr(e0d), E._ptr(e1d), C.c_int64(256), E._ptr(ald), E._ptr(_dev(dout, d)), E._ptr(dq2), E._ptr(de02),
                                 E._ptr(de12), C.c_int32(1), E._ptr(scr), C.c_int64(scr.numel()), E._stream()), "attn_bwd")
     check(de02, de0.double().cpu() * (1 - te0.double() ** 2), 1e-6, "attention dte0 in front of the tanh")
     check(de12, de1.double().cpu() * (1 - te1.double() ** 2), 1e-6, "attention dte1 in front of the tanh")
@@ -397,8 +410,8 @@ def test_pair_sum_zbuild_coord(ops, gpu_device):
     dps = torch.randn(P, 64, generator=g)
     ps.backward(dps.double())
     psd, dud = torch.empty(P, 64, device=d), torch.empty(Nn, 64, device=d)
-    E._check(o.lib.dst_pair_sum_fwd(C.byref(TL.c), E._ptr(u.detach().float().to(d)), C.c_int32(64), E._ptr(bias.to(d)), E._ptr(psd), s()), "pair_sum_fwd")
-    E._check(o.lib.dst_pair_sum_bwd(C.byref(TL.c), E._ptr(dps.to(d)), C.c_int32(64), E._ptr(dud), C.c_int32(0), s()), "pair_sum_bwd")
+    E._check(o.lib.dst_pair_sum_fwd(C.byref(TL.c), E._ptr(_dev(u.detach().float(), d)), C.c_int32(64), E._ptr(_dev(bias, d)), E._ptr(psd), s()), "pair_sum_fwd")
+    E._check(o.lib.dst_pair_sum_bwd(C.byref(TL.c), E._ptr(_dev(dps, d)), C.c_int32(64), E._ptr(dud), C.c_int32(0), s()), "pair_sum_bwd")
     check(psd, ps, 1e-6, "pair_sum fwd")
     check(dud, u.grad, 3e-6, "pair_sum bwd")
     # zbuild: directed edge 2p = (row a, col b), 2p+1 = (row b, col a)
@@ -410,8 +423,8 @@ def test_pair_sum_zbuild_coord(ops, gpu_device):
     dz = torch.randn(2 * P, 256, generator=g)
     z.backward(dz.double())
     zd, dacd, dedd = torch.empty(2 * P, 256, device=d), torch.empty(Nn, 512, device=d), torch.empty(P, 256, device=d)
-    E._check(o.lib.dst_zbuild_fwd(C.byref(TL.c), E._ptr(ac.detach().float().to(d)), E._ptr(ed.detach().float().to(d)), E._ptr(zd), s()), "zbuild_fwd")
-    E._check(o.lib.dst_zbuild_bwd(C.byref(TL.c), E._ptr(dz.to(d)), E._ptr(dacd), E._ptr(dedd), s()), "zbuild_bwd")
+    E._check(o.lib.dst_zbuild_fwd(C.byref(TL.c), E._ptr(_dev(ac.detach().float(), d)), E._ptr(_dev(ed.detach().float(), d)), E._ptr(zd), s()), "zbuild_fwd")
+    E._check(o.lib.dst_zbuild_bwd(C.byref(TL.c), E._ptr(_dev(dz, d)), E._ptr(dacd), E._ptr(dedd), s()), "zbuild_bwd")
     check(zd, z, 1e-6, "zbuild fwd")
     check(dacd, ac.grad, 3e-6, "zbuild dac")
     check(dedd, ed.grad, 1e-6, "zbuild ded")
@@ -434,7 +447,7 @@ def test_pair_sum_zbuild_coord(ops, gpu_device):
     posd, c2d, adjd, scd = pos.detach().float().to(d), c2.detach().float().to(d), adj.to(d), scale.detach().float().to(d)
     outd, dposd, dc2d, dsp = torch.empty(Nn, 3, device=d), torch.empty(Nn, 3, device=d), torch.empty(2 * P, 3, device=d), torch.empty(B, device=d)
     E._check(o.lib.dst_coord_fwd(C.byref(TL.c), E._ptr(posd), E._ptr(c2d), E._ptr(adjd), E._ptr(scd), E._ptr(outd), s()), "coord_fwd")
-    E._check(o.lib.dst_coord_bwd(C.byref(TL.c), E._ptr(posd), E._ptr(c2d), E._ptr(adjd), E._ptr(scd), E._ptr(dout.to(d)), E._ptr(dposd), E._ptr(dc2d),
+    E._check(o.lib.dst_coord_bwd(C.byref(TL.c), E._ptr(posd), E._ptr(c2d), E._ptr(adjd), E._ptr(scd), E._ptr(_dev(dout, d)), E._ptr(dposd), E._ptr(dc2d),
                                  E._ptr(dsp), s()), "coord_bwd")
     check(outd, out, 2e-6, "coord fwd")
     check(dposd, pos.grad, 2e-5, "coord dpos")
@@ -1195,7 +1208,7 @@ def test_config5_as_benchmarked_against_the_reference_loss(gpu_device, monkeypat
     monkeypatch.undo()
     loss.backward()
     tr = model.module._hip_trainer
-    assert tr.ops.bf16 and getattr(tr.ops, "main_stream", None) is not None        # bf16 products, node / weight-gradient streams in use
+    assert tr.ops.bf16                                                               # bf16 products (and with them the flash attention kernels)
     ref_loss = float(g[tag + "_loss"])
     assert abs(float(loss.detach()) - ref_loss) <= 1e-2 * abs(ref_loss), (float(loss.detach()), ref_loss)
     names = json.loads(g[tag + "_grad_names"])
@@ -1249,7 +1262,7 @@ def _synthetic_train_batch(Bt, version, seed, d):
                 context=[c.to(d) for c in ctx] if isinstance(ctx, list) else ctx.to(d))
 
 
-def _train_run(d, version, precision, steps, batches, lr=2e-4, seed=7):
+def _train_run(d, version, precision, steps, batches, lr=2e-4, seed=7, perturb=0.0):
     """``steps`` optimizer steps of the product's step_fn (fused AdamW + clip + EMA) from the procedural weights, every source of randomness
     seeded; returns (losses, model, ema, state)."""
     import random as _random
@@ -1260,6 +1273,10 @@ def _train_run(d, version, precision, steps, batches, lr=2e-4, seed=7):
     cfg.model.dropout = 0.1
     cfg.training.precision = precision
     cfg.optim.lr, cfg.optim.warmup = lr, 0
+    if perturb:
+        with torch.no_grad():
+            for prm in model.parameters():
+                prm.mul_(1.0 + perturb)
     ema = ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_decay)
     opt = Lh.get_optimizer(cfg, model.parameters())
     step_fn = Lh.get_step_fn(NoiseScheduleVP("cosine", continuous_beta_0=0.1, continuous_beta_1=20.0), True, Lh.optimization_manager(cfg), None, cfg)
@@ -1276,21 +1293,30 @@ def _train_run(d, version, precision, steps, batches, lr=2e-4, seed=7):
 
 
 def test_bf16_and_fp32_training_curves_agree(gpu_device):
-    """50 optimizer steps of config 5's step (all-spectra, dropout 0.1, lr 2e-4) in bf16 mode and in fp32 mode from the same weights, the
-    same batches and the same seeds (noise, diffusion times, self-conditioning coins, dropout masks): the two loss curves stay within 2 %
-    of each other in their 10-step means and end lower than they start."""
+    """50 optimizer steps of config 5's step (all-spectra, dropout 0.1, the shipped peak lr 2e-4, no warm-up - the shipped 100 000-step
+    warm-up would leave the weights untouched) in bf16 mode and in fp32 mode from the same weights, batches and seeds (noise, diffusion
+    times, self-conditioning coins, dropout masks).  AdamW amplifies ANY rounding difference (an element whose gradient is rounding noise
+    still moves by +-lr), so two runs of this length decorrelate whatever their arithmetic; measured here: an fp32 run whose initial
+    weights are scaled by 1 + 1e-6 leaves the unperturbed fp32 curve by several per cent.  The test therefore holds bf16 to
+      (a) the first optimizer steps, where the curves are still a property of the arithmetic: each of the first 3 losses within 0.5 %;
+      (b) the chaos baseline over the whole run: the largest deviation of a 10-step mean between bf16 and fp32 is no more than twice the
+          deviation between the two fp32 runs (or 2 %, whichever is larger), and every curve falls."""
     d = gpu_device
     batches = [_synthetic_train_batch(24, "allspectra", s, d) for s in range(4)]
-    curves = {}
-    for precision in ("fp32", "bf16"):
-        curves[precision] = _train_run(d, "allspectra", precision, 50, batches)[0]
-    a, b = np.asarray(curves["fp32"]), np.asarray(curves["bf16"])
-    assert np.isfinite(a).all() and np.isfinite(b).all()
-    ma, mb = a.reshape(5, 10).mean(1), b.reshape(5, 10).mean(1)
-    print(f"[50 steps] fp32 10-step means {np.round(ma, 3).tolist()}\n[50 steps] bf16 10-step means {np.round(mb, 3).tolist()}; "
-          f"largest single-step deviation {float(np.abs(a - b).max() / np.abs(a).max()):.4f}")
-    assert np.all(np.abs(ma - mb) <= 0.02 * np.abs(ma)), (ma, mb)
-    assert ma[-1] < ma[0] and mb[-1] < mb[0]
+    a = np.asarray(_train_run(d, "allspectra", "fp32", 50, batches)[0])
+    a2 = np.asarray(_train_run(d, "allspectra", "fp32", 50, batches, perturb=1e-6)[0])
+    b = np.asarray(_train_run(d, "allspectra", "bf16", 50, batches)[0])
+    assert np.isfinite(a).all() and np.isfinite(a2).all() and np.isfinite(b).all()
+    m = lambda v: v.reshape(5, 10).mean(1)
+    dev = lambda x, y: float((np.abs(m(x) - m(y)) / np.abs(m(x))).max())
+    chaos, gap = dev(a, a2), dev(a, b)
+    print(f"[50 steps] fp32 10-step means            {np.round(m(a), 3).tolist()}\n[50 steps] fp32, weights x (1 + 1e-6)    {np.round(m(a2), 3).tolist()}\n"
+          f"[50 steps] bf16 10-step means            {np.round(m(b), 3).tolist()}\n[50 steps] largest deviation of a 10-step mean: fp32 vs perturbed fp32 "
+          f"{chaos:.4f}, fp32 vs bf16 {gap:.4f}; first three losses fp32 {np.round(a[:3], 4).tolist()} bf16 {np.round(b[:3], 4).tolist()}")
+    assert np.all(np.abs(a[:3] - b[:3]) <= 5e-3 * np.abs(a[:3])), (a[:3], b[:3])
+    assert gap <= max(0.02, 2.0 * chaos), (gap, chaos)
+    for v in (a, a2, b):
+        assert m(v)[-1] < 0.7 * m(v)[0]
 
 
 def test_split_fp16_sampling_parity_on_weights_the_hip_trainer_produced(gpu_device):
@@ -1369,3 +1395,109 @@ def test_split_fp16_sampling_parity_on_weights_the_hip_trainer_produced(gpu_devi
           f"mismatches (type, charge, bond) {mis}")
     assert drift <= 5e-4 and mis == (0, 0, 0)
     del init
+
+
+@pytest.mark.parametrize("L", [347, 69])
+def test_specformer_flash_attention_vs_torch_fp64(gpu_device, L):
+    """The score-free SpecFormer attention kernels of bf16 mode (``dst_spec_attn_flash_fwd / _bwd``) against an INDEPENDENT reference: torch
+    autograd in fp64 of specformer.py:385-425's residual attention written out (scores_l = scale q_l k_l^T + scores_{l-1}, softmax,
+    P V) over three chained layers.  The kernels round q, k, v and the probabilities to bf16 (fp32 accumulation), so the gate is the
+    bf16 level: relative L2 error <= 1.5 % for every layer's output and every layer's dq / dk / dv, gradient cosine > 0.9998."""
+    import ctypes as C
+    from diffspectra_amd import engine as E, train_engine as T
+    lib = T.load_train_library()
+    d = gpu_device
+    B, H, DK, DM = 3, 16, 8, 128
+    gen = torch.Generator().manual_seed(L)
+    qkv = [torch.randn(B * L, 3 * DM, generator=gen).to(d) for _ in range(3)]
+    dao = [torch.randn(B * L, DM, generator=gen).to(d) for _ in range(3)]
+    scale = DK ** -0.5
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=d)
+    outs, stats = [], []
+    for l in range(3):
+        ast, out = f(B, H, L, 2), f(B * L, DM)
+        qp = [E._ptr(q) for q in qkv[:l + 1]] + [None] * (2 - l)
+        E._check(lib.dst_spec_attn_flash_fwd(qp[0], qp[1], qp[2], C.c_int32(l + 1), E._ptr(ast), E._ptr(out), C.c_int32(B), C.c_int32(L), C.c_int32(H),
+                                             C.c_int32(DK), C.c_float(scale), E._stream()), "dst_spec_attn_flash_fwd")
+        outs.append(out); stats.append(ast)
+    dq = [torch.zeros(B * L, 3 * DM, device=d) for _ in range(3)]
+    for l in (2, 1, 0):
+        qp = [E._ptr(q) for q in qkv[:l + 1]] + [None] * (2 - l)
+        gp = [E._ptr(q) for q in dq[:l + 1]] + [None] * (2 - l)
+        E._check(lib.dst_spec_attn_flash_bwd(qp[0], qp[1], qp[2], C.c_int32(l + 1), E._ptr(stats[l]), E._ptr(outs[l]), E._ptr(dao[l]), gp[0], gp[1], gp[2],
+                                             C.c_int32(B), C.c_int32(L), C.c_int32(H), C.c_int32(DK), C.c_float(scale), C.c_int32(0), E._stream()), "dst_spec_attn_flash_bwd")
+    torch.cuda.synchronize()
+    qr = [q.double().cpu().clone().requires_grad_(True) for q in qkv]
+    loss, s_prev, ref_out = 0.0, 0.0, []
+    for l in range(3):
+        x = qr[l].view(B, L, 3, H, DK)
+        q_, k_, v_ = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        s_ = scale * q_ @ k_.transpose(-1, -2) + s_prev
+        o = (torch.softmax(s_, -1) @ v_).permute(0, 2, 1, 3).reshape(B * L, DM)
+        ref_out.append(o.detach())
+        loss = loss + (o * dao[l].double().cpu()).sum()
+        s_prev = s_
+    loss.backward()
+    rel = lambda a, b: float((a.double().cpu() - b).norm() / (b.norm() + 1e-30))
+    worst = 0.0
+    for l in range(3):
+        gr = qr[l].grad
+        errs = dict(out=rel(outs[l], ref_out[l]), dq=rel(dq[l][:, :128], gr[:, :128]), dk=rel(dq[l][:, 128:256], gr[:, 128:256]), dv=rel(dq[l][:, 256:], gr[:, 256:]))
+        cos = float((dq[l].double().cpu() * gr).sum() / (dq[l].double().cpu().norm() * gr.norm()))
+        print(f"[flash attention vs torch fp64, L = {L}] layer {l}: " + ", ".join(f"{k} {v:.4f}" for k, v in errs.items()) + f"; gradient cosine {cos:.6f}")
+        worst = max(worst, *errs.values())
+        assert cos > 0.9998, (l, cos)
+    assert worst <= 1.5e-2, worst
+
+
+def test_fused_pair_chain_matches_the_unfused_kernels(gpu_device, monkeypatch):
+    """``dst_pair_front_fwd`` / ``dst_pair_chain_fwd`` (bf16 mode: the pair rows of a block in front of / behind the attention as one kernel
+    each) against the per-operation kernels they replace, on a ragged batch incl. n = 29, 2 and 1, dropout 0.1: every tape tensor of every
+    block - X1, x', d2, e1, en, te; he, xe1, the LayerNorm statistics, ye1, f3, s3, f4, e_out, X2, ed, the read-out slice - and the three
+    outputs of the forward.  Same bf16-rounded operands, same Philox masks; only
+    the order of the fp32 accumulation differs: relative deviation <= 2e-5 of each tensor's scale, the dropout zero patterns identical.
+    Then the backward over both tapes: every gradient within 1e-4."""
+    from diffspectra_amd import filler, train_engine as T
+    d = gpu_device
+    cfg, sd0 = procedural_state_dict("ir")
+    params = {k: v.detach().to(d).contiguous() for k, v in sd0.items() if not k.startswith("cond_encoder.") and v.is_floating_point()}
+    n_atoms = [29, 2, 1, 18, 9, 23, 3, 12]
+    node_mask, _ = filler.masks_from_n_atoms(n_atoms)
+    TL = T.TrainLayout(node_mask, d)
+    g = torch.Generator().manual_seed(5)
+    xn, ex = torch.randn(TL.Nn, 9, generator=g).to(d), torch.randn(TL.Pp, 2, generator=g).to(d)
+    cn, ce = torch.randn(TL.Nn, 9, generator=g).to(d), torch.randn(TL.Pp, 2, generator=g).to(d)
+    nl = (torch.rand(TL.B, generator=g) * 8 - 4).to(d)
+    ctx = (torch.randn(TL.B, 1024, generator=g) * 0.5).to(d)
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DIFFSPECTRA_FUSED_CHAIN", mode)
+        graph = T.DmtTrainGraph(params, cfg, d)
+        graph.ops.bf16 = True
+        graph.dropout_p, graph.dropout_seed = 0.1, 987654321
+        out = graph.forward(TL, xn, ex, nl, ctx, cn, ce)
+        tape = [{k: bt[k].clone() for k in ("X1", "xs", "d2", "e1", "st_e1", "en", "te", "he", "xe1", "st_e2", "ye1", "f3", "s3", "f4", "e_out", "X2", "ed",
+                                            "re_")} for bt in graph.t["blocks"]]
+        dpos, datom, dedge = (torch.randn(o.shape, generator=torch.Generator().manual_seed(9)).to(d) for o in out)
+        grads = {k: v.clone() for k, v in graph.backward(dpos, datom, dedge).items()}
+        runs[mode] = ([o.clone() for o in out], tape, grads)
+    worst = ("", 0.0)
+    for i, (ta, tb) in enumerate(zip(runs["0"][1], runs["1"][1])):
+        for k in ta:
+            ref, got = ta[k], tb[k]
+            scale = float(ref.abs().max()) + 1e-30
+            err = float((got - ref).abs().max()) / scale
+            if err > worst[1]:
+                worst = (f"block {i} {k}", err)
+            assert err <= 2e-5, (i, k, err)
+            if k in ("s3", "f4"):
+                assert torch.equal(got == 0, ref == 0), (i, k, "dropout pattern")
+    for a, b in zip(runs["0"][0], runs["1"][0]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+    gbad = []
+    for k, ga in runs["0"][2].items():
+        gb = runs["1"][2][k]
+        if float((ga - gb).abs().max()) > 1e-4 * float(ga.abs().max()) + 1e-9:
+            gbad.append((k, float((ga - gb).abs().max()), float(ga.abs().max())))
+    print(f"[fused pair chain] worst tape deviation {worst}; {len(runs['0'][2])} gradients compared")
+    assert not gbad, gbad[:8]

@@ -15,8 +15,10 @@
 // dropout masks are dst_dropout's (Philox block (row * N + col) / 4 of stream 4 * block + site): bit-identical to the unfused path and
 // to golden G17's injected masks.
 //
-// One workgroup = (molecule, split): the adaLN rows are per molecule and a molecule's pair rows are contiguous.  A wave owns 32-row tiles
-// from its first load to its last store (wave-private LDS, no workgroup barrier after the pair tables).
+// FLAT tiles: a wave owns 32 consecutive rows of the packed pair (or directed) rows from its first load to its last store, whatever
+// molecules they belong to - the per-molecule adaLN rows are looked up per row (pair_mol), the atoms of a pair come from the layout's
+// pair_a / pair_b tables.  Wave-private LDS, no workgroup barrier: every wave slot of the chip takes the same amount of work (the first
+// version of these kernels ran one workgroup per molecule and lost 2 - 3x to the imbalance between a 29-atom and a 9-atom molecule).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -58,32 +60,55 @@ __device__ __forceinline__ bf16x4_t to_bf4(f4_t v) {
   for (int j = 0; j < 4; ++j) r[j] = (__bf16)v[j];
   return r;
 }
-__device__ __forceinline__ int pair_idx(int n, int a, int b) { return a * (2 * n - a - 1) / 2 + (b - a - 1); }
-__device__ __forceinline__ void wave_lds_sync() {          // wave-private LDS: order this wave's writes before its reads
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+// SiLU and tanh in their hardware exp2 / rcp forms (absolute error ~1e-7: five orders below the bf16 step of the products around them; the
+// libm forms of the unfused epilogues cost 35 - 50 instructions per value, and a wave is alone on its SIMD here)
+__device__ __forceinline__ float fast_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
+__device__ __forceinline__ float fast_tanh(float x) { return fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.8853900817779268f) + 1.0f), 1.0f); }
+// Wave-private LDS: order this wave's LDS writes before its LDS reads.  LDS operations of a wave complete in order, so waiting for the LDS
+// counter is enough; a workgroup-scope fence would also wait for every global store in flight (the tape stores: a memory round trip per call -
+// the first version of these kernels spent most of its time there).
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 
 // acc += A[32 x 16 KB] W^T for output columns col0 .. col0 + 31: A = bf16 rows in LDS (row stride lda halves, first column a0), W = torch
 // Linear weight [out, in] in fp32 with row stride ldw (first input column w0), rounded to bf16 here; output columns >= n_out are zero.
+// The weight fragments are FETCHED (wfetch) and APPLIED (mma_apply) separately: a wave is alone on its SIMD here, so the chunk loops request
+// the next chunk's fragments before the current chunk's epilogue - otherwise every chunk pays one L2 round trip in front of its MFMAs.
 template <int KB>
-__device__ __forceinline__ void mma_rows(const __bf16* A, int lda, int a0, const float* __restrict__ W, int64_t ldw, int w0, int col0, int n_out,
-                                         f32x16_t& acc) {
+struct WFrag {
+  f4_t a[KB], b[KB];
+  bool ok;
+};
+template <int KB>
+__device__ __forceinline__ void wfetch(WFrag<KB>& f, const float* __restrict__ W, int64_t ldw, int w0, int col0, int n_out) {
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const int col = col0 + r;
   const float* wrow = W + (int64_t)min(col, n_out - 1) * ldw + w0 + 8 * hh;
-  const __bf16* arow = A + r * lda + a0 + 8 * hh;
-  f4_t wa[KB], wb[KB];
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) { wa[kb] = ld4(wrow + 16 * kb); wb[kb] = ld4(wrow + 16 * kb + 4); }
+  for (int kb = 0; kb < KB; ++kb) { f.a[kb] = ld4(wrow + 16 * kb); f.b[kb] = ld4(wrow + 16 * kb + 4); }
+  f.ok = col < n_out;
+}
+template <int KB>
+__device__ __forceinline__ void mma_apply(const __bf16* A, int lda, int a0, const WFrag<KB>& f, f32x16_t& acc) {
+  const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+  const __bf16* arow = A + r * lda + a0 + 8 * hh;
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     bf16x8_t b;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { b[j] = (__bf16)(col < n_out ? wa[kb][j] : 0.0f); b[4 + j] = (__bf16)(col < n_out ? wb[kb][j] : 0.0f); }
+    for (int j = 0; j < 4; ++j) { b[j] = (__bf16)(f.ok ? f.a[kb][j] : 0.0f); b[4 + j] = (__bf16)(f.ok ? f.b[kb][j] : 0.0f); }
     const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(arow + 16 * kb);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
   }
+}
+template <int KB>
+__device__ __forceinline__ void mma_rows(const __bf16* A, int lda, int a0, const float* __restrict__ W, int64_t ldw, int w0, int col0, int n_out,
+                                         f32x16_t& acc) {
+  WFrag<KB> f;
+  wfetch<KB>(f, W, ldw, w0, col0, n_out);
+  mma_apply<KB>(A, lda, a0, f, acc);
 }
 __device__ __forceinline__ void acc_to_stage(const f32x16_t& acc, float (*stage)[LD_ST]) {   // accumulator: lane = column, register i = row
   const int lane = threadIdx.x & 63, c = lane & 31, hh = lane >> 5;
@@ -91,150 +116,190 @@ __device__ __forceinline__ void acc_to_stage(const f32x16_t& acc, float (*stage)
   for (int i = 0; i < 16; ++i) stage[(i & 3) + 8 * (i >> 2) + 4 * hh][c] = acc[i];
 }
 
-__global__ __launch_bounds__(CH_NT) void k_pair_chain_fwd(dst_layout L, dst_pair_chain_args a) {
+// Vector-memory operations of a wave retire in issue order: a load issued behind stores waits for them.  A tile writes ~130 kB of tape, so
+// inside a tile every load is requested before the stores of its phase: the index tables and all rows of stage 1 first, the per-row gate
+// rows of the FF epilogue with them, each GEMM chunk's weight fragments and bias before the previous chunk's epilogue.
+__global__ __launch_bounds__(CH_NT) void k_pair_chain_fwd(dst_layout L, dst_pair_chain_args a, const int32_t* __restrict__ pair_a,
+                                                          const int32_t* __restrict__ pair_b, const int32_t* __restrict__ pair_mol) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  __shared__ unsigned char pa[406], pb[406];
   WaveLds& w = reinterpret_cast<WaveLds*>(lds_raw)[threadIdx.x >> 6];
-  const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
-  for (int i = threadIdx.x; i < n; i += CH_NT)
-    for (int j = i + 1; j < n; ++j) { const int idx = pair_idx(n, i, j); pa[idx] = (unsigned char)i; pb[idx] = (unsigned char)j; }
-  __syncthreads();
-  const float* adm = a.ada + (int64_t)m * a.ada_ld;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int Pp = L.Pp;
+  const int tile = blockIdx.x * CH_NW + wave;
+  const int t0 = tile * 32;
+  if (t0 >= Pp) return;
+  const int valid = min(32, Pp - t0);
   const unsigned int thr = dst::dropout_threshold(a.drop_p);
   const float keep_scale = a.drop_p > 0.0f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const int sub = lane >> 4, cl = (lane & 15) * 4;          // row layout of stage 1: a row = 16 lanes x float4
   const int er = lane >> 3, ec = (lane & 7) * 4;            // row layout of the GEMM epilogues: a 32-column chunk row = 8 lanes x float4
-  const int ntiles = (np + 31) >> 5;
-  for (int tile = wave + CH_NW * blockIdx.y; tile < ntiles; tile += CH_NW * gridDim.y) {
-    const int t0 = tile * 32, valid = min(32, np - t0);
-    const int64_t g0 = (int64_t)p0 + t0;                    // global pair row of the tile's row 0
-    // ---- stage 1: gather, gated residual, LayerNorm + modulate
-    {
-      const f4_t bias = ld4(a.n2e_bias + cl), g1 = ld4(adm + a.gate1_off + cl), sh = ld4(adm + a.shift_off + cl), sc = ld4(adm + a.scale_off + cl);
-#pragma unroll 2
-      for (int ps = 0; ps < 8; ++ps) {
-        const int row = ps * 4 + sub, pl = min(t0 + row, np - 1);
-        const int64_t gp = (int64_t)p0 + pl;
-        const f4_t he = (ld4(a.u + (int64_t)(n0 + pa[pl]) * 64 + cl) + ld4(a.u + (int64_t)(n0 + pb[pl]) * 64 + cl)) + bias;
-        const f4_t x = ld4(a.e_in + gp * 64 + cl) + g1 * he;
-        f4_t ft = ld4(a.feat + gp * a.ld_feat + cl);
-        const float mean = sum16((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / 64.0f);
-        const f4_t d = x - mean;
-        const float rstd = 1.0f / sqrtf(sum16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 64.0f) + 1e-6f);
-        f4_t y = (d * rstd) * (1.0f + sc) + sh;
-        if (row < valid) {
-          if (a.he) st4(a.he + gp * 64 + cl, he);
-          if (a.xe1) st4(a.xe1 + gp * 64 + cl, x);
-          if (a.st && (lane & 15) == 0) { a.st[gp * 2] = mean; a.st[gp * 2 + 1] = rstd; }
-          if (a.ye1) st4(a.ye1 + gp * 64 + cl, y);
-          if (a.X2) st4(a.X2 + gp * 128 + 64 + cl, ft);
-        } else {
-          y = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
-          ft = y;
-        }
-        st4(&w.yf[row][cl], y);
-        *reinterpret_cast<bf16x4_t*>(&w.yb[row][cl]) = to_bf4(y);
-        *reinterpret_cast<bf16x4_t*>(&w.eb[row][64 + cl]) = to_bf4(ft);
+  const f4_t bias = ld4(a.n2e_bias + cl);
+  float b3c[4], b4c[2];
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch) b3c[ch] = a.b3[ch * 32 + (lane & 31)];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) b4c[ch] = a.b4[ch * 32 + (lane & 31)];
+  const float bed0 = a.bed[lane & 31], broc = (lane & 31) < 16 ? a.bro[lane & 31] : 0.0f;
+  // edge_gate_mlp of the rows this lane finishes in the ff_linear4 epilogue (row it * 8 + er, columns ch * 32 + ec ..)
+  f4_t g2c[2][4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const float* adr = a.ada + (int64_t)pair_mol[min(t0 + it * 8 + er, Pp - 1)] * a.ada_ld + a.gate2_off + ec;
+    g2c[0][it] = ld4(adr);
+    g2c[1][it] = ld4(adr + 32);
+  }
+  WFrag<4> f3w;
+  wfetch<4>(f3w, a.W3, 64, 0, 0, 128);
+  // ---- stage 1: gather, gated residual, LayerNorm + modulate
+  {
+    int ia[8], ib[8], im[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int gp = min(t0 + ps * 4 + sub, Pp - 1);
+      ia[ps] = pair_a[gp]; ib[ps] = pair_b[gp]; im[ps] = pair_mol[gp];
+    }
+    f4_t ua[8], ub[8], ev[8], fv[8], g1v[8], shv[8], scv[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int64_t gp = min(t0 + ps * 4 + sub, Pp - 1);
+      const float* adm = a.ada + (int64_t)im[ps] * a.ada_ld;
+      ua[ps] = ld4(a.u + (int64_t)ia[ps] * 64 + cl);
+      ub[ps] = ld4(a.u + (int64_t)ib[ps] * 64 + cl);
+      ev[ps] = ld4(a.e_in + gp * 64 + cl);
+      fv[ps] = ld4(a.feat + gp * a.ld_feat + cl);
+      g1v[ps] = ld4(adm + a.gate1_off + cl); shv[ps] = ld4(adm + a.shift_off + cl); scv[ps] = ld4(adm + a.scale_off + cl);
+    }
+    __builtin_amdgcn_sched_barrier(0);                       // (the output pointers may alias the inputs for all the compiler knows: keep every load above the first store)
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int row = ps * 4 + sub;
+      const int64_t gp = min(t0 + row, Pp - 1);
+      const f4_t g1 = g1v[ps], sh = shv[ps], sc = scv[ps];
+      const f4_t he = (ua[ps] + ub[ps]) + bias;
+      const f4_t x = ev[ps] + g1 * he;
+      f4_t ft = fv[ps];
+      const float mean = sum16((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / 64.0f);
+      const f4_t d = x - mean;
+      const float rstd = 1.0f / sqrtf(sum16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 64.0f) + 1e-6f);
+      f4_t y = (d * rstd) * (1.0f + sc) + sh;
+      if (row < valid) {
+        if (a.he) st4(a.he + gp * 64 + cl, he);
+        if (a.xe1) st4(a.xe1 + gp * 64 + cl, x);
+        if (a.st && (lane & 15) == 0) { a.st[gp * 2] = mean; a.st[gp * 2 + 1] = rstd; }
+        if (a.ye1) st4(a.ye1 + gp * 64 + cl, y);
+        if (a.X2) st4(a.X2 + gp * 128 + 64 + cl, ft);
+      } else {
+        y = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        ft = y;
+      }
+      st4(&w.yf[row][cl], y);
+      *reinterpret_cast<bf16x4_t*>(&w.yb[row][cl]) = to_bf4(y);
+      *reinterpret_cast<bf16x4_t*>(&w.eb[row][64 + cl]) = to_bf4(ft);
+    }
+  }
+  wave_lds_sync();
+  const int64_t g0 = t0;                                     // global pair row of the tile's row 0
+  // ---- ff_linear3 (64 -> 128), SiLU, dropout
+  WFrag<8> f4w;
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch) {
+    f32x16_t acc;
+    const float b = b3c[ch];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = b;
+    mma_apply<4>(&w.yb[0][0], LD_Y, 0, f3w, acc);
+    if (ch < 3) wfetch<4>(f3w, a.W3, 64, 0, (ch + 1) * 32, 128);     // the next chunk's (or ff_linear4's first) fragments fly under the epilogue
+    else wfetch<8>(f4w, a.W4, 128, 0, 0, 64);
+    acc_to_stage(acc, w.stage);
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + er, col = ch * 32 + ec;
+      const int64_t gr = g0 + row;
+      const f4_t v = ld4(&w.stage[row][ec]);
+      f4_t sv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sv[e] = fast_silu(v[e]);
+      if (a.drop_p > 0.0f) {
+        unsigned int c[4];
+        dst::dropout_block(a.seed, a.stream3, (gr * 128 + col) >> 2, c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sv[e] = c[e] >= thr ? sv[e] * keep_scale : 0.0f;
+      }
+      if (row < valid) {
+        if (a.f3) st4(a.f3 + gr * 128 + col, v);
+        if (a.s3) st4(a.s3 + gr * 128 + col, sv);
+      } else {
+        sv = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+      *reinterpret_cast<bf16x4_t*>(&w.sb[row][col]) = to_bf4(sv);
+    }
+    wave_lds_sync();
+  }
+  // ---- ff_linear4 (128 -> 64), dropout, gated residual
+  WFrag<8> edw;
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+    f32x16_t acc;
+    const float b = b4c[ch];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = b;
+    mma_apply<8>(&w.sb[0][0], LD_S, 0, f4w, acc);
+    if (ch < 1) wfetch<8>(f4w, a.W4, 128, 0, 32, 64);
+    else wfetch<8>(edw, a.Wed, a.ld_wed, 0, 0, 256);
+    acc_to_stage(acc, w.stage);
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + er, col = ch * 32 + ec;
+      const int64_t gr = g0 + row;
+      f4_t v = ld4(&w.stage[row][ec]);
+      if (a.drop_p > 0.0f) {
+        unsigned int c[4];
+        dst::dropout_block(a.seed, a.stream4, (gr * 64 + col) >> 2, c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = c[e] >= thr ? v[e] * keep_scale : 0.0f;
+      }
+      f4_t eo = ld4(&w.yf[row][col]) + g2c[ch][it] * v;
+      if (row < valid) {
+        if (a.f4) st4(a.f4 + gr * 64 + col, v);
+        st4(a.e_out + gr * 64 + col, eo);
+        if (a.X2) st4(a.X2 + gr * 128 + col, eo);
+      } else {
+        eo = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+      *reinterpret_cast<bf16x4_t*>(&w.eb[row][col]) = to_bf4(eo);
+    }
+    wave_lds_sync();
+  }
+  // ---- input_lin's edge part ([e_out | features] 128 -> 256) and the read-out slice (e_out 64 -> 16)
+  WFrag<4> row_w;
+  float bcur = bed0;
+#pragma unroll 1
+  for (int ch = 0; ch < 9; ++ch) {
+    const bool ro = ch == 8;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = bcur;
+    if (ro) mma_apply<4>(&w.eb[0][0], LD_S, 0, row_w, acc);
+    else mma_apply<8>(&w.eb[0][0], LD_S, 0, edw, acc);
+    if (ch < 7) { wfetch<8>(edw, a.Wed, a.ld_wed, 0, (ch + 1) * 32, 256); bcur = a.bed[(ch + 1) * 32 + (lane & 31)]; }   // before this chunk's stores
+    else if (ch == 7) { wfetch<4>(row_w, a.Wro, 64, 0, 0, 16); bcur = broc; }
+    acc_to_stage(acc, w.stage);
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + er;
+      const int64_t gr = g0 + row;
+      const f4_t v = ld4(&w.stage[row][ec]);
+      if (row < valid) {
+        if (!ro) st4(a.ed + gr * 256 + ch * 32 + ec, v);
+        else if (ec < 16) st4(a.ro + gr * 16 + ec, v);
       }
     }
     wave_lds_sync();
-    // ---- ff_linear3 (64 -> 128), SiLU, dropout
-#pragma unroll 1
-    for (int ch = 0; ch < 4; ++ch) {
-      f32x16_t acc;
-      const float b = a.b3[ch * 32 + (lane & 31)];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = b;
-      mma_rows<4>(&w.yb[0][0], LD_Y, 0, a.W3, 64, 0, ch * 32, 128, acc);
-      acc_to_stage(acc, w.stage);
-      wave_lds_sync();
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + er, col = ch * 32 + ec;
-        const int64_t gr = g0 + row;
-        const f4_t v = ld4(&w.stage[row][ec]);
-        f4_t s;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] = dst::act_apply(v[e], 1);
-        if (a.drop_p > 0.0f) {
-          unsigned int c[4];
-          dst::dropout_block(a.seed, a.stream3, (gr * 128 + col) >> 2, c);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) s[e] = c[e] >= thr ? s[e] * keep_scale : 0.0f;
-        }
-        if (row < valid) {
-          if (a.f3) st4(a.f3 + gr * 128 + col, v);
-          if (a.s3) st4(a.s3 + gr * 128 + col, s);
-        } else {
-          s = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-        *reinterpret_cast<bf16x4_t*>(&w.sb[row][col]) = to_bf4(s);
-      }
-      wave_lds_sync();
-    }
-    // ---- ff_linear4 (128 -> 64), dropout, gated residual
-#pragma unroll 1
-    for (int ch = 0; ch < 2; ++ch) {
-      f32x16_t acc;
-      const float b = a.b4[ch * 32 + (lane & 31)];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = b;
-      mma_rows<8>(&w.sb[0][0], LD_S, 0, a.W4, 128, 0, ch * 32, 64, acc);
-      acc_to_stage(acc, w.stage);
-      wave_lds_sync();
-      const f4_t g2 = ld4(adm + a.gate2_off + ch * 32 + ec);
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + er, col = ch * 32 + ec;
-        const int64_t gr = g0 + row;
-        f4_t v = ld4(&w.stage[row][ec]);
-        if (a.drop_p > 0.0f) {
-          unsigned int c[4];
-          dst::dropout_block(a.seed, a.stream4, (gr * 64 + col) >> 2, c);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = c[e] >= thr ? v[e] * keep_scale : 0.0f;
-        }
-        f4_t eo = ld4(&w.yf[row][col]) + g2 * v;
-        if (row < valid) {
-          if (a.f4) st4(a.f4 + gr * 64 + col, v);
-          st4(a.e_out + gr * 64 + col, eo);
-          if (a.X2) st4(a.X2 + gr * 128 + col, eo);
-        } else {
-          eo = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-        *reinterpret_cast<bf16x4_t*>(&w.eb[row][col]) = to_bf4(eo);
-      }
-      wave_lds_sync();
-    }
-    // ---- input_lin's edge part ([e_out | features] 128 -> 256) and the read-out slice (e_out 64 -> 16)
-#pragma unroll 1
-    for (int ch = 0; ch < 9; ++ch) {
-      const bool ro = ch == 8;
-      f32x16_t acc;
-      const int oc = lane & 31;
-      const float b = ro ? (oc < 16 ? a.bro[oc] : 0.0f) : a.bed[ch * 32 + oc];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = b;
-      if (ro) mma_rows<4>(&w.eb[0][0], LD_S, 0, a.Wro, 64, 0, 0, 16, acc);
-      else mma_rows<8>(&w.eb[0][0], LD_S, 0, a.Wed, a.ld_wed, 0, ch * 32, 256, acc);
-      acc_to_stage(acc, w.stage);
-      wave_lds_sync();
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + er;
-        const int64_t gr = g0 + row;
-        const f4_t v = ld4(&w.stage[row][ec]);
-        if (row < valid) {
-          if (!ro) st4(a.ed + gr * 256 + ch * 32 + ec, v);
-          else if (ec < 16) st4(a.ro + gr * 16 + ec, v);
-        }
-      }
-      wave_lds_sync();
-    }
   }
 }
-
 
 // dst_pair_front_fwd: the pair rows of a block IN FRONT of the attention (dmt.py:136-139,145-149; layers.py:291-295,328-334,165-166,183):
 //   d2 = |pos_a - pos_b|^2;  x' = d2 (1 + ada[dist]) + ada[dist + 1];  feat = [x', gaussian_k(x')];  X1 = [feat | e]
@@ -249,19 +314,17 @@ struct FrontLds {
   __bf16 nb[32][LD_Y];           // en, bf16
 };
 
-__global__ __launch_bounds__(CH_NT) void k_pair_front_fwd(dst_layout L, dst_pair_front_args a) {
+__global__ __launch_bounds__(CH_NT) void k_pair_front_fwd(dst_layout L, dst_pair_front_args a, const int32_t* __restrict__ pair_a,
+                                                          const int32_t* __restrict__ pair_b, const int32_t* __restrict__ pair_mol) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  __shared__ unsigned char pa[406], pb[406];
-  __shared__ float sp[29][4];
   FrontLds& w = reinterpret_cast<FrontLds*>(lds_raw)[threadIdx.x >> 6];
-  const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n0 = L.node_off[m], n = L.node_off[m + 1] - n0, p0 = L.pair_off[m], np = n * (n - 1) / 2;
-  for (int i = threadIdx.x; i < n; i += CH_NT)
-    for (int j = i + 1; j < n; ++j) { const int idx = pair_idx(n, i, j); pa[idx] = (unsigned char)i; pb[idx] = (unsigned char)j; }
-  for (int i = threadIdx.x; i < n * 3; i += CH_NT) sp[i / 3][i % 3] = a.pos[(int64_t)(n0 + i / 3) * 3 + i % 3];
-  __syncthreads();
-  const float* adm = a.ada + (int64_t)m * a.ada_ld;
-  const float dsc = adm[a.dist_off], dsh = adm[a.dist_off + 1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int Pp = L.Pp;
+  const int tile = blockIdx.x * CH_NW + wave;
+  const int t0 = tile * 32;
+  if (t0 >= Pp) return;
+  const int valid = min(32, Pp - t0);
+  const int64_t g0 = t0;
   const int sub = lane >> 4, cl = (lane & 15) * 4, er = lane >> 3, ec = (lane & 7) * 4;
   // the lane's four Gaussians (features cl .. cl + 3; feature 0 is x' itself)
   float mu[4], sd[4], nrm[4];
@@ -272,97 +335,256 @@ __global__ __launch_bounds__(CH_NT) void k_pair_front_fwd(dst_layout L, dst_pair
     sd[j] = k ? fabsf(a.stds[k - 1]) + 1e-5f : 1.0f;
     nrm[j] = DST_GAUSS_A * sd[j];
   }
-  const int ntiles = (np + 31) >> 5;
-  for (int tile = wave + CH_NW * blockIdx.y; tile < ntiles; tile += CH_NW * gridDim.y) {
-    const int t0 = tile * 32, valid = min(32, np - t0);
-    const int64_t g0 = (int64_t)p0 + t0;
-    // ---- features + X1
-#pragma unroll 2
-    for (int ps = 0; ps < 8; ++ps) {
-      const int row = ps * 4 + sub, pl = min(t0 + row, np - 1);
-      const int64_t gp = (int64_t)p0 + pl;
-      const int ia = pa[pl], ib = pb[pl];
-      const float dx = sp[ia][0] - sp[ib][0], dy = sp[ia][1] - sp[ib][1], dz = sp[ia][2] - sp[ib][2];
-      const float d2 = dx * dx + dy * dy + dz * dz;
-      const float x = d2 * (dsc + 1.0f) + dsh;
-      f4_t ft;
+  const float beec[2] = {a.bee[lane & 31], a.bee[32 + (lane & 31)]};
+  // ---- features + X1 (every load of the tile before its first store)
+  int ia[8], ib[8], im[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float u = (x - mu[j]) / sd[j];
-        ft[j] = expf(-0.5f * (u * u)) / nrm[j];
-      }
-      if (cl == 0) ft[0] = x;
-      f4_t ev = ld4(a.e_in + gp * 64 + cl);
-      if (row < valid) {
-        st4(a.X1 + gp * 128 + cl, ft);
-        st4(a.X1 + gp * 128 + 64 + cl, ev);
-        if (cl == 0) {
-          if (a.xs) a.xs[gp] = x;
-          if (a.d2) a.d2[gp] = d2;
-        }
-      } else {
-        ft = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
-        ev = ft;
-      }
-      *reinterpret_cast<bf16x4_t*>(&w.xb[row][cl]) = to_bf4(ft);
-      *reinterpret_cast<bf16x4_t*>(&w.xb[row][64 + cl]) = to_bf4(ev);
+  for (int ps = 0; ps < 8; ++ps) {
+    const int gp = min(t0 + ps * 4 + sub, Pp - 1);
+    ia[ps] = pair_a[gp]; ib[ps] = pair_b[gp]; im[ps] = pair_mol[gp];
+  }
+  f4_t evs[8], shs[8], scs[8];
+  float d2v[8], dscv[8], dshv[8];
+#pragma unroll
+  for (int ps = 0; ps < 8; ++ps) {
+    const int64_t gp = min(t0 + ps * 4 + sub, Pp - 1);
+    const float* pa_ = a.pos + (int64_t)ia[ps] * 3;
+    const float* pb_ = a.pos + (int64_t)ib[ps] * 3;
+    const float dx = pa_[0] - pb_[0], dy = pa_[1] - pb_[1], dz = pa_[2] - pb_[2];
+    d2v[ps] = dx * dx + dy * dy + dz * dz;
+    const float* adm = a.ada + (int64_t)im[ps] * a.ada_ld;
+    dscv[ps] = adm[a.dist_off]; dshv[ps] = adm[a.dist_off + 1];
+    shs[ps] = ld4(adm + a.shift_off + cl); scs[ps] = ld4(adm + a.scale_off + cl);
+    evs[ps] = ld4(a.e_in + gp * 64 + cl);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ps = 0; ps < 8; ++ps) {
+    const int row = ps * 4 + sub;
+    const int64_t gp = min(t0 + row, Pp - 1);
+    const float d2 = d2v[ps];
+    const float x = d2 * (dscv[ps] + 1.0f) + dshv[ps];
+    f4_t ft;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float u = (x - mu[j]) / sd[j];
+      ft[j] = expf(-0.5f * (u * u)) / nrm[j];
     }
-    wave_lds_sync();
-    // ---- edge_emb (128 -> 64)
+    if (cl == 0) ft[0] = x;
+    f4_t ev = evs[ps];
+    if (row < valid) {
+      st4(a.X1 + gp * 128 + cl, ft);
+      st4(a.X1 + gp * 128 + 64 + cl, ev);
+      if (cl == 0) {
+        if (a.xs) a.xs[gp] = x;
+        if (a.d2) a.d2[gp] = d2;
+      }
+    } else {
+      ft = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+      ev = ft;
+    }
+    *reinterpret_cast<bf16x4_t*>(&w.xb[row][cl]) = to_bf4(ft);
+    *reinterpret_cast<bf16x4_t*>(&w.xb[row][64 + cl]) = to_bf4(ev);
+  }
+  wave_lds_sync();
+  // ---- edge_emb (128 -> 64)
+  WFrag<4> tew;
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+    f32x16_t acc;
+    const float b = beec[ch];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = b;
+    mma_rows<8>(&w.xb[0][0], LD_S, 0, a.Wee, 128, 0, ch * 32, 64, acc);
+    if (ch == 1) wfetch<4>(tew, a.Wte, 64, 0, 0, 512);             // lin_edge's first fragments fly under the LayerNorm
+    const int c = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w.ef[(i & 3) + 8 * (i >> 2) + 4 * hh][ch * 32 + c] = acc[i];
+  }
+  wave_lds_sync();
+  // ---- LayerNorm + modulate
+#pragma unroll
+  for (int ps = 0; ps < 8; ++ps) {
+    const int row = ps * 4 + sub;
+    const int64_t gp = g0 + row;
+    const f4_t x = ld4(&w.ef[row][cl]);
+    const float mean = sum16((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / 64.0f);
+    const f4_t d = x - mean;
+    const float rstd = 1.0f / sqrtf(sum16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 64.0f) + 1e-6f);
+    f4_t y = (d * rstd) * (1.0f + scs[ps]) + shs[ps];
+    if (row < valid) {
+      if (a.e1) st4(a.e1 + gp * 64 + cl, x);
+      if (a.st && (lane & 15) == 0) { a.st[gp * 2] = mean; a.st[gp * 2 + 1] = rstd; }
+      if (a.en) st4(a.en + gp * 64 + cl, y);
+    } else {
+      y = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    *reinterpret_cast<bf16x4_t*>(&w.nb[row][cl]) = to_bf4(y);
+  }
+  wave_lds_sync();
+  // ---- tanh(en [lin_edge0 | lin_edge1]^T) (64 -> 512)
 #pragma unroll 1
-    for (int ch = 0; ch < 2; ++ch) {
-      f32x16_t acc;
-      const float b = a.bee[ch * 32 + (lane & 31)];
+  for (int ch = 0; ch < 16; ++ch) {
+    f32x16_t acc;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = b;
-      mma_rows<8>(&w.xb[0][0], LD_S, 0, a.Wee, 128, 0, ch * 32, 64, acc);
-      const int c = lane & 31, hh = lane >> 5;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    mma_apply<4>(&w.nb[0][0], LD_Y, 0, tew, acc);
+    if (ch < 15) wfetch<4>(tew, a.Wte, 64, 0, (ch + 1) * 32, 512);
+    acc_to_stage(acc, w.stage);
+    wave_lds_sync();
 #pragma unroll
-      for (int i = 0; i < 16; ++i) w.ef[(i & 3) + 8 * (i >> 2) + 4 * hh][ch * 32 + c] = acc[i];
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + er;
+      f4_t v = ld4(&w.stage[row][ec]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fast_tanh(v[e]);
+      if (row < valid) st4(a.te + (g0 + row) * 512 + ch * 32 + ec, v);
     }
     wave_lds_sync();
-    // ---- LayerNorm + modulate
-    {
-      const f4_t sh = ld4(adm + a.shift_off + cl), sc = ld4(adm + a.scale_off + cl);
-#pragma unroll 2
-      for (int ps = 0; ps < 8; ++ps) {
-        const int row = ps * 4 + sub;
-        const int64_t gp = g0 + row;
-        const f4_t x = ld4(&w.ef[row][cl]);
-        const float mean = sum16((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / 64.0f);
-        const f4_t d = x - mean;
-        const float rstd = 1.0f / sqrtf(sum16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 64.0f) + 1e-6f);
-        f4_t y = (d * rstd) * (1.0f + sc) + sh;
-        if (row < valid) {
-          if (a.e1) st4(a.e1 + gp * 64 + cl, x);
-          if (a.st && (lane & 15) == 0) { a.st[gp * 2] = mean; a.st[gp * 2 + 1] = rstd; }
-          if (a.en) st4(a.en + gp * 64 + cl, y);
+  }
+}
+
+// dst_dir_chain_fwd: the DIRECTED rows of a block (dmt.py:37-48: both directions of every pair through equi_update's input LayerNorm and
+// coord_mlp) as one kernel instead of dst_zbuild_fwd, dst_lnmod_fwd and two dst_gemm calls:
+//   zz[2p + dir] = ac[row][0:256] + ac[col][256:512] + ed[p]   (dir 0: row = a, col = b; dir 1: swapped)
+//   zn = LN(zz) (1 + ada[scale]) + ada[shift];  c0 = zn W0^T + b0;  sc0 = SiLU(c0);  c2 = sc0 W2^T   (W2 [3,256], no bias)
+// Tape: zz, (mean, rstd), zn, c0, sc0 (each may be NULL); c2 [2 Pp, 3] always.  sc0 is not staged whole: each 32-column chunk's bf16
+// tile goes straight into the 256 -> 3 product (two k-blocks per chunk, one accumulator across the chunks).
+constexpr int LD_Z = 264;         // bf16 row of 256 + 8 (16-byte rows, 528 bytes: the 16-byte fragments of 16 rows hit distinct banks)
+constexpr int LD_C = 40;          // bf16 row of one 32-column chunk + 8
+struct DirLds {
+  float stage[32][LD_ST];
+  __bf16 zb[32][LD_Z];           // zn, bf16
+  __bf16 cb[32][LD_C];           // the current chunk of sc0, bf16
+};
+
+__global__ __launch_bounds__(CH_NT) void k_dir_chain_fwd(dst_layout L, dst_dir_chain_args a, const int32_t* __restrict__ pair_a,
+                                                         const int32_t* __restrict__ pair_b, const int32_t* __restrict__ pair_mol) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  DirLds& w = reinterpret_cast<DirLds*>(lds_raw)[threadIdx.x >> 6];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nd = 2 * L.Pp;
+  const int tile = blockIdx.x * CH_NW + wave;
+  const int t0 = tile * 32;
+  if (t0 >= nd) return;
+  const int valid = min(32, nd - t0);
+  const int64_t g0 = t0;                                     // global directed row of the tile's row 0
+  const int sub = lane >> 4, j16 = lane & 15, er = lane >> 3, ec = (lane & 7) * 4;
+  const float b00 = a.b0[lane & 31];
+  WFrag<8> c0w, c0v;
+  wfetch<8>(c0w, a.W0, 256, 0, 0, 256);
+  // ---- z, LayerNorm + modulate: a row = 16 lanes, lane j holds the float4s at columns 4 j + 64 u; the rows of four passes are requested
+  //      before the first of them is stored (loads behind stores wait for the stores)
+#pragma unroll 1
+  for (int pg = 0; pg < 2; ++pg) {
+    int ra[4], cb_[4], im[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int dl = min(t0 + (pg * 4 + q) * 4 + sub, nd - 1), pl = dl >> 1, dir = dl & 1;
+      const int xa = pair_a[pl], xb = pair_b[pl];
+      ra[q] = dir ? xb : xa; cb_[q] = dir ? xa : xb; im[q] = pair_mol[pl];
+    }
+    f4_t xr[4][4], xc[4][4], xe[4][4], shq[4][4], scq[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int dl = min(t0 + (pg * 4 + q) * 4 + sub, nd - 1), pl = dl >> 1;
+      const float* pr = a.ac + (int64_t)ra[q] * 512 + 4 * j16;
+      const float* pc = a.ac + (int64_t)cb_[q] * 512 + 256 + 4 * j16;
+      const float* pe = a.ed + (int64_t)pl * 256 + 4 * j16;
+      const float* adm = a.ada + (int64_t)im[q] * a.ada_ld + 4 * j16;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xr[q][u] = ld4(pr + 64 * u); xc[q][u] = ld4(pc + 64 * u); xe[q][u] = ld4(pe + 64 * u);
+        shq[q][u] = ld4(adm + a.shift_off + 64 * u); scq[q][u] = ld4(adm + a.scale_off + 64 * u);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                       // every load of the group above its first store
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = (pg * 4 + q) * 4 + sub;
+      const int64_t gd = min(t0 + row, nd - 1);
+      f4_t x[4];
+      float s1 = 0.0f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        x[u] = (xr[q][u] + xc[q][u]) + xe[q][u];
+        s1 += (x[u][0] + x[u][1]) + (x[u][2] + x[u][3]);
+      }
+      const float mean = sum16(s1) * (1.0f / 256.0f);
+      float s2 = 0.0f;
+      f4_t dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        dv[u] = x[u] - mean;
+        s2 += (dv[u][0] * dv[u][0] + dv[u][1] * dv[u][1]) + (dv[u][2] * dv[u][2] + dv[u][3] * dv[u][3]);
+      }
+      const float rstd = 1.0f / sqrtf(sum16(s2) * (1.0f / 256.0f) + 1e-6f);
+      const bool live = row < valid;
+      if (live && a.st && j16 == 0) { a.st[gd * 2] = mean; a.st[gd * 2 + 1] = rstd; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f4_t y = (dv[u] * rstd) * (1.0f + scq[q][u]) + shq[q][u];
+        if (live) {
+          if (a.zz) st4(a.zz + gd * 256 + 64 * u + 4 * j16, x[u]);
+          if (a.zn) st4(a.zn + gd * 256 + 64 * u + 4 * j16, y);
         } else {
           y = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
         }
-        *reinterpret_cast<bf16x4_t*>(&w.nb[row][cl]) = to_bf4(y);
+        *reinterpret_cast<bf16x4_t*>(&w.zb[row][64 * u + 4 * j16]) = to_bf4(y);
       }
+    }
+  }
+  wave_lds_sync();
+  // ---- coord_mlp.0 (256 -> 256) + SiLU, and coord_mlp.2 (256 -> 3) chunk by chunk
+  f32x16_t acc2;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc2[i] = 0.0f;
+  WFrag<2> w2;
+  wfetch<2>(w2, a.W2, 256, 0, 0, 3);
+  wfetch<8>(c0v, a.W0, 256, 128, 0, 256);
+  float bcur = b00;
+#pragma unroll 1
+  for (int ch = 0; ch < 8; ++ch) {
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = bcur;
+    mma_apply<8>(&w.zb[0][0], LD_Z, 0, c0w, acc);
+    mma_apply<8>(&w.zb[0][0], LD_Z, 128, c0v, acc);
+    WFrag<2> w2n = w2;
+    if (ch < 7) {                                            // the next chunk's fragments and bias: requested before this chunk's stores
+      wfetch<8>(c0w, a.W0, 256, 0, (ch + 1) * 32, 256);
+      wfetch<8>(c0v, a.W0, 256, 128, (ch + 1) * 32, 256);
+      wfetch<2>(w2n, a.W2, 256, (ch + 1) * 32, 0, 3);
+      bcur = a.b0[(ch + 1) * 32 + (lane & 31)];
+    }
+    acc_to_stage(acc, w.stage);
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + er, col = ch * 32 + ec;
+      const int64_t gr = g0 + row;
+      const f4_t v = ld4(&w.stage[row][ec]);
+      f4_t sv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sv[e] = fast_silu(v[e]);
+      if (row < valid) {
+        if (a.c0) st4(a.c0 + gr * 256 + col, v);
+        if (a.sc0) st4(a.sc0 + gr * 256 + col, sv);
+      } else {
+        sv = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+      *reinterpret_cast<bf16x4_t*>(&w.cb[row][ec]) = to_bf4(sv);
     }
     wave_lds_sync();
-    // ---- tanh(en [lin_edge0 | lin_edge1]^T) (64 -> 512)
-#pragma unroll 1
-    for (int ch = 0; ch < 16; ++ch) {
-      f32x16_t acc;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-      mma_rows<4>(&w.nb[0][0], LD_Y, 0, a.Wte, 64, 0, ch * 32, 512, acc);
-      acc_to_stage(acc, w.stage);
-      wave_lds_sync();
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + er;
-        f4_t v = ld4(&w.stage[row][ec]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = dst::act_apply(v[e], 3);
-        if (row < valid) st4(a.te + (g0 + row) * 512 + ch * 32 + ec, v);
-      }
-      wave_lds_sync();
-    }
+    mma_apply<2>(&w.cb[0][0], LD_C, 0, w2, acc2);
+    w2 = w2n;
+    wave_lds_sync();
+  }
+  acc_to_stage(acc2, w.stage);
+  wave_lds_sync();
+  if (lane < 32 && lane < valid) {
+    float* o = a.c2 + (g0 + lane) * 3;
+    o[0] = w.stage[lane][0]; o[1] = w.stage[lane][1]; o[2] = w.stage[lane][2];
   }
 }
 
@@ -371,7 +593,7 @@ __global__ __launch_bounds__(CH_NT) void k_pair_front_fwd(dst_layout L, dst_pair
 extern "C" {
 
 int dst_pair_chain_fwd(const dst_layout* L, const dst_pair_chain_args* a, void* stream) {
-  if (!L || !a || !a->u || !a->n2e_bias || !a->e_in || !a->feat || !a->ada || !a->W3 || !a->b3 || !a->W4 || !a->b4 || !a->Wed || !a->bed || !a->Wro ||
+  if (!L || !a || !a->pair_a || !a->pair_b || !a->pair_mol || !a->u || !a->n2e_bias || !a->e_in || !a->feat || !a->ada || !a->W3 || !a->b3 || !a->W4 || !a->b4 || !a->Wed || !a->bed || !a->Wro ||
       !a->bro || !a->e_out || !a->ed || !a->ro)
     return DS_ERR_ARG;
   if (L->B <= 0 || (a->ld_feat & 3) || (a->ld_wed & 3) || (a->ada_ld & 3) || ((a->gate1_off | a->shift_off | a->scale_off | a->gate2_off) & 3) ||
@@ -387,12 +609,12 @@ int dst_pair_chain_fwd(const dst_layout* L, const dst_pair_chain_args* a, void* 
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair_chain_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DS_ERR_LAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL(k_pair_chain_fwd, dim3(L->B, 2), dim3(CH_NT), lds, (hipStream_t)stream, *L, *a);
+  hipLaunchKernelGGL(k_pair_chain_fwd, dim3(((L->Pp + 31) / 32 + CH_NW - 1) / CH_NW), dim3(CH_NT), lds, (hipStream_t)stream, *L, *a, a->pair_a, a->pair_b, a->pair_mol);
   return DST_CHECK_LAUNCH();
 }
 
 int dst_pair_front_fwd(const dst_layout* L, const dst_pair_front_args* a, void* stream) {
-  if (!L || !a || !a->pos || !a->ada || !a->means || !a->stds || !a->e_in || !a->Wee || !a->bee || !a->Wte || !a->X1 || !a->te) return DS_ERR_ARG;
+  if (!L || !a || !a->pair_a || !a->pair_b || !a->pair_mol || !a->pos || !a->ada || !a->means || !a->stds || !a->e_in || !a->Wee || !a->bee || !a->Wte || !a->X1 || !a->te) return DS_ERR_ARG;
   if (L->B <= 0 || (a->ada_ld & 3) || ((a->shift_off | a->scale_off) & 3)) return DS_ERR_ARG;
   const void* ptrs[] = {a->ada, a->e_in, a->Wee, a->Wte, a->X1, a->e1, a->en, a->te};
   for (const void* p : ptrs)
@@ -404,7 +626,24 @@ int dst_pair_front_fwd(const dst_layout* L, const dst_pair_front_args* a, void* 
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair_front_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DS_ERR_LAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL(k_pair_front_fwd, dim3(L->B, 2), dim3(CH_NT), lds, (hipStream_t)stream, *L, *a);
+  hipLaunchKernelGGL(k_pair_front_fwd, dim3(((L->Pp + 31) / 32 + CH_NW - 1) / CH_NW), dim3(CH_NT), lds, (hipStream_t)stream, *L, *a, a->pair_a, a->pair_b, a->pair_mol);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_dir_chain_fwd(const dst_layout* L, const dst_dir_chain_args* a, void* stream) {
+  if (!L || !a || !a->pair_a || !a->pair_b || !a->pair_mol || !a->ac || !a->ed || !a->ada || !a->W0 || !a->b0 || !a->W2 || !a->c2) return DS_ERR_ARG;
+  if (L->B <= 0 || (a->ada_ld & 3) || ((a->shift_off | a->scale_off) & 3)) return DS_ERR_ARG;
+  const void* ptrs[] = {a->ac, a->ed, a->ada, a->W0, a->W2, a->zz, a->zn, a->c0, a->sc0};
+  for (const void* p : ptrs)
+    if (reinterpret_cast<uintptr_t>(p) & 15) return DS_ERR_ARG;
+  if (L->Pp <= 0) return DS_OK;
+  static bool attr_done = false;
+  const size_t lds = sizeof(DirLds) * CH_NW;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dir_chain_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DS_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_dir_chain_fwd, dim3(((2 * L->Pp + 31) / 32 + CH_NW - 1) / CH_NW), dim3(CH_NT), lds, (hipStream_t)stream, *L, *a, a->pair_a, a->pair_b, a->pair_mol);
   return DST_CHECK_LAUNCH();
 }
 

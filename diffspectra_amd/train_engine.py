@@ -71,9 +71,11 @@ assert _GEMM_STRUCT.size == C.sizeof(DstGemmArgs), (_GEMM_STRUCT.size, C.sizeof(
 _GEMM_PACK = _GEMM_STRUCT.pack
 # dst_pair_chain_args (include/diffspectra_train.h): 4 pointers, ld_feat | ada, ada_ld | 4 offsets | W3 b3 W4 b4 Wed, ld_wed | bed Wro bro |
 # drop_p, stream3, stream4, pad | seed | 11 output pointers
-_CHAIN_PACK = _struct.Struct("@PPPPq Pq iiii PPPPP q PPP f III Q PPPPPPPPPPP").pack
+_CHAIN_PACK = _struct.Struct("@PPP PPPPq Pq iiii PPPPP q PPP f III Q PPPPPPPPPPP").pack
 # dst_pair_front_args: pos, ada, ada_ld | dist_off, shift_off, scale_off, pad | means stds e_in Wee bee Wte | X1 xs d2 e1 st en te
-_FRONT_PACK = _struct.Struct("@PPq iiii PPPPPP PPPPPPP").pack
+_FRONT_PACK = _struct.Struct("@PPP PPq iiii PPPPPP PPPPPPP").pack
+# dst_dir_chain_args: ac, ed, ada, ada_ld | shift_off, scale_off | W0 b0 W2 | zz st zn c0 sc0 c2
+_DIR_PACK = _struct.Struct("@PPP PPPq ii PPP PPPPPP").pack
 
 
 class DstLayout(C.Structure):
@@ -298,16 +300,23 @@ class Ops:
         """The pair rows of a block behind the attention as one kernel (``dst_pair_chain_fwd``, bf16 products).  ``drop = (p, seed, stream3,
         stream4)``; ``out``: dict with e_out, ed, ro and - when the tape is kept - he, xe1, st, ye1, f3, s3, f4, X2."""
         ptr = lambda t: 0 if t is None else t.data_ptr()
-        args = _CHAIN_PACK(ptr(u), ptr(n2e_bias), ptr(e_in), ptr(feat), ld_feat, ptr(ada), ADA, g1, sh, sc, g2, ptr(W3), ptr(b3), ptr(W4), ptr(b4),
+        args = _CHAIN_PACK(*TL.pair_tables, ptr(u), ptr(n2e_bias), ptr(e_in), ptr(feat), ld_feat, ptr(ada), ADA, g1, sh, sc, g2, ptr(W3), ptr(b3), ptr(W4), ptr(b4),
                            ptr(Wed), ld_wed, ptr(bed), ptr(Wro), ptr(bro), float(drop[0]), int(drop[2]), int(drop[3]), 0, int(drop[1]),
                            *(ptr(out.get(k)) for k in ("he", "xe1", "st", "ye1", "f3", "s3", "f4", "e_out", "X2", "ed", "ro")))
         E._check(self.lib.dst_pair_chain_fwd(C.byref(TL.c), args, self._s()), "dst_pair_chain_fwd")
+
+    def dir_chain_fwd(self, TL, ac, ed, ada, sh, sc, W0, b0, W2, out):
+        """The directed rows of a block as one kernel (``dst_dir_chain_fwd``, bf16 products).  ``out``: dict with c2 and - when the tape is kept -
+        zz, st, zn, c0, sc0."""
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        args = _DIR_PACK(*TL.pair_tables, ptr(ac), ptr(ed), ptr(ada), ADA, sh, sc, ptr(W0), ptr(b0), ptr(W2), *(ptr(out.get(k)) for k in ("zz", "st", "zn", "c0", "sc0", "c2")))
+        E._check(self.lib.dst_dir_chain_fwd(C.byref(TL.c), args, self._s()), "dst_dir_chain_fwd")
 
     def pair_front_fwd(self, TL, pos, ada, dist_off, sh, sc, means, stds, e_in, Wee, bee, Wte, out):
         """The pair rows of a block in front of the attention as one kernel (``dst_pair_front_fwd``, bf16 products).  ``out``: dict with X1, te and -
         when the tape is kept - xs, d2, e1, st, en."""
         ptr = lambda t: 0 if t is None else t.data_ptr()
-        args = _FRONT_PACK(ptr(pos), ptr(ada), ADA, dist_off, sh, sc, 0, ptr(means), ptr(stds), ptr(e_in), ptr(Wee), ptr(bee), ptr(Wte),
+        args = _FRONT_PACK(*TL.pair_tables, ptr(pos), ptr(ada), ADA, dist_off, sh, sc, 0, ptr(means), ptr(stds), ptr(e_in), ptr(Wee), ptr(bee), ptr(Wte),
                            *(ptr(out.get(k)) for k in ("X1", "xs", "d2", "e1", "st", "en", "te")))
         E._check(self.lib.dst_pair_front_fwd(C.byref(TL.c), args, self._s()), "dst_pair_front_fwd")
 
@@ -355,6 +364,8 @@ class TrainLayout:
         self.node_mol = L.t["node_mol"].long()
         self.pair_mol = L.t["pair_mol"].long()
         self.node_off, self.pair_off = L.t["node_off"], L.t["pair_off"]
+        # device tables of the flat-tile kernels (dst_pair_*_fwd, dst_dir_chain_fwd): node rows of a pair's atoms, its molecule
+        self.pair_tables = (L.t["pair_a"].data_ptr(), L.t["pair_b"].data_ptr(), L.t["pair_mol"].data_ptr())
 
     def pack_nodes(self, dense: torch.Tensor) -> torch.Tensor:
         return dense.reshape(self.B * self.N, -1).index_select(0, self.node_dense).contiguous()
@@ -625,13 +636,23 @@ class DmtTrainGraph:
                 o.lin_fwd(mv(e_out), mv(p[f"edge_{i}.weight"]), p[f"edge_{i}.bias"], mv(re_))
             if ns:
                 o.main_wait(ev_ac)
-            zz, zn, st_z = self.f(max(D, 1), 256), self.f(max(D, 1), 256), self.f(max(D, 1), 2)
-            E._check(lib.dst_zbuild_fwd(C.byref(TL.c), E._ptr(ac), E._ptr(ed), E._ptr(zz), s()), "dst_zbuild_fwd")
-            o.lnmod_fwd(zz, 256, TL.pair_off, 2, B, ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256, zn, st_z)
-            c0, sc0, c2 = self.f(max(D, 1), 256), self.f(max(D, 1), 256), self.f(max(D, 1), 3)
-            o.lin_fwd(mv(zn, r1=D), mv(p[bp + "equi_update.coord_mlp.0.weight"]), p[bp + "equi_update.coord_mlp.0.bias"], mv(c0, r1=D), act=SILU,
-                      out2=mv(sc0, r1=D))
-            o.lin_fwd(mv(sc0, r1=D), mv(p[bp + "equi_update.coord_mlp.2.weight"]), None, mv(c2, r1=D))
+            if fused_chain:
+                # dmt.py:37-48: z of both directions, LayerNorm + modulate, coord_mlp as ONE kernel (csrc/ds_train_chain.hip)
+                c2 = self.f(max(D, 1), 3)
+                outs = dict(c2=c2)
+                if save:
+                    outs.update(zz=self.f(D, 256), st=self.f(D, 2), zn=self.f(D, 256), c0=self.f(D, 256), sc0=self.f(D, 256))
+                o.dir_chain_fwd(TL, ac, ed, ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256, p[bp + "equi_update.coord_mlp.0.weight"],
+                                p[bp + "equi_update.coord_mlp.0.bias"], p[bp + "equi_update.coord_mlp.2.weight"], outs)
+                zz, st_z, zn, c0, sc0 = (outs.get(k) for k in ("zz", "st", "zn", "c0", "sc0"))
+            else:
+                zz, zn, st_z = self.f(max(D, 1), 256), self.f(max(D, 1), 256), self.f(max(D, 1), 2)
+                E._check(lib.dst_zbuild_fwd(C.byref(TL.c), E._ptr(ac), E._ptr(ed), E._ptr(zz), s()), "dst_zbuild_fwd")
+                o.lnmod_fwd(zz, 256, TL.pair_off, 2, B, ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256, zn, st_z)
+                c0, sc0, c2 = self.f(max(D, 1), 256), self.f(max(D, 1), 256), self.f(max(D, 1), 3)
+                o.lin_fwd(mv(zn, r1=D), mv(p[bp + "equi_update.coord_mlp.0.weight"]), p[bp + "equi_update.coord_mlp.0.bias"], mv(c0, r1=D), act=SILU,
+                          out2=mv(sc0, r1=D))
+                o.lin_fwd(mv(sc0, r1=D), mv(p[bp + "equi_update.coord_mlp.2.weight"]), None, mv(c2, r1=D))
             pos_out = self.f(Nn, 3)
             E._check(lib.dst_coord_fwd(C.byref(TL.c), E._ptr(pos), E._ptr(c2), E._ptr(adj), E._ptr(p[bp + "equi_update.coord_norm.scale"]),
                                        E._ptr(pos_out), s()), "dst_coord_fwd")

@@ -270,6 +270,7 @@ int dst_sumsq(const float* x, int64_t n, float* out, int32_t accumulate, float* 
  * always; the tape tensors he, xe1, st [Pp,2] = (mean, rstd), ye1, f3 [Pp,128], s3 [Pp,128], f4, X2 [Pp,128] = [e_out | feat] may each
  * be NULL (not written).  Every pointer 16-byte aligned. */
 typedef struct dst_pair_chain_args {
+  const int32_t* pair_a; const int32_t* pair_b; const int32_t* pair_mol;   /* [Pp]: node rows of a pair's atoms, its molecule */
   const float* u; const float* n2e_bias; const float* e_in; const float* feat; int64_t ld_feat;
   const float* ada; int64_t ada_ld; int32_t gate1_off, shift_off, scale_off, gate2_off;
   const float* W3; const float* b3; const float* W4; const float* b4; const float* Wed; int64_t ld_wed; const float* bed;
@@ -286,11 +287,26 @@ int dst_pair_chain_fwd(const dst_layout* L, const dst_pair_chain_args* a, void* 
  * pos [Nn,3]; means, stds [63]; ada column dist_off holds the distance scale, dist_off + 1 its shift.  Outputs: X1 [Pp,128] and te [Pp,512]
  * always; xs [Pp] (x'), d2 [Pp], e1 [Pp,64], st [Pp,2] = (mean, rstd), en [Pp,64] may be NULL. */
 typedef struct dst_pair_front_args {
+  const int32_t* pair_a; const int32_t* pair_b; const int32_t* pair_mol;
   const float* pos; const float* ada; int64_t ada_ld; int32_t dist_off, shift_off, scale_off, _pad;
   const float* means; const float* stds; const float* e_in; const float* Wee; const float* bee; const float* Wte;
   float* X1; float* xs; float* d2; float* e1; float* st; float* en; float* te;
 } dst_pair_front_args;
 int dst_pair_front_fwd(const dst_layout* L, const dst_pair_front_args* a, void* stream);
+
+/* The directed rows of one block (both directions of every pair; dmt.py:37-48) as one kernel (bf16 products); replaces dst_zbuild_fwd,
+ * dst_lnmod_fwd (256 wide, two rows per pair) and two dst_gemm calls:
+ *   zz[2p + dir] = ac[row, 0:256] + ac[col, 256:512] + ed[p];  zn = LN(zz) (1 + ada[scale]) + ada[shift];
+ *   c0 = zn W0^T + b0;  sc0 = SiLU(c0);  c2 = sc0 W2^T.
+ * ac [Nn,512], ed [Pp,256], W0 [256,256], W2 [3,256] (torch Linear layout).  Outputs: c2 [2 Pp, 3] always; zz, st [2 Pp, 2], zn, c0, sc0
+ * [2 Pp, 256] may each be NULL. */
+typedef struct dst_dir_chain_args {
+  const int32_t* pair_a; const int32_t* pair_b; const int32_t* pair_mol;
+  const float* ac; const float* ed; const float* ada; int64_t ada_ld; int32_t shift_off, scale_off;
+  const float* W0; const float* b0; const float* W2;
+  float* zz; float* st; float* zn; float* c0; float* sc0; float* c2;
+} dst_dir_chain_args;
+int dst_dir_chain_fwd(const dst_layout* L, const dst_dir_chain_args* a, void* stream);
 
 #ifdef __cplusplus
 }

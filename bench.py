@@ -320,7 +320,9 @@ def parse_args(argv=None):
                     help="train mode: GEMM arithmetic (bf16 = config 5: bf16 products, fp32 accumulation and master weights)")
     ap.add_argument("--train-batch", type=int, default=256, help="train mode: molecules per GPU and step (config 5: 2048 over 8 GPUs)")
     ap.add_argument("--samples", type=int, default=10000, help="eval mode: samples per GPU")
-    ap.add_argument("--batch", type=int, default=5000, help="eval mode: micro-batch (molecules resident at a time)")
+    ap.add_argument("--batch", type=int, default=10000,
+                    help="eval mode: micro-batch (molecules resident at a time).  10 000 = the whole per-GPU evaluation in one batch (~6 GB of workspace; "
+                         "same-box round 5: 235.6 molecules/s against 233.4 with two micro-batches of 5 000)")
     ap.add_argument("--mols", type=int, default=4096, help="resident mode: molecules resident per GPU")
     ap.add_argument("--denoise-steps", type=int, default=1000)
     ap.add_argument("--steps-per-pass", type=int, default=20,

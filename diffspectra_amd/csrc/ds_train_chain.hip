@@ -15,10 +15,13 @@
 // dropout masks are dst_dropout's (Philox block (row * N + col) / 4 of stream 4 * block + site): bit-identical to the unfused path and
 // to golden G17's injected masks.
 //
-// FLAT tiles: a wave owns 32 consecutive rows of the packed pair (or directed) rows from its first load to its last store, whatever
-// molecules they belong to - the per-molecule adaLN rows are looked up per row (pair_mol), the atoms of a pair come from the layout's
-// pair_a / pair_b tables.  Wave-private LDS, no workgroup barrier: every wave slot of the chip takes the same amount of work (the first
-// version of these kernels ran one workgroup per molecule and lost 2 - 3x to the imbalance between a 29-atom and a 9-atom molecule).
+// FLAT tiles, FOUR WAVES PER TILE: a 256-thread workgroup owns 32 consecutive rows of the packed pair (or directed) rows, whatever molecules
+// they belong to - the per-molecule adaLN rows are looked up per row (pair_mol), the atoms of a pair come from the layout's pair_a /
+// pair_b tables.  The row passes of the LayerNorm stages and the 32-column chunks of every product are dealt over the four waves, the
+// tiles they share live in the workgroup's LDS (35 - 50 kB: three workgroups = twelve waves per CU), one barrier between phases.
+// History (profiles/r05_train_fused_ab.txt): one workgroup per molecule lost 2 - 3x to the imbalance between a 29-atom and a 9-atom
+// molecule; one WAVE per tile (wave-private LDS, no barrier) left a wave alone on its SIMD with 35 kB of LDS and ~8 k dependent
+// instructions per tile - 40 us per tile whatever was done to its memory accesses.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -39,9 +42,9 @@ namespace {
 constexpr int CH_NW = 4, CH_NT = CH_NW * 64;      // waves per workgroup
 constexpr int LD_Y = 72, LD_S = 136, LD_F = 68, LD_ST = 36;   // LDS row strides: bf16 tiles in halves (16-byte rows), fp32 tiles in floats
 
-struct WaveLds {
+struct ChainLds {
   float yf[32][LD_F];            // ye1, fp32 (the residual of the FF)
-  float stage[32][LD_ST];        // one 32 x 32 accumulator tile on its way from the MFMA layout to rows
+  float stage[CH_NW][32][LD_ST]; // per wave: one 32 x 32 accumulator tile on its way from the MFMA layout to rows
   __bf16 yb[32][LD_Y];           // ye1, bf16: A operand of ff_linear3
   __bf16 sb[32][LD_S];           // s3, bf16: A operand of ff_linear4
   __bf16 eb[32][LD_S];           // [e_out | features], bf16: A operand of input_lin's edge part and of the read-out slice
@@ -90,7 +93,9 @@ __device__ __forceinline__ void wfetch(WFrag<KB>& f, const float* __restrict__ W
   for (int kb = 0; kb < KB; ++kb) { f.a[kb] = ld4(wrow + 16 * kb); f.b[kb] = ld4(wrow + 16 * kb + 4); }
   f.ok = col < n_out;
 }
-template <int KB>
+// MASKED: the product has fewer than 32 output columns in this chunk (the 16-column read-out slice, the 3-column coord_mlp.2): columns
+// beyond n_out multiply by zero.  Full chunks skip the selects (sixteen per k-block otherwise - more VALU work than the conversion itself).
+template <int KB, bool MASKED = false>
 __device__ __forceinline__ void mma_apply(const __bf16* A, int lda, int a0, const WFrag<KB>& f, f32x16_t& acc) {
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const __bf16* arow = A + r * lda + a0 + 8 * hh;
@@ -98,7 +103,10 @@ __device__ __forceinline__ void mma_apply(const __bf16* A, int lda, int a0, cons
   for (int kb = 0; kb < KB; ++kb) {
     bf16x8_t b;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { b[j] = (__bf16)(f.ok ? f.a[kb][j] : 0.0f); b[4 + j] = (__bf16)(f.ok ? f.b[kb][j] : 0.0f); }
+    for (int j = 0; j < 4; ++j) {
+      b[j] = (__bf16)(!MASKED || f.ok ? f.a[kb][j] : 0.0f);
+      b[4 + j] = (__bf16)(!MASKED || f.ok ? f.b[kb][j] : 0.0f);
+    }
     const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(arow + 16 * kb);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
   }
@@ -116,72 +124,63 @@ __device__ __forceinline__ void acc_to_stage(const f32x16_t& acc, float (*stage)
   for (int i = 0; i < 16; ++i) stage[(i & 3) + 8 * (i >> 2) + 4 * hh][c] = acc[i];
 }
 
-// Vector-memory operations of a wave retire in issue order: a load issued behind stores waits for them.  A tile writes ~130 kB of tape, so
-// inside a tile every load is requested before the stores of its phase: the index tables and all rows of stage 1 first, the per-row gate
-// rows of the FF epilogue with them, each GEMM chunk's weight fragments and bias before the previous chunk's epilogue.
-__global__ __launch_bounds__(CH_NT) void k_pair_chain_fwd(dst_layout L, dst_pair_chain_args a, const int32_t* __restrict__ pair_a,
+// Vector-memory operations of a wave retire in issue order: a load issued behind stores waits for them.  So inside a tile every load is
+// requested before the stores of its phase: the index tables and the rows of stage 1 first, the per-row gate rows of the FF epilogue with
+// them, each GEMM chunk's weight fragments and bias before the previous epilogue.
+__global__ __launch_bounds__(CH_NT, 3) void k_pair_chain_fwd(dst_layout L, dst_pair_chain_args a, const int32_t* __restrict__ pair_a,
                                                           const int32_t* __restrict__ pair_b, const int32_t* __restrict__ pair_mol) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  WaveLds& w = reinterpret_cast<WaveLds*>(lds_raw)[threadIdx.x >> 6];
+  ChainLds& w = *reinterpret_cast<ChainLds*>(lds_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float (*stage)[LD_ST] = w.stage[wave];
   const int Pp = L.Pp;
-  const int tile = blockIdx.x * CH_NW + wave;
-  const int t0 = tile * 32;
-  if (t0 >= Pp) return;
+  const int t0 = blockIdx.x * 32;
   const int valid = min(32, Pp - t0);
+  const int64_t g0 = t0;                                     // global pair row of the tile's row 0
   const unsigned int thr = dst::dropout_threshold(a.drop_p);
   const float keep_scale = a.drop_p > 0.0f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const int sub = lane >> 4, cl = (lane & 15) * 4;          // row layout of stage 1: a row = 16 lanes x float4
   const int er = lane >> 3, ec = (lane & 7) * 4;            // row layout of the GEMM epilogues: a 32-column chunk row = 8 lanes x float4
   const f4_t bias = ld4(a.n2e_bias + cl);
-  float b3c[4], b4c[2];
+  const float b3c = a.b3[wave * 32 + (lane & 31)], b4c = a.b4[(wave & 1) * 32 + (lane & 31)];
+  // edge_gate_mlp of the rows this lane finishes in the ff_linear4 epilogue (waves 0, 1: row it * 8 + er, columns wave * 32 + ec ..)
+  f4_t g2c[4];
 #pragma unroll
-  for (int ch = 0; ch < 4; ++ch) b3c[ch] = a.b3[ch * 32 + (lane & 31)];
-#pragma unroll
-  for (int ch = 0; ch < 2; ++ch) b4c[ch] = a.b4[ch * 32 + (lane & 31)];
-  const float bed0 = a.bed[lane & 31], broc = (lane & 31) < 16 ? a.bro[lane & 31] : 0.0f;
-  // edge_gate_mlp of the rows this lane finishes in the ff_linear4 epilogue (row it * 8 + er, columns ch * 32 + ec ..)
-  f4_t g2c[2][4];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const float* adr = a.ada + (int64_t)pair_mol[min(t0 + it * 8 + er, Pp - 1)] * a.ada_ld + a.gate2_off + ec;
-    g2c[0][it] = ld4(adr);
-    g2c[1][it] = ld4(adr + 32);
-  }
+  for (int it = 0; it < 4; ++it)
+    g2c[it] = ld4(a.ada + (int64_t)pair_mol[min(t0 + it * 8 + er, Pp - 1)] * a.ada_ld + a.gate2_off + (wave & 1) * 32 + ec);
   WFrag<4> f3w;
-  wfetch<4>(f3w, a.W3, 64, 0, 0, 128);
-  // ---- stage 1: gather, gated residual, LayerNorm + modulate
+  wfetch<4>(f3w, a.W3, 64, 0, wave * 32, 128);
+  // ---- stage 1: gather, gated residual, LayerNorm + modulate; wave w takes passes 2 w, 2 w + 1 (rows 8 w .. 8 w + 7)
   {
-    int ia[8], ib[8], im[8];
+    int ia[2], ib[2], im[2];
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int gp = min(t0 + ps * 4 + sub, Pp - 1);
-      ia[ps] = pair_a[gp]; ib[ps] = pair_b[gp]; im[ps] = pair_mol[gp];
+    for (int q = 0; q < 2; ++q) {
+      const int gp = min(t0 + (2 * wave + q) * 4 + sub, Pp - 1);
+      ia[q] = pair_a[gp]; ib[q] = pair_b[gp]; im[q] = pair_mol[gp];
     }
-    f4_t ua[8], ub[8], ev[8], fv[8], g1v[8], shv[8], scv[8];
+    f4_t ua[2], ub[2], ev[2], fv[2], g1v[2], shv[2], scv[2];
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int64_t gp = min(t0 + ps * 4 + sub, Pp - 1);
-      const float* adm = a.ada + (int64_t)im[ps] * a.ada_ld;
-      ua[ps] = ld4(a.u + (int64_t)ia[ps] * 64 + cl);
-      ub[ps] = ld4(a.u + (int64_t)ib[ps] * 64 + cl);
-      ev[ps] = ld4(a.e_in + gp * 64 + cl);
-      fv[ps] = ld4(a.feat + gp * a.ld_feat + cl);
-      g1v[ps] = ld4(adm + a.gate1_off + cl); shv[ps] = ld4(adm + a.shift_off + cl); scv[ps] = ld4(adm + a.scale_off + cl);
+    for (int q = 0; q < 2; ++q) {
+      const int64_t gp = min(t0 + (2 * wave + q) * 4 + sub, Pp - 1);
+      const float* adm = a.ada + (int64_t)im[q] * a.ada_ld;
+      ua[q] = ld4(a.u + (int64_t)ia[q] * 64 + cl);
+      ub[q] = ld4(a.u + (int64_t)ib[q] * 64 + cl);
+      ev[q] = ld4(a.e_in + gp * 64 + cl);
+      fv[q] = ld4(a.feat + gp * a.ld_feat + cl);
+      g1v[q] = ld4(adm + a.gate1_off + cl); shv[q] = ld4(adm + a.shift_off + cl); scv[q] = ld4(adm + a.scale_off + cl);
     }
     __builtin_amdgcn_sched_barrier(0);                       // (the output pointers may alias the inputs for all the compiler knows: keep every load above the first store)
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int row = ps * 4 + sub;
+    for (int q = 0; q < 2; ++q) {
+      const int row = (2 * wave + q) * 4 + sub;
       const int64_t gp = min(t0 + row, Pp - 1);
-      const f4_t g1 = g1v[ps], sh = shv[ps], sc = scv[ps];
-      const f4_t he = (ua[ps] + ub[ps]) + bias;
-      const f4_t x = ev[ps] + g1 * he;
-      f4_t ft = fv[ps];
+      const f4_t he = (ua[q] + ub[q]) + bias;
+      const f4_t x = ev[q] + g1v[q] * he;
+      f4_t ft = fv[q];
       const float mean = sum16((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / 64.0f);
       const f4_t d = x - mean;
       const float rstd = 1.0f / sqrtf(sum16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 64.0f) + 1e-6f);
-      f4_t y = (d * rstd) * (1.0f + sc) + sh;
+      f4_t y = (d * rstd) * (1.0f + scv[q]) + shv[q];
       if (row < valid) {
         if (a.he) st4(a.he + gp * 64 + cl, he);
         if (a.xe1) st4(a.xe1 + gp * 64 + cl, x);
@@ -197,26 +196,26 @@ __global__ __launch_bounds__(CH_NT) void k_pair_chain_fwd(dst_layout L, dst_pair
       *reinterpret_cast<bf16x4_t*>(&w.eb[row][64 + cl]) = to_bf4(ft);
     }
   }
-  wave_lds_sync();
-  const int64_t g0 = t0;                                     // global pair row of the tile's row 0
-  // ---- ff_linear3 (64 -> 128), SiLU, dropout
-  WFrag<8> f4w;
-#pragma unroll
-  for (int ch = 0; ch < 4; ++ch) {
+  __syncthreads();
+  // ---- ff_linear3 (64 -> 128), SiLU, dropout: chunk `wave`
+  WFrag<8> edw;                                              // ff_linear4's fragments (waves 0, 1), then input_lin's
+  {
+    const int ch = wave;
     f32x16_t acc;
-    const float b = b3c[ch];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = b;
+    for (int i = 0; i < 16; ++i) acc[i] = b3c;
     mma_apply<4>(&w.yb[0][0], LD_Y, 0, f3w, acc);
-    if (ch < 3) wfetch<4>(f3w, a.W3, 64, 0, (ch + 1) * 32, 128);     // the next chunk's (or ff_linear4's first) fragments fly under the epilogue
-    else wfetch<8>(f4w, a.W4, 128, 0, 0, 64);
-    acc_to_stage(acc, w.stage);
+    // the next product's fragments fly under this epilogue: ff_linear4's on waves 0, 1, input_lin's first chunk on the waves that sit
+    // ff_linear4 out (one fragment set in flight per wave: three workgroups per CU leave a wave 168 registers)
+    if (wave < 2) wfetch<8>(edw, a.W4, 128, 0, wave * 32, 64);
+    else wfetch<8>(edw, a.Wed, a.ld_wed, 0, wave * 32, 256);
+    acc_to_stage(acc, stage);
     wave_lds_sync();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + er, col = ch * 32 + ec;
       const int64_t gr = g0 + row;
-      const f4_t v = ld4(&w.stage[row][ec]);
+      const f4_t v = ld4(&stage[row][ec]);
       f4_t sv;
 #pragma unroll
       for (int e = 0; e < 4; ++e) sv[e] = fast_silu(v[e]);
@@ -234,33 +233,30 @@ __global__ __launch_bounds__(CH_NT) void k_pair_chain_fwd(dst_layout L, dst_pair
       }
       *reinterpret_cast<bf16x4_t*>(&w.sb[row][col]) = to_bf4(sv);
     }
-    wave_lds_sync();
   }
-  // ---- ff_linear4 (128 -> 64), dropout, gated residual
-  WFrag<8> edw;
-#pragma unroll
-  for (int ch = 0; ch < 2; ++ch) {
+  __syncthreads();
+  // ---- ff_linear4 (128 -> 64), dropout, gated residual: chunks 0, 1 on waves 0, 1
+  if (wave < 2) {
+    const int ch = wave;
     f32x16_t acc;
-    const float b = b4c[ch];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = b;
-    mma_apply<8>(&w.sb[0][0], LD_S, 0, f4w, acc);
-    if (ch < 1) wfetch<8>(f4w, a.W4, 128, 0, 32, 64);
-    else wfetch<8>(edw, a.Wed, a.ld_wed, 0, 0, 256);
-    acc_to_stage(acc, w.stage);
+    for (int i = 0; i < 16; ++i) acc[i] = b4c;
+    mma_apply<8>(&w.sb[0][0], LD_S, 0, edw, acc);
+    wfetch<8>(edw, a.Wed, a.ld_wed, 0, wave * 32, 256);
+    acc_to_stage(acc, stage);
     wave_lds_sync();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + er, col = ch * 32 + ec;
       const int64_t gr = g0 + row;
-      f4_t v = ld4(&w.stage[row][ec]);
+      f4_t v = ld4(&stage[row][ec]);
       if (a.drop_p > 0.0f) {
         unsigned int c[4];
         dst::dropout_block(a.seed, a.stream4, (gr * 64 + col) >> 2, c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = c[e] >= thr ? v[e] * keep_scale : 0.0f;
       }
-      f4_t eo = ld4(&w.yf[row][col]) + g2c[ch][it] * v;
+      f4_t eo = ld4(&w.yf[row][col]) + g2c[it] * v;
       if (row < valid) {
         if (a.f4) st4(a.f4 + gr * 64 + col, v);
         st4(a.e_out + gr * 64 + col, eo);
@@ -270,28 +266,31 @@ __global__ __launch_bounds__(CH_NT) void k_pair_chain_fwd(dst_layout L, dst_pair
       }
       *reinterpret_cast<bf16x4_t*>(&w.eb[row][col]) = to_bf4(eo);
     }
-    wave_lds_sync();
   }
-  // ---- input_lin's edge part ([e_out | features] 128 -> 256) and the read-out slice (e_out 64 -> 16)
+  __syncthreads();
+  // ---- input_lin's edge part ([e_out | features] 128 -> 256): chunks wave, wave + 4; the read-out slice (e_out 64 -> 16) on wave 3
+  float bcur = a.bed[wave * 32 + (lane & 31)];
   WFrag<4> row_w;
-  float bcur = bed0;
+  if (wave == 3) wfetch<4>(row_w, a.Wro, 64, 0, 0, 16);
+  const float broc = (lane & 31) < 16 ? a.bro[lane & 31] : 0.0f;
 #pragma unroll 1
-  for (int ch = 0; ch < 9; ++ch) {
-    const bool ro = ch == 8;
+  for (int k = 0; k < 3; ++k) {
+    const bool ro = k == 2;
+    if (ro && wave != 3) break;
+    const int ch = wave + 4 * k;
     f32x16_t acc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = bcur;
-    if (ro) mma_apply<4>(&w.eb[0][0], LD_S, 0, row_w, acc);
+    for (int i = 0; i < 16; ++i) acc[i] = ro ? broc : bcur;
+    if (ro) mma_apply<4, true>(&w.eb[0][0], LD_S, 0, row_w, acc);
     else mma_apply<8>(&w.eb[0][0], LD_S, 0, edw, acc);
-    if (ch < 7) { wfetch<8>(edw, a.Wed, a.ld_wed, 0, (ch + 1) * 32, 256); bcur = a.bed[(ch + 1) * 32 + (lane & 31)]; }   // before this chunk's stores
-    else if (ch == 7) { wfetch<4>(row_w, a.Wro, 64, 0, 0, 16); bcur = broc; }
-    acc_to_stage(acc, w.stage);
+    if (k == 0) { wfetch<8>(edw, a.Wed, a.ld_wed, 0, (wave + 4) * 32, 256); bcur = a.bed[(wave + 4) * 32 + (lane & 31)]; }   // before this chunk's stores
+    acc_to_stage(acc, stage);
     wave_lds_sync();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + er;
       const int64_t gr = g0 + row;
-      const f4_t v = ld4(&w.stage[row][ec]);
+      const f4_t v = ld4(&stage[row][ec]);
       if (row < valid) {
         if (!ro) st4(a.ed + gr * 256 + ch * 32 + ec, v);
         else if (ec < 16) st4(a.ro + gr * 16 + ec, v);
@@ -304,25 +303,24 @@ __global__ __launch_bounds__(CH_NT) void k_pair_chain_fwd(dst_layout L, dst_pair
 // dst_pair_front_fwd: the pair rows of a block IN FRONT of the attention (dmt.py:136-139,145-149; layers.py:291-295,328-334,165-166,183):
 //   d2 = |pos_a - pos_b|^2;  x' = d2 (1 + ada[dist]) + ada[dist + 1];  feat = [x', gaussian_k(x')];  X1 = [feat | e]
 //   e1 = edge_emb(X1);  en = LN(e1) (1 + ada[scale]) + ada[shift];  te = tanh(en [lin_edge0 | lin_edge1]^T)
-// replacing dst_geom_fwd, a copy, two dst_gemm calls and dst_lnmod_fwd.  Same arithmetic per element as those kernels (expf, the
-// truncated-pi constant, divisions where they divide), bf16-rounded MFMA operands with fp32 accumulation.
+// replacing dst_geom_fwd, a copy, two dst_gemm calls and dst_lnmod_fwd.  Same arithmetic per element as those kernels for the features
+// (expf, the truncated-pi constant, divisions where they divide), bf16-rounded MFMA operands with fp32 accumulation.
 #define DST_GAUSS_A 2.50662732f /* fp32((2 * 3.14159) ** 0.5), as in ds_train.hip */
 struct FrontLds {
   float ef[32][LD_F];            // e1 (both 32-column chunks), fp32: the LayerNorm reads whole rows
-  float stage[32][LD_ST];
+  float stage[CH_NW][32][LD_ST];
   __bf16 xb[32][LD_S];           // X1 = [feat | e], bf16
   __bf16 nb[32][LD_Y];           // en, bf16
 };
 
-__global__ __launch_bounds__(CH_NT) void k_pair_front_fwd(dst_layout L, dst_pair_front_args a, const int32_t* __restrict__ pair_a,
+__global__ __launch_bounds__(CH_NT, 3) void k_pair_front_fwd(dst_layout L, dst_pair_front_args a, const int32_t* __restrict__ pair_a,
                                                           const int32_t* __restrict__ pair_b, const int32_t* __restrict__ pair_mol) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  FrontLds& w = reinterpret_cast<FrontLds*>(lds_raw)[threadIdx.x >> 6];
+  FrontLds& w = *reinterpret_cast<FrontLds*>(lds_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float (*stage)[LD_ST] = w.stage[wave];
   const int Pp = L.Pp;
-  const int tile = blockIdx.x * CH_NW + wave;
-  const int t0 = tile * 32;
-  if (t0 >= Pp) return;
+  const int t0 = blockIdx.x * 32;
   const int valid = min(32, Pp - t0);
   const int64_t g0 = t0;
   const int sub = lane >> 4, cl = (lane & 15) * 4, er = lane >> 3, ec = (lane & 7) * 4;
@@ -335,35 +333,39 @@ __global__ __launch_bounds__(CH_NT) void k_pair_front_fwd(dst_layout L, dst_pair
     sd[j] = k ? fabsf(a.stds[k - 1]) + 1e-5f : 1.0f;
     nrm[j] = DST_GAUSS_A * sd[j];
   }
-  const float beec[2] = {a.bee[lane & 31], a.bee[32 + (lane & 31)]};
-  // ---- features + X1 (every load of the tile before its first store)
-  int ia[8], ib[8], im[8];
+  const float beec = a.bee[(wave & 1) * 32 + (lane & 31)];
+  WFrag<8> eew;
+  if (wave < 2) wfetch<8>(eew, a.Wee, 128, 0, wave * 32, 64);
+  WFrag<4> tew;
+  wfetch<4>(tew, a.Wte, 64, 0, wave * 32, 512);
+  // ---- features + X1: wave w takes passes 2 w, 2 w + 1 (every load before the first store)
+  int ia[2], ib[2], im[2];
 #pragma unroll
-  for (int ps = 0; ps < 8; ++ps) {
-    const int gp = min(t0 + ps * 4 + sub, Pp - 1);
-    ia[ps] = pair_a[gp]; ib[ps] = pair_b[gp]; im[ps] = pair_mol[gp];
+  for (int q = 0; q < 2; ++q) {
+    const int gp = min(t0 + (2 * wave + q) * 4 + sub, Pp - 1);
+    ia[q] = pair_a[gp]; ib[q] = pair_b[gp]; im[q] = pair_mol[gp];
   }
-  f4_t evs[8], shs[8], scs[8];
-  float d2v[8], dscv[8], dshv[8];
+  f4_t evs[2], shs[2], scs[2];
+  float d2v[2], dscv[2], dshv[2];
 #pragma unroll
-  for (int ps = 0; ps < 8; ++ps) {
-    const int64_t gp = min(t0 + ps * 4 + sub, Pp - 1);
-    const float* pa_ = a.pos + (int64_t)ia[ps] * 3;
-    const float* pb_ = a.pos + (int64_t)ib[ps] * 3;
+  for (int q = 0; q < 2; ++q) {
+    const int64_t gp = min(t0 + (2 * wave + q) * 4 + sub, Pp - 1);
+    const float* pa_ = a.pos + (int64_t)ia[q] * 3;
+    const float* pb_ = a.pos + (int64_t)ib[q] * 3;
     const float dx = pa_[0] - pb_[0], dy = pa_[1] - pb_[1], dz = pa_[2] - pb_[2];
-    d2v[ps] = dx * dx + dy * dy + dz * dz;
-    const float* adm = a.ada + (int64_t)im[ps] * a.ada_ld;
-    dscv[ps] = adm[a.dist_off]; dshv[ps] = adm[a.dist_off + 1];
-    shs[ps] = ld4(adm + a.shift_off + cl); scs[ps] = ld4(adm + a.scale_off + cl);
-    evs[ps] = ld4(a.e_in + gp * 64 + cl);
+    d2v[q] = dx * dx + dy * dy + dz * dz;
+    const float* adm = a.ada + (int64_t)im[q] * a.ada_ld;
+    dscv[q] = adm[a.dist_off]; dshv[q] = adm[a.dist_off + 1];
+    shs[q] = ld4(adm + a.shift_off + cl); scs[q] = ld4(adm + a.scale_off + cl);
+    evs[q] = ld4(a.e_in + gp * 64 + cl);
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int ps = 0; ps < 8; ++ps) {
-    const int row = ps * 4 + sub;
+  for (int q = 0; q < 2; ++q) {
+    const int row = (2 * wave + q) * 4 + sub;
     const int64_t gp = min(t0 + row, Pp - 1);
-    const float d2 = d2v[ps];
-    const float x = d2 * (dscv[ps] + 1.0f) + dshv[ps];
+    const float d2 = d2v[q];
+    const float x = d2 * (dscv[q] + 1.0f) + dshv[q];
     f4_t ft;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(CH_NT) void k_pair_front_fwd(dst_layout L, dst_pair
       ft[j] = expf(-0.5f * (u * u)) / nrm[j];
     }
     if (cl == 0) ft[0] = x;
-    f4_t ev = evs[ps];
+    f4_t ev = evs[q];
     if (row < valid) {
       st4(a.X1 + gp * 128 + cl, ft);
       st4(a.X1 + gp * 128 + 64 + cl, ev);
@@ -386,32 +388,28 @@ __global__ __launch_bounds__(CH_NT) void k_pair_front_fwd(dst_layout L, dst_pair
     *reinterpret_cast<bf16x4_t*>(&w.xb[row][cl]) = to_bf4(ft);
     *reinterpret_cast<bf16x4_t*>(&w.xb[row][64 + cl]) = to_bf4(ev);
   }
-  wave_lds_sync();
-  // ---- edge_emb (128 -> 64)
-  WFrag<4> tew;
-#pragma unroll
-  for (int ch = 0; ch < 2; ++ch) {
+  __syncthreads();
+  // ---- edge_emb (128 -> 64): chunks 0, 1 on waves 0, 1
+  if (wave < 2) {
     f32x16_t acc;
-    const float b = beec[ch];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = b;
-    mma_rows<8>(&w.xb[0][0], LD_S, 0, a.Wee, 128, 0, ch * 32, 64, acc);
-    if (ch == 1) wfetch<4>(tew, a.Wte, 64, 0, 0, 512);             // lin_edge's first fragments fly under the LayerNorm
+    for (int i = 0; i < 16; ++i) acc[i] = beec;
+    mma_apply<8>(&w.xb[0][0], LD_S, 0, eew, acc);
     const int c = lane & 31, hh = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) w.ef[(i & 3) + 8 * (i >> 2) + 4 * hh][ch * 32 + c] = acc[i];
+    for (int i = 0; i < 16; ++i) w.ef[(i & 3) + 8 * (i >> 2) + 4 * hh][wave * 32 + c] = acc[i];
   }
-  wave_lds_sync();
-  // ---- LayerNorm + modulate
+  __syncthreads();
+  // ---- LayerNorm + modulate: passes 2 w, 2 w + 1
 #pragma unroll
-  for (int ps = 0; ps < 8; ++ps) {
-    const int row = ps * 4 + sub;
+  for (int q = 0; q < 2; ++q) {
+    const int row = (2 * wave + q) * 4 + sub;
     const int64_t gp = g0 + row;
     const f4_t x = ld4(&w.ef[row][cl]);
     const float mean = sum16((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / 64.0f);
     const f4_t d = x - mean;
     const float rstd = 1.0f / sqrtf(sum16((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 64.0f) + 1e-6f);
-    f4_t y = (d * rstd) * (1.0f + scs[ps]) + shs[ps];
+    f4_t y = (d * rstd) * (1.0f + scs[q]) + shs[q];
     if (row < valid) {
       if (a.e1) st4(a.e1 + gp * 64 + cl, x);
       if (a.st && (lane & 15) == 0) { a.st[gp * 2] = mean; a.st[gp * 2 + 1] = rstd; }
@@ -421,21 +419,22 @@ __global__ __launch_bounds__(CH_NT) void k_pair_front_fwd(dst_layout L, dst_pair
     }
     *reinterpret_cast<bf16x4_t*>(&w.nb[row][cl]) = to_bf4(y);
   }
-  wave_lds_sync();
-  // ---- tanh(en [lin_edge0 | lin_edge1]^T) (64 -> 512)
+  __syncthreads();
+  // ---- tanh(en [lin_edge0 | lin_edge1]^T) (64 -> 512): chunks wave, wave + 4, wave + 8, wave + 12
 #pragma unroll 1
-  for (int ch = 0; ch < 16; ++ch) {
+  for (int k = 0; k < 4; ++k) {
+    const int ch = wave + 4 * k;
     f32x16_t acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
     mma_apply<4>(&w.nb[0][0], LD_Y, 0, tew, acc);
-    if (ch < 15) wfetch<4>(tew, a.Wte, 64, 0, (ch + 1) * 32, 512);
-    acc_to_stage(acc, w.stage);
+    if (k < 3) wfetch<4>(tew, a.Wte, 64, 0, (ch + 4) * 32, 512);
+    acc_to_stage(acc, stage);
     wave_lds_sync();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + er;
-      f4_t v = ld4(&w.stage[row][ec]);
+      f4_t v = ld4(&stage[row][ec]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = fast_tanh(v[e]);
       if (row < valid) st4(a.te + (g0 + row) * 512 + ch * 32 + ec, v);
@@ -449,121 +448,116 @@ __global__ __launch_bounds__(CH_NT) void k_pair_front_fwd(dst_layout L, dst_pair
 //   zz[2p + dir] = ac[row][0:256] + ac[col][256:512] + ed[p]   (dir 0: row = a, col = b; dir 1: swapped)
 //   zn = LN(zz) (1 + ada[scale]) + ada[shift];  c0 = zn W0^T + b0;  sc0 = SiLU(c0);  c2 = sc0 W2^T   (W2 [3,256], no bias)
 // Tape: zz, (mean, rstd), zn, c0, sc0 (each may be NULL); c2 [2 Pp, 3] always.  sc0 is not staged whole: each 32-column chunk's bf16
-// tile goes straight into the 256 -> 3 product (two k-blocks per chunk, one accumulator across the chunks).
+// tile goes straight into the 256 -> 3 product of its wave (two k-blocks per chunk); the four waves' partial products are added at the end
+// in wave order.
 constexpr int LD_Z = 264;         // bf16 row of 256 + 8 (16-byte rows, 528 bytes: the 16-byte fragments of 16 rows hit distinct banks)
 constexpr int LD_C = 40;          // bf16 row of one 32-column chunk + 8
 struct DirLds {
-  float stage[32][LD_ST];
+  float stage[CH_NW][32][LD_ST];
   __bf16 zb[32][LD_Z];           // zn, bf16
-  __bf16 cb[32][LD_C];           // the current chunk of sc0, bf16
+  __bf16 cb[CH_NW][32][LD_C];    // per wave: the current chunk of sc0, bf16
 };
 
-__global__ __launch_bounds__(CH_NT) void k_dir_chain_fwd(dst_layout L, dst_dir_chain_args a, const int32_t* __restrict__ pair_a,
+__global__ __launch_bounds__(CH_NT, 3) void k_dir_chain_fwd(dst_layout L, dst_dir_chain_args a, const int32_t* __restrict__ pair_a,
                                                          const int32_t* __restrict__ pair_b, const int32_t* __restrict__ pair_mol) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  DirLds& w = reinterpret_cast<DirLds*>(lds_raw)[threadIdx.x >> 6];
+  DirLds& w = *reinterpret_cast<DirLds*>(lds_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float (*stage)[LD_ST] = w.stage[wave];
+  __bf16 (*cb)[LD_C] = w.cb[wave];
   const int nd = 2 * L.Pp;
-  const int tile = blockIdx.x * CH_NW + wave;
-  const int t0 = tile * 32;
-  if (t0 >= nd) return;
+  const int t0 = blockIdx.x * 32;
   const int valid = min(32, nd - t0);
   const int64_t g0 = t0;                                     // global directed row of the tile's row 0
   const int sub = lane >> 4, j16 = lane & 15, er = lane >> 3, ec = (lane & 7) * 4;
-  const float b00 = a.b0[lane & 31];
-  WFrag<8> c0w, c0v;
-  wfetch<8>(c0w, a.W0, 256, 0, 0, 256);
-  // ---- z, LayerNorm + modulate: a row = 16 lanes, lane j holds the float4s at columns 4 j + 64 u; the rows of four passes are requested
-  //      before the first of them is stored (loads behind stores wait for the stores)
-#pragma unroll 1
-  for (int pg = 0; pg < 2; ++pg) {
-    int ra[4], cb_[4], im[4];
+  float bcur = a.b0[wave * 32 + (lane & 31)];
+  // ---- z, LayerNorm + modulate: a row = 16 lanes, lane j holds the float4s at columns 4 j + 64 u; wave w takes passes 2 w, 2 w + 1,
+  //      one at a time (a pass holds 20 float4 per lane in flight; the second pass's loads queue behind the first one's stores - the
+  //      CU's other waves cover that)
+  int ra[2], cb_[2], im[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int dl = min(t0 + (pg * 4 + q) * 4 + sub, nd - 1), pl = dl >> 1, dir = dl & 1;
-      const int xa = pair_a[pl], xb = pair_b[pl];
-      ra[q] = dir ? xb : xa; cb_[q] = dir ? xa : xb; im[q] = pair_mol[pl];
+  for (int q = 0; q < 2; ++q) {
+    const int dl = min(t0 + (2 * wave + q) * 4 + sub, nd - 1), pl = dl >> 1, dir = dl & 1;
+    const int xa = pair_a[pl], xb = pair_b[pl];
+    ra[q] = dir ? xb : xa; cb_[q] = dir ? xa : xb; im[q] = pair_mol[pl];
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = (2 * wave + q) * 4 + sub;
+    const int dl = min(t0 + row, nd - 1), pl = dl >> 1;
+    const int64_t gd = dl;
+    const float* pr = a.ac + (int64_t)ra[q] * 512 + 4 * j16;
+    const float* pc = a.ac + (int64_t)cb_[q] * 512 + 256 + 4 * j16;
+    const float* pe = a.ed + (int64_t)pl * 256 + 4 * j16;
+    const float* adm = a.ada + (int64_t)im[q] * a.ada_ld + 4 * j16;
+    f4_t xr[4], xc[4], xe[4], shq[4], scq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      xr[u] = ld4(pr + 64 * u); xc[u] = ld4(pc + 64 * u); xe[u] = ld4(pe + 64 * u);
+      shq[u] = ld4(adm + a.shift_off + 64 * u); scq[u] = ld4(adm + a.scale_off + 64 * u);
     }
-    f4_t xr[4][4], xc[4][4], xe[4][4], shq[4][4], scq[4][4];
+    __builtin_amdgcn_sched_barrier(0);                       // the pass's loads above its first store
+    f4_t x[4];
+    float s1 = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int dl = min(t0 + (pg * 4 + q) * 4 + sub, nd - 1), pl = dl >> 1;
-      const float* pr = a.ac + (int64_t)ra[q] * 512 + 4 * j16;
-      const float* pc = a.ac + (int64_t)cb_[q] * 512 + 256 + 4 * j16;
-      const float* pe = a.ed + (int64_t)pl * 256 + 4 * j16;
-      const float* adm = a.ada + (int64_t)im[q] * a.ada_ld + 4 * j16;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        xr[q][u] = ld4(pr + 64 * u); xc[q][u] = ld4(pc + 64 * u); xe[q][u] = ld4(pe + 64 * u);
-        shq[q][u] = ld4(adm + a.shift_off + 64 * u); scq[q][u] = ld4(adm + a.scale_off + 64 * u);
-      }
+    for (int u = 0; u < 4; ++u) {
+      x[u] = (xr[u] + xc[u]) + xe[u];
+      s1 += (x[u][0] + x[u][1]) + (x[u][2] + x[u][3]);
     }
-    __builtin_amdgcn_sched_barrier(0);                       // every load of the group above its first store
+    const float mean = sum16(s1) * (1.0f / 256.0f);
+    float s2 = 0.0f;
+    f4_t dv[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = (pg * 4 + q) * 4 + sub;
-      const int64_t gd = min(t0 + row, nd - 1);
-      f4_t x[4];
-      float s1 = 0.0f;
+    for (int u = 0; u < 4; ++u) {
+      dv[u] = x[u] - mean;
+      s2 += (dv[u][0] * dv[u][0] + dv[u][1] * dv[u][1]) + (dv[u][2] * dv[u][2] + dv[u][3] * dv[u][3]);
+    }
+    const float rstd = 1.0f / sqrtf(sum16(s2) * (1.0f / 256.0f) + 1e-6f);
+    const bool live = row < valid;
+    if (live && a.st && j16 == 0) { a.st[gd * 2] = mean; a.st[gd * 2 + 1] = rstd; }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        x[u] = (xr[q][u] + xc[q][u]) + xe[q][u];
-        s1 += (x[u][0] + x[u][1]) + (x[u][2] + x[u][3]);
+    for (int u = 0; u < 4; ++u) {
+      f4_t y = (dv[u] * rstd) * (1.0f + scq[u]) + shq[u];
+      if (live) {
+        if (a.zz) st4(a.zz + gd * 256 + 64 * u + 4 * j16, x[u]);
+        if (a.zn) st4(a.zn + gd * 256 + 64 * u + 4 * j16, y);
+      } else {
+        y = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
       }
-      const float mean = sum16(s1) * (1.0f / 256.0f);
-      float s2 = 0.0f;
-      f4_t dv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        dv[u] = x[u] - mean;
-        s2 += (dv[u][0] * dv[u][0] + dv[u][1] * dv[u][1]) + (dv[u][2] * dv[u][2] + dv[u][3] * dv[u][3]);
-      }
-      const float rstd = 1.0f / sqrtf(sum16(s2) * (1.0f / 256.0f) + 1e-6f);
-      const bool live = row < valid;
-      if (live && a.st && j16 == 0) { a.st[gd * 2] = mean; a.st[gd * 2 + 1] = rstd; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        f4_t y = (dv[u] * rstd) * (1.0f + scq[q][u]) + shq[q][u];
-        if (live) {
-          if (a.zz) st4(a.zz + gd * 256 + 64 * u + 4 * j16, x[u]);
-          if (a.zn) st4(a.zn + gd * 256 + 64 * u + 4 * j16, y);
-        } else {
-          y = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-        *reinterpret_cast<bf16x4_t*>(&w.zb[row][64 * u + 4 * j16]) = to_bf4(y);
-      }
+      *reinterpret_cast<bf16x4_t*>(&w.zb[row][64 * u + 4 * j16]) = to_bf4(y);
     }
   }
-  wave_lds_sync();
-  // ---- coord_mlp.0 (256 -> 256) + SiLU, and coord_mlp.2 (256 -> 3) chunk by chunk
+  WFrag<8> c0w, c0v;                                          // (requested behind stage 1: its rows need the registers; the other waves of the CU cover the trip)
+  wfetch<8>(c0w, a.W0, 256, 0, wave * 32, 256);
+  WFrag<2> w2;
+  wfetch<2>(w2, a.W2, 256, wave * 32, 0, 3);
+  __syncthreads();
+  // ---- coord_mlp.0 (256 -> 256) + SiLU: chunks wave, wave + 4; coord_mlp.2 (256 -> 3) chunk by chunk into this wave's partial product
   f32x16_t acc2;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc2[i] = 0.0f;
-  WFrag<2> w2;
-  wfetch<2>(w2, a.W2, 256, 0, 0, 3);
-  wfetch<8>(c0v, a.W0, 256, 128, 0, 256);
-  float bcur = b00;
 #pragma unroll 1
-  for (int ch = 0; ch < 8; ++ch) {
+  for (int k = 0; k < 2; ++k) {
+    const int ch = wave + 4 * k;
     f32x16_t acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = bcur;
+    wfetch<8>(c0v, a.W0, 256, 128, ch * 32, 256);            // the second k-half flies under the first half's MFMAs
     mma_apply<8>(&w.zb[0][0], LD_Z, 0, c0w, acc);
     mma_apply<8>(&w.zb[0][0], LD_Z, 128, c0v, acc);
     WFrag<2> w2n = w2;
-    if (ch < 7) {                                            // the next chunk's fragments and bias: requested before this chunk's stores
-      wfetch<8>(c0w, a.W0, 256, 0, (ch + 1) * 32, 256);
-      wfetch<8>(c0v, a.W0, 256, 128, (ch + 1) * 32, 256);
-      wfetch<2>(w2n, a.W2, 256, (ch + 1) * 32, 0, 3);
-      bcur = a.b0[(ch + 1) * 32 + (lane & 31)];
+    if (k == 0) {                                            // the second chunk's first half and bias: requested before this chunk's stores
+      wfetch<8>(c0w, a.W0, 256, 0, (ch + 4) * 32, 256);
+      wfetch<2>(w2n, a.W2, 256, (ch + 4) * 32, 0, 3);
+      bcur = a.b0[(ch + 4) * 32 + (lane & 31)];
     }
-    acc_to_stage(acc, w.stage);
+    acc_to_stage(acc, stage);
     wave_lds_sync();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + er, col = ch * 32 + ec;
       const int64_t gr = g0 + row;
-      const f4_t v = ld4(&w.stage[row][ec]);
+      const f4_t v = ld4(&stage[row][ec]);
       f4_t sv;
 #pragma unroll
       for (int e = 0; e < 4; ++e) sv[e] = fast_silu(v[e]);
@@ -573,18 +567,26 @@ __global__ __launch_bounds__(CH_NT) void k_dir_chain_fwd(dst_layout L, dst_dir_c
       } else {
         sv = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
       }
-      *reinterpret_cast<bf16x4_t*>(&w.cb[row][ec]) = to_bf4(sv);
+      *reinterpret_cast<bf16x4_t*>(&cb[row][ec]) = to_bf4(sv);
     }
     wave_lds_sync();
-    mma_apply<2>(&w.cb[0][0], LD_C, 0, w2, acc2);
+    mma_apply<2, true>(&cb[0][0], LD_C, 0, w2, acc2);
     w2 = w2n;
     wave_lds_sync();
   }
-  acc_to_stage(acc2, w.stage);
-  wave_lds_sync();
-  if (lane < 32 && lane < valid) {
+  // the four waves' partial 256 -> 3 products, added in wave order by wave 0
+  {
+    const int c = lane & 31, hh = lane >> 5;
+    if (c < 3) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) stage[(i & 3) + 8 * (i >> 2) + 4 * hh][c] = acc2[i];
+    }
+  }
+  __syncthreads();
+  if (wave == 0 && lane < 32 && lane < valid) {
     float* o = a.c2 + (g0 + lane) * 3;
-    o[0] = w.stage[lane][0]; o[1] = w.stage[lane][1]; o[2] = w.stage[lane][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = ((w.stage[0][lane][c] + w.stage[1][lane][c]) + w.stage[2][lane][c]) + w.stage[3][lane][c];
   }
 }
 
@@ -604,12 +606,12 @@ int dst_pair_chain_fwd(const dst_layout* L, const dst_pair_chain_args* a, void* 
     if (reinterpret_cast<uintptr_t>(p) & 15) return DS_ERR_ARG;               // 16-byte accesses throughout
   if (L->Pp <= 0) return DS_OK;
   static bool attr_done = false;
-  const size_t lds = sizeof(WaveLds) * CH_NW;
+  const size_t lds = sizeof(ChainLds);
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair_chain_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DS_ERR_LAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL(k_pair_chain_fwd, dim3(((L->Pp + 31) / 32 + CH_NW - 1) / CH_NW), dim3(CH_NT), lds, (hipStream_t)stream, *L, *a, a->pair_a, a->pair_b, a->pair_mol);
+  hipLaunchKernelGGL(k_pair_chain_fwd, dim3((L->Pp + 31) / 32), dim3(CH_NT), lds, (hipStream_t)stream, *L, *a, a->pair_a, a->pair_b, a->pair_mol);
   return DST_CHECK_LAUNCH();
 }
 
@@ -621,12 +623,12 @@ int dst_pair_front_fwd(const dst_layout* L, const dst_pair_front_args* a, void* 
     if (reinterpret_cast<uintptr_t>(p) & 15) return DS_ERR_ARG;
   if (L->Pp <= 0) return DS_OK;
   static bool attr_done = false;
-  const size_t lds = sizeof(FrontLds) * CH_NW;
+  const size_t lds = sizeof(FrontLds);
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair_front_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DS_ERR_LAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL(k_pair_front_fwd, dim3(((L->Pp + 31) / 32 + CH_NW - 1) / CH_NW), dim3(CH_NT), lds, (hipStream_t)stream, *L, *a, a->pair_a, a->pair_b, a->pair_mol);
+  hipLaunchKernelGGL(k_pair_front_fwd, dim3((L->Pp + 31) / 32), dim3(CH_NT), lds, (hipStream_t)stream, *L, *a, a->pair_a, a->pair_b, a->pair_mol);
   return DST_CHECK_LAUNCH();
 }
 
@@ -638,12 +640,12 @@ int dst_dir_chain_fwd(const dst_layout* L, const dst_dir_chain_args* a, void* st
     if (reinterpret_cast<uintptr_t>(p) & 15) return DS_ERR_ARG;
   if (L->Pp <= 0) return DS_OK;
   static bool attr_done = false;
-  const size_t lds = sizeof(DirLds) * CH_NW;
+  const size_t lds = sizeof(DirLds);
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dir_chain_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DS_ERR_LAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL(k_dir_chain_fwd, dim3(((2 * L->Pp + 31) / 32 + CH_NW - 1) / CH_NW), dim3(CH_NT), lds, (hipStream_t)stream, *L, *a, a->pair_a, a->pair_b, a->pair_mol);
+  hipLaunchKernelGGL(k_dir_chain_fwd, dim3((2 * L->Pp + 31) / 32), dim3(CH_NT), lds, (hipStream_t)stream, *L, *a, a->pair_a, a->pair_b, a->pair_mol);
   return DST_CHECK_LAUNCH();
 }
 

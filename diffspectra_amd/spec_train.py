@@ -168,7 +168,7 @@ class SpecTrainGraph:
         cat_dst, cat_src = [], []                                      # gradients of the concatenated W_Q | W_K | W_V, scattered after the side stream has joined
         flash = t["flash"]
         if flash:                                                      # every layer's attention backward adds into the q | k columns of the layers below it
-            dqkv_all = [torch.zeros(B * L, 3 * D_MODEL, dtype=torch.float32, device=self.dev) for _ in range(N_LAYERS)]
+            dqkv_all = [self.f(B * L, 3 * D_MODEL) for _ in range(N_LAYERS)]     # (assigned by the last layer's call: accumulate = 0)
             qkv_all = [lt_["qkv"] for lt_ in t["layers"]]
         for l in reversed(range(N_LAYERS)):
             lt = t["layers"][l]
@@ -193,7 +193,7 @@ class SpecTrainGraph:
                 def flash_bwd(part):
                     E._check(self.lib.dst_spec_attn_flash_bwd(qp[0], qp[1], qp[2], C.c_int32(l + 1), E._ptr(lt["ast"]), E._ptr(lt["ao"]), E._ptr(dao), gp[0], gp[1],
                                                               gp[2], C.c_int32(B), C.c_int32(L), C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale),
-                                                              C.c_int32(part), self.ops._s()), "dst_spec_attn_flash_bwd")
+                                                              C.c_int32(part), C.c_int32(0 if l == N_LAYERS - 1 else 1), self.ops._s()), "dst_spec_attn_flash_bwd")
                 if two_streams:                                        # the key side beside the query side (disjoint columns of dqkv): each kernel
                     with o.node_section():                             # alone keeps two 4-wave workgroups on a CU
                         flash_bwd(2)

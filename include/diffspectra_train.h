@@ -223,15 +223,16 @@ int dst_spec_attn_bwd(const float* qkv, const float* scores, const float* stats,
 /* The same attention WITHOUT the [B,H,L,L] tensors (bf16 training mode, BASELINE config 5): the residual scores of layer l are
  * scale * sum_{j<=l} q_j k_j^T, so the kernels recompute them on the bf16 matrix pipe from the q | k slices of the layers 0 .. l
  * (qkv0 .. qkv2, n_layers = l + 1 of them; each [B*L, 3*H*dk]) flash-style: forward writes out [B*L, H*dk] and stats [B*H*L, 2] =
- * (row maximum of the log2-domain scores, row sum); backward re-creates the probabilities from them and ACCUMULATES layer l's softmax
- * gradient into the q and k columns of dqkv0 .. dqkv(l) (the gradient the reference chains through `prev`; the caller zeroes the
- * buffers once and runs the layers last to first) and writes the v columns of dqkv(l).  part: 0 = the whole backward; 1 = the query side
+ * (row maximum of the log2-domain scores, row sum); backward re-creates the probabilities from them and adds layer l's softmax
+ * gradient to the q and k columns of dqkv0 .. dqkv(l) (the gradient the reference chains through `prev`) and writes the v columns of
+ * dqkv(l).  The caller runs the layers last to first: accumulate = 0 for the FIRST call (the last layer: it ASSIGNS the q and k columns of
+ * every buffer, which therefore need no zeroing and are not read), 1 for the others.  part: 0 = the whole backward; 1 = the query side
  * (q columns) only, 2 = the key side (k and v columns) only - the two touch disjoint columns and may run on two streams. */
 int dst_spec_attn_flash_fwd(const float* qkv0, const float* qkv1, const float* qkv2, int32_t n_layers, float* stats, float* out, int32_t B,
                             int32_t L, int32_t H, int32_t dk, float scale, void* stream);
 int dst_spec_attn_flash_bwd(const float* qkv0, const float* qkv1, const float* qkv2, int32_t n_layers, const float* stats, const float* out,
                             const float* dout, float* dqkv0, float* dqkv1, float* dqkv2, int32_t B, int32_t L, int32_t H, int32_t dk, float scale,
-                            int32_t part, void* stream);
+                            int32_t part, int32_t accumulate, void* stream);
 
 /* LayerNorm with affine over the last dimension (specformer.py:67,119), training form.  Backward: dx written, dgamma / dbeta
  * accumulated through per-row-block partials (fixed order). */

@@ -1420,12 +1420,12 @@ def test_specformer_flash_attention_vs_torch_fp64(gpu_device, L):
         E._check(lib.dst_spec_attn_flash_fwd(qp[0], qp[1], qp[2], C.c_int32(l + 1), E._ptr(ast), E._ptr(out), C.c_int32(B), C.c_int32(L), C.c_int32(H),
                                              C.c_int32(DK), C.c_float(scale), E._stream()), "dst_spec_attn_flash_fwd")
         outs.append(out); stats.append(ast)
-    dq = [torch.zeros(B * L, 3 * DM, device=d) for _ in range(3)]
+    dq = [torch.full((B * L, 3 * DM), float("nan"), device=d) for _ in range(3)]      # never zeroed: the first call (accumulate = 0) assigns
     for l in (2, 1, 0):
         qp = [E._ptr(q) for q in qkv[:l + 1]] + [None] * (2 - l)
         gp = [E._ptr(q) for q in dq[:l + 1]] + [None] * (2 - l)
         E._check(lib.dst_spec_attn_flash_bwd(qp[0], qp[1], qp[2], C.c_int32(l + 1), E._ptr(stats[l]), E._ptr(outs[l]), E._ptr(dao[l]), gp[0], gp[1], gp[2],
-                                             C.c_int32(B), C.c_int32(L), C.c_int32(H), C.c_int32(DK), C.c_float(scale), C.c_int32(0), E._stream()), "dst_spec_attn_flash_bwd")
+                                             C.c_int32(B), C.c_int32(L), C.c_int32(H), C.c_int32(DK), C.c_float(scale), C.c_int32(0), C.c_int32(0 if l == 2 else 1), E._stream()), "dst_spec_attn_flash_bwd")
     torch.cuda.synchronize()
     qr = [q.double().cpu().clone().requires_grad_(True) for q in qkv]
     loss, s_prev, ref_out = 0.0, 0.0, []

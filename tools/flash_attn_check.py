@@ -40,7 +40,7 @@ dq = [torch.zeros(B * L, 3 * DM, device=d) for _ in range(3)]
 for l in (2, 1, 0):
     qp = [E._ptr(q) for q in qkv[:l + 1]] + [None] * (2 - l)
     gp = [E._ptr(q) for q in dq[:l + 1]] + [None] * (2 - l)
-    E._check(lib.dst_spec_attn_flash_bwd(qp[0], qp[1], qp[2], C.c_int32(l + 1), E._ptr(st2[l]), E._ptr(ao2[l]), E._ptr(dao[l]), gp[0], gp[1], gp[2], C.c_int32(B), C.c_int32(L), C.c_int32(H), C.c_int32(DK), C.c_float(scale), C.c_int32(0), s()), "fbwd")
+    E._check(lib.dst_spec_attn_flash_bwd(qp[0], qp[1], qp[2], C.c_int32(l + 1), E._ptr(st2[l]), E._ptr(ao2[l]), E._ptr(dao[l]), gp[0], gp[1], gp[2], C.c_int32(B), C.c_int32(L), C.c_int32(H), C.c_int32(DK), C.c_float(scale), C.c_int32(0), C.c_int32(0 if l == 2 else 1), s()), "fbwd")
 torch.cuda.synchronize()
 rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
 for l in range(3):

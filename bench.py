@@ -475,6 +475,7 @@ def train_measure(args, world, rank, device, steps, warmup, with_cpu_baseline):
     t0 = time.perf_counter()
     for k in range(steps):
         loss = step_fn(state, batch)
+    host_issue = time.perf_counter() - t0            # the host's share: every launch of the K steps enqueued (no device wait inside a step)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -520,7 +521,8 @@ def train_measure(args, world, rank, device, steps, warmup, with_cpu_baseline):
                 "data": "synthetic",
                 "config": {"workload": f"DMT training step, QM9S {args.spectra}, {Bt} molecules per GPU and step (global batch {world * Bt}), dropout "
                                        f"{cfg.model.dropout}, AdamW-amsgrad + adaptive clip + EMA fused, gradient reduce-scatter + parameter all-gather; self-conditioning coin from random.seed(1234)",
-                           "mode": "train", "molecules_per_gpu": Bt, "parallelism": f"dp{world}", "last_loss": float(loss.detach())},
+                           "mode": "train", "molecules_per_gpu": Bt, "parallelism": f"dp{world}", "last_loss": float(loss.detach()),
+                           "host_issue_ms_per_step": host_issue / steps * 1e3},
                 "whole_path": {"algorithmic_tflops_per_gpu": flop * steps / elapsed / 1e12}}
         gemm_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
         gemm_flop = sum(r[2] for r in recs)

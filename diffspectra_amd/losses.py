@@ -475,7 +475,15 @@ class HipTrainer:
         return target
 
     def layout(self, atom_mask) -> TrainLayout:
+        # The packed layout is a function of the mask's CONTENT: reading it is a device -> host copy, i.e. the host waits for everything the
+        # stream still holds (the previous step's tail) - the one synchronisation of a step.  A mask tensor that was seen before (same
+        # storage, same version counter: an epoch over pre-uploaded batches, bench.py) is recognised without reading it.
+        ident = (atom_mask.data_ptr(), atom_mask._version, tuple(atom_mask.shape), atom_mask.dtype)
+        seen = getattr(self, "_layout_ident", None)
+        if seen is not None and seen[0] == ident and seen[1] in self._layouts:
+            return self._layouts[seen[1]]
         key = (atom_mask != 0).to("cpu").numpy().tobytes() + bytes(atom_mask.shape[1])
+        self._layout_ident = (ident, key)
         if key not in self._layouts:
             if len(self._layouts) >= 8:
                 self._layouts.pop(next(iter(self._layouts)))
@@ -484,9 +492,13 @@ class HipTrainer:
 
     def graphs(self):
         from .spec_train import SpecTrainGraph
-        named = dict(self.module.named_parameters())
+        # (the module tree is walked once: named_parameters() / named_buffers() of ~400 modules cost 2 ms of host time per step)
+        reg = getattr(self, "_registry", None)
+        if reg is None or reg[0] != (id(self.module), len(self.module._modules)):          # (set tr._registry = None after surgery on the module tree)
+            reg = ((id(self.module), len(self.module._modules)), dict(self.module.named_parameters()), {k: v for k, v in self.module.named_buffers()})
+            self._registry = reg
+        named, bufs = reg[1], reg[2]
         pd = {k: v.data for k, v in named.items()}
-        bufs = {k: v for k, v in self.module.named_buffers()}
         dmt = DmtTrainGraph.__new__(DmtTrainGraph)
         dmt.p, dmt.cfg, dmt.dev, dmt.ops, dmt.lib = pd, self.cfg, self.dev, self.ops, self.lib
         dmt.edge_th, dmt.cutoff = float(self.cfg.model.edge_quan_th), float(self.cfg.model.spatial_cut_off)
@@ -535,7 +547,8 @@ def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None
             tr.ops.end()
 
     def _loss_fn(model, batch, tr):
-        model.train() if train else model.eval()
+        if model.training != bool(train):                              # (Module.train() walks every sub-module: 1.6 ms per call)
+            model.train() if train else model.eval()
         dev, lib = tr.dev, tr.lib
         named, dmt, spec = tr.graphs()
         tr.ops.bf16 = precision == "bf16"          # config 5: bf16 products with fp32 accumulation, fp32 master weights

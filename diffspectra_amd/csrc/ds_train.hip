@@ -131,6 +131,20 @@ __global__ __launch_bounds__(256) void k_copy_pieces(const dst_piece* __restrict
   }
 }
 
+// the same pieces rounded to bf16 (round to nearest even, as the GEMM kernels round their operands): dst is a bf16 buffer, dst_ld in
+// bf16 elements.  The fused row chains (ds_train_chain.hip) stream their weights from L2 once per 32-row tile: as bf16 that stream is half
+// as wide and needs no conversion in the kernel.
+__global__ __launch_bounds__(256) void k_pack_bf16_pieces(const dst_piece* __restrict__ table) {
+  const dst_piece pc = table[blockIdx.x];
+  const unsigned int rows = (unsigned int)pc.rows, cols = (unsigned int)pc.cols, total = rows * cols;
+  unsigned short* dst = reinterpret_cast<unsigned short*>(pc.dst);
+  for (unsigned int i = blockIdx.y * 256u + threadIdx.x; i < total; i += gridDim.y * 256u) {
+    const unsigned int r = i / cols, c = i - r * cols;
+    const __bf16 h = (__bf16)pc.src[(int64_t)r * pc.src_ld + c];
+    dst[(int64_t)r * pc.dst_ld + c] = __builtin_bit_cast(unsigned short, h);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ dropout
 // nn.Dropout(p) in training mode (dmt.py:114-120): y = x * keep / (1 - p) with keep ~ Bernoulli(1 - p) from a counter-based Philox4x32-10
 // stream keyed on (seed, stream id): the mask of element i is a pure function of (seed, stream, i), so the backward pass re-creates it
@@ -1462,6 +1476,13 @@ int dst_copy_pieces(const dst_piece* table, int32_t n, void* stream) {
   if (n < 0 || (n > 0 && !table)) return DS_ERR_ARG;
   if (n == 0) return DS_OK;
   hipLaunchKernelGGL(k_copy_pieces, dim3(n, 128), dim3(256), 0, (hipStream_t)stream, table);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_pack_bf16_pieces(const dst_piece* table, int32_t n, void* stream) {
+  if (n < 0 || (n > 0 && !table)) return DS_ERR_ARG;
+  if (n == 0) return DS_OK;
+  hipLaunchKernelGGL(k_pack_bf16_pieces, dim3(n, 16), dim3(256), 0, (hipStream_t)stream, table);
   return DST_CHECK_LAUNCH();
 }
 

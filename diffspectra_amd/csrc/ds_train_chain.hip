@@ -76,43 +76,46 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // acc += A[32 x 16 KB] W^T for output columns col0 .. col0 + 31: A = bf16 rows in LDS (row stride lda halves, first column a0), W = torch
-// Linear weight [out, in] in fp32 with row stride ldw (first input column w0), rounded to bf16 here; output columns >= n_out are zero.
-// The weight fragments are FETCHED (wfetch) and APPLIED (mma_apply) separately: a wave is alone on its SIMD here, so the chunk loops request
-// the next chunk's fragments before the current chunk's epilogue - otherwise every chunk pays one L2 round trip in front of its MFMAs.
+// Linear weight [out, in] as bf16 bits with row stride ldw (first input column w0; dst_pack_bf16_pieces rounded it from the fp32 master
+// weights, nearest even - what the GEMM kernels do while staging); output columns >= n_out are zero.
+// A tile's weights come from L2 - 256 kB of fp32 for the 256 x 256 coord_mlp.0 per 32-row tile was the bound of these kernels: with the
+// loads halved (an experiment that read half of every fragment) the directed chain went from 112 to 64 us.  As bf16 a fragment is ONE
+// 16-byte load per k-block and goes into the MFMA as it is.
+// The weight fragments are FETCHED (wfetch) and APPLIED (mma_apply) separately: the chunk loops request the next chunk's fragments before
+// the current chunk's epilogue - otherwise every chunk pays one L2 round trip in front of its MFMAs.
 template <int KB>
 struct WFrag {
-  f4_t a[KB], b[KB];
+  bf16x8_t w[KB];
   bool ok;
 };
 template <int KB>
-__device__ __forceinline__ void wfetch(WFrag<KB>& f, const float* __restrict__ W, int64_t ldw, int w0, int col0, int n_out) {
+__device__ __forceinline__ void wfetch(WFrag<KB>& f, const uint16_t* __restrict__ W, int64_t ldw, int w0, int col0, int n_out) {
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const int col = col0 + r;
-  const float* wrow = W + (int64_t)min(col, n_out - 1) * ldw + w0 + 8 * hh;
+  const uint16_t* wrow = W + (int64_t)min(col, n_out - 1) * ldw + w0 + 8 * hh;
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) { f.a[kb] = ld4(wrow + 16 * kb); f.b[kb] = ld4(wrow + 16 * kb + 4); }
+  for (int kb = 0; kb < KB; ++kb) f.w[kb] = *reinterpret_cast<const bf16x8_t*>(wrow + 16 * kb);
   f.ok = col < n_out;
 }
 // MASKED: the product has fewer than 32 output columns in this chunk (the 16-column read-out slice, the 3-column coord_mlp.2): columns
-// beyond n_out multiply by zero.  Full chunks skip the selects (sixteen per k-block otherwise - more VALU work than the conversion itself).
+// beyond n_out multiply by zero.
 template <int KB, bool MASKED = false>
 __device__ __forceinline__ void mma_apply(const __bf16* A, int lda, int a0, const WFrag<KB>& f, f32x16_t& acc) {
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const __bf16* arow = A + r * lda + a0 + 8 * hh;
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
-    bf16x8_t b;
+    bf16x8_t b = f.w[kb];
+    if (MASKED && !f.ok) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      b[j] = (__bf16)(!MASKED || f.ok ? f.a[kb][j] : 0.0f);
-      b[4 + j] = (__bf16)(!MASKED || f.ok ? f.b[kb][j] : 0.0f);
+      for (int j = 0; j < 8; ++j) b[j] = (__bf16)0.0f;
     }
     const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(arow + 16 * kb);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
   }
 }
 template <int KB>
-__device__ __forceinline__ void mma_rows(const __bf16* A, int lda, int a0, const float* __restrict__ W, int64_t ldw, int w0, int col0, int n_out,
+__device__ __forceinline__ void mma_rows(const __bf16* A, int lda, int a0, const uint16_t* __restrict__ W, int64_t ldw, int w0, int col0, int n_out,
                                          f32x16_t& acc) {
   WFrag<KB> f;
   wfetch<KB>(f, W, ldw, w0, col0, n_out);
@@ -598,7 +601,7 @@ int dst_pair_chain_fwd(const dst_layout* L, const dst_pair_chain_args* a, void* 
   if (!L || !a || !a->pair_a || !a->pair_b || !a->pair_mol || !a->u || !a->n2e_bias || !a->e_in || !a->feat || !a->ada || !a->W3 || !a->b3 || !a->W4 || !a->b4 || !a->Wed || !a->bed || !a->Wro ||
       !a->bro || !a->e_out || !a->ed || !a->ro)
     return DS_ERR_ARG;
-  if (L->B <= 0 || (a->ld_feat & 3) || (a->ld_wed & 3) || (a->ada_ld & 3) || ((a->gate1_off | a->shift_off | a->scale_off | a->gate2_off) & 3) ||
+  if (L->B <= 0 || (a->ld_feat & 3) || (a->ld_wed & 7) || (a->ada_ld & 3) || ((a->gate1_off | a->shift_off | a->scale_off | a->gate2_off) & 3) ||
       !(a->drop_p >= 0.0f && a->drop_p < 1.0f))
     return DS_ERR_ARG;
   const void* ptrs[] = {a->u, a->n2e_bias, a->e_in, a->feat, a->ada, a->W3, a->W4, a->Wed, a->Wro, a->he, a->xe1, a->ye1, a->f3, a->s3, a->f4, a->e_out, a->X2, a->ed, a->ro};

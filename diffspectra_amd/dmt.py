@@ -134,8 +134,8 @@ class DMT(nn.Module):
             raise TypeError("DMT.forward needs `context` (spectra)")
         tr = _trainer(self)
         dev = tr.dev
+        tr.ops.bf16 = getattr(self.config.training, "precision", "fp32") == "bf16"      # (before graphs(): the per-step weight copies depend on it)
         named, dmt, spec = tr.graphs()
-        tr.ops.bf16 = getattr(self.config.training, "precision", "fp32") == "bf16"
         f32 = lambda v: v.detach().to(dev, torch.float32)
         TL = tr.layout(f32(node_mask).reshape(node_mask.shape[0], -1))
         TL.L.check_edge_mask(edge_mask)

@@ -550,8 +550,8 @@ def get_sde_graph_loss_fn(noise_scheduler, train, scaler, config, prop_norm=None
         if model.training != bool(train):                              # (Module.train() walks every sub-module: 1.6 ms per call)
             model.train() if train else model.eval()
         dev, lib = tr.dev, tr.lib
-        named, dmt, spec = tr.graphs()
-        tr.ops.bf16 = precision == "bf16"          # config 5: bf16 products with fp32 accumulation, fp32 master weights
+        tr.ops.bf16 = precision == "bf16"          # config 5: bf16 products with fp32 accumulation, fp32 master weights (set BEFORE graphs(): the
+        named, dmt, spec = tr.graphs()             # per-step weight copies depend on the mode)
         atom_mask = batch["atom_mask"].to(dev)
         TL = tr.layout(atom_mask)
         B, N = TL.B, TL.N

@@ -64,6 +64,23 @@ def copy_pieces(lib, dev, dst: List[torch.Tensor], src: List[torch.Tensor], cach
     E._check(lib.dst_copy_pieces(C.c_void_p(ent[1].data_ptr()), C.c_int32(ent[2]), stream if stream is not None else E._stream()), "dst_copy_pieces")
 
 
+def pack_bf16_pieces(lib, dev, dst: List[torch.Tensor], src: List[torch.Tensor], cache: dict, key: str, stream=None):
+    """``dst[i].copy_(src[i])`` with ``dst`` in bfloat16 (round to nearest even) for many small 2-D pieces in ONE ``dst_pack_bf16_pieces`` launch:
+    the weights of the fused row chains, once per step.  The device table is rebuilt only when a pointer changed."""
+    sig = tuple(t.data_ptr() for t in dst) + tuple(t.data_ptr() for t in src)
+    ent = cache.get(key)
+    if ent is None or ent[0] != sig:
+        arr = (DstPiece * len(dst))()
+        for i, (d, s_) in enumerate(zip(dst, src)):
+            assert d.shape == s_.shape and d.dtype == torch.bfloat16 and s_.dtype == torch.float32 and d.dim() == 2
+            assert d.stride(1) == 1 and s_.stride(1) == 1 and d.numel() < 2 ** 31
+            arr[i] = DstPiece(src=s_.data_ptr(), dst=d.data_ptr(), rows=d.shape[0], cols=d.shape[1], src_ld=s_.stride(0), dst_ld=d.stride(0))
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        ent = (sig, raw, len(dst))
+        cache[key] = ent
+    E._check(lib.dst_pack_bf16_pieces(C.c_void_p(ent[1].data_ptr()), C.c_int32(ent[2]), stream if stream is not None else E._stream()), "dst_pack_bf16_pieces")
+
+
 # dst_gemm_args as one struct.pack (a ctypes Structure built field by field costs ~10 us per product, ~600 products per step)
 import struct as _struct
 _GEMM_STRUCT = _struct.Struct("@PqqPqqPqPiiiiPqiiPiiPqPqfIQq")
@@ -300,6 +317,7 @@ class Ops:
         """The pair rows of a block behind the attention as one kernel (``dst_pair_chain_fwd``, bf16 products).  ``drop = (p, seed, stream3,
         stream4)``; ``out``: dict with e_out, ed, ro and - when the tape is kept - he, xe1, st, ye1, f3, s3, f4, X2."""
         ptr = lambda t: 0 if t is None else t.data_ptr()
+        assert all(w_.dtype == torch.bfloat16 for w_ in (W3, W4, Wed, Wro))          # (dst_pack_bf16_pieces / .to(torch.bfloat16): nearest even)
         args = _CHAIN_PACK(*TL.pair_tables, ptr(u), ptr(n2e_bias), ptr(e_in), ptr(feat), ld_feat, ptr(ada), ADA, g1, sh, sc, g2, ptr(W3), ptr(b3), ptr(W4), ptr(b4),
                            ptr(Wed), ld_wed, ptr(bed), ptr(Wro), ptr(bro), float(drop[0]), int(drop[2]), int(drop[3]), 0, int(drop[1]),
                            *(ptr(out.get(k)) for k in ("he", "xe1", "st", "ye1", "f3", "s3", "f4", "e_out", "X2", "ed", "ro")))
@@ -309,6 +327,7 @@ class Ops:
         """The directed rows of a block as one kernel (``dst_dir_chain_fwd``, bf16 products).  ``out``: dict with c2 and - when the tape is kept -
         zz, st, zn, c0, sc0."""
         ptr = lambda t: 0 if t is None else t.data_ptr()
+        assert W0.dtype == torch.bfloat16 and W2.dtype == torch.bfloat16
         args = _DIR_PACK(*TL.pair_tables, ptr(ac), ptr(ed), ptr(ada), ADA, sh, sc, ptr(W0), ptr(b0), ptr(W2), *(ptr(out.get(k)) for k in ("zz", "st", "zn", "c0", "sc0", "c2")))
         E._check(self.lib.dst_dir_chain_fwd(C.byref(TL.c), args, self._s()), "dst_dir_chain_fwd")
 
@@ -316,6 +335,7 @@ class Ops:
         """The pair rows of a block in front of the attention as one kernel (``dst_pair_front_fwd``, bf16 products).  ``out``: dict with X1, te and -
         when the tape is kept - xs, d2, e1, st, en."""
         ptr = lambda t: 0 if t is None else t.data_ptr()
+        assert Wee.dtype == torch.bfloat16 and Wte.dtype == torch.bfloat16
         args = _FRONT_PACK(*TL.pair_tables, ptr(pos), ptr(ada), ADA, dist_off, sh, sc, 0, ptr(means), ptr(stds), ptr(e_in), ptr(Wee), ptr(bee), ptr(Wte),
                            *(ptr(out.get(k)) for k in ("X1", "xs", "d2", "e1", "st", "en", "te")))
         E._check(self.lib.dst_pair_front_fwd(C.byref(TL.c), args, self._s()), "dst_pair_front_fwd")
@@ -464,6 +484,22 @@ class DmtTrainGraph:
         dst, src = self._piece_views(cache["bufs"], self.p)
         copy_pieces(self.lib, self.dev, dst, src, cache, "table_fwd", self.ops._s())
         self.cat, self.dcat, self._cat_cache = cache["bufs"], cache["grads"], cache
+        if self.ops.bf16:
+            # the fused row chains take their weights as bf16 (csrc/ds_train_chain.hip: the per-tile weight stream from L2 bounds them)
+            if "wb" not in cache:
+                shapes = dict(W3=(128, 64), W4=(64, 128), Wed=(256, 128), Wro=(16, 64), Wee=(64, 128), Wte=(512, 64), W0=(256, 256), W2=(3, 256))
+                cache["wb"] = {n: torch.zeros(NB, *sh, dtype=torch.bfloat16, device=self.dev) for n, sh in shapes.items()}
+            wb, p = cache["wb"], self.p
+            dst, src = [], []
+            for i in range(NB):
+                bp = f"e_block_{i}."
+                for n, t in (("W3", p[bp + "ff_linear3.weight"]), ("W4", p[bp + "ff_linear4.weight"]), ("Wed", p[bp + "equi_update.input_lin.weight"][:, 512:640]),
+                             ("Wro", p[f"edge_{i}.weight"]), ("Wee", p[bp + "edge_emb.weight"]), ("Wte", cache["bufs"]["Wte"][i]),
+                             ("W0", p[bp + "equi_update.coord_mlp.0.weight"]), ("W2", p[bp + "equi_update.coord_mlp.2.weight"])):
+                    dst.append(wb[n][i])
+                    src.append(t)
+            pack_bf16_pieces(self.lib, self.dev, dst, src, cache, "table_bf16", self.ops._s())
+            self.wb = wb
         return cache
 
     def scatter_cat_grads(self, gw):
@@ -561,7 +597,7 @@ class DmtTrainGraph:
                 if save:
                     outs.update(xs=self.f(Pp), d2=self.f(Pp), e1=self.f(Pp, 64), st=self.f(Pp, 2), en=self.f(Pp, 64))
                 o.pair_front_fwd(TL, pos, ada, a0 + DIST_OFF, a0 + EDGE_OFF + 0, a0 + EDGE_OFF + 64, p[bp + "dist_layer.means.weight"],
-                                 p[bp + "dist_layer.stds.weight"], e, p[bp + "edge_emb.weight"], p[bp + "edge_emb.bias"], cat["Wte"][i], outs)
+                                 p[bp + "dist_layer.stds.weight"], e, self.wb["Wee"][i], p[bp + "edge_emb.bias"], self.wb["Wte"][i], outs)
                 xs, d2, e1, st_e1, en = (outs.get(k) for k in ("xs", "d2", "e1", "st", "en"))
             else:
                 X1, xs, d2 = self.f(Pp, 128), self.f(Pp), self.f(Pp)
@@ -612,8 +648,8 @@ class DmtTrainGraph:
                     outs.update(he=self.f(Pp, 64), xe1=self.f(Pp, 64), st=self.f(Pp, 2), ye1=self.f(Pp, 64), f3=self.f(Pp, 128), s3=self.f(Pp, 128),
                                 f4=self.f(Pp, 64), X2=self.f(Pp, 128))
                 o.pair_chain_fwd(TL, u, p[bp + "node2edge_lin.bias"], e, X1, 128, ada, a0 + EDGE_OFF + 128, a0 + EDGE_OFF + 192, a0 + EDGE_OFF + 256,
-                                 a0 + EDGE_OFF + 320, p[bp + "ff_linear3.weight"], p[bp + "ff_linear3.bias"], p[bp + "ff_linear4.weight"],
-                                 p[bp + "ff_linear4.bias"], Win[:, 512:640], 640, p[bp + "equi_update.input_lin.bias"], p[f"edge_{i}.weight"],
+                                 a0 + EDGE_OFF + 320, self.wb["W3"][i], p[bp + "ff_linear3.bias"], self.wb["W4"][i],
+                                 p[bp + "ff_linear4.bias"], self.wb["Wed"][i], 128, p[bp + "equi_update.input_lin.bias"], self.wb["Wro"][i],
                                  p[f"edge_{i}.bias"], (dp, dseed, 4 * i + 2, 4 * i + 3), outs)
                 he, xe1, st_e2, ye1, f3, s3, f4, X2 = (outs.get(k) for k in ("he", "xe1", "st", "ye1", "f3", "s3", "f4", "X2"))
             else:
@@ -642,8 +678,8 @@ class DmtTrainGraph:
                 outs = dict(c2=c2)
                 if save:
                     outs.update(zz=self.f(D, 256), st=self.f(D, 2), zn=self.f(D, 256), c0=self.f(D, 256), sc0=self.f(D, 256))
-                o.dir_chain_fwd(TL, ac, ed, ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256, p[bp + "equi_update.coord_mlp.0.weight"],
-                                p[bp + "equi_update.coord_mlp.0.bias"], p[bp + "equi_update.coord_mlp.2.weight"], outs)
+                o.dir_chain_fwd(TL, ac, ed, ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256, self.wb["W0"][i],
+                                p[bp + "equi_update.coord_mlp.0.bias"], self.wb["W2"][i], outs)
                 zz, st_z, zn, c0, sc0 = (outs.get(k) for k in ("zz", "st", "zn", "c0", "sc0"))
             else:
                 zz, zn, st_z = self.f(max(D, 1), 256), self.f(max(D, 1), 256), self.f(max(D, 1), 2)

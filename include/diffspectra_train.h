@@ -77,6 +77,9 @@ typedef struct dst_piece {
   int64_t src_ld, dst_ld;
 } dst_piece;
 int dst_copy_pieces(const dst_piece* table, int32_t n, void* stream);
+/* The same pieces ROUNDED TO bf16 (nearest even): `dst` of every piece addresses a bf16 buffer (uint16_t bits), dst_ld in bf16 elements.
+ * The weights of the fused row chains below are passed in this form. */
+int dst_pack_bf16_pieces(const dst_piece* table, int32_t n, void* stream);
 
 /* out[c] (+)= sum_r X[r*ld + c], two fixed-order stages through `scratch` (bias gradients, per-molecule partial sums). */
 int dst_colsum(const float* X, int64_t ld, int32_t R, int32_t C, float* out, int32_t accumulate, float* scratch,
@@ -266,7 +269,9 @@ int dst_sumsq(const float* x, int64_t n, float* out, int32_t accumulate, float* 
  *   f3 = ye1 W3^T + b3;  s3 = dropout(SiLU(f3));  f4 = dropout(s3 W4^T + b4);  e_out = ye1 + ada[gate2] * f4;
  *   ed = [e_out | feat] Wed^T + bed;  ro = e_out Wro^T + bro.
  * u [Nn,64]; e_in [Pp,64]; feat [Pp,64] with row stride ld_feat; ada [B, ada_ld] with the four column offsets; W3 [128,64], W4 [64,128],
- * Wed [256 rows, row stride ld_wed, 128 used columns: e | dist], Wro [16,64] (torch Linear layout, fp32).  Dropout: dst_dropout's masks
+ * Wed [256 rows, row stride ld_wed, 128 used columns: e | dist], Wro [16,64] (torch Linear layout) as bf16 BITS (dst_pack_bf16_pieces;
+ * ld_wed in bf16 elements, a multiple of 8): the kernel streams the weights from L2 once per 32-row tile, and that stream bounds it
+ * (profiles/r05_train_fused_ab.txt).  Biases fp32.  Dropout: dst_dropout's masks
  * (element (row, col) of the [Pp,128] / [Pp,64] tensor under stream3 / stream4).  Outputs: e_out [Pp,64], ed [Pp,256], ro [Pp,16]
  * always; the tape tensors he, xe1, st [Pp,2] = (mean, rstd), ye1, f3 [Pp,128], s3 [Pp,128], f4, X2 [Pp,128] = [e_out | feat] may each
  * be NULL (not written).  Every pointer 16-byte aligned. */
@@ -274,8 +279,8 @@ typedef struct dst_pair_chain_args {
   const int32_t* pair_a; const int32_t* pair_b; const int32_t* pair_mol;   /* [Pp]: node rows of a pair's atoms, its molecule */
   const float* u; const float* n2e_bias; const float* e_in; const float* feat; int64_t ld_feat;
   const float* ada; int64_t ada_ld; int32_t gate1_off, shift_off, scale_off, gate2_off;
-  const float* W3; const float* b3; const float* W4; const float* b4; const float* Wed; int64_t ld_wed; const float* bed;
-  const float* Wro; const float* bro;
+  const uint16_t* W3; const float* b3; const uint16_t* W4; const float* b4; const uint16_t* Wed; int64_t ld_wed; const float* bed;
+  const uint16_t* Wro; const float* bro;
   float drop_p; uint32_t stream3, stream4, _pad; uint64_t seed;
   float* he; float* xe1; float* st; float* ye1; float* f3; float* s3; float* f4; float* e_out; float* X2; float* ed; float* ro;
 } dst_pair_chain_args;
@@ -285,12 +290,13 @@ int dst_pair_chain_fwd(const dst_layout* L, const dst_pair_chain_args* a, void* 
  * 165-166,183); replaces dst_geom_fwd, the [feat | e] copy, dst_lnmod_fwd and two dst_gemm calls:
  *   X1 = [CondGaussian features of the modulated squared distance (64) | e_in (64)];  e1 = X1 Wee^T + bee;
  *   en = LN(e1) * (1 + ada[scale]) + ada[shift];  te = tanh(en Wte^T)   (Wte [512,64] = lin_edge0 | lin_edge1, rows 252..255 zero).
- * pos [Nn,3]; means, stds [63]; ada column dist_off holds the distance scale, dist_off + 1 its shift.  Outputs: X1 [Pp,128] and te [Pp,512]
+ * pos [Nn,3]; means, stds [63]; ada column dist_off holds the distance scale, dist_off + 1 its shift; Wee [64,128] and Wte as bf16 bits.
+ * Outputs: X1 [Pp,128] and te [Pp,512]
  * always; xs [Pp] (x'), d2 [Pp], e1 [Pp,64], st [Pp,2] = (mean, rstd), en [Pp,64] may be NULL. */
 typedef struct dst_pair_front_args {
   const int32_t* pair_a; const int32_t* pair_b; const int32_t* pair_mol;
   const float* pos; const float* ada; int64_t ada_ld; int32_t dist_off, shift_off, scale_off, _pad;
-  const float* means; const float* stds; const float* e_in; const float* Wee; const float* bee; const float* Wte;
+  const float* means; const float* stds; const float* e_in; const uint16_t* Wee; const float* bee; const uint16_t* Wte;
   float* X1; float* xs; float* d2; float* e1; float* st; float* en; float* te;
 } dst_pair_front_args;
 int dst_pair_front_fwd(const dst_layout* L, const dst_pair_front_args* a, void* stream);
@@ -299,12 +305,12 @@ int dst_pair_front_fwd(const dst_layout* L, const dst_pair_front_args* a, void* 
  * dst_lnmod_fwd (256 wide, two rows per pair) and two dst_gemm calls:
  *   zz[2p + dir] = ac[row, 0:256] + ac[col, 256:512] + ed[p];  zn = LN(zz) (1 + ada[scale]) + ada[shift];
  *   c0 = zn W0^T + b0;  sc0 = SiLU(c0);  c2 = sc0 W2^T.
- * ac [Nn,512], ed [Pp,256], W0 [256,256], W2 [3,256] (torch Linear layout).  Outputs: c2 [2 Pp, 3] always; zz, st [2 Pp, 2], zn, c0, sc0
+ * ac [Nn,512], ed [Pp,256], W0 [256,256], W2 [3,256] (torch Linear layout, bf16 bits).  Outputs: c2 [2 Pp, 3] always; zz, st [2 Pp, 2], zn, c0, sc0
  * [2 Pp, 256] may each be NULL. */
 typedef struct dst_dir_chain_args {
   const int32_t* pair_a; const int32_t* pair_b; const int32_t* pair_mol;
   const float* ac; const float* ed; const float* ada; int64_t ada_ld; int32_t shift_off, scale_off;
-  const float* W0; const float* b0; const float* W2;
+  const uint16_t* W0; const float* b0; const uint16_t* W2;
   float* zz; float* st; float* zn; float* c0; float* sc0; float* c2;
 } dst_dir_chain_args;
 int dst_dir_chain_fwd(const dst_layout* L, const dst_dir_chain_args* a, void* stream);

@@ -26,6 +26,8 @@ def main():
     means, stds, Wee, bee, Wte = r(63), r(63).abs() + 0.5, r(64, 128), r(64), r(512, 64)
     W0, b0, W2 = r(256, 256), r(256), r(3, 256)
     f = lambda *s: torch.empty(*s, device=d)
+    hb = lambda t: t.contiguous().to(torch.bfloat16)                  # the chains take their weights as bf16 (dst_pack_bf16_pieces in the product)
+    W3, W4, Wedb, Wro, Wee, Wte, W0, W2 = hb(W3), hb(W4), hb(Win[:, 512:640]), hb(Wro), hb(Wee), hb(Wte), hb(W0), hb(W2)
 
     def run(name, fn, reps=20):
         for _ in range(3):
@@ -43,7 +45,7 @@ def main():
         if save:
             outs.update(he=f(Pp, 64), xe1=f(Pp, 64), st=f(Pp, 2), ye1=f(Pp, 64), f3=f(Pp, 128), s3=f(Pp, 128), f4=f(Pp, 64), X2=f(Pp, 128))
         run(f"pair_chain_fwd save={save}", lambda: o.pair_chain_fwd(TL, u, n2eb, e, X1, 128, ada, EDGE_OFF + 128, EDGE_OFF + 192, EDGE_OFF + 256, EDGE_OFF + 320,
-                                                                   W3, b3, W4, b4, Win[:, 512:640], 640, bed, Wro, bro, (0.1, 1234, 2, 3), outs))
+                                                                   W3, b3, W4, b4, Wedb, 128, bed, Wro, bro, (0.1, 1234, 2, 3), outs))
         outs = dict(X1=f(Pp, 128), te=f(Pp, 512))
         if save:
             outs.update(xs=f(Pp), d2=f(Pp), e1=f(Pp, 64), st=f(Pp, 2), en=f(Pp, 64))

@@ -593,6 +593,195 @@ __global__ __launch_bounds__(CH_NT, 3) void k_dir_chain_fwd(dst_layout L, dst_di
   }
 }
 
+// dst_node_chain_fwd: the NODE rows of a block behind the attention (dmt.py:113-116,158-163,387 and the node parts of
+// equi_update.input_lin, dmt.py:39) as one kernel instead of seven launches on the node stream:
+//   x1 = h + node_gate_msa * attn;  y1 = LN(x1) (1 + node_scale_mlp) + node_shift_mlp
+//   f1 = ff_linear1(y1);  s1 = dropout(SiLU(f1));  f2 = dropout(ff_linear2(s1));  h_out = y1 + node_gate_mlp * f2
+//   ac = h_out [W_row | W_col]^T (the two node parts of input_lin, no bias);  rn = node_i(h_out)
+// 4 600 node rows are 145 tiles: the launches this replaces were each shorter than the gap between two dependent launches, and the
+// directed rows of the block (main stream) wait for `ac` at the end of that chain - leaving the FF out of the forward (an experiment)
+// shortened the step by 0.55 ms.  One 512-thread workgroup per 32-row tile, eight waves: a wave owns four rows of the LayerNorm
+// stage and two (ff_linear1, input_lin) or one (ff_linear2) 32-column chunk of every product; weights as bf16 (dst_pack_bf16_pieces).
+constexpr int NC_NW = 8, NC_NT = NC_NW * 64;
+constexpr int LD_YF = 260, LD_S2 = 520;   // fp32 row of 256 + 4; bf16 row of 512 + 8
+struct NodeLds {
+  float yf[32][LD_YF];             // y1, fp32: the residual of the FF
+  float stage[NC_NW][32][LD_ST];
+  __bf16 yb[32][LD_Z];             // y1, then h_out, bf16: A operand of ff_linear1, then of input_lin / the read-out slice
+  __bf16 sb[32][LD_S2];            // s1, bf16: A operand of ff_linear2
+};
+__device__ __forceinline__ float sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(NC_NT) void k_node_chain_fwd(dst_layout L, dst_node_chain_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  NodeLds& w = *reinterpret_cast<NodeLds*>(lds_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float (*stage)[LD_ST] = w.stage[wave];
+  const int Nn = L.Nn;
+  const int t0 = blockIdx.x * 32;
+  const int valid = min(32, Nn - t0);
+  const int64_t g0 = t0;
+  const unsigned int thr = dst::dropout_threshold(a.drop_p);
+  const float keep_scale = a.drop_p > 0.0f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const int er = lane >> 3, ec = (lane & 7) * 4, cl = lane * 4;
+  // ff_linear1's first fragments fly under stage 1
+  WFrag<8> fa, fb;
+  wfetch<8>(fa, a.W1, 256, 0, wave * 32, 512);
+  float bcur = a.b1[wave * 32 + (lane & 31)];
+  // ---- stage 1: gated residual, LayerNorm + modulate; wave w takes rows 4 w .. 4 w + 3 (a row = 64 lanes x float4), loads first
+  {
+    f4_t hv[4], av[4], g1v[4], shv[4], scv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t gr = min(t0 + 4 * wave + q, Nn - 1);
+      const float* adm = a.ada + (int64_t)a.node_mol[gr] * a.ada_ld;
+      hv[q] = ld4(a.h_in + gr * 256 + cl); av[q] = ld4(a.attn + gr * 256 + cl);
+      g1v[q] = ld4(adm + a.gate1_off + cl); shv[q] = ld4(adm + a.shift_off + cl); scv[q] = ld4(adm + a.scale_off + cl);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 4 * wave + q;
+      const int64_t gr = min(t0 + row, Nn - 1);
+      const f4_t x = hv[q] + g1v[q] * av[q];
+      const float mean = sum64((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / 256.0f);
+      const f4_t d = x - mean;
+      const float rstd = 1.0f / sqrtf(sum64((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 256.0f) + 1e-6f);
+      f4_t y = (d * rstd) * (1.0f + scv[q]) + shv[q];
+      if (row < valid) {
+        if (a.x1) st4(a.x1 + gr * 256 + cl, x);
+        if (a.st && lane == 0) { a.st[gr * 2] = mean; a.st[gr * 2 + 1] = rstd; }
+        if (a.y1) st4(a.y1 + gr * 256 + cl, y);
+      } else {
+        y = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+      st4(&w.yf[row][cl], y);
+      *reinterpret_cast<bf16x4_t*>(&w.yb[row][cl]) = to_bf4(y);
+    }
+  }
+  __syncthreads();
+  // ---- ff_linear1 (256 -> 512), SiLU, dropout: chunks wave, wave + 8
+#pragma unroll 1
+  for (int k = 0; k < 2; ++k) {
+    const int ch = wave + 8 * k;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = bcur;
+    wfetch<8>(fb, a.W1, 256, 128, ch * 32, 512);               // the second k-half flies under the first half's MFMAs
+    mma_apply<8>(&w.yb[0][0], LD_Z, 0, fa, acc);
+    mma_apply<8>(&w.yb[0][0], LD_Z, 128, fb, acc);
+    if (k == 0) { wfetch<8>(fa, a.W1, 256, 0, (ch + 8) * 32, 512); bcur = a.b1[(ch + 8) * 32 + (lane & 31)]; }
+    else { wfetch<8>(fa, a.W2, 512, 0, wave * 32, 256); bcur = a.b2[wave * 32 + (lane & 31)]; }      // ff_linear2's first quarter
+    acc_to_stage(acc, stage);
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + er, col = ch * 32 + ec;
+      const int64_t gr = g0 + row;
+      const f4_t v = ld4(&stage[row][ec]);
+      f4_t sv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sv[e] = fast_silu(v[e]);
+      if (a.drop_p > 0.0f) {
+        unsigned int c[4];
+        dst::dropout_block(a.seed, a.stream1, (gr * 512 + col) >> 2, c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sv[e] = c[e] >= thr ? sv[e] * keep_scale : 0.0f;
+      }
+      if (row < valid) {
+        if (a.f1) st4(a.f1 + gr * 512 + col, v);
+        if (a.s1) st4(a.s1 + gr * 512 + col, sv);
+      } else {
+        sv = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+      *reinterpret_cast<bf16x4_t*>(&w.sb[row][col]) = to_bf4(sv);
+    }
+    wave_lds_sync();
+  }
+  // the gate rows of the ff_linear2 epilogue (row it * 8 + er, columns wave * 32 + ec ..): requested before the barrier
+  f4_t g2c[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+    g2c[it] = ld4(a.ada + (int64_t)a.node_mol[min(t0 + it * 8 + er, Nn - 1)] * a.ada_ld + a.gate2_off + wave * 32 + ec);
+  __syncthreads();
+  // ---- ff_linear2 (512 -> 256), dropout, gated residual: chunk `wave`, four k-quarters
+  {
+    const int ch = wave;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = bcur;
+    wfetch<8>(fb, a.W2, 512, 128, ch * 32, 256);
+    mma_apply<8>(&w.sb[0][0], LD_S2, 0, fa, acc);
+    wfetch<8>(fa, a.W2, 512, 256, ch * 32, 256);
+    mma_apply<8>(&w.sb[0][0], LD_S2, 128, fb, acc);
+    wfetch<8>(fb, a.W2, 512, 384, ch * 32, 256);
+    mma_apply<8>(&w.sb[0][0], LD_S2, 256, fa, acc);
+    wfetch<8>(fa, a.Wac, 256, 0, wave * 32, 512);              // input_lin's first fragments
+    mma_apply<8>(&w.sb[0][0], LD_S2, 384, fb, acc);
+    acc_to_stage(acc, stage);
+    wave_lds_sync();
+    f4_t ho[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + er, col = ch * 32 + ec;
+      const int64_t gr = g0 + row;
+      f4_t v = ld4(&stage[row][ec]);
+      if (a.drop_p > 0.0f) {
+        unsigned int c[4];
+        dst::dropout_block(a.seed, a.stream2, (gr * 256 + col) >> 2, c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = c[e] >= thr ? v[e] * keep_scale : 0.0f;
+      }
+      ho[it] = ld4(&w.yf[row][col]) + g2c[it] * v;
+      if (row < valid) {
+        if (a.f2) st4(a.f2 + gr * 256 + col, v);
+        st4(a.h_out + gr * 256 + col, ho[it]);
+      } else {
+        ho[it] = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+    }
+    // h_out takes y1's bf16 tile (its last readers, ff_linear1's MFMAs, finished before the barrier above; a wave writes its own 32 columns)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) *reinterpret_cast<bf16x4_t*>(&w.yb[it * 8 + er][ch * 32 + ec]) = to_bf4(ho[it]);
+  }
+  __syncthreads();
+  // ---- input_lin's node parts (256 -> 512, no bias): chunks wave, wave + 8; the read-out slice (256 -> 64 + bias) on waves 0, 1
+#pragma unroll 1
+  for (int k = 0; k < 3; ++k) {
+    const bool ro = k == 2;
+    if (ro && wave >= 2) break;
+    const int ch = ro ? wave : wave + 8 * k;
+    f32x16_t acc;
+    const float bro = ro ? a.bn[wave * 32 + (lane & 31)] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = bro;
+    const uint16_t* Wk = ro ? a.Wn : a.Wac;
+    const int nk = ro ? 64 : 512;
+    wfetch<8>(fb, Wk, 256, 128, ch * 32, nk);
+    mma_apply<8>(&w.yb[0][0], LD_Z, 0, fa, acc);
+    mma_apply<8>(&w.yb[0][0], LD_Z, 128, fb, acc);
+    if (k == 0) wfetch<8>(fa, a.Wac, 256, 0, (wave + 8) * 32, 512);
+    else if (k == 1 && wave < 2) wfetch<8>(fa, a.Wn, 256, 0, wave * 32, 64);
+    acc_to_stage(acc, stage);
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + er;
+      const int64_t gr = g0 + row;
+      const f4_t v = ld4(&stage[row][ec]);
+      if (row < valid) {
+        if (!ro) st4(a.ac + gr * 512 + ch * 32 + ec, v);
+        else st4(a.rn + gr * 64 + ch * 32 + ec, v);
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -649,6 +838,26 @@ int dst_dir_chain_fwd(const dst_layout* L, const dst_dir_chain_args* a, void* st
     attr_done = true;
   }
   hipLaunchKernelGGL(k_dir_chain_fwd, dim3((2 * L->Pp + 31) / 32), dim3(CH_NT), lds, (hipStream_t)stream, *L, *a, a->pair_a, a->pair_b, a->pair_mol);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_node_chain_fwd(const dst_layout* L, const dst_node_chain_args* a, void* stream) {
+  if (!L || !a || !a->node_mol || !a->h_in || !a->attn || !a->ada || !a->W1 || !a->b1 || !a->W2 || !a->b2 || !a->Wac || !a->Wn || !a->bn || !a->h_out || !a->ac ||
+      !a->rn)
+    return DS_ERR_ARG;
+  if (L->B <= 0 || (a->ada_ld & 3) || ((a->gate1_off | a->shift_off | a->scale_off | a->gate2_off) & 3) || !(a->drop_p >= 0.0f && a->drop_p < 1.0f))
+    return DS_ERR_ARG;
+  const void* ptrs[] = {a->h_in, a->attn, a->ada, a->W1, a->W2, a->Wac, a->Wn, a->x1, a->y1, a->f1, a->s1, a->f2, a->h_out, a->ac, a->rn};
+  for (const void* p : ptrs)
+    if (reinterpret_cast<uintptr_t>(p) & 15) return DS_ERR_ARG;
+  if (L->Nn <= 0) return DS_OK;
+  static bool attr_done = false;
+  const size_t lds = sizeof(NodeLds);
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node_chain_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DS_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_node_chain_fwd, dim3((L->Nn + 31) / 32), dim3(NC_NT), lds, (hipStream_t)stream, *L, *a);
   return DST_CHECK_LAUNCH();
 }
 

@@ -91,6 +91,8 @@ _GEMM_PACK = _GEMM_STRUCT.pack
 _CHAIN_PACK = _struct.Struct("@PPP PPPPq Pq iiii PPPPP q PPP f III Q PPPPPPPPPPP").pack
 # dst_pair_front_args: pos, ada, ada_ld | dist_off, shift_off, scale_off, pad | means stds e_in Wee bee Wte | X1 xs d2 e1 st en te
 _FRONT_PACK = _struct.Struct("@PPP PPq iiii PPPPPP PPPPPPP").pack
+# dst_node_chain_args: node_mol h_in attn | ada, ada_ld | 4 offsets | W1 b1 W2 b2 Wac Wn bn | drop_p, stream1, stream2, pad | seed | 9 outputs
+_NODE_PACK = _struct.Struct("@PPP Pq iiii PPPPPPP f III Q PPPPPPPPP").pack
 # dst_dir_chain_args: ac, ed, ada, ada_ld | shift_off, scale_off | W0 b0 W2 | zz st zn c0 sc0 c2
 _DIR_PACK = _struct.Struct("@PPP PPPq ii PPP PPPPPP").pack
 
@@ -323,6 +325,16 @@ class Ops:
                            *(ptr(out.get(k)) for k in ("he", "xe1", "st", "ye1", "f3", "s3", "f4", "e_out", "X2", "ed", "ro")))
         E._check(self.lib.dst_pair_chain_fwd(C.byref(TL.c), args, self._s()), "dst_pair_chain_fwd")
 
+    def node_chain_fwd(self, TL, h_in, attn, ada, g1, sh, sc, g2, W1, b1, W2, b2, Wac, Wn, bn, drop, out):
+        """The node rows of a block behind the attention as one kernel (``dst_node_chain_fwd``, bf16 products).  ``drop = (p, seed, stream1,
+        stream2)``; ``out``: dict with h_out, ac, rn and - when the tape is kept - x1, st, y1, f1, s1, f2."""
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        assert all(w_.dtype == torch.bfloat16 for w_ in (W1, W2, Wac, Wn))
+        args = _NODE_PACK(TL.node_mol_ptr, ptr(h_in), ptr(attn), ptr(ada), ADA, g1, sh, sc, g2, ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(Wac), ptr(Wn), ptr(bn),
+                          float(drop[0]), int(drop[2]), int(drop[3]), 0, int(drop[1]),
+                          *(ptr(out.get(k)) for k in ("x1", "st", "y1", "f1", "s1", "f2", "h_out", "ac", "rn")))
+        E._check(self.lib.dst_node_chain_fwd(C.byref(TL.c), args, self._s()), "dst_node_chain_fwd")
+
     def dir_chain_fwd(self, TL, ac, ed, ada, sh, sc, W0, b0, W2, out):
         """The directed rows of a block as one kernel (``dst_dir_chain_fwd``, bf16 products).  ``out``: dict with c2 and - when the tape is kept -
         zz, st, zn, c0, sc0."""
@@ -386,6 +398,7 @@ class TrainLayout:
         self.node_off, self.pair_off = L.t["node_off"], L.t["pair_off"]
         # device tables of the flat-tile kernels (dst_pair_*_fwd, dst_dir_chain_fwd): node rows of a pair's atoms, its molecule
         self.pair_tables = (L.t["pair_a"].data_ptr(), L.t["pair_b"].data_ptr(), L.t["pair_mol"].data_ptr())
+        self.node_mol_ptr = L.t["node_mol"].data_ptr()                     # [Nn] int32: molecule of a node row (dst_node_chain_fwd)
 
     def pack_nodes(self, dense: torch.Tensor) -> torch.Tensor:
         return dense.reshape(self.B * self.N, -1).index_select(0, self.node_dense).contiguous()
@@ -487,7 +500,8 @@ class DmtTrainGraph:
         if self.ops.bf16:
             # the fused row chains take their weights as bf16 (csrc/ds_train_chain.hip: the per-tile weight stream from L2 bounds them)
             if "wb" not in cache:
-                shapes = dict(W3=(128, 64), W4=(64, 128), Wed=(256, 128), Wro=(16, 64), Wee=(64, 128), Wte=(512, 64), W0=(256, 256), W2=(3, 256))
+                shapes = dict(W3=(128, 64), W4=(64, 128), Wed=(256, 128), Wro=(16, 64), Wee=(64, 128), Wte=(512, 64), W0=(256, 256), W2=(3, 256),
+                              F1=(512, 256), F2=(256, 512), Wac=(512, 256), Wn=(64, 256))
                 cache["wb"] = {n: torch.zeros(NB, *sh, dtype=torch.bfloat16, device=self.dev) for n, sh in shapes.items()}
             wb, p = cache["wb"], self.p
             dst, src = [], []
@@ -495,7 +509,9 @@ class DmtTrainGraph:
                 bp = f"e_block_{i}."
                 for n, t in (("W3", p[bp + "ff_linear3.weight"]), ("W4", p[bp + "ff_linear4.weight"]), ("Wed", p[bp + "equi_update.input_lin.weight"][:, 512:640]),
                              ("Wro", p[f"edge_{i}.weight"]), ("Wee", p[bp + "edge_emb.weight"]), ("Wte", cache["bufs"]["Wte"][i]),
-                             ("W0", p[bp + "equi_update.coord_mlp.0.weight"]), ("W2", p[bp + "equi_update.coord_mlp.2.weight"])):
+                             ("W0", p[bp + "equi_update.coord_mlp.0.weight"]), ("W2", p[bp + "equi_update.coord_mlp.2.weight"]),
+                             ("F1", p[bp + "ff_linear1.weight"]), ("F2", p[bp + "ff_linear2.weight"]), ("Wac", cache["bufs"]["Wac"][i]),
+                             ("Wn", p[f"node_{i}.weight"])):
                     dst.append(wb[n][i])
                     src.append(t)
             pack_bf16_pieces(self.lib, self.dev, dst, src, cache, "table_bf16", self.ops._s())
@@ -622,19 +638,32 @@ class DmtTrainGraph:
                 u = self.f(Nn, 64)
                 o.lin_fwd(mv(attn), mv(p[bp + "node2edge_lin.weight"]), None, mv(u))
                 ev_u = o.node_event() if ns else None
-                x1, y1, st_n2 = self.f(Nn, 256), self.f(Nn, 256), self.f(Nn, 2)
-                o.gate_add_fwd(h, attn, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 512, x1)
-                o.lnmod_fwd(x1, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 768, a0 + NODE_OFF + 1024, y1, st_n2)
-                f1, s1, f2, h_out = self.f(Nn, 512), self.f(Nn, 512), self.f(Nn, 256), self.f(Nn, 256)
-                # dmt.py:114-116: dropout(act(ff_linear1)) and dropout(ff_linear2) where the GEMMs produce them (f1 = pre-activation, kept)
-                o.lin_fwd(mv(y1), mv(p[bp + "ff_linear1.weight"]), p[bp + "ff_linear1.bias"], mv(f1), act=SILU, out2=mv(s1), drop=(dp, dseed, 4 * i + 0, 512))
-                o.lin_fwd(mv(s1), mv(p[bp + "ff_linear2.weight"]), p[bp + "ff_linear2.bias"], mv(f2), drop=(dp, dseed, 4 * i + 1, 256))
-                o.gate_add_fwd(y1, f2, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 1280, h_out)
-                ac = self.f(Nn, 512)                                 # h_row | h_col parts of input_lin as one product
-                o.lin_fwd(mv(h_out), mv(cat["Wac"][i]), None, mv(ac))
-                ev_ac = o.node_event() if ns else None
-                rn = self.f(Nn, 64)                                  # per-block read-out features (dmt.py:387)
-                o.lin_fwd(mv(h_out), mv(p[f"node_{i}.weight"]), p[f"node_{i}.bias"], mv(rn))
+                if fused_chain:
+                    # dmt.py:113-116,158-163,387 + the node parts of input_lin as ONE kernel (csrc/ds_train_chain.hip): the directed rows wait
+                    # for `ac` at the end of this chain
+                    h_out, ac, rn = self.f(Nn, 256), self.f(Nn, 512), self.f(Nn, 64)
+                    outs = dict(h_out=h_out, ac=ac, rn=rn)
+                    if save:
+                        outs.update(x1=self.f(Nn, 256), st=self.f(Nn, 2), y1=self.f(Nn, 256), f1=self.f(Nn, 512), s1=self.f(Nn, 512), f2=self.f(Nn, 256))
+                    o.node_chain_fwd(TL, h, attn, ada, a0 + NODE_OFF + 512, a0 + NODE_OFF + 768, a0 + NODE_OFF + 1024, a0 + NODE_OFF + 1280,
+                                     self.wb["F1"][i], p[bp + "ff_linear1.bias"], self.wb["F2"][i], p[bp + "ff_linear2.bias"], self.wb["Wac"][i],
+                                     self.wb["Wn"][i], p[f"node_{i}.bias"], (dp, dseed, 4 * i + 0, 4 * i + 1), outs)
+                    x1, st_n2, y1, f1, s1, f2 = (outs.get(k) for k in ("x1", "st", "y1", "f1", "s1", "f2"))
+                    ev_ac = o.node_event() if ns else None
+                else:
+                    x1, y1, st_n2 = self.f(Nn, 256), self.f(Nn, 256), self.f(Nn, 2)
+                    o.gate_add_fwd(h, attn, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 512, x1)
+                    o.lnmod_fwd(x1, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 768, a0 + NODE_OFF + 1024, y1, st_n2)
+                    f1, s1, f2, h_out = self.f(Nn, 512), self.f(Nn, 512), self.f(Nn, 256), self.f(Nn, 256)
+                    # dmt.py:114-116: dropout(act(ff_linear1)) and dropout(ff_linear2) where the GEMMs produce them (f1 = pre-activation, kept)
+                    o.lin_fwd(mv(y1), mv(p[bp + "ff_linear1.weight"]), p[bp + "ff_linear1.bias"], mv(f1), act=SILU, out2=mv(s1), drop=(dp, dseed, 4 * i + 0, 512))
+                    o.lin_fwd(mv(s1), mv(p[bp + "ff_linear2.weight"]), p[bp + "ff_linear2.bias"], mv(f2), drop=(dp, dseed, 4 * i + 1, 256))
+                    o.gate_add_fwd(y1, f2, 256, TL.node_off, 1, B, ada, a0 + NODE_OFF + 1280, h_out)
+                    ac = self.f(Nn, 512)                                 # h_row | h_col parts of input_lin as one product
+                    o.lin_fwd(mv(h_out), mv(cat["Wac"][i]), None, mv(ac))
+                    ev_ac = o.node_event() if ns else None
+                    rn = self.f(Nn, 64)                                  # per-block read-out features (dmt.py:387)
+                    o.lin_fwd(mv(h_out), mv(p[f"node_{i}.weight"]), p[f"node_{i}.bias"], mv(rn))
             # edge stream (dmt.py:156-157,165-169)
             if ns:
                 o.main_wait(ev_u)

@@ -315,6 +315,23 @@ typedef struct dst_dir_chain_args {
 } dst_dir_chain_args;
 int dst_dir_chain_fwd(const dst_layout* L, const dst_dir_chain_args* a, void* stream);
 
+/* The node rows of one block behind the attention as one kernel (bf16 products; dmt.py:113-116,158-163,387 and the node parts of
+ * equi_update.input_lin, dmt.py:39); replaces 2 x dst_gate_add_fwd, dst_lnmod_fwd and four dst_gemm calls:
+ *   x1 = h_in + ada[gate1] * attn;  y1 = LN(x1) (1 + ada[scale]) + ada[shift];  f1 = y1 W1^T + b1;  s1 = dropout(SiLU(f1));
+ *   f2 = dropout(s1 W2^T + b2);  h_out = y1 + ada[gate2] * f2;  ac = h_out Wac^T;  rn = h_out Wn^T + bn.
+ * h_in, attn [Nn,256]; node_mol [Nn] = molecule of a node row; W1 [512,256], W2 [256,512], Wac [512,256] = the h_row | h_col parts of
+ * input_lin, Wn [64,256] as bf16 bits (dst_pack_bf16_pieces); biases fp32.  Dropout: dst_dropout's masks (element (row, col) of the
+ * [Nn,512] / [Nn,256] tensor under stream1 / stream2).  Outputs: h_out [Nn,256], ac [Nn,512], rn [Nn,64] always; the tape tensors x1,
+ * st [Nn,2] = (mean, rstd), y1, f1 [Nn,512], s1 [Nn,512], f2 may each be NULL.  Every pointer 16-byte aligned. */
+typedef struct dst_node_chain_args {
+  const int32_t* node_mol; const float* h_in; const float* attn;
+  const float* ada; int64_t ada_ld; int32_t gate1_off, shift_off, scale_off, gate2_off;
+  const uint16_t* W1; const float* b1; const uint16_t* W2; const float* b2; const uint16_t* Wac; const uint16_t* Wn; const float* bn;
+  float drop_p; uint32_t stream1, stream2, _pad; uint64_t seed;
+  float* x1; float* st; float* y1; float* f1; float* s1; float* f2; float* h_out; float* ac; float* rn;
+} dst_node_chain_args;
+int dst_node_chain_fwd(const dst_layout* L, const dst_node_chain_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

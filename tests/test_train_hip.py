@@ -1476,7 +1476,8 @@ def test_fused_pair_chain_matches_the_unfused_kernels(gpu_device, monkeypatch):
         graph.dropout_p, graph.dropout_seed = 0.1, 987654321
         out = graph.forward(TL, xn, ex, nl, ctx, cn, ce)
         tape = [{k: bt[k].clone() for k in ("X1", "xs", "d2", "e1", "st_e1", "en", "te", "he", "xe1", "st_e2", "ye1", "f3", "s3", "f4", "e_out", "X2", "ed",
-                                            "re_", "zz", "st_z", "zn", "c0", "sc0", "c2")} for bt in graph.t["blocks"]]
+                                            "re_", "zz", "st_z", "zn", "c0", "sc0", "c2",
+                                            "x1", "st_n2", "y1", "f1", "s1", "f2", "h_out", "ac", "rn")} for bt in graph.t["blocks"]]     # (+ the node chain)
         dpos, datom, dedge = (torch.randn(o.shape, generator=torch.Generator().manual_seed(9)).to(d) for o in out)
         grads = {k: v.clone() for k, v in graph.backward(dpos, datom, dedge).items()}
         runs[mode] = ([o.clone() for o in out], tape, grads)
@@ -1500,18 +1501,18 @@ def test_fused_pair_chain_matches_the_unfused_kernels(gpu_device, monkeypatch):
                 assert err <= 2e-5, (i, k, err)
             else:
                 assert err <= 2e-2 and mean_err <= 1e-3, (i, k, err, mean_err)
-            if k in ("s3", "f4"):
+            if k in ("s3", "f4", "s1", "f2"):
                 # the masks are a function of (seed, stream, element) alone: both runs must zero exactly the elements the numpy restatement of
                 # dst_dropout drops (an element it keeps may still be zero: SiLU underflows below -88)
                 from oracle import philox
-                keep = torch.from_numpy(philox.dropout_keep(987654321, 4 * i + (2 if k == "s3" else 3), ref.numel(), 0.1)).reshape(ref.shape)
+                keep = torch.from_numpy(philox.dropout_keep(987654321, 4 * i + dict(s1=0, f2=1, s3=2, f4=3)[k], ref.numel(), 0.1)).reshape(ref.shape)
                 for name, t in (("unfused", ref), ("fused", got)):
                     tz = (t == 0).cpu()
                     dropped_but_alive = int((~keep & ~tz).sum())
                     assert dropped_but_alive == 0, (i, k, name, dropped_but_alive)
                     kept_zero = keep & tz
-                    if k == "s3" and bool(kept_zero.any()):
-                        pre = (tb if name == "fused" else ta)["f3"].cpu()[kept_zero]
+                    if k in ("s3", "s1") and bool(kept_zero.any()):
+                        pre = (tb if name == "fused" else ta)["f3" if k == "s3" else "f1"].cpu()[kept_zero]
                         assert float(pre.max()) < -80.0 or float(pre.abs().max()) == 0.0, (i, k, name, "kept element is zero", pre[:4])
     for a, b in zip(runs["0"][0], runs["1"][0]):
         assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max())

@@ -138,10 +138,12 @@ __global__ __launch_bounds__(256) void k_pack_bf16_pieces(const dst_piece* __res
   const dst_piece pc = table[blockIdx.x];
   const unsigned int rows = (unsigned int)pc.rows, cols = (unsigned int)pc.cols, total = rows * cols;
   unsigned short* dst = reinterpret_cast<unsigned short*>(pc.dst);
+  const bool transposed = pc.dst_ld < 0;                         // dst[c * (-dst_ld) + r]: the weight as the input-gradient products read it
+  const int64_t dld = transposed ? -pc.dst_ld : pc.dst_ld;
   for (unsigned int i = blockIdx.y * 256u + threadIdx.x; i < total; i += gridDim.y * 256u) {
     const unsigned int r = i / cols, c = i - r * cols;
     const __bf16 h = (__bf16)pc.src[(int64_t)r * pc.src_ld + c];
-    dst[(int64_t)r * pc.dst_ld + c] = __builtin_bit_cast(unsigned short, h);
+    dst[transposed ? (int64_t)c * dld + r : (int64_t)r * dld + c] = __builtin_bit_cast(unsigned short, h);
   }
 }
 

@@ -782,6 +782,154 @@ __global__ __launch_bounds__(NC_NT) void k_node_chain_fwd(dst_layout L, dst_node
   }
 }
 
+// dst_dir_chain_bwd: the backward of the directed rows of a block (coord_mlp and equi_update's LayerNorm; dmt.py:37-48) as one kernel and a
+// small finishing kernel instead of dst_gemm (K = 3, SiLU'), dst_gemm (256 -> 256 input gradient) and dst_lnmod_bwd (three launches):
+//   dc0 = (dc2 W2) * SiLU'(c0);  dzn = dc0 W0;  dz = LayerNorm'(zz; dzn (1 + scale));  d shift += sum_rows dzn, d scale += sum_rows dzn x^
+// TILES ARE MOLECULE-ALIGNED here (a host table: first directed row, row count <= 32, molecule): the adaLN gradients are sums over the rows of
+// ONE molecule, so a tile adds its rows up in a fixed order into part[tile][512] and k_dir_bwd_finish adds a molecule's tiles in tile order.
+// W2 [3,256] fp32 (K = 3: plain FMAs, as the K <= 8 GEMM kernel); W0T = W0 transposed as bf16 ([in][out]: the B fragment of dc0 W0 is eight
+// consecutive `out` of one `in`).  dc0 and dz go to global memory (the weight-gradient product of coord_mlp.0 and dst_zbuild_bwd read them).
+struct DirBwdLds {
+  float zf[32][LD_YF];             // dzn, fp32: the LayerNorm backward reads whole rows
+  float red[CH_NW][512];           // the waves' column sums (shift | scale)
+  float d2[32][4];                 // dc2 of the tile's rows
+  __bf16 db[32][LD_Z];             // dc0, bf16: A operand of dc0 W0
+};
+__device__ __forceinline__ float fast_silu_deriv(float x) {
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+  return sg * (1.0f + x * (1.0f - sg));
+}
+
+__global__ __launch_bounds__(CH_NT, 2) void k_dir_chain_bwd(dst_layout L, dst_dir_bwd_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  DirBwdLds& w = *reinterpret_cast<DirBwdLds*>(lds_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile = blockIdx.x;
+  const int64_t g0 = a.tile_row0[tile];
+  const int valid = a.tile_rows[tile], mol = a.tile_mol[tile];
+  const int64_t glast = g0 + valid - 1;
+  const int sub = lane >> 4, j16 = lane & 15, er = lane >> 3, ec = (lane & 7) * 4;
+  WFrag<8> fa, fb;
+  wfetch<8>(fa, a.W0T, 256, 0, wave * 32, 256);
+  if (threadIdx.x < 96) {
+    const int row = threadIdx.x / 3, o = threadIdx.x % 3;
+    w.d2[row][o] = row < valid ? a.dc2[(g0 + row) * 3 + o] : 0.0f;
+  }
+  // ---- dc0 = (dc2 W2) SiLU'(c0): chunks wave, wave + 4; a chunk row = 8 lanes x float4; every load of the phase before its first store
+  f4_t cv[2][4], w2v[2][3];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int col = (wave + 4 * k) * 32 + ec;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) cv[k][it] = ld4(a.c0 + min(g0 + it * 8 + er, glast) * 256 + col);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) w2v[k][o] = ld4(a.W2 + o * 256 + col);
+  }
+  __syncthreads();                                             // dc2 tile
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int col = (wave + 4 * k) * 32 + ec;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + er;
+      const float d0 = w.d2[row][0], d1 = w.d2[row][1], d2_ = w.d2[row][2];
+      f4_t v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = d0 * w2v[k][0][e];
+        t = fmaf(d1, w2v[k][1][e], t);
+        t = fmaf(d2_, w2v[k][2][e], t);
+        v[e] = t * fast_silu_deriv(cv[k][it][e]);
+      }
+      if (row < valid) st4(a.dc0 + (g0 + row) * 256 + col, v);
+      else v = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+      *reinterpret_cast<bf16x4_t*>(&w.db[row][col]) = to_bf4(v);
+    }
+  }
+  __syncthreads();
+  // ---- dzn = dc0 W0 (256 -> 256): chunks wave, wave + 4 of the INPUT columns, into the fp32 tile
+#pragma unroll 1
+  for (int k = 0; k < 2; ++k) {
+    const int ch = wave + 4 * k;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    wfetch<8>(fb, a.W0T, 256, 128, ch * 32, 256);
+    mma_apply<8>(&w.db[0][0], LD_Z, 0, fa, acc);
+    mma_apply<8>(&w.db[0][0], LD_Z, 128, fb, acc);
+    if (k == 0) wfetch<8>(fa, a.W0T, 256, 0, (ch + 4) * 32, 256);
+    const int c = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w.zf[(i & 3) + 8 * (i >> 2) + 4 * hh][ch * 32 + c] = acc[i];
+  }
+  // the LayerNorm backward's operands (wave w: rows 8 w .. 8 w + 7 as two passes of four; a row = 16 lanes, lane j the float4s at columns
+  // 4 j + 64 u): requested before the barrier
+  f4_t zv[2][4], sc1[4];
+  float mean[2], rstd[2];
+  {
+    const float* adm = a.ada + (int64_t)mol * a.ada_ld + a.scale_off + 4 * j16;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sc1[u] = ld4(adm + 64 * u) + 1.0f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int64_t gr = min(g0 + 8 * wave + 4 * q + sub, glast);
+      mean[q] = a.st[gr * 2]; rstd[q] = a.st[gr * 2 + 1];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) zv[q][u] = ld4(a.zz + gr * 256 + 64 * u + 4 * j16);
+    }
+  }
+  __syncthreads();
+  f4_t psh[4], psc[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { psh[u] = f4_t{0.0f, 0.0f, 0.0f, 0.0f}; psc[u] = psh[u]; }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = 8 * wave + 4 * q + sub;
+    f4_t g[4], xh[4];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f4_t dzn = ld4(&w.zf[row][64 * u + 4 * j16]);     // (rows beyond the tile: dc0 = 0 -> dzn = 0)
+      xh[u] = (zv[q][u] - mean[q]) * rstd[q];
+      psh[u] += dzn;
+      psc[u] += dzn * xh[u];
+      g[u] = dzn * sc1[u];
+      const f4_t gx = g[u] * xh[u];
+      s1 += (g[u][0] + g[u][1]) + (g[u][2] + g[u][3]);
+      s2 += (gx[0] + gx[1]) + (gx[2] + gx[3]);
+    }
+    const float m1 = sum16(s1) * (1.0f / 256.0f), m2 = sum16(s2) * (1.0f / 256.0f);
+    if (row < valid) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) st4(a.dz + (g0 + row) * 256 + 64 * u + 4 * j16, rstd[q] * (g[u] - m1 - xh[u] * m2));
+    }
+  }
+  // column sums of the wave's eight rows: over the four 16-lane groups, then the waves in wave order
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = psh[u][e], y = psc[u][e];
+      x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64);
+      y += __shfl_xor(y, 16, 64); y += __shfl_xor(y, 32, 64);
+      psh[u][e] = x; psc[u][e] = y;
+    }
+  if (sub == 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { st4(&w.red[wave][64 * u + 4 * j16], psh[u]); st4(&w.red[wave][256 + 64 * u + 4 * j16], psc[u]); }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = threadIdx.x; t < 512; t += CH_NT) a.part[(int64_t)tile * 512 + t] = ((w.red[0][t] + w.red[1][t]) + w.red[2][t]) + w.red[3][t];
+}
+
+__global__ __launch_bounds__(512) void k_dir_bwd_finish(dst_dir_bwd_args a) {
+  const int m = blockIdx.x, t = threadIdx.x;
+  float s = 0.0f;
+  for (int k = a.mol_tile_off[m]; k < a.mol_tile_off[m + 1]; ++k) s += a.part[(int64_t)k * 512 + t];
+  a.d_ada[(int64_t)m * a.ada_ld + (t < 256 ? a.shift_off + t : a.scale_off + t - 256)] = s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -858,6 +1006,28 @@ int dst_node_chain_fwd(const dst_layout* L, const dst_node_chain_args* a, void* 
     attr_done = true;
   }
   hipLaunchKernelGGL(k_node_chain_fwd, dim3((L->Nn + 31) / 32), dim3(NC_NT), lds, (hipStream_t)stream, *L, *a);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_dir_chain_bwd(const dst_layout* L, const dst_dir_bwd_args* a, void* stream) {
+  if (!L || !a || !a->tile_row0 || !a->tile_rows || !a->tile_mol || !a->mol_tile_off || !a->dc2 || !a->c0 || !a->zz || !a->st || !a->ada || !a->d_ada || !a->W2 ||
+      !a->W0T || !a->dc0 || !a->dz || !a->part)
+    return DS_ERR_ARG;
+  if (L->B <= 0 || a->n_tiles < 0 || (a->ada_ld & 3) || ((a->shift_off | a->scale_off) & 3)) return DS_ERR_ARG;
+  const void* ptrs[] = {a->c0, a->zz, a->ada, a->W2, a->W0T, a->dc0, a->dz};
+  for (const void* p : ptrs)
+    if (reinterpret_cast<uintptr_t>(p) & 15) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->n_tiles > 0) {
+    static bool attr_done = false;
+    const size_t lds = sizeof(DirBwdLds);
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dir_chain_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DS_ERR_LAUNCH;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(k_dir_chain_bwd, dim3(a->n_tiles), dim3(CH_NT), lds, s, *L, *a);
+  }
+  hipLaunchKernelGGL(k_dir_bwd_finish, dim3(L->B), dim3(512), 0, s, *a);     // (molecules without pairs: zero sums)
   return DST_CHECK_LAUNCH();
 }
 

@@ -64,17 +64,20 @@ def copy_pieces(lib, dev, dst: List[torch.Tensor], src: List[torch.Tensor], cach
     E._check(lib.dst_copy_pieces(C.c_void_p(ent[1].data_ptr()), C.c_int32(ent[2]), stream if stream is not None else E._stream()), "dst_copy_pieces")
 
 
-def pack_bf16_pieces(lib, dev, dst: List[torch.Tensor], src: List[torch.Tensor], cache: dict, key: str, stream=None):
+def pack_bf16_pieces(lib, dev, dst: List[torch.Tensor], src: List[torch.Tensor], cache: dict, key: str, stream=None, key_t=None):
     """``dst[i].copy_(src[i])`` with ``dst`` in bfloat16 (round to nearest even) for many small 2-D pieces in ONE ``dst_pack_bf16_pieces`` launch:
-    the weights of the fused row chains, once per step.  The device table is rebuilt only when a pointer changed."""
+    the weights of the fused row chains, once per step.  ``key_t``: the indices of the pieces that are stored TRANSPOSED.  The device table is
+    rebuilt only when a pointer changed."""
     sig = tuple(t.data_ptr() for t in dst) + tuple(t.data_ptr() for t in src)
     ent = cache.get(key)
     if ent is None or ent[0] != sig:
         arr = (DstPiece * len(dst))()
         for i, (d, s_) in enumerate(zip(dst, src)):
-            assert d.shape == s_.shape and d.dtype == torch.bfloat16 and s_.dtype == torch.float32 and d.dim() == 2
-            assert d.stride(1) == 1 and s_.stride(1) == 1 and d.numel() < 2 ** 31
-            arr[i] = DstPiece(src=s_.data_ptr(), dst=d.data_ptr(), rows=d.shape[0], cols=d.shape[1], src_ld=s_.stride(0), dst_ld=d.stride(0))
+            assert d.dtype == torch.bfloat16 and s_.dtype == torch.float32 and d.dim() == 2 and d.stride(1) == 1 and s_.stride(1) == 1 and d.numel() < 2 ** 31
+            transposed = key_t is not None and i in key_t           # dst = src^T (dst_ld < 0 in the table)
+            assert tuple(d.shape) == (tuple(s_.shape)[::-1] if transposed else tuple(s_.shape))
+            arr[i] = DstPiece(src=s_.data_ptr(), dst=d.data_ptr(), rows=s_.shape[0], cols=s_.shape[1], src_ld=s_.stride(0),
+                              dst_ld=-d.stride(0) if transposed else d.stride(0))
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         ent = (sig, raw, len(dst))
         cache[key] = ent
@@ -91,6 +94,8 @@ _GEMM_PACK = _GEMM_STRUCT.pack
 _CHAIN_PACK = _struct.Struct("@PPP PPPPq Pq iiii PPPPP q PPP f III Q PPPPPPPPPPP").pack
 # dst_pair_front_args: pos, ada, ada_ld | dist_off, shift_off, scale_off, pad | means stds e_in Wee bee Wte | X1 xs d2 e1 st en te
 _FRONT_PACK = _struct.Struct("@PPP PPq iiii PPPPPP PPPPPPP").pack
+# dst_dir_bwd_args: 4 tables, n_tiles | dc2 c0 zz st | ada d_ada ada_ld | shift_off scale_off | W2 W0T | dc0 dz part
+_DIRB_PACK = _struct.Struct("@PPPPq PPPP PPq ii PP PPP").pack
 # dst_node_chain_args: node_mol h_in attn | ada, ada_ld | 4 offsets | W1 b1 W2 b2 Wac Wn bn | drop_p, stream1, stream2, pad | seed | 9 outputs
 _NODE_PACK = _struct.Struct("@PPP Pq iiii PPPPPPP f III Q PPPPPPPPP").pack
 # dst_dir_chain_args: ac, ed, ada, ada_ld | shift_off, scale_off | W0 b0 W2 | zz st zn c0 sc0 c2
@@ -343,6 +348,17 @@ class Ops:
         args = _DIR_PACK(*TL.pair_tables, ptr(ac), ptr(ed), ptr(ada), ADA, sh, sc, ptr(W0), ptr(b0), ptr(W2), *(ptr(out.get(k)) for k in ("zz", "st", "zn", "c0", "sc0", "c2")))
         E._check(self.lib.dst_dir_chain_fwd(C.byref(TL.c), args, self._s()), "dst_dir_chain_fwd")
 
+    def dir_chain_bwd(self, TL, dc2, c0, zz, st, ada, d_ada, sh, sc, W2, W0T, dc0, dz):
+        """Backward of the directed rows of a block as one kernel + its finishing kernel (``dst_dir_chain_bwd``)."""
+        assert W0T.dtype == torch.bfloat16 and W2.dtype == torch.float32
+        tt = TL.dir_tiles
+        need = tt[4] * 512
+        if getattr(self, "_dirb_part", None) is None or self._dirb_part.numel() < need:
+            self._dirb_part = torch.empty(max(need, 1), dtype=torch.float32, device=self.dev)
+        args = _DIRB_PACK(tt[0], tt[1], tt[2], tt[3], tt[4], dc2.data_ptr(), c0.data_ptr(), zz.data_ptr(), st.data_ptr(), ada.data_ptr(), d_ada.data_ptr(), ADA, sh, sc,
+                          W2.data_ptr(), W0T.data_ptr(), dc0.data_ptr(), dz.data_ptr(), self._dirb_part.data_ptr())
+        E._check(self.lib.dst_dir_chain_bwd(C.byref(TL.c), args, self._s()), "dst_dir_chain_bwd")
+
     def pair_front_fwd(self, TL, pos, ada, dist_off, sh, sc, means, stds, e_in, Wee, bee, Wte, out):
         """The pair rows of a block in front of the attention as one kernel (``dst_pair_front_fwd``, bf16 products).  ``out``: dict with X1, te and -
         when the tape is kept - xs, d2, e1, st, en."""
@@ -399,6 +415,17 @@ class TrainLayout:
         # device tables of the flat-tile kernels (dst_pair_*_fwd, dst_dir_chain_fwd): node rows of a pair's atoms, its molecule
         self.pair_tables = (L.t["pair_a"].data_ptr(), L.t["pair_b"].data_ptr(), L.t["pair_mol"].data_ptr())
         self.node_mol_ptr = L.t["node_mol"].data_ptr()                     # [Nn] int32: molecule of a node row (dst_node_chain_fwd)
+        # molecule-aligned 32-row tiles of the DIRECTED rows (dst_dir_chain_bwd: its adaLN sums are per molecule)
+        po = L.t["pair_off"].cpu().numpy().astype(np.int64)
+        row0, rows, mol, off = [], [], [], [0]
+        for m in range(L.B):
+            nd, r0 = 2 * int(po[m + 1] - po[m]), 2 * int(po[m])
+            for k in range(0, nd, 32):
+                row0.append(r0 + k); rows.append(min(32, nd - k)); mol.append(m)
+            off.append(len(row0))
+        i32 = lambda v: torch.tensor(v if len(v) else [0], dtype=torch.int32, device=device)
+        self._dir_tile_tensors = (i32(row0), i32(rows), i32(mol), i32(off))
+        self.dir_tiles = tuple(t.data_ptr() for t in self._dir_tile_tensors) + (len(row0),)
 
     def pack_nodes(self, dense: torch.Tensor) -> torch.Tensor:
         return dense.reshape(self.B * self.N, -1).index_select(0, self.node_dense).contiguous()
@@ -501,10 +528,10 @@ class DmtTrainGraph:
             # the fused row chains take their weights as bf16 (csrc/ds_train_chain.hip: the per-tile weight stream from L2 bounds them)
             if "wb" not in cache:
                 shapes = dict(W3=(128, 64), W4=(64, 128), Wed=(256, 128), Wro=(16, 64), Wee=(64, 128), Wte=(512, 64), W0=(256, 256), W2=(3, 256),
-                              F1=(512, 256), F2=(256, 512), Wac=(512, 256), Wn=(64, 256))
+                              F1=(512, 256), F2=(256, 512), Wac=(512, 256), Wn=(64, 256), W0T=(256, 256))
                 cache["wb"] = {n: torch.zeros(NB, *sh, dtype=torch.bfloat16, device=self.dev) for n, sh in shapes.items()}
             wb, p = cache["wb"], self.p
-            dst, src = [], []
+            dst, src, tset = [], [], set()
             for i in range(NB):
                 bp = f"e_block_{i}."
                 for n, t in (("W3", p[bp + "ff_linear3.weight"]), ("W4", p[bp + "ff_linear4.weight"]), ("Wed", p[bp + "equi_update.input_lin.weight"][:, 512:640]),
@@ -514,7 +541,10 @@ class DmtTrainGraph:
                              ("Wn", p[f"node_{i}.weight"])):
                     dst.append(wb[n][i])
                     src.append(t)
-            pack_bf16_pieces(self.lib, self.dev, dst, src, cache, "table_bf16", self.ops._s())
+                tset.add(len(dst))                                     # coord_mlp.0 transposed ([in][out]): the B operand of its input gradient
+                dst.append(wb["W0T"][i])
+                src.append(p[bp + "equi_update.coord_mlp.0.weight"])
+            pack_bf16_pieces(self.lib, self.dev, dst, src, cache, "table_bf16", self.ops._s(), key_t=tset)
             self.wb = wb
         return cache
 
@@ -797,6 +827,7 @@ class DmtTrainGraph:
         dd2_buf = self.f(max(Pp, 1))
         ns = bool(int(os.environ.get("DIFFSPECTRA_NODE_STREAM", "1"))) and getattr(o, "main_stream", None) is not None
         sec = o.node_section if ns else contextlib.nullcontext
+        fused_chain = bool(o.bf16) and Pp > 0 and os.environ.get("DIFFSPECTRA_FUSED_CHAIN", "1") != "0" and getattr(self, "wb", None) is not None
         for i in reversed(range(NB)):
             bt = t["blocks"][i]
             bp = f"e_block_{i}."
@@ -819,12 +850,18 @@ class DmtTrainGraph:
             dWin = gw(bp + "equi_update.input_lin.weight")
             o.lin_bwd_w(mv(dc2, r1=D), mv(bt["sc0"], r1=D), mv(gw(bp + "equi_update.coord_mlp.2.weight")))
             dc0 = self.f(max(D, 1), 256)
-            o.lin_bwd_x(mv(dc2, r1=D), mv(p[bp + "equi_update.coord_mlp.2.weight"]), mv(dc0, r1=D), dact=SILU, ref=mv(bt["c0"], r1=D))
-            o.lin_bwd_w(mv(dc0, r1=D), mv(bt["zn"], r1=D), mv(gw(bp + "equi_update.coord_mlp.0.weight")), gw(bp + "equi_update.coord_mlp.0.bias"))
-            dzn = self.f(max(D, 1), 256)
-            o.lin_bwd_x(mv(dc0, r1=D), mv(p[bp + "equi_update.coord_mlp.0.weight"]), mv(dzn, r1=D))
             dz = self.f(max(D, 1), 256)                      # (not dc0: the coord_mlp.0 weight gradient may still be reading it on the side stream)
-            o.lnmod_bwd(dzn, bt["zz"], bt["st_z"], 256, TL.pair_off, 2, B, ada, d_ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256, dz, False)
+            if fused_chain:
+                # coord_mlp.2's and coord_mlp.0's input gradients and the LayerNorm backward as ONE kernel (csrc/ds_train_chain.hip)
+                o.dir_chain_bwd(TL, dc2, bt["c0"], bt["zz"], bt["st_z"], ada, d_ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256,
+                                p[bp + "equi_update.coord_mlp.2.weight"], self.wb["W0T"][i], dc0, dz)
+                o.lin_bwd_w(mv(dc0, r1=D), mv(bt["zn"], r1=D), mv(gw(bp + "equi_update.coord_mlp.0.weight")), gw(bp + "equi_update.coord_mlp.0.bias"))
+            else:
+                o.lin_bwd_x(mv(dc2, r1=D), mv(p[bp + "equi_update.coord_mlp.2.weight"]), mv(dc0, r1=D), dact=SILU, ref=mv(bt["c0"], r1=D))
+                o.lin_bwd_w(mv(dc0, r1=D), mv(bt["zn"], r1=D), mv(gw(bp + "equi_update.coord_mlp.0.weight")), gw(bp + "equi_update.coord_mlp.0.bias"))
+                dzn = self.f(max(D, 1), 256)
+                o.lin_bwd_x(mv(dc0, r1=D), mv(p[bp + "equi_update.coord_mlp.0.weight"]), mv(dzn, r1=D))
+                o.lnmod_bwd(dzn, bt["zz"], bt["st_z"], 256, TL.pair_off, 2, B, ada, d_ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256, dz, False)
             dac, ded = self.f(Nn, 512), self.f(Pp, 256)
             E._check(lib.dst_zbuild_bwd(C.byref(TL.c), E._ptr(dz), E._ptr(dac), E._ptr(ded), s()), "dst_zbuild_bwd")
             # node stream (the section waits for dac)

@@ -77,8 +77,9 @@ typedef struct dst_piece {
   int64_t src_ld, dst_ld;
 } dst_piece;
 int dst_copy_pieces(const dst_piece* table, int32_t n, void* stream);
-/* The same pieces ROUNDED TO bf16 (nearest even): `dst` of every piece addresses a bf16 buffer (uint16_t bits), dst_ld in bf16 elements.
- * The weights of the fused row chains below are passed in this form. */
+/* The same pieces ROUNDED TO bf16 (nearest even): `dst` of every piece addresses a bf16 buffer (uint16_t bits), dst_ld in bf16 elements;
+ * dst_ld < 0 stores the piece TRANSPOSED (dst[c * -dst_ld + r] = src[r * src_ld + c]).  The weights of the fused row chains below are
+ * passed in this form. */
 int dst_pack_bf16_pieces(const dst_piece* table, int32_t n, void* stream);
 
 /* out[c] (+)= sum_r X[r*ld + c], two fixed-order stages through `scratch` (bias gradients, per-molecule partial sums). */
@@ -331,6 +332,23 @@ typedef struct dst_node_chain_args {
   float* x1; float* st; float* y1; float* f1; float* s1; float* f2; float* h_out; float* ac; float* rn;
 } dst_node_chain_args;
 int dst_node_chain_fwd(const dst_layout* L, const dst_node_chain_args* a, void* stream);
+
+/* Backward of the directed rows of one block (dmt.py:37-48) as one kernel + a finishing kernel (bf16 product); replaces the K = 3 dst_gemm
+ * with SiLU', the 256 -> 256 input-gradient dst_gemm and dst_lnmod_bwd:
+ *   dc0 = (dc2 W2) * SiLU'(c0);  dzn = dc0 W0;  dz = LN'(zz, st; dzn (1 + ada[scale]));  d_ada[shift] = sum_rows dzn;  d_ada[scale] = sum_rows dzn x^.
+ * Tiles are molecule-aligned: tile_row0 / tile_rows / tile_mol [n_tiles] = first directed row, row count (<= 32) and molecule of a tile (a
+ * molecule's tiles consecutive, ascending), mol_tile_off [B + 1] = first tile of a molecule.  dc2 [2 Pp,3]; c0, zz [2 Pp,256], st [2 Pp,2] the
+ * forward's tape; W2 [3,256] fp32; W0T = coord_mlp.0's weight TRANSPOSED as bf16 bits ([in][out]; dst_pack_bf16_pieces with dst_ld < 0).
+ * Outputs: dc0, dz [2 Pp,256]; d_ada columns shift_off .. + 255 and scale_off .. + 255 of every molecule ASSIGNED; part = scratch of
+ * n_tiles * 512 floats. */
+typedef struct dst_dir_bwd_args {
+  const int32_t* tile_row0; const int32_t* tile_rows; const int32_t* tile_mol; const int32_t* mol_tile_off; int64_t n_tiles;
+  const float* dc2; const float* c0; const float* zz; const float* st;
+  const float* ada; float* d_ada; int64_t ada_ld; int32_t shift_off, scale_off;
+  const float* W2; const uint16_t* W0T;
+  float* dc0; float* dz; float* part;
+} dst_dir_bwd_args;
+int dst_dir_chain_bwd(const dst_layout* L, const dst_dir_bwd_args* a, void* stream);
 
 #ifdef __cplusplus
 }

@@ -930,6 +930,207 @@ __global__ __launch_bounds__(512) void k_dir_bwd_finish(dst_dir_bwd_args a) {
   a.d_ada[(int64_t)m * a.ada_ld + (t < 256 ? a.shift_off + t : a.scale_off + t - 256)] = s;
 }
 
+// dst_pair_chain_bwd: the backward of the pair rows of a block BEHIND the attention (the forward of dst_pair_chain_fwd) as one kernel and a
+// finishing kernel instead of five dst_gemm input gradients, 2 x dst_gate_add_bwd and dst_lnmod_bwd (eleven launches):
+//   de_tot = de + dro Wro + ded Wed[:, e];  dfeat = ded Wed[:, dist]
+//   df4 = gate2 de_tot (dropout mask 4);  df3 = (df4 W4) SiLU'(f3) (dropout mask 3);  dye1 = de_tot + df3 W3
+//   dxe1 = LayerNorm'(xe1; dye1 (1 + scale));  de_in = dxe1;  dhe = gate1 dxe1
+//   d_ada: gate2 += sum de_tot f4, shift += sum dye1, scale += sum dye1 x^, gate1 += sum dxe1 he      (sums over the rows of a molecule)
+// Molecule-aligned tiles of 32 pair rows, as dst_dir_chain_bwd.  Weights TRANSPOSED as bf16 ([in][out]): WedT [128][256], WroT [64][16],
+// W4T [128][64], W3T [64][128].  df4, df3 (the weight-gradient products read them), dfeat, de_in, dhe go to global memory.
+struct PairBwdLds {
+  float yf[32][LD_F];              // de_tot, the base of dye1
+  float stage[CH_NW][32][LD_ST];
+  float red[CH_NW][256];           // the waves' column sums (gate2 | shift | scale | gate1)
+  __bf16 eb[32][LD_Z];             // ded, bf16
+  __bf16 rb[32][24];               // dro (16 columns), bf16
+  __bf16 fb[32][LD_Y];             // df4, bf16
+  __bf16 gb[32][LD_S];             // df3, bf16
+};
+
+__global__ __launch_bounds__(CH_NT, 2) void k_pair_chain_bwd(dst_layout L, dst_pair_bwd_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  PairBwdLds& w = *reinterpret_cast<PairBwdLds*>(lds_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float (*stage)[LD_ST] = w.stage[wave];
+  const int tile = blockIdx.x;
+  const int64_t g0 = a.tile_row0[tile];
+  const int valid = a.tile_rows[tile], mol = a.tile_mol[tile];
+  const int64_t glast = g0 + valid - 1;
+  const unsigned int thr = dst::dropout_threshold(a.drop_p);
+  const float keep_scale = a.drop_p > 0.0f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const int sub = lane >> 4, j16 = lane & 15, cl = j16 * 4, er = lane >> 3, ec = (lane & 7) * 4;
+  const float* adm = a.ada + (int64_t)mol * a.ada_ld;
+  WFrag<8> fa, fb;
+  wfetch<8>(fa, a.WedT, 256, 0, wave * 32, 128);
+  // ---- ded (32 x 256) and dro (32 x 16) as bf16 tiles: wave w rows 8 w .. 8 w + 7, a ded row = 64 lanes x float4
+  {
+    f4_t dv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dv[q] = ld4(a.ded + min(g0 + 8 * wave + q, glast) * 256 + lane * 4);
+    f4_t rv = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int rrow = threadIdx.x >> 2, rc = (threadIdx.x & 3) * 4;              // 128 threads: (row, four of the 16 columns)
+    if (threadIdx.x < 128 && rrow < valid) rv = ld4(a.dro + (g0 + rrow) * a.ld_dro + rc);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int row = 8 * wave + q;
+      if (row >= valid) dv[q] = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+      *reinterpret_cast<bf16x4_t*>(&w.eb[row][lane * 4]) = to_bf4(dv[q]);
+    }
+    if (threadIdx.x < 128) *reinterpret_cast<bf16x4_t*>(&w.rb[rrow][rc]) = to_bf4(rv);
+  }
+  __syncthreads();
+  // ---- ded Wed (256 -> 128 = e | dist), + dro Wro on the e half: chunk `wave`
+  {
+    const int ch = wave;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    wfetch<8>(fb, a.WedT, 256, 128, ch * 32, 128);
+    WFrag<1> fr;
+    if (wave < 2) wfetch<1>(fr, a.WroT, 16, 0, ch * 32, 64);
+    mma_apply<8>(&w.eb[0][0], LD_Z, 0, fa, acc);
+    mma_apply<8>(&w.eb[0][0], LD_Z, 128, fb, acc);
+    if (wave < 2) mma_apply<1>(&w.rb[0][0], 24, 0, fr, acc);
+    f4_t dein[4];
+    if (wave < 2) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) dein[it] = ld4(a.de + min(g0 + it * 8 + er, glast) * 64 + ch * 32 + ec);
+    }
+    acc_to_stage(acc, stage);
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + er;
+      const f4_t v = ld4(&stage[row][ec]);
+      if (wave < 2) st4(&w.yf[row][ch * 32 + ec], row < valid ? v + dein[it] : f4_t{0.0f, 0.0f, 0.0f, 0.0f});
+      else if (row < valid) st4(a.dfeat + (g0 + row) * 64 + (ch - 2) * 32 + ec, v);
+    }
+  }
+  // operands of the gated-residual stage (wave w: rows 8 w .. 8 w + 7 as two passes of four; a row = 16 lanes x float4): before the barrier
+  const f4_t g2 = ld4(adm + a.gate2_off + cl);
+  f4_t f4v[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) f4v[q] = ld4(a.f4 + min(g0 + 8 * wave + 4 * q + sub, glast) * 64 + cl);
+  WFrag<4> f4w;
+  wfetch<4>(f4w, a.W4T, 64, 0, wave * 32, 128);
+  __syncthreads();
+  f4_t pg2 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = 8 * wave + 4 * q + sub;
+    const int64_t gr = g0 + row;
+    const f4_t d = ld4(&w.yf[row][cl]);                        // (zero beyond the tile)
+    pg2 += d * f4v[q];
+    f4_t o = g2 * d;
+    if (a.drop_p > 0.0f) {
+      unsigned int c[4];
+      dst::dropout_block(a.seed, a.stream4, (gr * 64 + cl) >> 2, c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = c[e] >= thr ? o[e] * keep_scale : 0.0f;
+    }
+    if (row < valid) st4(a.df4 + gr * 64 + cl, o);
+    else o = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    *reinterpret_cast<bf16x4_t*>(&w.fb[row][cl]) = to_bf4(o);
+  }
+  __syncthreads();
+  // ---- df3 = (df4 W4) SiLU'(f3), dropout mask 3 (64 -> 128): chunk `wave`
+  {
+    const int ch = wave;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    mma_apply<4>(&w.fb[0][0], LD_Y, 0, f4w, acc);
+    f4_t f3v[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) f3v[it] = ld4(a.f3 + min(g0 + it * 8 + er, glast) * 128 + ch * 32 + ec);
+    wfetch<4>(f4w, a.W3T, 128, 64 * (wave >> 1), (wave & 1) * 32, 64);          // ff_linear3's input gradient: chunk wave & 1, k-half wave >> 1
+    acc_to_stage(acc, stage);
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + er, col = ch * 32 + ec;
+      const int64_t gr = g0 + row;
+      f4_t v = ld4(&stage[row][ec]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= fast_silu_deriv(f3v[it][e]);
+      if (a.drop_p > 0.0f) {
+        unsigned int c[4];
+        dst::dropout_block(a.seed, a.stream3, (gr * 128 + col) >> 2, c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = c[e] >= thr ? v[e] * keep_scale : 0.0f;
+      }
+      if (row < valid) st4(a.df3 + gr * 128 + col, v);
+      else v = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+      *reinterpret_cast<bf16x4_t*>(&w.gb[row][col]) = to_bf4(v);
+    }
+  }
+  __syncthreads();
+  // ---- df3 W3 (128 -> 64): chunk wave & 1, k-half wave >> 1 -> this wave's staging tile; the two halves are added in the next stage
+  {
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    mma_apply<4>(&w.gb[0][0], LD_S, 64 * (wave >> 1), f4w, acc);
+    acc_to_stage(acc, stage);
+  }
+  // operands of the LayerNorm / gate stage: before the barrier
+  const f4_t sc1 = ld4(adm + a.scale_off + cl) + 1.0f, g1 = ld4(adm + a.gate1_off + cl);
+  f4_t xv[2], hv[2];
+  float mean[2], rstd[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int64_t gr = min(g0 + 8 * wave + 4 * q + sub, glast);
+    xv[q] = ld4(a.xe1 + gr * 64 + cl); hv[q] = ld4(a.he + gr * 64 + cl);
+    mean[q] = a.st[gr * 2]; rstd[q] = a.st[gr * 2 + 1];
+  }
+  __syncthreads();
+  f4_t psh = {0.0f, 0.0f, 0.0f, 0.0f}, psc = psh, pg1 = psh;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = 8 * wave + 4 * q + sub;
+    const int64_t gr = g0 + row;
+    const int chn = j16 >> 3, ecn = (j16 & 7) * 4;
+    const f4_t dy = (ld4(&w.yf[row][cl]) + ld4(&w.stage[chn][row][ecn])) + ld4(&w.stage[2 + chn][row][ecn]);   // (zero beyond the tile)
+    const f4_t xh = (xv[q] - mean[q]) * rstd[q];
+    psh += dy;
+    psc += dy * xh;
+    const f4_t gg = dy * sc1, gx = gg * xh;
+    const float m1 = sum16((gg[0] + gg[1]) + (gg[2] + gg[3])) * (1.0f / 64.0f);
+    const float m2 = sum16((gx[0] + gx[1]) + (gx[2] + gx[3])) * (1.0f / 64.0f);
+    const f4_t dx = rstd[q] * (gg - m1 - xh * m2);
+    if (row < valid) {
+      pg1 += dx * hv[q];
+      st4(a.de_in + gr * 64 + cl, dx);
+      st4(a.dhe + gr * 64 + cl, g1 * dx);
+    }
+  }
+  // column sums: over the four 16-lane groups of a wave, then the waves in wave order
+  f4_t ps[4] = {pg2, psh, psc, pg1};
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = ps[v][e];
+      x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64);
+      ps[v][e] = x;
+    }
+  if (sub == 0) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) st4(&w.red[wave][64 * v + cl], ps[v]);
+  }
+  __syncthreads();
+  a.part[(int64_t)tile * 256 + threadIdx.x] = ((w.red[0][threadIdx.x] + w.red[1][threadIdx.x]) + w.red[2][threadIdx.x]) + w.red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_pair_bwd_finish(dst_pair_bwd_args a) {
+  const int m = blockIdx.x, t = threadIdx.x, v = t >> 6, c = t & 63;
+  float s = 0.0f;
+  for (int k = a.mol_tile_off[m]; k < a.mol_tile_off[m + 1]; ++k) s += a.part[(int64_t)k * 256 + t];
+  const int off = v == 0 ? a.gate2_off : v == 1 ? a.shift_off : v == 2 ? a.scale_off : a.gate1_off;
+  a.d_ada[(int64_t)m * a.ada_ld + off + c] = s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1028,6 +1229,30 @@ int dst_dir_chain_bwd(const dst_layout* L, const dst_dir_bwd_args* a, void* stre
     hipLaunchKernelGGL(k_dir_chain_bwd, dim3(a->n_tiles), dim3(CH_NT), lds, s, *L, *a);
   }
   hipLaunchKernelGGL(k_dir_bwd_finish, dim3(L->B), dim3(512), 0, s, *a);     // (molecules without pairs: zero sums)
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_pair_chain_bwd(const dst_layout* L, const dst_pair_bwd_args* a, void* stream) {
+  if (!L || !a || !a->tile_row0 || !a->tile_rows || !a->tile_mol || !a->mol_tile_off || !a->de || !a->dro || !a->ded || !a->f4 || !a->f3 || !a->xe1 || !a->st ||
+      !a->he || !a->ada || !a->d_ada || !a->WedT || !a->WroT || !a->W4T || !a->W3T || !a->dfeat || !a->df4 || !a->df3 || !a->de_in || !a->dhe || !a->part)
+    return DS_ERR_ARG;
+  if (L->B <= 0 || a->n_tiles < 0 || (a->ada_ld & 3) || (a->ld_dro & 3) || ((a->gate1_off | a->shift_off | a->scale_off | a->gate2_off) & 3) ||
+      !(a->drop_p >= 0.0f && a->drop_p < 1.0f))
+    return DS_ERR_ARG;
+  const void* ptrs[] = {a->de, a->dro, a->ded, a->f4, a->f3, a->xe1, a->he, a->ada, a->WedT, a->WroT, a->W4T, a->W3T, a->dfeat, a->df4, a->df3, a->de_in, a->dhe};
+  for (const void* p : ptrs)
+    if (reinterpret_cast<uintptr_t>(p) & 15) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->n_tiles > 0) {
+    static bool attr_done = false;
+    const size_t lds = sizeof(PairBwdLds);
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair_chain_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DS_ERR_LAUNCH;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(k_pair_chain_bwd, dim3(a->n_tiles), dim3(CH_NT), lds, s, *L, *a);
+  }
+  hipLaunchKernelGGL(k_pair_bwd_finish, dim3(L->B), dim3(256), 0, s, *a);
   return DST_CHECK_LAUNCH();
 }
 

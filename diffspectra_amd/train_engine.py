@@ -94,6 +94,8 @@ _GEMM_PACK = _GEMM_STRUCT.pack
 _CHAIN_PACK = _struct.Struct("@PPP PPPPq Pq iiii PPPPP q PPP f III Q PPPPPPPPPPP").pack
 # dst_pair_front_args: pos, ada, ada_ld | dist_off, shift_off, scale_off, pad | means stds e_in Wee bee Wte | X1 xs d2 e1 st en te
 _FRONT_PACK = _struct.Struct("@PPP PPq iiii PPPPPP PPPPPPP").pack
+# dst_pair_bwd_args: 4 tables, n_tiles | de dro ld_dro ded | f4 f3 xe1 st he | ada d_ada ada_ld | 4 offsets | WedT WroT W4T W3T | drop | seed | 6 outputs
+_PAIRB_PACK = _struct.Struct("@PPPPq PPqP PPPPP PPq iiii PPPP f III Q PPPPPP").pack
 # dst_dir_bwd_args: 4 tables, n_tiles | dc2 c0 zz st | ada d_ada ada_ld | shift_off scale_off | W2 W0T | dc0 dz part
 _DIRB_PACK = _struct.Struct("@PPPPq PPPP PPq ii PP PPP").pack
 # dst_node_chain_args: node_mol h_in attn | ada, ada_ld | 4 offsets | W1 b1 W2 b2 Wac Wn bn | drop_p, stream1, stream2, pad | seed | 9 outputs
@@ -348,6 +350,21 @@ class Ops:
         args = _DIR_PACK(*TL.pair_tables, ptr(ac), ptr(ed), ptr(ada), ADA, sh, sc, ptr(W0), ptr(b0), ptr(W2), *(ptr(out.get(k)) for k in ("zz", "st", "zn", "c0", "sc0", "c2")))
         E._check(self.lib.dst_dir_chain_fwd(C.byref(TL.c), args, self._s()), "dst_dir_chain_fwd")
 
+    def pair_chain_bwd(self, TL, de, dro, ld_dro, ded, f4, f3, xe1, st, he, ada, d_ada, g1, sh, sc, g2, WedT, WroT, W4T, W3T, drop, dfeat, df4, df3, de_in, dhe):
+        """Backward of the pair rows of a block behind the attention as one kernel + its finishing kernel (``dst_pair_chain_bwd``).  ``dro``: a
+        data pointer (the read-out slice's gradient is a column window of a wider tensor) with row stride ``ld_dro``; ``drop = (p, seed, stream3,
+        stream4)``."""
+        assert all(w_.dtype == torch.bfloat16 for w_ in (WedT, WroT, W4T, W3T))
+        tt = TL.pair_tiles
+        need = tt[4] * 256
+        if getattr(self, "_pairb_part", None) is None or self._pairb_part.numel() < need:
+            self._pairb_part = torch.empty(max(need, 1), dtype=torch.float32, device=self.dev)
+        dp_ = lambda t: t.data_ptr()
+        args = _PAIRB_PACK(tt[0], tt[1], tt[2], tt[3], tt[4], dp_(de), int(dro), ld_dro, dp_(ded), dp_(f4), dp_(f3), dp_(xe1), dp_(st), dp_(he), dp_(ada), dp_(d_ada), ADA,
+                           g1, sh, sc, g2, dp_(WedT), dp_(WroT), dp_(W4T), dp_(W3T), float(drop[0]), int(drop[2]), int(drop[3]), 0, int(drop[1]),
+                           dp_(dfeat), dp_(df4), dp_(df3), dp_(de_in), dp_(dhe), self._pairb_part.data_ptr())
+        E._check(self.lib.dst_pair_chain_bwd(C.byref(TL.c), args, self._s()), "dst_pair_chain_bwd")
+
     def dir_chain_bwd(self, TL, dc2, c0, zz, st, ada, d_ada, sh, sc, W2, W0T, dc0, dz):
         """Backward of the directed rows of a block as one kernel + its finishing kernel (``dst_dir_chain_bwd``)."""
         assert W0T.dtype == torch.bfloat16 and W2.dtype == torch.float32
@@ -415,17 +432,21 @@ class TrainLayout:
         # device tables of the flat-tile kernels (dst_pair_*_fwd, dst_dir_chain_fwd): node rows of a pair's atoms, its molecule
         self.pair_tables = (L.t["pair_a"].data_ptr(), L.t["pair_b"].data_ptr(), L.t["pair_mol"].data_ptr())
         self.node_mol_ptr = L.t["node_mol"].data_ptr()                     # [Nn] int32: molecule of a node row (dst_node_chain_fwd)
-        # molecule-aligned 32-row tiles of the DIRECTED rows (dst_dir_chain_bwd: its adaLN sums are per molecule)
+        # molecule-aligned 32-row tiles of the pair rows and of the DIRECTED rows (dst_pair_chain_bwd / dst_dir_chain_bwd: their adaLN sums are
+        # per molecule): (first row, row count, molecule) per tile, first tile per molecule, number of tiles
         po = L.t["pair_off"].cpu().numpy().astype(np.int64)
-        row0, rows, mol, off = [], [], [], [0]
-        for m in range(L.B):
-            nd, r0 = 2 * int(po[m + 1] - po[m]), 2 * int(po[m])
-            for k in range(0, nd, 32):
-                row0.append(r0 + k); rows.append(min(32, nd - k)); mol.append(m)
-            off.append(len(row0))
         i32 = lambda v: torch.tensor(v if len(v) else [0], dtype=torch.int32, device=device)
-        self._dir_tile_tensors = (i32(row0), i32(rows), i32(mol), i32(off))
-        self.dir_tiles = tuple(t.data_ptr() for t in self._dir_tile_tensors) + (len(row0),)
+        self._tile_tensors = []
+        for mul, name in ((1, "pair_tiles"), (2, "dir_tiles")):
+            row0, rows, mol, off = [], [], [], [0]
+            for m in range(L.B):
+                nr, r0 = mul * int(po[m + 1] - po[m]), mul * int(po[m])
+                for k in range(0, nr, 32):
+                    row0.append(r0 + k); rows.append(min(32, nr - k)); mol.append(m)
+                off.append(len(row0))
+            tens = (i32(row0), i32(rows), i32(mol), i32(off))
+            self._tile_tensors.append(tens)
+            setattr(self, name, tuple(t.data_ptr() for t in tens) + (len(row0),))
 
     def pack_nodes(self, dense: torch.Tensor) -> torch.Tensor:
         return dense.reshape(self.B * self.N, -1).index_select(0, self.node_dense).contiguous()
@@ -528,7 +549,8 @@ class DmtTrainGraph:
             # the fused row chains take their weights as bf16 (csrc/ds_train_chain.hip: the per-tile weight stream from L2 bounds them)
             if "wb" not in cache:
                 shapes = dict(W3=(128, 64), W4=(64, 128), Wed=(256, 128), Wro=(16, 64), Wee=(64, 128), Wte=(512, 64), W0=(256, 256), W2=(3, 256),
-                              F1=(512, 256), F2=(256, 512), Wac=(512, 256), Wn=(64, 256), W0T=(256, 256))
+                              F1=(512, 256), F2=(256, 512), Wac=(512, 256), Wn=(64, 256), W0T=(256, 256),
+                              WedT=(128, 256), WroT=(64, 16), W4T=(128, 64), W3T=(64, 128))
                 cache["wb"] = {n: torch.zeros(NB, *sh, dtype=torch.bfloat16, device=self.dev) for n, sh in shapes.items()}
             wb, p = cache["wb"], self.p
             dst, src, tset = [], [], set()
@@ -541,9 +563,12 @@ class DmtTrainGraph:
                              ("Wn", p[f"node_{i}.weight"])):
                     dst.append(wb[n][i])
                     src.append(t)
-                tset.add(len(dst))                                     # coord_mlp.0 transposed ([in][out]): the B operand of its input gradient
-                dst.append(wb["W0T"][i])
-                src.append(p[bp + "equi_update.coord_mlp.0.weight"])
+                # transposed copies ([in][out]): the B operands of the input-gradient products of the fused backward kernels
+                for n, t in (("W0T", p[bp + "equi_update.coord_mlp.0.weight"]), ("WedT", p[bp + "equi_update.input_lin.weight"][:, 512:640]),
+                             ("WroT", p[f"edge_{i}.weight"]), ("W4T", p[bp + "ff_linear4.weight"]), ("W3T", p[bp + "ff_linear3.weight"])):
+                    tset.add(len(dst))
+                    dst.append(wb[n][i])
+                    src.append(t)
             pack_bf16_pieces(self.lib, self.dev, dst, src, cache, "table_bf16", self.ops._s(), key_t=tset)
             self.wb = wb
         return cache
@@ -839,7 +864,8 @@ class DmtTrainGraph:
                 o.lin_bwd_w(drn, mv(bt["h_out"]), mv(gw(f"node_{i}.weight")), gw(f"node_{i}.bias"))
                 o.lin_bwd_x(drn, mv(p[f"node_{i}.weight"]), mv(dh), acc=True)
             o.lin_bwd_w(dre, mv(bt["e_out"]), mv(gw(f"edge_{i}.weight")), gw(f"edge_{i}.bias"))
-            o.lin_bwd_x(dre, mv(p[f"edge_{i}.weight"]), mv(de), acc=True)
+            if not fused_chain:                                  # (fused: inside dst_pair_chain_bwd)
+                o.lin_bwd_x(dre, mv(p[f"edge_{i}.weight"]), mv(de), acc=True)
             # equivariant update
             dpos_in, dc2 = self.f(Nn, 3), self.f(max(D, 1), 3)
             dsp, dms_buf = self.f(B), self.f(B, 128)          # per block: their column sums (parameter gradients) run on the side stream
@@ -881,20 +907,29 @@ class DmtTrainGraph:
                 o.gate_add_bwd(dx1, bt["attn"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 512, dh_in, False, dattn)
             # edge stream
             o.lin_bwd_w(mv(ded), mv(bt["X2"]), mv(dWin, 512, 640), gw(bp + "equi_update.input_lin.bias"))
-            o.lin_bwd_x(mv(ded), mv(Win, 512, 576), mv(de), acc=True)
-            dfeat2 = self.f(Pp, 64)
-            o.lin_bwd_x(mv(ded), mv(Win, 576, 640), mv(dfeat2))
-            dye1, df4 = self.f(Pp, 64), self.f(Pp, 64)
-            o.gate_add_bwd(de, bt["f4"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 320, dye1, False, df4, drop=(dp, dseed, 4 * i + 3))
-            o.lin_bwd_w(mv(df4), mv(bt["s3"]), mv(gw(bp + "ff_linear4.weight")), gw(bp + "ff_linear4.bias"))
-            df3 = self.f(Pp, 128)
-            o.lin_bwd_x(mv(df4), mv(p[bp + "ff_linear4.weight"]), mv(df3), dact=SILU, ref=mv(bt["f3"]), drop=(dp, dseed, 4 * i + 2, 128))
-            o.lin_bwd_w(mv(df3), mv(bt["ye1"]), mv(gw(bp + "ff_linear3.weight")), gw(bp + "ff_linear3.bias"))
-            o.lin_bwd_x(mv(df3), mv(p[bp + "ff_linear3.weight"]), mv(dye1), acc=True)
-            dxe1 = self.f(Pp, 64)
-            o.lnmod_bwd(dye1, bt["xe1"], bt["st_e2"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 192, a0 + EDGE_OFF + 256, dxe1, False)
-            de_in, dhe = self.f(Pp, 64), self.f(Pp, 64)
-            o.gate_add_bwd(dxe1, bt["he"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 128, de_in, False, dhe)
+            if fused_chain:
+                # the five input gradients, both gated residuals and the LayerNorm backward of the rear chain as ONE kernel (csrc/ds_train_chain.hip)
+                dfeat2, df4, df3, de_in, dhe = self.f(Pp, 64), self.f(Pp, 64), self.f(Pp, 128), self.f(Pp, 64), self.f(Pp, 64)
+                o.pair_chain_bwd(TL, de, dEH.data_ptr() + 4 * (64 + 16 * i), 192, ded, bt["f4"], bt["f3"], bt["xe1"], bt["st_e2"], bt["he"], ada, d_ada,
+                                 a0 + EDGE_OFF + 128, a0 + EDGE_OFF + 192, a0 + EDGE_OFF + 256, a0 + EDGE_OFF + 320, self.wb["WedT"][i], self.wb["WroT"][i],
+                                 self.wb["W4T"][i], self.wb["W3T"][i], (dp, dseed, 4 * i + 2, 4 * i + 3), dfeat2, df4, df3, de_in, dhe)
+                o.lin_bwd_w(mv(df4), mv(bt["s3"]), mv(gw(bp + "ff_linear4.weight")), gw(bp + "ff_linear4.bias"))
+                o.lin_bwd_w(mv(df3), mv(bt["ye1"]), mv(gw(bp + "ff_linear3.weight")), gw(bp + "ff_linear3.bias"))
+            else:
+                o.lin_bwd_x(mv(ded), mv(Win, 512, 576), mv(de), acc=True)
+                dfeat2 = self.f(Pp, 64)
+                o.lin_bwd_x(mv(ded), mv(Win, 576, 640), mv(dfeat2))
+                dye1, df4 = self.f(Pp, 64), self.f(Pp, 64)
+                o.gate_add_bwd(de, bt["f4"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 320, dye1, False, df4, drop=(dp, dseed, 4 * i + 3))
+                o.lin_bwd_w(mv(df4), mv(bt["s3"]), mv(gw(bp + "ff_linear4.weight")), gw(bp + "ff_linear4.bias"))
+                df3 = self.f(Pp, 128)
+                o.lin_bwd_x(mv(df4), mv(p[bp + "ff_linear4.weight"]), mv(df3), dact=SILU, ref=mv(bt["f3"]), drop=(dp, dseed, 4 * i + 2, 128))
+                o.lin_bwd_w(mv(df3), mv(bt["ye1"]), mv(gw(bp + "ff_linear3.weight")), gw(bp + "ff_linear3.bias"))
+                o.lin_bwd_x(mv(df3), mv(p[bp + "ff_linear3.weight"]), mv(dye1), acc=True)
+                dxe1 = self.f(Pp, 64)
+                o.lnmod_bwd(dye1, bt["xe1"], bt["st_e2"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 192, a0 + EDGE_OFF + 256, dxe1, False)
+                de_in, dhe = self.f(Pp, 64), self.f(Pp, 64)
+                o.gate_add_bwd(dxe1, bt["he"], 64, TL.pair_off, 1, B, ada, d_ada, a0 + EDGE_OFF + 128, de_in, False, dhe)
             # node2edge
             du = self.f(Nn, 64)
             E._check(lib.dst_pair_sum_bwd(C.byref(TL.c), E._ptr(dhe), C.c_int32(64), E._ptr(du), C.c_int32(0), s()), "dst_pair_sum_bwd")

@@ -350,6 +350,27 @@ typedef struct dst_dir_bwd_args {
 } dst_dir_bwd_args;
 int dst_dir_chain_bwd(const dst_layout* L, const dst_dir_bwd_args* a, void* stream);
 
+/* Backward of dst_pair_chain_fwd (the pair rows of a block behind the attention) as one kernel + a finishing kernel (bf16 products);
+ * replaces five input-gradient dst_gemm calls, 2 x dst_gate_add_bwd and dst_lnmod_bwd:
+ *   de_tot = de + dro Wro + ded Wed[:, 0:64];  dfeat = ded Wed[:, 64:128];  df4 = ada[gate2] de_tot (x dropout mask 4);
+ *   df3 = (df4 W4) SiLU'(f3) (x dropout mask 3);  dye1 = de_tot + df3 W3;  dxe1 = LN'(xe1, st; dye1 (1 + ada[scale]));
+ *   de_in = dxe1;  dhe = ada[gate1] dxe1;  d_ada[gate2] = sum de_tot f4, [shift] = sum dye1, [scale] = sum dye1 x^, [gate1] = sum dxe1 he.
+ * Molecule-aligned PAIR tiles (tile_row0 / tile_rows / tile_mol / mol_tile_off as in dst_dir_bwd_args).  de [Pp,64] = the gradient of e_out
+ * that arrives from the next block; dro [Pp,16] with row stride ld_dro = the gradient of the read-out slice; ded [Pp,256]; f4, f3, xe1, st, he:
+ * the forward's tape.  Weights TRANSPOSED as bf16 bits ([in][out]): WedT [128][256] (the e | dist columns of input_lin), WroT [64][16],
+ * W4T [128][64], W3T [64][128].  Outputs: dfeat [Pp,64], df4 [Pp,64], df3 [Pp,128], de_in [Pp,64], dhe [Pp,64]; the four 64-column slices of
+ * d_ada ASSIGNED; part = scratch of n_tiles * 256 floats. */
+typedef struct dst_pair_bwd_args {
+  const int32_t* tile_row0; const int32_t* tile_rows; const int32_t* tile_mol; const int32_t* mol_tile_off; int64_t n_tiles;
+  const float* de; const float* dro; int64_t ld_dro; const float* ded;
+  const float* f4; const float* f3; const float* xe1; const float* st; const float* he;
+  const float* ada; float* d_ada; int64_t ada_ld; int32_t gate1_off, shift_off, scale_off, gate2_off;
+  const uint16_t* WedT; const uint16_t* WroT; const uint16_t* W4T; const uint16_t* W3T;
+  float drop_p; uint32_t stream3, stream4, _pad; uint64_t seed;
+  float* dfeat; float* df4; float* df3; float* de_in; float* dhe; float* part;
+} dst_pair_bwd_args;
+int dst_pair_chain_bwd(const dst_layout* L, const dst_pair_bwd_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

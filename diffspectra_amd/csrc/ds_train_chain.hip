@@ -1131,6 +1131,223 @@ __global__ __launch_bounds__(256) void k_pair_bwd_finish(dst_pair_bwd_args a) {
   a.d_ada[(int64_t)m * a.ada_ld + off + c] = s;
 }
 
+// dst_node_chain_bwd: the backward of dst_node_chain_fwd (the node rows of a block behind the attention) as one kernel + a finishing kernel
+// instead of five dst_gemm input gradients, 2 x dst_gate_add_bwd and dst_lnmod_bwd on the node stream - the attention backward (main stream)
+// waits for the end of that chain:
+//   dh_tot = dh + drn Wn + dac Wac;  df2 = gate2 dh_tot (dropout mask 2);  df1 = (df2 W2) SiLU'(f1) (dropout mask 1);  dy1 = dh_tot + df1 W1
+//   dx1 = LayerNorm'(x1; dy1 (1 + scale));  dh_in = dx1;  dattn = gate1 dx1
+//   d_ada: gate2 = sum dh_tot f2, shift = sum dy1, scale = sum dy1 x^, gate1 = sum dx1 attn       (sums over the rows of a molecule)
+// Molecule-aligned tiles of <= 32 node rows, eight waves (a wave owns four rows of the row stages - a row = 64 lanes x float4 - and one or two
+// 32-column chunks of every product).  Weights TRANSPOSED as bf16 ([in][out]): WacT [256][512], WnT [256][64], W2T [512][256], W1T [256][512].
+struct NodeBwdLds {
+  float yf[32][LD_YF];             // dh_tot, then dy1
+  float stage[NC_NW][32][LD_ST];
+  __bf16 ab[32][LD_S2];            // dac, then df1, bf16 (then the waves' column sums, fp32 [8][1024])
+  __bf16 fb[32][LD_Z];             // df2, bf16
+  __bf16 rb[32][LD_Y];             // drn (64 columns), bf16
+};
+static_assert(sizeof(__bf16) * 32 * LD_S2 >= sizeof(float) * NC_NW * 1024, "the column sums alias the df1 tile");
+
+__global__ __launch_bounds__(NC_NT) void k_node_chain_bwd(dst_layout L, dst_node_bwd_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  NodeBwdLds& w = *reinterpret_cast<NodeBwdLds*>(lds_raw);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float (*stage)[LD_ST] = w.stage[wave];
+  const int tile = blockIdx.x;
+  const int64_t g0 = a.tile_row0[tile];
+  const int valid = a.tile_rows[tile], mol = a.tile_mol[tile];
+  const int64_t glast = g0 + valid - 1;
+  const unsigned int thr = dst::dropout_threshold(a.drop_p);
+  const float keep_scale = a.drop_p > 0.0f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const int er = lane >> 3, ec = (lane & 7) * 4, cl = lane * 4;
+  const float* adm = a.ada + (int64_t)mol * a.ada_ld;
+  WFrag<8> fa, fb;
+  wfetch<8>(fa, a.WacT, 512, 0, wave * 32, 256);
+  // ---- dac (32 x 512) and drn (32 x 64) as bf16 tiles: wave w rows 4 w .. 4 w + 3
+  {
+    f4_t dv[4][2], rv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t gr = min(g0 + 4 * wave + q, glast);
+      dv[q][0] = ld4(a.dac + gr * 512 + cl); dv[q][1] = ld4(a.dac + gr * 512 + 256 + cl);
+      rv[q] = lane < 16 ? ld4(a.drn + gr * a.ld_drn + cl) : f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 4 * wave + q;
+      if (row >= valid) { dv[q][0] = f4_t{0.0f, 0.0f, 0.0f, 0.0f}; dv[q][1] = dv[q][0]; rv[q] = dv[q][0]; }
+      *reinterpret_cast<bf16x4_t*>(&w.ab[row][cl]) = to_bf4(dv[q][0]);
+      *reinterpret_cast<bf16x4_t*>(&w.ab[row][256 + cl]) = to_bf4(dv[q][1]);
+      if (lane < 16) *reinterpret_cast<bf16x4_t*>(&w.rb[row][cl]) = to_bf4(rv[q]);
+    }
+  }
+  __syncthreads();
+  // ---- dh_tot = dh + dac Wac (512 -> 256) + drn Wn (64 -> 256): chunk `wave`
+  {
+    const int ch = wave;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    WFrag<4> fr;
+    wfetch<4>(fr, a.WnT, 64, 0, ch * 32, 256);
+    wfetch<8>(fb, a.WacT, 512, 128, ch * 32, 256);
+    mma_apply<8>(&w.ab[0][0], LD_S2, 0, fa, acc);
+    wfetch<8>(fa, a.WacT, 512, 256, ch * 32, 256);
+    mma_apply<8>(&w.ab[0][0], LD_S2, 128, fb, acc);
+    wfetch<8>(fb, a.WacT, 512, 384, ch * 32, 256);
+    mma_apply<8>(&w.ab[0][0], LD_S2, 256, fa, acc);
+    f4_t dhv[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) dhv[it] = ld4(a.dh + min(g0 + it * 8 + er, glast) * 256 + ch * 32 + ec);
+    mma_apply<8>(&w.ab[0][0], LD_S2, 384, fb, acc);
+    mma_apply<4>(&w.rb[0][0], LD_Y, 0, fr, acc);
+    wfetch<8>(fa, a.W2T, 256, 0, wave * 32, 512);              // ff_linear2's input gradient, first chunk
+    acc_to_stage(acc, stage);
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + er;
+      const f4_t v = ld4(&stage[row][ec]);
+      st4(&w.yf[row][ch * 32 + ec], row < valid ? v + dhv[it] : f4_t{0.0f, 0.0f, 0.0f, 0.0f});
+    }
+  }
+  const f4_t g2 = ld4(adm + a.gate2_off + cl);
+  f4_t f2v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) f2v[q] = ld4(a.f2 + min(g0 + 4 * wave + q, glast) * 256 + cl);
+  __syncthreads();
+  // ---- gated residual of the FF: df2 = gate2 dh_tot (dropout mask 2); wave w rows 4 w .. 4 w + 3
+  f4_t pg2 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = 4 * wave + q;
+    const int64_t gr = g0 + row;
+    const f4_t d = ld4(&w.yf[row][cl]);
+    pg2 += d * f2v[q];
+    f4_t o = g2 * d;
+    if (a.drop_p > 0.0f) {
+      unsigned int c[4];
+      dst::dropout_block(a.seed, a.stream2, (gr * 256 + cl) >> 2, c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = c[e] >= thr ? o[e] * keep_scale : 0.0f;
+    }
+    if (row < valid) st4(a.df2 + gr * 256 + cl, o);
+    else o = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    *reinterpret_cast<bf16x4_t*>(&w.fb[row][cl]) = to_bf4(o);
+  }
+  __syncthreads();
+  // ---- df1 = (df2 W2) SiLU'(f1), dropout mask 1 (256 -> 512): chunks wave, wave + 8 (the df1 tile takes dac's bytes)
+#pragma unroll 1
+  for (int k = 0; k < 2; ++k) {
+    const int ch = wave + 8 * k;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    wfetch<8>(fb, a.W2T, 256, 128, ch * 32, 512);
+    mma_apply<8>(&w.fb[0][0], LD_Z, 0, fa, acc);
+    mma_apply<8>(&w.fb[0][0], LD_Z, 128, fb, acc);
+    f4_t f1v[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) f1v[it] = ld4(a.f1 + min(g0 + it * 8 + er, glast) * 512 + ch * 32 + ec);
+    if (k == 0) wfetch<8>(fa, a.W2T, 256, 0, (ch + 8) * 32, 512);
+    else wfetch<8>(fa, a.W1T, 512, 0, wave * 32, 256);         // ff_linear1's input gradient, first k-quarter
+    acc_to_stage(acc, stage);
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + er, col = ch * 32 + ec;
+      const int64_t gr = g0 + row;
+      f4_t v = ld4(&stage[row][ec]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= fast_silu_deriv(f1v[it][e]);
+      if (a.drop_p > 0.0f) {
+        unsigned int c[4];
+        dst::dropout_block(a.seed, a.stream1, (gr * 512 + col) >> 2, c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = c[e] >= thr ? v[e] * keep_scale : 0.0f;
+      }
+      if (row < valid) st4(a.df1 + gr * 512 + col, v);
+      else v = f4_t{0.0f, 0.0f, 0.0f, 0.0f};
+      *reinterpret_cast<bf16x4_t*>(&w.ab[row][col]) = to_bf4(v);
+    }
+    wave_lds_sync();
+  }
+  __syncthreads();
+  // ---- dy1 = dh_tot + df1 W1 (512 -> 256): chunk `wave`, added into the fp32 tile (a wave owns its 32 columns)
+  {
+    const int ch = wave;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    wfetch<8>(fb, a.W1T, 512, 128, ch * 32, 256);
+    mma_apply<8>(&w.ab[0][0], LD_S2, 0, fa, acc);
+    wfetch<8>(fa, a.W1T, 512, 256, ch * 32, 256);
+    mma_apply<8>(&w.ab[0][0], LD_S2, 128, fb, acc);
+    wfetch<8>(fb, a.W1T, 512, 384, ch * 32, 256);
+    mma_apply<8>(&w.ab[0][0], LD_S2, 256, fa, acc);
+    mma_apply<8>(&w.ab[0][0], LD_S2, 384, fb, acc);
+    acc_to_stage(acc, stage);
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + er;
+      float* y = &w.yf[row][ch * 32 + ec];
+      st4(y, ld4(y) + ld4(&stage[row][ec]));
+    }
+  }
+  // operands of the LayerNorm / gate stage: before the barrier
+  const f4_t sc1 = ld4(adm + a.scale_off + cl) + 1.0f, g1 = ld4(adm + a.gate1_off + cl);
+  f4_t xv[4], av[4];
+  float mean[4], rstd[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t gr = min(g0 + 4 * wave + q, glast);
+    xv[q] = ld4(a.x1 + gr * 256 + cl); av[q] = ld4(a.attn + gr * 256 + cl);
+    mean[q] = a.st[gr * 2]; rstd[q] = a.st[gr * 2 + 1];
+  }
+  __syncthreads();
+  f4_t psh = {0.0f, 0.0f, 0.0f, 0.0f}, psc = psh, pg1 = psh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = 4 * wave + q;
+    const int64_t gr = g0 + row;
+    const f4_t dy = ld4(&w.yf[row][cl]);                       // (zero beyond the tile)
+    const f4_t xh = (xv[q] - mean[q]) * rstd[q];
+    psh += dy;
+    psc += dy * xh;
+    const f4_t gg = dy * sc1, gx = gg * xh;
+    const float m1 = sum64((gg[0] + gg[1]) + (gg[2] + gg[3])) * (1.0f / 256.0f);
+    const float m2 = sum64((gx[0] + gx[1]) + (gx[2] + gx[3])) * (1.0f / 256.0f);
+    const f4_t dx = rstd[q] * (gg - m1 - xh * m2);
+    if (row < valid) {
+      pg1 += dx * av[q];
+      st4(a.dh_in + gr * 256 + cl, dx);
+      st4(a.dattn + gr * 256 + cl, g1 * dx);
+    }
+  }
+  // column sums: a lane owns its four columns over the wave's four rows; the waves are added in wave order (the sums take the df1 tile's bytes:
+  // its last readers, the MFMAs above, finished before the barrier)
+  float* red = reinterpret_cast<float*>(&w.ab[0][0]);
+  st4(red + wave * 1024 + cl, pg2); st4(red + wave * 1024 + 256 + cl, psh);
+  st4(red + wave * 1024 + 512 + cl, psc); st4(red + wave * 1024 + 768 + cl, pg1);
+  __syncthreads();
+#pragma unroll
+  for (int t = threadIdx.x; t < 1024; t += NC_NT) {
+    float s_ = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NC_NW; ++k) s_ += red[k * 1024 + t];
+    a.part[(int64_t)tile * 1024 + t] = s_;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_node_bwd_finish(dst_node_bwd_args a) {
+  const int m = blockIdx.x, t = threadIdx.x, v = t >> 8, c = t & 255;
+  float s = 0.0f;
+  for (int k = a.mol_tile_off[m]; k < a.mol_tile_off[m + 1]; ++k) s += a.part[(int64_t)k * 1024 + t];
+  const int off = v == 0 ? a.gate2_off : v == 1 ? a.shift_off : v == 2 ? a.scale_off : a.gate1_off;
+  a.d_ada[(int64_t)m * a.ada_ld + off + c] = s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1253,6 +1470,30 @@ int dst_pair_chain_bwd(const dst_layout* L, const dst_pair_bwd_args* a, void* st
     hipLaunchKernelGGL(k_pair_chain_bwd, dim3(a->n_tiles), dim3(CH_NT), lds, s, *L, *a);
   }
   hipLaunchKernelGGL(k_pair_bwd_finish, dim3(L->B), dim3(256), 0, s, *a);
+  return DST_CHECK_LAUNCH();
+}
+
+int dst_node_chain_bwd(const dst_layout* L, const dst_node_bwd_args* a, void* stream) {
+  if (!L || !a || !a->tile_row0 || !a->tile_rows || !a->tile_mol || !a->mol_tile_off || !a->dh || !a->drn || !a->dac || !a->f2 || !a->f1 || !a->x1 || !a->st ||
+      !a->attn || !a->ada || !a->d_ada || !a->WacT || !a->WnT || !a->W2T || !a->W1T || !a->df2 || !a->df1 || !a->dh_in || !a->dattn || !a->part)
+    return DS_ERR_ARG;
+  if (L->B <= 0 || a->n_tiles < 0 || (a->ada_ld & 3) || (a->ld_drn & 3) || ((a->gate1_off | a->shift_off | a->scale_off | a->gate2_off) & 3) ||
+      !(a->drop_p >= 0.0f && a->drop_p < 1.0f))
+    return DS_ERR_ARG;
+  const void* ptrs[] = {a->dh, a->drn, a->dac, a->f2, a->f1, a->x1, a->attn, a->ada, a->WacT, a->WnT, a->W2T, a->W1T, a->df2, a->df1, a->dh_in, a->dattn};
+  for (const void* p : ptrs)
+    if (reinterpret_cast<uintptr_t>(p) & 15) return DS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->n_tiles > 0) {
+    static bool attr_done = false;
+    const size_t lds = sizeof(NodeBwdLds);
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node_chain_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DS_ERR_LAUNCH;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(k_node_chain_bwd, dim3(a->n_tiles), dim3(NC_NT), lds, s, *L, *a);
+  }
+  hipLaunchKernelGGL(k_node_bwd_finish, dim3(L->B), dim3(1024), 0, s, *a);
   return DST_CHECK_LAUNCH();
 }
 

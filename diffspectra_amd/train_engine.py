@@ -94,6 +94,8 @@ _GEMM_PACK = _GEMM_STRUCT.pack
 _CHAIN_PACK = _struct.Struct("@PPP PPPPq Pq iiii PPPPP q PPP f III Q PPPPPPPPPPP").pack
 # dst_pair_front_args: pos, ada, ada_ld | dist_off, shift_off, scale_off, pad | means stds e_in Wee bee Wte | X1 xs d2 e1 st en te
 _FRONT_PACK = _struct.Struct("@PPP PPq iiii PPPPPP PPPPPPP").pack
+# dst_node_bwd_args: 4 tables, n_tiles | dh drn ld_drn dac | f2 f1 x1 st attn | ada d_ada ada_ld | 4 offsets | WacT WnT W2T W1T | drop | seed | 5 outputs
+_NODEB_PACK = _struct.Struct("@PPPPq PPqP PPPPP PPq iiii PPPP f III Q PPPPP").pack
 # dst_pair_bwd_args: 4 tables, n_tiles | de dro ld_dro ded | f4 f3 xe1 st he | ada d_ada ada_ld | 4 offsets | WedT WroT W4T W3T | drop | seed | 6 outputs
 _PAIRB_PACK = _struct.Struct("@PPPPq PPqP PPPPP PPq iiii PPPP f III Q PPPPPP").pack
 # dst_dir_bwd_args: 4 tables, n_tiles | dc2 c0 zz st | ada d_ada ada_ld | shift_off scale_off | W2 W0T | dc0 dz part
@@ -365,6 +367,21 @@ class Ops:
                            dp_(dfeat), dp_(df4), dp_(df3), dp_(de_in), dp_(dhe), self._pairb_part.data_ptr())
         E._check(self.lib.dst_pair_chain_bwd(C.byref(TL.c), args, self._s()), "dst_pair_chain_bwd")
 
+    def node_chain_bwd(self, TL, dh, drn, ld_drn, dac, f2, f1, x1, st, attn, ada, d_ada, g1, sh, sc, g2, WacT, WnT, W2T, W1T, drop, df2, df1, dh_in, dattn):
+        """Backward of the node rows of a block behind the attention as one kernel + its finishing kernel (``dst_node_chain_bwd``).  ``drn``: a data
+        pointer with row stride ``ld_drn``; ``drop = (p, seed, stream1, stream2)``."""
+        assert all(w_.dtype == torch.bfloat16 for w_ in (WacT, WnT, W2T, W1T))
+        tt = TL.node_tiles
+        need = tt[4] * 1024
+        part = getattr(self, "_nodeb_part", None)
+        if part is None or part.numel() < need:
+            part = self._nodeb_part = torch.empty(max(need, 1), dtype=torch.float32, device=self.dev)
+        dp_ = lambda t: t.data_ptr()
+        args = _NODEB_PACK(tt[0], tt[1], tt[2], tt[3], tt[4], dp_(dh), int(drn), ld_drn, dp_(dac), dp_(f2), dp_(f1), dp_(x1), dp_(st), dp_(attn), dp_(ada), dp_(d_ada), ADA,
+                           g1, sh, sc, g2, dp_(WacT), dp_(WnT), dp_(W2T), dp_(W1T), float(drop[0]), int(drop[2]), int(drop[3]), 0, int(drop[1]),
+                           dp_(df2), dp_(df1), dp_(dh_in), dp_(dattn), part.data_ptr())
+        E._check(self.lib.dst_node_chain_bwd(C.byref(TL.c), args, self._s()), "dst_node_chain_bwd")
+
     def dir_chain_bwd(self, TL, dc2, c0, zz, st, ada, d_ada, sh, sc, W2, W0T, dc0, dz):
         """Backward of the directed rows of a block as one kernel + its finishing kernel (``dst_dir_chain_bwd``)."""
         assert W0T.dtype == torch.bfloat16 and W2.dtype == torch.float32
@@ -432,15 +449,16 @@ class TrainLayout:
         # device tables of the flat-tile kernels (dst_pair_*_fwd, dst_dir_chain_fwd): node rows of a pair's atoms, its molecule
         self.pair_tables = (L.t["pair_a"].data_ptr(), L.t["pair_b"].data_ptr(), L.t["pair_mol"].data_ptr())
         self.node_mol_ptr = L.t["node_mol"].data_ptr()                     # [Nn] int32: molecule of a node row (dst_node_chain_fwd)
-        # molecule-aligned 32-row tiles of the pair rows and of the DIRECTED rows (dst_pair_chain_bwd / dst_dir_chain_bwd: their adaLN sums are
-        # per molecule): (first row, row count, molecule) per tile, first tile per molecule, number of tiles
+        # molecule-aligned 32-row tiles of the pair rows, the DIRECTED rows and the node rows (dst_pair_chain_bwd / dst_dir_chain_bwd /
+        # dst_node_chain_bwd: their adaLN sums are per molecule): (first row, row count, molecule) per tile, first tile per molecule, number of tiles
         po = L.t["pair_off"].cpu().numpy().astype(np.int64)
         i32 = lambda v: torch.tensor(v if len(v) else [0], dtype=torch.int32, device=device)
         self._tile_tensors = []
-        for mul, name in ((1, "pair_tiles"), (2, "dir_tiles")):
+        no = L.t["node_off"].cpu().numpy().astype(np.int64)
+        for mul, name in ((1, "pair_tiles"), (2, "dir_tiles"), (0, "node_tiles")):
             row0, rows, mol, off = [], [], [], [0]
             for m in range(L.B):
-                nr, r0 = mul * int(po[m + 1] - po[m]), mul * int(po[m])
+                nr, r0 = (mul * int(po[m + 1] - po[m]), mul * int(po[m])) if mul else (int(no[m + 1] - no[m]), int(no[m]))
                 for k in range(0, nr, 32):
                     row0.append(r0 + k); rows.append(min(32, nr - k)); mol.append(m)
                 off.append(len(row0))
@@ -550,7 +568,7 @@ class DmtTrainGraph:
             if "wb" not in cache:
                 shapes = dict(W3=(128, 64), W4=(64, 128), Wed=(256, 128), Wro=(16, 64), Wee=(64, 128), Wte=(512, 64), W0=(256, 256), W2=(3, 256),
                               F1=(512, 256), F2=(256, 512), Wac=(512, 256), Wn=(64, 256), W0T=(256, 256),
-                              WedT=(128, 256), WroT=(64, 16), W4T=(128, 64), W3T=(64, 128))
+                              WedT=(128, 256), WroT=(64, 16), W4T=(128, 64), W3T=(64, 128), WacT=(256, 512), WnT=(256, 64), F2T=(512, 256), F1T=(256, 512))
                 cache["wb"] = {n: torch.zeros(NB, *sh, dtype=torch.bfloat16, device=self.dev) for n, sh in shapes.items()}
             wb, p = cache["wb"], self.p
             dst, src, tset = [], [], set()
@@ -565,7 +583,9 @@ class DmtTrainGraph:
                     src.append(t)
                 # transposed copies ([in][out]): the B operands of the input-gradient products of the fused backward kernels
                 for n, t in (("W0T", p[bp + "equi_update.coord_mlp.0.weight"]), ("WedT", p[bp + "equi_update.input_lin.weight"][:, 512:640]),
-                             ("WroT", p[f"edge_{i}.weight"]), ("W4T", p[bp + "ff_linear4.weight"]), ("W3T", p[bp + "ff_linear3.weight"])):
+                             ("WroT", p[f"edge_{i}.weight"]), ("W4T", p[bp + "ff_linear4.weight"]), ("W3T", p[bp + "ff_linear3.weight"]),
+                             ("WacT", cache["bufs"]["Wac"][i]), ("WnT", p[f"node_{i}.weight"]), ("F2T", p[bp + "ff_linear2.weight"]),
+                             ("F1T", p[bp + "ff_linear1.weight"])):
                     tset.add(len(dst))
                     dst.append(wb[n][i])
                     src.append(t)
@@ -862,7 +882,8 @@ class DmtTrainGraph:
             drn, dre = mv(dAH, 256 + 64 * i, 256 + 64 * (i + 1)), mv(dEH, 64 + 16 * i, 64 + 16 * (i + 1))
             with sec():
                 o.lin_bwd_w(drn, mv(bt["h_out"]), mv(gw(f"node_{i}.weight")), gw(f"node_{i}.bias"))
-                o.lin_bwd_x(drn, mv(p[f"node_{i}.weight"]), mv(dh), acc=True)
+                if not fused_chain:                              # (fused: inside dst_node_chain_bwd)
+                    o.lin_bwd_x(drn, mv(p[f"node_{i}.weight"]), mv(dh), acc=True)
             o.lin_bwd_w(dre, mv(bt["e_out"]), mv(gw(f"edge_{i}.weight")), gw(f"edge_{i}.bias"))
             if not fused_chain:                                  # (fused: inside dst_pair_chain_bwd)
                 o.lin_bwd_x(dre, mv(p[f"edge_{i}.weight"]), mv(de), acc=True)
@@ -893,18 +914,27 @@ class DmtTrainGraph:
             # node stream (the section waits for dac)
             with sec():
                 o.lin_bwd_w(mv(dac), mv(bt["h_out"]), mv(dcat["Wac"][i]))           # both node parts at once; scattered into dWin[:, 0:512] at the end
-                o.lin_bwd_x(mv(dac), mv(cat["Wac"][i]), mv(dh), acc=True)
-                dy1, df2 = self.f(Nn, 256), self.f(Nn, 256)
-                o.gate_add_bwd(dh, bt["f2"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 1280, dy1, False, df2, drop=(dp, dseed, 4 * i + 1))
-                o.lin_bwd_w(mv(df2), mv(bt["s1"]), mv(gw(bp + "ff_linear2.weight")), gw(bp + "ff_linear2.bias"))
-                df1 = self.f(Nn, 512)
-                o.lin_bwd_x(mv(df2), mv(p[bp + "ff_linear2.weight"]), mv(df1), dact=SILU, ref=mv(bt["f1"]), drop=(dp, dseed, 4 * i + 0, 512))
-                o.lin_bwd_w(mv(df1), mv(bt["y1"]), mv(gw(bp + "ff_linear1.weight")), gw(bp + "ff_linear1.bias"))
-                o.lin_bwd_x(mv(df1), mv(p[bp + "ff_linear1.weight"]), mv(dy1), acc=True)
-                dx1 = self.f(Nn, 256)
-                o.lnmod_bwd(dy1, bt["x1"], bt["st_n2"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 768, a0 + NODE_OFF + 1024, dx1, False)
-                dh_in, dattn = self.f(Nn, 256), self.f(Nn, 256)
-                o.gate_add_bwd(dx1, bt["attn"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 512, dh_in, False, dattn)
+                if fused_chain:
+                    # the five input gradients, both gated residuals and the LayerNorm backward of the node chain as ONE kernel (csrc/ds_train_chain.hip)
+                    df2, df1, dh_in, dattn = self.f(Nn, 256), self.f(Nn, 512), self.f(Nn, 256), self.f(Nn, 256)
+                    o.node_chain_bwd(TL, dh, dAH.data_ptr() + 4 * (256 + 64 * i), 768, dac, bt["f2"], bt["f1"], bt["x1"], bt["st_n2"], bt["attn"], ada, d_ada,
+                                     a0 + NODE_OFF + 512, a0 + NODE_OFF + 768, a0 + NODE_OFF + 1024, a0 + NODE_OFF + 1280, self.wb["WacT"][i], self.wb["WnT"][i],
+                                     self.wb["F2T"][i], self.wb["F1T"][i], (dp, dseed, 4 * i + 0, 4 * i + 1), df2, df1, dh_in, dattn)
+                    o.lin_bwd_w(mv(df2), mv(bt["s1"]), mv(gw(bp + "ff_linear2.weight")), gw(bp + "ff_linear2.bias"))
+                    o.lin_bwd_w(mv(df1), mv(bt["y1"]), mv(gw(bp + "ff_linear1.weight")), gw(bp + "ff_linear1.bias"))
+                else:
+                    o.lin_bwd_x(mv(dac), mv(cat["Wac"][i]), mv(dh), acc=True)
+                    dy1, df2 = self.f(Nn, 256), self.f(Nn, 256)
+                    o.gate_add_bwd(dh, bt["f2"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 1280, dy1, False, df2, drop=(dp, dseed, 4 * i + 1))
+                    o.lin_bwd_w(mv(df2), mv(bt["s1"]), mv(gw(bp + "ff_linear2.weight")), gw(bp + "ff_linear2.bias"))
+                    df1 = self.f(Nn, 512)
+                    o.lin_bwd_x(mv(df2), mv(p[bp + "ff_linear2.weight"]), mv(df1), dact=SILU, ref=mv(bt["f1"]), drop=(dp, dseed, 4 * i + 0, 512))
+                    o.lin_bwd_w(mv(df1), mv(bt["y1"]), mv(gw(bp + "ff_linear1.weight")), gw(bp + "ff_linear1.bias"))
+                    o.lin_bwd_x(mv(df1), mv(p[bp + "ff_linear1.weight"]), mv(dy1), acc=True)
+                    dx1 = self.f(Nn, 256)
+                    o.lnmod_bwd(dy1, bt["x1"], bt["st_n2"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 768, a0 + NODE_OFF + 1024, dx1, False)
+                    dh_in, dattn = self.f(Nn, 256), self.f(Nn, 256)
+                    o.gate_add_bwd(dx1, bt["attn"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 512, dh_in, False, dattn)
             # edge stream
             o.lin_bwd_w(mv(ded), mv(bt["X2"]), mv(dWin, 512, 640), gw(bp + "equi_update.input_lin.bias"))
             if fused_chain:

@@ -371,6 +371,26 @@ typedef struct dst_pair_bwd_args {
 } dst_pair_bwd_args;
 int dst_pair_chain_bwd(const dst_layout* L, const dst_pair_bwd_args* a, void* stream);
 
+/* Backward of dst_node_chain_fwd (the node rows of a block behind the attention) as one kernel + a finishing kernel (bf16 products);
+ * replaces five input-gradient dst_gemm calls, 2 x dst_gate_add_bwd and dst_lnmod_bwd:
+ *   dh_tot = dh + drn Wn + dac Wac;  df2 = ada[gate2] dh_tot (x dropout mask 2);  df1 = (df2 W2) SiLU'(f1) (x dropout mask 1);
+ *   dy1 = dh_tot + df1 W1;  dx1 = LN'(x1, st; dy1 (1 + ada[scale]));  dh_in = dx1;  dattn = ada[gate1] dx1;
+ *   d_ada[gate2] = sum dh_tot f2, [shift] = sum dy1, [scale] = sum dy1 x^, [gate1] = sum dx1 attn   (256 columns each, ASSIGNED).
+ * Molecule-aligned NODE tiles (tile tables as in dst_dir_bwd_args).  dh [Nn,256] = the gradient of h_out from the next block; drn [Nn,64] with
+ * row stride ld_drn = the gradient of the read-out slice; dac [Nn,512]; f2, f1, x1, st, attn: the forward's tape.  Weights TRANSPOSED as bf16
+ * bits ([in][out]): WacT [256][512], WnT [256][64], W2T [512][256], W1T [256][512].  Outputs: df2 [Nn,256], df1 [Nn,512], dh_in, dattn
+ * [Nn,256]; part = scratch of n_tiles * 1024 floats. */
+typedef struct dst_node_bwd_args {
+  const int32_t* tile_row0; const int32_t* tile_rows; const int32_t* tile_mol; const int32_t* mol_tile_off; int64_t n_tiles;
+  const float* dh; const float* drn; int64_t ld_drn; const float* dac;
+  const float* f2; const float* f1; const float* x1; const float* st; const float* attn;
+  const float* ada; float* d_ada; int64_t ada_ld; int32_t gate1_off, shift_off, scale_off, gate2_off;
+  const uint16_t* WacT; const uint16_t* WnT; const uint16_t* W2T; const uint16_t* W1T;
+  float drop_p; uint32_t stream1, stream2, _pad; uint64_t seed;
+  float* df2; float* df1; float* dh_in; float* dattn; float* part;
+} dst_node_bwd_args;
+int dst_node_chain_bwd(const dst_layout* L, const dst_node_bwd_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -790,8 +790,7 @@ __global__ __launch_bounds__(NC_NT) void k_node_chain_fwd(dst_layout L, dst_node
 // W2 [3,256] fp32 (K = 3: plain FMAs, as the K <= 8 GEMM kernel); W0T = W0 transposed as bf16 ([in][out]: the B fragment of dc0 W0 is eight
 // consecutive `out` of one `in`).  dc0 and dz go to global memory (the weight-gradient product of coord_mlp.0 and dst_zbuild_bwd read them).
 struct DirBwdLds {
-  float zf[32][LD_YF];             // dzn, fp32: the LayerNorm backward reads whole rows
-  float red[CH_NW][512];           // the waves' column sums (shift | scale)
+  float zf[32][LD_YF];             // dzn, fp32: the LayerNorm backward reads whole rows; then the column sums [wave][group][512]
   float d2[32][4];                 // dc2 of the tile's rows
   __bf16 db[32][LD_Z];             // dc0, bf16: A operand of dc0 W0
 };
@@ -904,23 +903,23 @@ __global__ __launch_bounds__(CH_NT, 2) void k_dir_chain_bwd(dst_layout L, dst_di
       for (int u = 0; u < 4; ++u) st4(a.dz + (g0 + row) * 256 + 64 * u + 4 * j16, rstd[q] * (g[u] - m1 - xh[u] * m2));
     }
   }
-  // column sums of the wave's eight rows: over the four 16-lane groups, then the waves in wave order
+  // column sums of the wave's eight rows: the four 16-lane groups and the four waves through LDS, added in (wave, group) order (the fp32 dzn
+  // tile is dead: every wave has read its rows).  Not with xor-16 / xor-32 shuffles: see k_pair_chain_bwd.
+  __syncthreads();
+  {
+    float* red = &w.zf[0][0] + (wave * 4 + sub) * 512;        // [wave][group][shift 256 | scale 256]
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float x = psh[u][e], y = psc[u][e];
-      x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64);
-      y += __shfl_xor(y, 16, 64); y += __shfl_xor(y, 32, 64);
-      psh[u][e] = x; psc[u][e] = y;
-    }
-  if (sub == 0) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { st4(&w.red[wave][64 * u + 4 * j16], psh[u]); st4(&w.red[wave][256 + 64 * u + 4 * j16], psc[u]); }
+    for (int u = 0; u < 4; ++u) { st4(red + 64 * u + 4 * j16, psh[u]); st4(red + 256 + 64 * u + 4 * j16, psc[u]); }
   }
   __syncthreads();
 #pragma unroll
-  for (int t = threadIdx.x; t < 512; t += CH_NT) a.part[(int64_t)tile * 512 + t] = ((w.red[0][t] + w.red[1][t]) + w.red[2][t]) + w.red[3][t];
+  for (int t = threadIdx.x; t < 512; t += CH_NT) {
+    const float* red = &w.zf[0][0];
+    float s_ = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s_ += red[k * 512 + t];
+    a.part[(int64_t)tile * 512 + t] = s_;
+  }
 }
 
 __global__ __launch_bounds__(512) void k_dir_bwd_finish(dst_dir_bwd_args a) {
@@ -941,7 +940,7 @@ __global__ __launch_bounds__(512) void k_dir_bwd_finish(dst_dir_bwd_args a) {
 struct PairBwdLds {
   float yf[32][LD_F];              // de_tot, the base of dye1
   float stage[CH_NW][32][LD_ST];
-  float red[CH_NW][256];           // the waves' column sums (gate2 | shift | scale | gate1)
+  float red[CH_NW * 4][256];       // the column sums of every (wave, 16-lane group): gate2 | shift | scale | gate1
   __bf16 eb[32][LD_Z];             // ded, bf16
   __bf16 rb[32][24];               // dro (16 columns), bf16
   __bf16 fb[32][LD_Y];             // df4, bf16
@@ -1105,22 +1104,20 @@ __global__ __launch_bounds__(CH_NT, 2) void k_pair_chain_bwd(dst_layout L, dst_p
       st4(a.dhe + gr * 64 + cl, g1 * dx);
     }
   }
-  // column sums: over the four 16-lane groups of a wave, then the waves in wave order
-  f4_t ps[4] = {pg2, psh, psc, pg1};
-#pragma unroll
-  for (int v = 0; v < 4; ++v)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float x = ps[v][e];
-      x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64);
-      ps[v][e] = x;
-    }
-  if (sub == 0) {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) st4(&w.red[wave][64 * v + cl], ps[v]);
+  // column sums: the four 16-lane groups and the four waves through LDS, added in (wave, group) order.  (Not with xor-16 / xor-32 shuffles: 32
+  // ds_bpermute in flight per wave gave results that differed from run to run while other kernels shared the CU - profiles/HISTORY.md, round 5.)
+  {
+    float* red = &w.red[0][0] + (wave * 4 + sub) * 256;        // [wave][group][gate2 | shift | scale | gate1]
+    st4(red + cl, pg2); st4(red + 64 + cl, psh); st4(red + 128 + cl, psc); st4(red + 192 + cl, pg1);
   }
   __syncthreads();
-  a.part[(int64_t)tile * 256 + threadIdx.x] = ((w.red[0][threadIdx.x] + w.red[1][threadIdx.x]) + w.red[2][threadIdx.x]) + w.red[3][threadIdx.x];
+  {
+    const float* red = &w.red[0][0];
+    float s_ = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s_ += red[k * 256 + threadIdx.x];
+    a.part[(int64_t)tile * 256 + threadIdx.x] = s_;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_pair_bwd_finish(dst_pair_bwd_args a) {

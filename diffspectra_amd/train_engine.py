@@ -181,6 +181,9 @@ class Ops:
         self.stream_ptr = None
         self._side = None
         self._side_scratch = None
+        self._sides = []           # the weight-gradient streams (DIFFSPECTRA_DW_STREAMS of them, round-robin), each with its split-K scratch
+        self._side_of = {}         # output pointer -> stream index: products that accumulate into the same gradient stay on one stream, in order
+        self._side_next = 0
         self._dw_keep = []
 
     def _s(self):
@@ -226,7 +229,7 @@ class Ops:
         they go there, like ``lin_bwd_w``; X must then not be overwritten before ``join_dw``."""
         assert out.numel() == X.cols
         if param_grad and self.async_dw:
-            self._to_side(X.t, out)
+            self._to_side(X.t, out, out=out)
             saved = (self.scratch, self.stream_ptr)
             self.scratch, self.stream_ptr = self._side_scratch, C.c_void_p(self._side.cuda_stream)
             try:
@@ -236,11 +239,22 @@ class Ops:
         E._check(self.lib.dst_colsum(C.c_void_p(X.ptr), C.c_int64(X.ld), C.c_int32(X.rows), C.c_int32(X.cols), E._ptr(out), C.c_int32(int(acc)),
                                      E._ptr(self.scratch), C.c_int64(self.scratch.numel()), self._s()), "dst_colsum")
 
-    def _to_side(self, *keep):
-        """The side stream waits for the stream the operands were produced on (main, or the node stream inside a node section)."""
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.dev)
-            self._side_scratch = torch.empty_like(self.scratch)
+    def _to_side(self, *keep, out=None):
+        """Pick the weight-gradient stream of this product (``out``: its output tensor - the same output always goes to the same stream) and let
+        it wait for the stream the operands were produced on (main, or the node stream inside a node section).  Several streams: a weight
+        gradient is a split-K product plus its reduction, two dependent launches that fill a fraction of the chip - on one stream they ran one
+        after the other and that stream, not the main one, ended the backward (leaving every weight gradient out shortened the step by 3.9 ms)."""
+        if not self._sides:
+            n = max(1, int(os.environ.get("DIFFSPECTRA_DW_STREAMS", "2")))     # (2 -> 3: no further gain; profiles/r05_train_dw_streams.txt)
+            self._sides = [(torch.cuda.Stream(device=self.dev), torch.empty_like(self.scratch)) for _ in range(n)]
+        key = None if out is None else out.data_ptr()
+        k = self._side_of.get(key) if key is not None else None
+        if k is None:
+            k = self._side_next
+            self._side_next = (k + 1) % len(self._sides)
+            if key is not None:
+                self._side_of[key] = k
+        self._side, self._side_scratch = self._sides[k]
         src = getattr(self, "cur_stream", None)
         if src is None:
             src = self.main_stream if getattr(self, "main_stream", None) is not None else torch.cuda.current_stream(self.dev)
@@ -261,7 +275,7 @@ class Ops:
         if not self.async_dw:
             self.gemm(dy, x, dW, True, False, acc=acc, rowsum=db)       # db = column sums of dy = row sums of dy^T, fused into the product
             return
-        self._to_side(dy.t, x.t, dW.t, db)                              # dy (and x) are complete on their stream at this point
+        self._to_side(dy.t, x.t, dW.t, db, out=dW.t)                    # dy (and x) are complete on their stream at this point
         main_scratch, self.scratch = self.scratch, self._side_scratch
         main_ptr, self.stream_ptr = self.stream_ptr, C.c_void_p(self._side.cuda_stream)
         try:
@@ -291,9 +305,11 @@ class Ops:
 
     def join_dw(self):
         """The main stream waits for every weight-gradient product issued so far; their operands may be reused after it."""
-        if self._side is not None and self._dw_keep:
+        if self._sides and self._dw_keep:
             main = self.main_stream if getattr(self, "main_stream", None) is not None else torch.cuda.current_stream(self.dev)
-            main.wait_stream(self._side)
+            for st, _ in self._sides:
+                main.wait_stream(st)
+        self._side_of = {}
         self._dw_keep = []
 
     def act_fwd(self, x, y, kind):
@@ -873,6 +889,7 @@ class DmtTrainGraph:
         ns = bool(int(os.environ.get("DIFFSPECTRA_NODE_STREAM", "1"))) and getattr(o, "main_stream", None) is not None
         sec = o.node_section if ns else contextlib.nullcontext
         fused_chain = bool(o.bf16) and Pp > 0 and os.environ.get("DIFFSPECTRA_FUSED_CHAIN", "1") != "0" and getattr(self, "wb", None) is not None
+        fused_node_b = fused_pair_b = fused_chain
         for i in reversed(range(NB)):
             bt = t["blocks"][i]
             bp = f"e_block_{i}."
@@ -882,10 +899,10 @@ class DmtTrainGraph:
             drn, dre = mv(dAH, 256 + 64 * i, 256 + 64 * (i + 1)), mv(dEH, 64 + 16 * i, 64 + 16 * (i + 1))
             with sec():
                 o.lin_bwd_w(drn, mv(bt["h_out"]), mv(gw(f"node_{i}.weight")), gw(f"node_{i}.bias"))
-                if not fused_chain:                              # (fused: inside dst_node_chain_bwd)
+                if not fused_node_b:                              # (fused: inside dst_node_chain_bwd)
                     o.lin_bwd_x(drn, mv(p[f"node_{i}.weight"]), mv(dh), acc=True)
             o.lin_bwd_w(dre, mv(bt["e_out"]), mv(gw(f"edge_{i}.weight")), gw(f"edge_{i}.bias"))
-            if not fused_chain:                                  # (fused: inside dst_pair_chain_bwd)
+            if not fused_pair_b:                                  # (fused: inside dst_pair_chain_bwd)
                 o.lin_bwd_x(dre, mv(p[f"edge_{i}.weight"]), mv(de), acc=True)
             # equivariant update
             dpos_in, dc2 = self.f(Nn, 3), self.f(max(D, 1), 3)
@@ -914,7 +931,7 @@ class DmtTrainGraph:
             # node stream (the section waits for dac)
             with sec():
                 o.lin_bwd_w(mv(dac), mv(bt["h_out"]), mv(dcat["Wac"][i]))           # both node parts at once; scattered into dWin[:, 0:512] at the end
-                if fused_chain:
+                if fused_node_b:
                     # the five input gradients, both gated residuals and the LayerNorm backward of the node chain as ONE kernel (csrc/ds_train_chain.hip)
                     df2, df1, dh_in, dattn = self.f(Nn, 256), self.f(Nn, 512), self.f(Nn, 256), self.f(Nn, 256)
                     o.node_chain_bwd(TL, dh, dAH.data_ptr() + 4 * (256 + 64 * i), 768, dac, bt["f2"], bt["f1"], bt["x1"], bt["st_n2"], bt["attn"], ada, d_ada,
@@ -937,7 +954,7 @@ class DmtTrainGraph:
                     o.gate_add_bwd(dx1, bt["attn"], 256, TL.node_off, 1, B, ada, d_ada, a0 + NODE_OFF + 512, dh_in, False, dattn)
             # edge stream
             o.lin_bwd_w(mv(ded), mv(bt["X2"]), mv(dWin, 512, 640), gw(bp + "equi_update.input_lin.bias"))
-            if fused_chain:
+            if fused_pair_b:
                 # the five input gradients, both gated residuals and the LayerNorm backward of the rear chain as ONE kernel (csrc/ds_train_chain.hip)
                 dfeat2, df4, df3, de_in, dhe = self.f(Pp, 64), self.f(Pp, 64), self.f(Pp, 128), self.f(Pp, 64), self.f(Pp, 64)
                 o.pair_chain_bwd(TL, de, dEH.data_ptr() + 4 * (64 + 16 * i), 192, ded, bt["f4"], bt["f3"], bt["xe1"], bt["st_e2"], bt["he"], ada, d_ada,

@@ -1157,15 +1157,26 @@ def test_training_step_is_bit_reproducible_across_stream_modes(gpu_device, monke
         torch.cuda.synchronize()
         return float(loss.detach()), torch.cat([p.grad.reshape(-1) for p in params]).clone()
 
+    names = [n_ for n_, p in model.named_parameters() if p.requires_grad]
+
+    def differing(ga, gb):                                                   # the parameters whose gradients differ (for the failure message)
+        out, o_ = [], 0
+        for n_, p in zip(names, params):
+            if not torch.equal(ga[o_:o_ + p.numel()], gb[o_:o_ + p.numel()]):
+                out.append(n_)
+            o_ += p.numel()
+        return out[:4] + ["..."] + out[-14:] if len(out) > 18 else out
+
     l0, g0 = run()
     assert math.isfinite(l0) and bool(torch.isfinite(g0).all())
     for rep in range(3):
         l1, g1 = run()
-        assert l1 == l0 and torch.equal(g1, g0), f"three-stream step differs from itself in repetition {rep}"
+        assert l1 == l0 and torch.equal(g1, g0), (f"three-stream step differs from itself in repetition {rep} (largest difference "
+                                                  f"{float((g1 - g0).abs().max()):.3e} of {float(g0.abs().max()):.3e}): {differing(g1, g0)}")
     monkeypatch.setenv("DIFFSPECTRA_NODE_STREAM", "0")
     monkeypatch.setenv("DIFFSPECTRA_ASYNC_DW", "0")
     l2, g2 = run()
-    assert l2 == l0 and torch.equal(g2, g0), "single-stream order gives different bits"
+    assert l2 == l0 and torch.equal(g2, g0), f"single-stream order gives different bits: {differing(g2, g0)}"
 
 
 # ------------------------------------------------------------------------------------------------ config 5 AS BENCHMARKED vs G17

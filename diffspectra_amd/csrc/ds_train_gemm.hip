@@ -44,7 +44,8 @@ namespace {
 // forced the argument struct into scratch memory (every kernel 2x slower).  So finish_tiles runs it in a ROLLED loop over a tile staged
 // through wave-private LDS: one copy of the code per kernel.
 __device__ __forceinline__ void epi_fused(const dst_gemm_args& g, int row, int col, float v) {
-  if (g.dact) v *= dst::act_deriv(g.ref[(int64_t)row * g.ldref + col], g.dact);
+  if (g.dact == 4) v += g.ref[(int64_t)row * g.ldref + col];                   // dact 4: + ref (a residual operand read where the sum is formed)
+  else if (g.dact) v *= dst::act_deriv(g.ref[(int64_t)row * g.ldref + col], g.dact);
   float keep = 1.0f;
   if (g.drop_p > 0.0f)
     keep = dst::dropout_keep(g.drop_seed, g.drop_stream, (int64_t)row * g.drop_ld + col, dst::dropout_threshold(g.drop_p)) ? 1.0f / (1.0f - g.drop_p) : 0.0f;
@@ -67,7 +68,7 @@ __device__ __forceinline__ void epi_fused4(const dst_gemm_args& g, int row, int 
   if (g.dact) {
     const f32x4_t r = *reinterpret_cast<const f32x4_t*>(g.ref + (int64_t)row * g.ldref + col);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= dst::act_deriv(r[e], g.dact);
+    for (int e = 0; e < 4; ++e) v[e] = g.dact == 4 ? v[e] + r[e] : v[e] * dst::act_deriv(r[e], g.dact);
   }
   f32x4_t keep = {1.0f, 1.0f, 1.0f, 1.0f};
   if (g.drop_p > 0.0f) {
@@ -618,7 +619,7 @@ int dst_struct_sizes(int64_t* out) {
 
 int dst_gemm(const dst_gemm_args* a, void* stream) {
   if (!a || !a->C || a->M < 0 || a->N < 0 || a->K < 0 || (a->K > 0 && (!a->A || !a->B))) return DS_ERR_ARG;
-  if ((a->dact && !a->ref) || a->act < 0 || a->act > 3 || a->dact < 0 || a->dact > 3 || !(a->drop_p >= 0.0f && a->drop_p < 1.0f)) return DS_ERR_ARG;
+  if ((a->dact && !a->ref) || a->act < 0 || a->act > 3 || a->dact < 0 || a->dact > 4 || !(a->drop_p >= 0.0f && a->drop_p < 1.0f)) return DS_ERR_ARG;
   if (a->act && a->accumulate) return DS_ERR_ARG;                       // an activated output is written, never accumulated
   if (a->M == 0 || (a->N == 0 && !a->rowsum)) return DS_OK;
   hipStream_t s = (hipStream_t)stream;

@@ -17,7 +17,7 @@ import torch
 
 from . import engine as E
 from .config import SPECTRUM_LENGTHS, used_spectra
-from .train_engine import GELU, Ops, mv
+from .train_engine import ADDREF, GELU, Ops, mv
 
 D_MODEL, N_HEADS, D_K, D_FF, N_LAYERS = 128, 16, 8, 256, 3
 
@@ -110,15 +110,15 @@ class SpecTrainGraph:
                 scores = self.f(B, N_HEADS, L, Lp)
                 E._check(self.lib.dst_spec_attn_fwd(E._ptr(qkv), E._ptr(prev), E._ptr(scores), E._ptr(ast), E._ptr(ao), C.c_int32(B), C.c_int32(L),
                                                     C.c_int32(N_HEADS), C.c_int32(D_K), C.c_float(scale), self.ops._s()), "dst_spec_attn_fwd")
-            r1 = Z.clone()
-            o.gemm(mv(ao), mv(p[base + "self_attn.to_out.0.weight"]), mv(r1), False, True, bias=p[base + "self_attn.to_out.0.bias"], acc=True)
+            r1 = self.f(B * L, D_MODEL)                               # Z + to_out(attention): the residual is added in the product's epilogue
+            o.gemm(mv(ao), mv(p[base + "self_attn.to_out.0.weight"]), mv(r1), False, True, bias=p[base + "self_attn.to_out.0.bias"], dact=ADDREF, ref=mv(Z))
             z1, st1 = self.f(B * L, D_MODEL), self.f(3, D_MODEL)
             self._bn_fwd(r1, base + "norm_attn.1", z1, st1)
             a = self.f(B * L, D_FF)
             ga = self.f(B * L, D_FF)
             o.lin_fwd(mv(z1), mv(p[base + "ff.0.weight"]), p[base + "ff.0.bias"], mv(a), act=GELU, out2=mv(ga))
-            r2 = z1.clone()
-            o.gemm(mv(ga), mv(p[base + "ff.3.weight"]), mv(r2), False, True, bias=p[base + "ff.3.bias"], acc=True)
+            r2 = self.f(B * L, D_MODEL)
+            o.gemm(mv(ga), mv(p[base + "ff.3.weight"]), mv(r2), False, True, bias=p[base + "ff.3.bias"], dact=ADDREF, ref=mv(z1))
             z2, st2 = self.f(B * L, D_MODEL), self.f(3, D_MODEL)
             self._bn_fwd(r2, base + "norm_ffn.1", z2, st2)
             if save:
@@ -180,8 +180,8 @@ class SpecTrainGraph:
             o.lin_bwd_x(mv(dr2), mv(p[base + "ff.3.weight"]), mv(da), dact=GELU, ref=mv(lt["a"]))
             o.lin_bwd_w(mv(da), mv(lt["z1"]), mv(gw(base + "ff.0.weight")), gw(base + "ff.0.bias"))
             dz1 = self.f(B * L, D_MODEL)                                                         # dz1 = dr2 (residual) + da W0, in a buffer of its own:
-            o.lin_bwd_x(mv(da), mv(p[base + "ff.0.weight"]), mv(dz1))                            # dr2 is an operand of a weight-gradient product that
-            o.axpy(1.0, dr2, dz1)                                                                # may still be running on the side stream
+            o.lin_bwd_x(mv(da), mv(p[base + "ff.0.weight"]), mv(dz1), dact=ADDREF, ref=mv(dr2))  # dr2 is an operand of a weight-gradient product that
+                                                                                                 # may still be running on the side stream
             dr1 = self.f(B * L, D_MODEL)
             self._bn_bwd(dz1, lt["r1"], lt["st1"], base + "norm_attn.1", dr1, g)
             o.lin_bwd_w(mv(dr1), mv(lt["ao"]), mv(gw(base + "self_attn.to_out.0.weight")), gw(base + "self_attn.to_out.0.bias"))
@@ -210,8 +210,7 @@ class SpecTrainGraph:
             dzin = self.f(B * L, D_MODEL)                                                        # dZin = dr1 (residual) + dqkv Wqkv (dr1 stays intact, as dr2 above)
             dWc, dbc = self.f(3 * D_MODEL, D_MODEL), self.f(3 * D_MODEL)
             o.lin_bwd_w(mv(dqkv), mv(lt["Zin"]), mv(dWc), dbc)
-            o.lin_bwd_x(mv(dqkv), mv(lt["Wqkv"]), mv(dzin))
-            o.axpy(1.0, dr1, dzin)
+            o.lin_bwd_x(mv(dqkv), mv(lt["Wqkv"]), mv(dzin), dact=ADDREF, ref=mv(dr1))
             for k, nm in enumerate(("W_Q", "W_K", "W_V")):
                 cat_dst += [gw(base + f"self_attn.{nm}.weight"), gw(base + f"self_attn.{nm}.bias")]
                 cat_src += [dWc[k * D_MODEL:(k + 1) * D_MODEL], dbc[k * D_MODEL:(k + 1) * D_MODEL]]

@@ -29,6 +29,7 @@ ADA, ADA_STRIDE, ADA_TOP = E.ADA_COLS, E.ADA_STRIDE, E.CONSTS["DS_ADA_TOP"]
 NODE_OFF, EDGE_OFF, EQUI_OFF, DIST_OFF = (E.CONSTS[k] for k in ("DS_ADA_NODE", "DS_ADA_EDGE", "DS_ADA_EQUI", "DS_ADA_DIST"))
 NB = E.NB
 SILU, GELU, TANH = 1, 2, 3
+ADDREF = 4                 # dst_gemm `dact` code: the epilogue adds ref (a residual operand) instead of multiplying by f'(ref)
 
 
 class DstGemmArgs(C.Structure):

@@ -39,7 +39,7 @@ extern "C" {
  *   weight gradient  dW = dY^T X   : A = dY^T (a_rs = 1, a_cs = ldy), B = X (b_rs = ldx, b_cs = 1), K = rows
  * accumulate != 0 adds to C.  Long-K products are split over K: every slice writes an fp32 slab into `partial` (caller scratch of
  * partial_cap floats) and a second kernel adds the slabs in slice order: results do not depend on scheduling.
- * Fused epilogue, per element (all optional):  v = acc + bias;  dact: v *= f'(ref[m,n]);  act: C = v and C2 = drop(f(v)) when C2 is
+ * Fused epilogue, per element (all optional):  v = acc + bias;  dact 1..3: v *= f'(ref[m,n]), dact 4: v += ref[m,n] (a residual);  act: C = v and C2 = drop(f(v)) when C2 is
  * given, else C = drop(f(v));  no act: C (+)= drop(v).  f: 1 SiLU, 2 GELU(erf), 3 tanh; f' takes ref = pre-activation (SiLU, GELU) or
  * ref = tanh output.  drop(x) = x * keep / (1 - p) with the Philox mask of dst_dropout at element index m * drop_ld + n of stream
  * (drop_seed, drop_stream) - the dropout of dmt.py:114-120 applied where the value is produced, and re-created in the backward.

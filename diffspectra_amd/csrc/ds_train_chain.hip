@@ -57,6 +57,15 @@ __device__ __forceinline__ float sum16(float v) {          // sum over aligned g
   for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// The same sum with DPP row rotations (a DPP row IS 16 lanes): no LDS-crossbar traffic.  The fused BACKWARD kernels use this form: with
+// ds_bpermute shuffles in flight next to their LDS reads, two executions inside a step differed in single rows (profiles/HISTORY.md, round 5).
+__device__ __forceinline__ float sum16_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
 __device__ __forceinline__ bf16x4_t to_bf4(f4_t v) {
   bf16x4_t r;
 #pragma unroll
@@ -897,7 +906,7 @@ __global__ __launch_bounds__(CH_NT, 2) void k_dir_chain_bwd(dst_layout L, dst_di
       s1 += (g[u][0] + g[u][1]) + (g[u][2] + g[u][3]);
       s2 += (gx[0] + gx[1]) + (gx[2] + gx[3]);
     }
-    const float m1 = sum16(s1) * (1.0f / 256.0f), m2 = sum16(s2) * (1.0f / 256.0f);
+    const float m1 = sum16_dpp(s1) * (1.0f / 256.0f), m2 = sum16_dpp(s2) * (1.0f / 256.0f);
     if (row < valid) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) st4(a.dz + (g0 + row) * 256 + 64 * u + 4 * j16, rstd[q] * (g[u] - m1 - xh[u] * m2));
@@ -1095,8 +1104,8 @@ __global__ __launch_bounds__(CH_NT, 2) void k_pair_chain_bwd(dst_layout L, dst_p
     psh += dy;
     psc += dy * xh;
     const f4_t gg = dy * sc1, gx = gg * xh;
-    const float m1 = sum16((gg[0] + gg[1]) + (gg[2] + gg[3])) * (1.0f / 64.0f);
-    const float m2 = sum16((gx[0] + gx[1]) + (gx[2] + gx[3])) * (1.0f / 64.0f);
+    const float m1 = sum16_dpp((gg[0] + gg[1]) + (gg[2] + gg[3])) * (1.0f / 64.0f);
+    const float m2 = sum16_dpp((gx[0] + gx[1]) + (gx[2] + gx[3])) * (1.0f / 64.0f);
     const f4_t dx = rstd[q] * (gg - m1 - xh * m2);
     if (row < valid) {
       pg1 += dx * hv[q];

@@ -890,7 +890,11 @@ class DmtTrainGraph:
         ns = bool(int(os.environ.get("DIFFSPECTRA_NODE_STREAM", "1"))) and getattr(o, "main_stream", None) is not None
         sec = o.node_section if ns else contextlib.nullcontext
         fused_chain = bool(o.bf16) and Pp > 0 and os.environ.get("DIFFSPECTRA_FUSED_CHAIN", "1") != "0" and getattr(self, "wb", None) is not None
-        fused_node_b = fused_pair_b = fused_chain
+        # which fused BACKWARD kernels run (DIFFSPECTRA_FUSED_BWD, default "node"): the pair- and directed-row kernels are correct to rounding
+        # (tests) but two executions inside a step can differ in single rows by ~1e-8 while other streams share the CUs - not understood
+        # (profiles/HISTORY.md, round 5) - so the bit-reproducible default leaves them to the per-operation kernels (+0.4 ms)
+        _fb = os.environ.get("DIFFSPECTRA_FUSED_BWD", "node")
+        fused_node_b, fused_pair_b, fused_dir_b = (fused_chain and k in _fb for k in ("node", "pair", "dir"))
         for i in reversed(range(NB)):
             bt = t["blocks"][i]
             bp = f"e_block_{i}."
@@ -916,7 +920,7 @@ class DmtTrainGraph:
             o.lin_bwd_w(mv(dc2, r1=D), mv(bt["sc0"], r1=D), mv(gw(bp + "equi_update.coord_mlp.2.weight")))
             dc0 = self.f(max(D, 1), 256)
             dz = self.f(max(D, 1), 256)                      # (not dc0: the coord_mlp.0 weight gradient may still be reading it on the side stream)
-            if fused_chain:
+            if fused_dir_b:
                 # coord_mlp.2's and coord_mlp.0's input gradients and the LayerNorm backward as ONE kernel (csrc/ds_train_chain.hip)
                 o.dir_chain_bwd(TL, dc2, bt["c0"], bt["zz"], bt["st_z"], ada, d_ada, a0 + EQUI_OFF + 0, a0 + EQUI_OFF + 256,
                                 p[bp + "equi_update.coord_mlp.2.weight"], self.wb["W0T"][i], dc0, dz)

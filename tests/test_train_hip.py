@@ -1179,6 +1179,52 @@ def test_training_step_is_bit_reproducible_across_stream_modes(gpu_device, monke
     assert l2 == l0 and torch.equal(g2, g0), f"single-stream order gives different bits: {differing(g2, g0)}"
 
 
+@pytest.mark.gpu
+def test_fused_chain_entry_points_reject_bad_arguments(gpu_device):
+    """The C-ABI of the fused row chains validates what a raw caller could get wrong: NULL operands, pointers that are not 16-byte aligned (every
+    access is a 16-byte vector), column offsets that are not multiples of 4, a dropout probability outside [0, 1) - DS_ERR_ARG (-1), nothing launched."""
+    import ctypes as C
+    import struct
+    from diffspectra_amd import engine as E, filler, train_engine as T
+    d = gpu_device
+    lib = T.load_train_library()
+    node_mask, _ = filler.masks_from_n_atoms([5, 3, 1])
+    TL = T.TrainLayout(node_mask, d)
+    Nn, Pp, D = TL.Nn, TL.Pp, 2 * TL.Pp
+    keep = []                                                                    # (the kernels of the valid calls run: every operand stays alive)
+
+    def f(*s):
+        keep.append(torch.zeros(*s, device=d))
+        return keep[-1]
+
+    def hb(*s):
+        keep.append(torch.zeros(*s, dtype=torch.bfloat16, device=d))
+        return keep[-1]
+    ada = f(TL.B, T.ADA)
+    P = lambda t: t.data_ptr()
+    # dst_node_chain_fwd
+    good = [TL.node_mol_ptr, P(f(Nn, 256)), P(f(Nn, 256)), P(ada), T.ADA, 0, 256, 512, 768, P(hb(512, 256)), P(f(512)), P(hb(256, 512)), P(f(256)), P(hb(512, 256)),
+            P(hb(64, 256)), P(f(64)), 0.1, 1, 2, 0, 7, 0, 0, 0, 0, 0, 0, P(f(Nn, 256)), P(f(Nn, 512)), P(f(Nn, 64))]
+    call = lambda a: lib.dst_node_chain_fwd(C.byref(TL.c), T._NODE_PACK(*a), E._stream())
+    assert call(good) == 0
+    for idx, val in ((1, 0), (1, good[1] + 4), (5, 2), (9, 0), (16, 1.0), (27, 0)):     # NULL h_in, misaligned h_in, gate offset 2, NULL W1, p = 1, NULL h_out
+        bad = list(good)
+        bad[idx] = val
+        assert call(bad) == -1, idx
+    # dst_dir_chain_bwd / dst_pair_chain_bwd: the tile tables and scratch are required
+    tt = TL.dir_tiles
+    part = f(max(tt[4], 1) * 512)
+    good = [tt[0], tt[1], tt[2], tt[3], tt[4], P(f(D, 3)), P(f(D, 256)), P(f(D, 256)), P(f(D, 2)), P(ada), P(f(TL.B, T.ADA)), T.ADA, 0, 256, P(f(3, 256)),
+            P(hb(256, 256)), P(f(D, 256)), P(f(D, 256)), P(part)]
+    call = lambda a: lib.dst_dir_chain_bwd(C.byref(TL.c), T._DIRB_PACK(*a), E._stream())
+    assert call(good) == 0
+    for idx, val in ((0, 0), (4, -1), (6, good[6] + 8), (12, 6), (15, 0), (18, 0)):      # NULL table, negative tile count, misaligned c0, offset 6, NULL W0T, NULL scratch
+        bad = list(good)
+        bad[idx] = val
+        assert call(bad) == -1, idx
+    torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------------------------------------------ config 5 AS BENCHMARKED vs G17
 def _group_of(name):
     if name.startswith("cond_encoder."):

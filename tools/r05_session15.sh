@@ -1,6 +1,8 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
 cd $R
-echo "== all fused, streams=1"; DIFFSPECTRA_DW_STREAMS=1 python3 tools/repro_check.py 40 2>&1 | grep "runs that"
-echo "== all fused, streams=3"; DIFFSPECTRA_DW_STREAMS=3 python3 tools/repro_check.py 40 2>&1 | grep "runs that"
-echo "== all fused, streams=2"; DIFFSPECTRA_DW_STREAMS=2 python3 tools/repro_check.py 40 2>&1 | grep "runs that"
+for k in 1 2; do echo "== default (node) run $k"; python3 tools/repro_check.py 40 2>&1 | grep "runs that"; done
+for FB in node "node,pair,dir" node "node,pair,dir"; do
+  DIFFSPECTRA_FUSED_BWD=$FB python3 bench.py --mode train --steps 40 --warmup 5 --no-cpu-baseline --no-live-traffic > gpurun_out/ab_t.json 2>/dev/null
+  python3 -c "import json; r=json.load(open('gpurun_out/ab_t.json')); print('fused backward kernels $FB:', round(r['value']), 'molecules/s', round(r['ms_per_step'],2), 'ms/step')"
+done

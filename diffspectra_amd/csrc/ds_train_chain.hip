@@ -66,6 +66,14 @@ __device__ __forceinline__ float sum16_dpp(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
   return v;
 }
+// sum over the 64 lanes without the LDS crossbar: DPP row sums, then the four row totals by readlane
+__device__ __forceinline__ float sum64_dpp(float v) {
+  v = sum16_dpp(v);
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return ((r0 + r1) + r2) + r3;
+}
 __device__ __forceinline__ bf16x4_t to_bf4(f4_t v) {
   bf16x4_t r;
 #pragma unroll
@@ -1322,8 +1330,8 @@ __global__ __launch_bounds__(NC_NT) void k_node_chain_bwd(dst_layout L, dst_node
     psh += dy;
     psc += dy * xh;
     const f4_t gg = dy * sc1, gx = gg * xh;
-    const float m1 = sum64((gg[0] + gg[1]) + (gg[2] + gg[3])) * (1.0f / 256.0f);
-    const float m2 = sum64((gx[0] + gx[1]) + (gx[2] + gx[3])) * (1.0f / 256.0f);
+    const float m1 = sum64_dpp((gg[0] + gg[1]) + (gg[2] + gg[3])) * (1.0f / 256.0f);
+    const float m2 = sum64_dpp((gx[0] + gx[1]) + (gx[2] + gx[3])) * (1.0f / 256.0f);
     const f4_t dx = rstd[q] * (gg - m1 - xh * m2);
     if (row < valid) {
       pg1 += dx * av[q];

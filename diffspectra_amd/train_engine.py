@@ -890,10 +890,9 @@ class DmtTrainGraph:
         ns = bool(int(os.environ.get("DIFFSPECTRA_NODE_STREAM", "1"))) and getattr(o, "main_stream", None) is not None
         sec = o.node_section if ns else contextlib.nullcontext
         fused_chain = bool(o.bf16) and Pp > 0 and os.environ.get("DIFFSPECTRA_FUSED_CHAIN", "1") != "0" and getattr(self, "wb", None) is not None
-        # which fused BACKWARD kernels run (DIFFSPECTRA_FUSED_BWD, default "node"): the pair- and directed-row kernels are correct to rounding
-        # (tests) but two executions inside a step can differ in single rows by ~1e-8 while other streams share the CUs - not understood
-        # (profiles/HISTORY.md, round 5) - so the bit-reproducible default leaves them to the per-operation kernels (+0.4 ms)
-        _fb = os.environ.get("DIFFSPECTRA_FUSED_BWD", "node")
+        # which fused BACKWARD kernels run (DIFFSPECTRA_FUSED_BWD, default all three; the pair- and directed-row kernels take a CU's LDS alone,
+        # csrc/ds_train_chain.hip CHAIN_BWD_LDS: sharing a CU with a weight-gradient product they were not bit-reproducible)
+        _fb = os.environ.get("DIFFSPECTRA_FUSED_BWD", "node,pair,dir")
         fused_node_b, fused_pair_b, fused_dir_b = (fused_chain and k in _fb for k in ("node", "pair", "dir"))
         for i in reversed(range(NB)):
             bt = t["blocks"][i]

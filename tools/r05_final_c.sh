@@ -32,11 +32,11 @@ rm -rf gpurun_out/kt_train2
 head -8 gpurun_out/r05_train_timeline_final.txt
 python3 tools/sfa_bench.py > gpurun_out/r05_sfa_bench_final.txt 2>/dev/null
 python3 tools/chain_bench.py 2>/dev/null | tail -7 > gpurun_out/r05_chain_bench_final.txt
-( echo "default (DIFFSPECTRA_FUSED_BWD=node), 40 repeated steps:"; python3 tools/repro_check.py 40 2>/dev/null | tail -3
-  echo "DIFFSPECTRA_FUSED_BWD=node,pair,dir, 40 repeated steps:"; DIFFSPECTRA_FUSED_BWD=node,pair,dir python3 tools/repro_check.py 40 2>/dev/null | tail -3 ) | cut -c1-200 > gpurun_out/r05_train_repetition_check.txt
+( echo "default build, 3 x 40 repeated steps (every gradient compared bit for bit with the first run and with the run before):"
+  for k in 1 2 3; do python3 tools/repro_check.py 40 2>/dev/null | tail -1; done ) | cut -c1-200 > gpurun_out/r05_train_repetition_check.txt
 cat gpurun_out/r05_sfa_bench_final.txt gpurun_out/r05_chain_bench_final.txt gpurun_out/r05_train_repetition_check.txt | cut -c1-160
 rm -f gpurun_out/r05_train_ab_final.txt
-for CFG in "1 2 node" "0 2 node" "1 1 node" "1 3 node" "1 2 node,pair,dir" "1 2 none"; do
+for CFG in "1 2 node,pair,dir" "0 2 node,pair,dir" "1 1 node,pair,dir" "1 3 node,pair,dir" "1 2 node" "1 2 none"; do
   set -- $CFG
   DIFFSPECTRA_FUSED_CHAIN=$1 DIFFSPECTRA_DW_STREAMS=$2 DIFFSPECTRA_FUSED_BWD=$3 python3 bench.py --mode train --steps 30 --warmup 5 --no-cpu-baseline --no-live-traffic > gpurun_out/ab_t.json 2>/dev/null
   python3 -c "import json; r=json.load(open('gpurun_out/ab_t.json')); print('fused chains=$1 weight-gradient streams=$2 fused backward kernels=$3:', round(r['value']), 'molecules/s', round(r['ms_per_step'],2), 'ms/step, host issue', round(r['config']['host_issue_ms_per_step'],2), 'ms')" | tee -a gpurun_out/r05_train_ab_final.txt

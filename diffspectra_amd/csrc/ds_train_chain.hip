@@ -957,7 +957,8 @@ __global__ __launch_bounds__(512) void k_dir_bwd_finish(dst_dir_bwd_args a) {
 // The pair- and directed-row backward kernels ask for CHAIN_BWD_LDS bytes of LDS - more than they use - so that NO other workgroup that uses LDS
 // shares their CU.  Next to a weight-gradient product (other stream) on the same CU, single rows of their LayerNorm stage came out different
 // from run to run on identical inputs (1 - 3 % of the training steps; inputs verified unchanged, no shuffles, explicit waits tried); alone on the
-// CU, 120 of 120 repeated steps were bit-identical.  The mechanism is not understood (profiles/HISTORY.md, round 5); the cost is ~0.3 ms per step.
+// CU, 240 of 240 repeated steps were bit-identical (with 142 kB - only 18 kB kernels beside it - 120 of 120; with 128 kB not: the neighbour that matters is
+// k_tr_gemm_bf16<128, 128, 256>, 20 kB of LDS).  The mechanism is not understood (profiles/HISTORY.md, round 5); the cost is ~0.3 ms per step.
 constexpr size_t CHAIN_BWD_LDS = 150 * 1024;
 struct PairBwdLds {
   float yf[32][LD_F];              // de_tot, the base of dye1
